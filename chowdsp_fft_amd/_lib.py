@@ -1,0 +1,77 @@
+"""ctypes binding of libchowdsp_fft_hip.so -- the C-ABI drop-in library (include/chowdsp_fft.h,
+include/chowdsp_fft_gpu.h).
+
+The library is the product; this module only declares its prototypes.  There is deliberately no
+fallback: if the shared object is missing or fails to load, importing raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libchowdsp_fft_hip.so")
+
+# enums of include/chowdsp_fft.h (reference chowdsp_fft.h:64-75)
+FFT_FORWARD, FFT_BACKWARD = 0, 1
+FFT_REAL, FFT_COMPLEX = 0, 1
+
+# every symbol include/*.h declares: name -> (restype, argtypes)
+_vp, _fp, _sz, _i, _b, _f = C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_bool, C.c_float
+PROTOTYPES = {
+    # --- legacy (include/chowdsp_fft.h)
+    "fft_bytes_required": (_sz, [_i, _i, _b]),
+    "fft_new_setup": (_vp, [_i, _i, _b]),
+    "fft_new_setup_preallocated": (_vp, [_i, _i, _vp, _b]),
+    "fft_destroy_setup": (None, [_vp]),
+    "fft_simd_width_bytes": (_i, [_vp]),
+    "fft_transform": (None, [_vp, _fp, _fp, _fp, _i]),
+    "fft_transform_unordered": (None, [_vp, _fp, _fp, _fp, _i]),
+    "fft_convolve_unordered": (None, [_vp, _fp, _fp, _fp, _f]),
+    "fft_accumulate": (None, [_vp, _fp, _fp, _fp, _i]),
+    "aligned_malloc": (_vp, [_sz]),
+    "aligned_free": (None, [_vp]),
+    # --- extension (include/chowdsp_fft_gpu.h)
+    "fft_gpu_device_count": (_i, []),
+    "fft_gpu_set_device": (_i, [_i]),
+    "fft_gpu_malloc": (_vp, [_sz]),
+    "fft_gpu_free": (None, [_vp]),
+    "fft_gpu_host_malloc": (_vp, [_sz]),
+    "fft_gpu_host_free": (None, [_vp]),
+    "fft_gpu_memcpy": (_i, [_vp, _vp, _sz, _i, _vp]),
+    "fft_gpu_stream_synchronize": (_i, [_vp]),
+    "fft_gpu_last_error": (C.c_char_p, []),
+    "fft_gpu_setup_size": (_i, [_vp]),
+    "fft_gpu_setup_is_real": (_i, [_vp]),
+    "fft_gpu_workspace_bytes": (_sz, [_vp, _sz]),
+    "fft_transform_batch": (_i, [_vp, _fp, _fp, _sz, _i, _vp]),
+    "fft_transform_unordered_batch": (_i, [_vp, _fp, _fp, _sz, _i, _vp]),
+    "fft_convolve_unordered_batch": (_i, [_vp, _fp, _fp, _fp, _f, _sz, _i, _vp]),
+    "fft_accumulate_batch": (_i, [_vp, _fp, _fp, _fp, _sz, _vp]),
+    "fft_convolve_frames_batch": (_i, [_vp, _fp, _fp, _fp, _f, _sz, _vp]),
+}
+
+
+def load(path: str = LIB_PATH) -> C.CDLL:
+    """dlopen the library (RTLD_LOCAL) and attach prototypes.  Raises OSError if it is not built."""
+    if not os.path.exists(path):
+        raise OSError(
+            f"{path} not found: build it with `make -C chowdsp_fft_amd/csrc` "
+            "(or python -c 'import __graft_entry__ as g; g.build()'). There is no fallback path."
+        )
+    lib = C.CDLL(path, mode=getattr(os, "RTLD_LOCAL", 0) | getattr(os, "RTLD_NOW", 2))
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing -> loud failure
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+_LIB = None
+
+
+def lib() -> C.CDLL:
+    global _LIB
+    if _LIB is None:
+        _LIB = load()
+    return _LIB

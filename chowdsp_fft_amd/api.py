@@ -1,0 +1,170 @@
+"""Python mirror of the chowdsp_fft operator interface, calling the HIP backend through its C ABI.
+
+Function names, argument order and semantics follow include/chowdsp_fft.h (reference chowdsp_fft.h:81-163)
+so that the parity tests read like the reference's own tests (reference test/test.cpp):
+
+    setup = fft_new_setup(N, FFT_COMPLEX)
+    fft_transform(setup, x, y, None, FFT_FORWARD)        # numpy (host pointers) or torch (device pointers)
+    fft_transform_batch(setup, X, Y, FFT_FORWARD)        # torch tensors [batch, frame_floats] on the GPU
+
+Arrays are passed by pointer, never copied here: numpy arrays go down as host pointers (the library
+stages them), torch CUDA tensors as device pointers.  PyTorch is used only as a device-memory / stream
+provider.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import FFT_BACKWARD, FFT_COMPLEX, FFT_FORWARD, FFT_REAL  # noqa: F401  (re-exported)
+
+
+class FFTError(RuntimeError):
+    pass
+
+
+def _ptr(a) -> int:
+    """Raw address of a numpy array or torch tensor (must be contiguous fp32)."""
+    if a is None:
+        return 0
+    if isinstance(a, np.ndarray):
+        if a.dtype != np.float32 or not a.flags["C_CONTIGUOUS"]:
+            raise TypeError("expected a C-contiguous float32 numpy array")
+        return a.ctypes.data
+    if hasattr(a, "data_ptr"):  # torch tensor
+        import torch
+
+        if a.dtype != torch.float32 or not a.is_contiguous():
+            raise TypeError("expected a contiguous float32 tensor")
+        return a.data_ptr()
+    raise TypeError(f"unsupported buffer type {type(a)!r}")
+
+
+def _stream_handle(stream) -> int:
+    """hipStream_t as an integer.  None -> torch's current stream if torch has initialised HIP, else NULL."""
+    if stream is None:
+        try:
+            import torch
+
+            if torch.cuda.is_available() and torch.cuda.is_initialized():
+                return int(torch.cuda.current_stream().cuda_stream)
+        except ImportError:
+            pass
+        return 0
+    if isinstance(stream, int):
+        return stream
+    return int(stream.cuda_stream)
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = _lib.lib().fft_gpu_last_error().decode(errors="replace")
+        raise FFTError(f"{what} failed (code {rc}): {msg}")
+
+
+# ---- legacy single-frame interface (names as in the reference header) -----------------------------
+def fft_bytes_required(N: int, transform: int, use_avx_if_available: bool = True) -> int:
+    return int(_lib.lib().fft_bytes_required(N, transform, use_avx_if_available))
+
+
+def fft_new_setup(N: int, transform: int, use_avx_if_available: bool = True):
+    """Returns an opaque handle (int) or None for an unsupported size / no device."""
+    h = _lib.lib().fft_new_setup(N, transform, use_avx_if_available)
+    return h or None
+
+
+def fft_new_setup_preallocated(N: int, transform: int, data, use_avx_if_available: bool = True):
+    h = _lib.lib().fft_new_setup_preallocated(N, transform, data, use_avx_if_available)
+    return h or None
+
+
+def fft_destroy_setup(setup) -> None:
+    _lib.lib().fft_destroy_setup(setup)
+
+
+def fft_simd_width_bytes(setup) -> int:
+    return int(_lib.lib().fft_simd_width_bytes(setup))
+
+
+def fft_transform(setup, input, output, work, direction: int) -> None:
+    _lib.lib().fft_transform(setup, _ptr(input), _ptr(output), _ptr(work), direction)
+
+
+def fft_transform_unordered(setup, input, output, work, direction: int) -> None:
+    _lib.lib().fft_transform_unordered(setup, _ptr(input), _ptr(output), _ptr(work), direction)
+
+
+def fft_convolve_unordered(setup, a, b, ab, scaling: float) -> None:
+    _lib.lib().fft_convolve_unordered(setup, _ptr(a), _ptr(b), _ptr(ab), scaling)
+
+
+def fft_accumulate(setup, a, b, ab, N: int) -> None:
+    _lib.lib().fft_accumulate(setup, _ptr(a), _ptr(b), _ptr(ab), N)
+
+
+def aligned_malloc(nb_bytes: int) -> int:
+    return int(_lib.lib().aligned_malloc(nb_bytes) or 0)
+
+
+def aligned_free(p: int) -> None:
+    _lib.lib().aligned_free(p)
+
+
+def aligned_array(n_floats: int):
+    """float32 numpy view over a 64-byte aligned host block from aligned_malloc; returns (array, pointer)."""
+    p = aligned_malloc(4 * n_floats)
+    if not p:
+        raise MemoryError
+    arr = np.ctypeslib.as_array((C.c_float * n_floats).from_address(p))
+    return arr, p
+
+
+# ---- batched device-pointer extension (include/chowdsp_fft_gpu.h) -----------------------------------
+def _batch_of(setup, t) -> int:
+    n = _lib.lib().fft_gpu_setup_size(setup)
+    if n < 0:
+        raise FFTError("invalid setup handle")
+    frame = n if _lib.lib().fft_gpu_setup_is_real(setup) else 2 * n
+    total = t.numel() if hasattr(t, "numel") else t.size
+    if total % frame:
+        raise ValueError(f"buffer of {total} floats is not a whole number of {frame}-float frames")
+    return total // frame
+
+
+def fft_transform_batch(setup, input, output, direction: int, batch: int | None = None, stream=None) -> None:
+    b = _batch_of(setup, input) if batch is None else batch
+    _check(_lib.lib().fft_transform_batch(setup, _ptr(input), _ptr(output), b, direction, _stream_handle(stream)),
+           "fft_transform_batch")
+
+
+def fft_transform_unordered_batch(setup, input, output, direction: int, batch: int | None = None, stream=None) -> None:
+    b = _batch_of(setup, input) if batch is None else batch
+    _check(_lib.lib().fft_transform_unordered_batch(setup, _ptr(input), _ptr(output), b, direction, _stream_handle(stream)),
+           "fft_transform_unordered_batch")
+
+
+def fft_convolve_unordered_batch(setup, a, b, ab, scaling: float, b_is_shared: bool = False,
+                                 batch: int | None = None, stream=None) -> None:
+    nb = _batch_of(setup, a) if batch is None else batch
+    _check(_lib.lib().fft_convolve_unordered_batch(setup, _ptr(a), _ptr(b), _ptr(ab), scaling, nb,
+                                                   1 if b_is_shared else 0, _stream_handle(stream)),
+           "fft_convolve_unordered_batch")
+
+
+def fft_accumulate_batch(setup, a, b, ab, count: int | None = None, stream=None) -> None:
+    n = (a.numel() if hasattr(a, "numel") else a.size) if count is None else count
+    _check(_lib.lib().fft_accumulate_batch(setup, _ptr(a), _ptr(b), _ptr(ab), n, _stream_handle(stream)),
+           "fft_accumulate_batch")
+
+
+def fft_convolve_frames_batch(setup, x, dft_filter, y, scaling: float, batch: int | None = None, stream=None) -> None:
+    nb = _batch_of(setup, x) if batch is None else batch
+    _check(_lib.lib().fft_convolve_frames_batch(setup, _ptr(x), _ptr(dft_filter), _ptr(y), scaling, nb,
+                                                _stream_handle(stream)),
+           "fft_convolve_frames_batch")
+
+
+def device_count() -> int:
+    return int(_lib.lib().fft_gpu_device_count())

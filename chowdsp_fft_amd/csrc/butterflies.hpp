@@ -1,0 +1,136 @@
+// In-register forward DFT butterflies of length 2, 4, 8 and 16 on float2 (re, im) values.
+//
+// These replace the per-pass butterflies of the reference's SIMD code
+// (passf2_ps / passf4_ps, simd/chowdsp_fft_impl_sse.cpp:148-180, 221-296): there one "scalar" is a
+// 4- or 8-wide vector and every radix-4 pass is a sweep over the whole frame in memory; here one
+// work-item keeps 16 complex points in VGPRs and finishes log2(16) = 4 radix-2 levels per pass, so a
+// 4096-point frame needs 3 passes instead of 6.
+//
+// Only the FORWARD (e^{-i...}) direction is implemented: the backward transform is obtained by
+// swapping re<->im on load and on store (IDFT(x) = swap(DFT(swap(x)))), which costs nothing in registers.
+//
+// Output is in natural order: after fft_reg<R>(u), u[k] = sum_n u_in[n] * exp(-2*pi*i*n*k/R).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace cfft
+{
+__device__ __forceinline__ float2 cadd (float2 a, float2 b) { return make_float2 (a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub (float2 a, float2 b) { return make_float2 (a.x - b.x, a.y - b.y); }
+// a * b
+__device__ __forceinline__ float2 cmul (float2 a, float2 b)
+{
+    return make_float2 (a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+// a * conj(b)
+__device__ __forceinline__ float2 cmulc (float2 a, float2 b)
+{
+    return make_float2 (a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+// a * (-i)
+__device__ __forceinline__ float2 mul_mi (float2 a) { return make_float2 (a.y, -a.x); }
+// a * (+i)
+__device__ __forceinline__ float2 mul_pi (float2 a) { return make_float2 (-a.y, a.x); }
+
+static constexpr float kSqrtHalf = 0.70710678118654752440f;
+static constexpr float kCosPi8 = 0.92387953251128675613f;
+static constexpr float kSinPi8 = 0.38268343236508977173f;
+
+// a * W8^1 = a * (1 - i)/sqrt2
+__device__ __forceinline__ float2 mul_w8_1 (float2 a) { return make_float2 ((a.x + a.y) * kSqrtHalf, (a.y - a.x) * kSqrtHalf); }
+// a * W8^3 = a * (-1 - i)/sqrt2
+__device__ __forceinline__ float2 mul_w8_3 (float2 a) { return make_float2 ((a.y - a.x) * kSqrtHalf, -(a.x + a.y) * kSqrtHalf); }
+
+__device__ __forceinline__ void bfly2 (float2& a, float2& b)
+{
+    const float2 t = csub (a, b);
+    a = cadd (a, b);
+    b = t;
+}
+
+// 4-point forward DFT, natural order in / natural order out.
+__device__ __forceinline__ void bfly4 (float2& x0, float2& x1, float2& x2, float2& x3)
+{
+    const float2 s02 = cadd (x0, x2), d02 = csub (x0, x2);
+    const float2 s13 = cadd (x1, x3), d13 = mul_mi (csub (x1, x3));
+    x0 = cadd (s02, s13);
+    x1 = cadd (d02, d13);
+    x2 = csub (s02, s13);
+    x3 = csub (d02, d13);
+}
+
+template <int R>
+__device__ __forceinline__ void fft_reg (float2 (&u)[R]);
+
+template <>
+__device__ __forceinline__ void fft_reg<2> (float2 (&u)[2])
+{
+    bfly2 (u[0], u[1]);
+}
+
+template <>
+__device__ __forceinline__ void fft_reg<4> (float2 (&u)[4])
+{
+    bfly4 (u[0], u[1], u[2], u[3]);
+}
+
+// 8 = 2 (n2) x 4 (n1):  X[2*k1 + k2] = sum_{n1<4} W4^{n1 k1} [ W8^{n1 k2} sum_{n2<2} x[n1 + 4 n2] W2^{n2 k2} ]
+template <>
+__device__ __forceinline__ void fft_reg<8> (float2 (&u)[8])
+{
+    bfly2 (u[0], u[4]);
+    bfly2 (u[1], u[5]);
+    bfly2 (u[2], u[6]);
+    bfly2 (u[3], u[7]);
+    // k2 = 1 column gets W8^{n1}
+    u[5] = mul_w8_1 (u[5]);
+    u[6] = mul_mi (u[6]);
+    u[7] = mul_w8_3 (u[7]);
+    bfly4 (u[0], u[1], u[2], u[3]); // k2 = 0 -> X[0], X[2], X[4], X[6]
+    bfly4 (u[4], u[5], u[6], u[7]); // k2 = 1 -> X[1], X[3], X[5], X[7]
+    // reorder to natural order
+    const float2 e0 = u[0], e1 = u[1], e2 = u[2], e3 = u[3];
+    const float2 o0 = u[4], o1 = u[5], o2 = u[6], o3 = u[7];
+    u[0] = e0; u[1] = o0; u[2] = e1; u[3] = o1;
+    u[4] = e2; u[5] = o2; u[6] = e3; u[7] = o3;
+}
+
+// 16 = 4 (n2) x 4 (n1):  X[4*k1 + k2] = sum_{n1<4} W4^{n1 k1} [ W16^{n1 k2} sum_{n2<4} x[n1 + 4 n2] W4^{n2 k2} ]
+template <>
+__device__ __forceinline__ void fft_reg<16> (float2 (&u)[16])
+{
+    // inner 4-point DFTs over n2 for each n1 : A[n1][k2] lands in u[n1 + 4*k2]
+    bfly4 (u[0], u[4], u[8], u[12]);
+    bfly4 (u[1], u[5], u[9], u[13]);
+    bfly4 (u[2], u[6], u[10], u[14]);
+    bfly4 (u[3], u[7], u[11], u[15]);
+    // twiddles W16^{n1*k2} on u[n1 + 4*k2]
+    const float2 w1 = make_float2 (kCosPi8, -kSinPi8); // W16^1
+    const float2 w3 = make_float2 (kSinPi8, -kCosPi8); // W16^3
+    u[5] = cmul (u[5], w1);          // n1=1,k2=1 : W^1
+    u[6] = mul_w8_1 (u[6]);          // n1=2,k2=1 : W^2
+    u[7] = cmul (u[7], w3);          // n1=3,k2=1 : W^3
+    u[9] = mul_w8_1 (u[9]);          // n1=1,k2=2 : W^2
+    u[10] = mul_mi (u[10]);          // n1=2,k2=2 : W^4
+    u[11] = mul_w8_3 (u[11]);        // n1=3,k2=2 : W^6
+    u[13] = cmul (u[13], w3);        // n1=1,k2=3 : W^3
+    u[14] = mul_w8_3 (u[14]);        // n1=2,k2=3 : W^6
+    {                                // n1=3,k2=3 : W^9 = -W^1
+        const float2 t = cmul (u[15], w1);
+        u[15] = make_float2 (-t.x, -t.y);
+    }
+    // outer 4-point DFTs over n1 for each k2 : X[4*k1 + k2] lands in u[4*k2 + k1]
+    bfly4 (u[0], u[1], u[2], u[3]);
+    bfly4 (u[4], u[5], u[6], u[7]);
+    bfly4 (u[8], u[9], u[10], u[11]);
+    bfly4 (u[12], u[13], u[14], u[15]);
+    // transpose the 4x4 register tile so that u[k] = X[k]
+    float2 t;
+    t = u[1]; u[1] = u[4]; u[4] = t;
+    t = u[2]; u[2] = u[8]; u[8] = t;
+    t = u[3]; u[3] = u[12]; u[12] = t;
+    t = u[6]; u[6] = u[9]; u[9] = t;
+    t = u[7]; u[7] = u[13]; u[13] = t;
+    t = u[11]; u[11] = u[14]; u[14] = t;
+}
+} // namespace cfft

@@ -1,0 +1,104 @@
+// Error capture, device facts and the process-wide device-table cache (host side, no kernels).
+#include "host_common.hpp"
+#include "tables.hpp"
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <tuple>
+#include <vector>
+
+namespace cfft::host
+{
+namespace
+{
+thread_local std::string g_last_error;
+std::mutex g_cache_mutex;
+std::map<std::tuple<int, int, int>, DeviceTables*> g_tables; // (device, N, transform) -> tables
+std::map<int, DeviceInfo> g_devinfo;
+
+float2* upload (const std::vector<float2>& h)
+{
+    if (h.empty())
+        return nullptr;
+    float2* d = nullptr;
+    if (hipMalloc ((void**) &d, h.size() * sizeof (float2)) != hipSuccess)
+        return nullptr;
+    if (hipMemcpy (d, h.data(), h.size() * sizeof (float2), hipMemcpyHostToDevice) != hipSuccess)
+    {
+        (void) hipFree (d);
+        return nullptr;
+    }
+    return d;
+}
+} // namespace
+
+void set_last_error (const char* what, hipError_t e)
+{
+    g_last_error = std::string (what) + ": " + hipGetErrorString (e);
+}
+void set_last_error (const char* what) { g_last_error = what; }
+const char* last_error() { return g_last_error.c_str(); }
+
+bool current_device_info (DeviceInfo& out)
+{
+    int dev = -1;
+    if (hipGetDevice (&dev) != hipSuccess || dev < 0)
+    {
+        set_last_error ("hipGetDevice failed (no usable HIP device)");
+        return false;
+    }
+    std::lock_guard<std::mutex> lock (g_cache_mutex);
+    auto it = g_devinfo.find (dev);
+    if (it == g_devinfo.end())
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties (&prop, dev) != hipSuccess)
+        {
+            set_last_error ("hipGetDeviceProperties failed");
+            return false;
+        }
+        DeviceInfo info;
+        info.ordinal = dev;
+        info.num_cus = prop.multiProcessorCount;
+        info.lds_per_cu = prop.maxSharedMemoryPerMultiProcessor;
+        it = g_devinfo.emplace (dev, info).first;
+    }
+    out = it->second;
+    return true;
+}
+
+const DeviceTables* acquire_tables (int device, int N, int transform)
+{
+    std::lock_guard<std::mutex> lock (g_cache_mutex);
+    const auto key = std::make_tuple (device, N, transform);
+    auto it = g_tables.find (key);
+    if (it != g_tables.end())
+        return it->second;
+
+    HostTables h;
+    if (! build_host_tables (N, transform, h))
+    {
+        set_last_error ("unsupported transform size");
+        return nullptr;
+    }
+    auto* t = new DeviceTables();
+    t->core_n = h.core_n;
+    t->stage_twiddles = upload (h.stage_twiddles);
+    t->real_twiddles = upload (h.real_twiddles);
+    t->big_twiddles = upload (h.big_twiddles);
+    if ((! h.stage_twiddles.empty() && t->stage_twiddles == nullptr)
+        || (! h.real_twiddles.empty() && t->real_twiddles == nullptr)
+        || (! h.big_twiddles.empty() && t->big_twiddles == nullptr))
+    {
+        set_last_error ("device table upload failed");
+        (void) hipFree (t->stage_twiddles);
+        (void) hipFree (t->real_twiddles);
+        (void) hipFree (t->big_twiddles);
+        delete t;
+        return nullptr;
+    }
+    g_tables.emplace (key, t);
+    return t;
+}
+} // namespace cfft::host

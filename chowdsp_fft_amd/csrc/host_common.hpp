@@ -1,0 +1,69 @@
+// Host-side plumbing shared by the C-ABI translation units: error capture, device properties,
+// the process-wide device-table cache and the plan header.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+namespace cfft::host
+{
+// ---- error capture (nothing throws across the C ABI) -------------------------------------------
+void set_last_error (const char* what, hipError_t e);
+void set_last_error (const char* what);
+const char* last_error();
+
+#define CFFT_HIP_TRY(expr, failret)                        \
+    do                                                     \
+    {                                                      \
+        hipError_t cfft_e_ = (expr);                       \
+        if (cfft_e_ != hipSuccess)                         \
+        {                                                  \
+            ::cfft::host::set_last_error (#expr, cfft_e_); \
+            return failret;                                \
+        }                                                  \
+    } while (0)
+
+// ---- per-device facts ----------------------------------------------------------------------------
+struct DeviceInfo
+{
+    int ordinal = -1;
+    int num_cus = 0;
+    size_t lds_per_cu = 0;
+};
+// Info for the CURRENT device (cached); returns false if no device is usable.
+bool current_device_info (DeviceInfo& out);
+
+// ---- device tables shared by all plans of one (device, N, transform) --------------------------
+struct DeviceTables
+{
+    float2* stage_twiddles = nullptr; // per-stage Stockham twiddles for the LDS-resident core
+    float2* real_twiddles = nullptr;  // W_N^k, k < N/4+1, for the real <-> half-length complex split
+    float2* big_twiddles = nullptr;   // W_N^{a*b} table for the multi-pass (N > 4096) decomposition
+    int core_n = 0;                   // length handled by the LDS-resident core (N, N/2 for REAL, or N2)
+};
+
+// The plan header.  Lives either in a block we allocated (fft_new_setup) or in caller memory
+// (fft_new_setup_preallocated) -- the counterpart of the reference's FFT_Setup
+// (simd/chowdsp_fft_impl_sse.cpp:56-65), minus the twiddle arrays, which are device-resident here.
+struct Setup
+{
+    uint32_t magic;     // kMagic
+    int N;
+    int transform;      // fft_transform_t
+    int device;         // HIP ordinal the tables live on
+    void* owned_block;  // block to aligned_free in fft_destroy_setup, or nullptr (preallocated)
+    const DeviceTables* tables;
+};
+static constexpr uint32_t kMagic = 0xC4F7A355u;
+
+inline Setup* as_setup (void* p)
+{
+    auto* s = reinterpret_cast<Setup*> (p);
+    return (s != nullptr && s->magic == kMagic) ? s : nullptr;
+}
+
+const DeviceTables* acquire_tables (int device, int N, int transform);
+} // namespace cfft::host

@@ -1,0 +1,76 @@
+// The compile-time radix plans of the LDS-resident core, one per supported frame length, shared by the
+// kernels (template instantiation) and by the host (twiddle-table layout).
+//
+// Counterpart of the reference's run-time factorisation `decompose` / `cffti1_ps`
+// (simd/chowdsp_fft_impl_common.hpp:51-82, 120-160): there N/V is split into radix-4 (+ one radix-2)
+// passes; here N is split into at most four radix <= 16 stages so that a whole frame needs at most
+// three LDS exchanges.
+#pragma once
+#include "stockham.hpp"
+
+namespace cfft
+{
+template <int N>
+struct CorePlan;
+// clang-format off
+template <> struct CorePlan<16>   { using type = Plan<16,   4,   4, 4>;          };
+template <> struct CorePlan<32>   { using type = Plan<32,   4,   8, 4>;          };
+template <> struct CorePlan<64>   { using type = Plan<64,   8,   8, 8>;          };
+template <> struct CorePlan<128>  { using type = Plan<128,  8,  16, 8>;          };
+template <> struct CorePlan<256>  { using type = Plan<256,  16, 16, 16>;         };
+template <> struct CorePlan<512>  { using type = Plan<512,  64,  8, 8, 8>;       };
+template <> struct CorePlan<1024> { using type = Plan<1024, 64, 16, 16, 4>;      };
+template <> struct CorePlan<2048> { using type = Plan<2048, 128, 16, 16, 8>;     };
+template <> struct CorePlan<4096> { using type = Plan<4096, 256, 16, 16, 16>;    };
+// clang-format on
+
+static constexpr int kMaxCoreN = 4096;
+static constexpr int kMinCoreN = 16;
+static constexpr int kBlockThreads = 256;
+
+template <class P>
+struct Geometry
+{
+    static constexpr int FPB = (kBlockThreads / P::T) > 0 ? (kBlockThreads / P::T) : 1; // frames per workgroup
+    static constexpr int threads = P::T * FPB;
+    static constexpr size_t lds_bytes = (size_t) FPB * LdsFrame<P::N>::floats2 * sizeof (float2);
+};
+
+// Run-time mirror of a Plan, for the host-side table builder.
+struct PlanDesc
+{
+    int N = 0, T = 0, ns = 0;
+    int radix[4] = { 1, 1, 1, 1 };
+    int tw_total = 0;
+};
+
+template <class P>
+constexpr PlanDesc describe()
+{
+    PlanDesc d;
+    d.N = P::N;
+    d.T = P::T;
+    d.ns = P::NS;
+    for (int s = 0; s < 4; ++s)
+        d.radix[s] = s < P::NS ? P::radix (s) : 1;
+    d.tw_total = P::tw_total;
+    return d;
+}
+
+inline bool core_plan_desc (int n, PlanDesc& d)
+{
+    switch (n)
+    {
+        case 16: d = describe<CorePlan<16>::type>(); return true;
+        case 32: d = describe<CorePlan<32>::type>(); return true;
+        case 64: d = describe<CorePlan<64>::type>(); return true;
+        case 128: d = describe<CorePlan<128>::type>(); return true;
+        case 256: d = describe<CorePlan<256>::type>(); return true;
+        case 512: d = describe<CorePlan<512>::type>(); return true;
+        case 1024: d = describe<CorePlan<1024>::type>(); return true;
+        case 2048: d = describe<CorePlan<2048>::type>(); return true;
+        case 4096: d = describe<CorePlan<4096>::type>(); return true;
+        default: return false;
+    }
+}
+} // namespace cfft

@@ -1,0 +1,225 @@
+// LDS-resident Stockham (autosort) FFT core for one frame of N <= 4096 complex points.
+//
+// A "team" of T work-items owns one frame; every work-item keeps R = N/T complex points in VGPRs.
+// The transform is  N = r0 * r1 * ... (radices <= 16); stage s with radix r and p = r0*...*r(s-1):
+//
+//     butterfly i in [0, N/r):   k = i mod p,  j = (i - k) * r + k
+//         u[a]  = X[i + a*N/r]                 a = 0..r-1      (stride N/r: lane-contiguous)
+//         u[a] *= W_{p*r}^{a*k}
+//         v     = DFT_r(u)
+//         Y[j + b*p] = v[b]                    b = 0..r-1
+//
+// Stage 0 reads straight from global memory, the last stage writes straight to global memory
+// (both lane-contiguous), the stages in between exchange through a padded LDS image.
+// This is the MI355X counterpart of the reference's pass driver cfftf1_ps
+// (simd/chowdsp_fft_impl_sse.cpp:372-432): same autosort idea, but the ping-pong buffers are LDS,
+// not memory, the V-lane finalize (`pffft_cplx_finalize`, :434-496) and `pffft_zreorder` (:1466-1515)
+// have no counterpart because the index algebra already ends in natural order.
+//
+// Per-stage twiddles W_{p*r}^{a*k} depend only on (work-item, butterfly slot), not on the frame, so a
+// persistent team loads them ONCE into VGPRs and reuses them for every frame it transforms.
+#pragma once
+#include "butterflies.hpp"
+
+namespace cfft
+{
+// ---- compile-time plan -------------------------------------------------------------------------
+template <int N_, int T_, int R0, int R1 = 1, int R2 = 1, int R3 = 1>
+struct Plan
+{
+    static constexpr int N = N_;
+    static constexpr int T = T_;           // work-items per frame
+    static constexpr int R = N_ / T_;      // points per work-item
+    static constexpr int NS = (R1 == 1 ? 1 : (R2 == 1 ? 2 : (R3 == 1 ? 3 : 4)));
+    static constexpr int radix (int s) { return s == 0 ? R0 : (s == 1 ? R1 : (s == 2 ? R2 : R3)); }
+    static constexpr int prod (int s) // product of radices before stage s
+    {
+        int p = 1;
+        for (int i = 0; i < s; ++i)
+            p *= radix (i);
+        return p;
+    }
+    // offset (in float2) of stage s inside the twiddle table: stage s>=1 stores (r-1)*p entries [a-1][k]
+    static constexpr int tw_offset (int s)
+    {
+        int o = 0;
+        for (int i = 1; i < s; ++i)
+            o += (radix (i) - 1) * prod (i);
+        return o;
+    }
+    static constexpr int tw_total = tw_offset (NS);
+    // twiddle registers per work-item
+    static constexpr int tw_regs (int s) { return (radix (s) - 1) * (R / radix (s)); }
+    static_assert (R0 * R1 * R2 * R3 == N_, "radices must multiply to N");
+    static_assert (N_ % T_ == 0, "T must divide N");
+    static_assert (R % R0 == 0 && R % R1 == 0 && R % R2 == 0 && R % R3 == 0, "each radix must divide R");
+};
+
+// LDS padding: one float2 of padding after every 16 (keeps b64 accesses conflict-light for both the
+// stride-r writes of stage 0 and the p-run writes of later stages; see DESIGN.md "LDS image").
+__device__ __forceinline__ constexpr int lds_phys (int idx) { return idx + (idx >> 4); }
+template <int N>
+struct LdsFrame
+{
+    static constexpr int floats2 = N + (N >> 4);
+};
+
+template <int T>
+__device__ __forceinline__ void team_sync()
+{
+    if constexpr (T > 64)
+    {
+        __syncthreads();
+    }
+    else
+    {
+        // the whole team lives in one wavefront: LDS operations of a wave execute in order, only the
+        // compiler has to be kept from moving them across this point.
+        __builtin_amdgcn_fence (__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// ---- twiddle registers -------------------------------------------------------------------------
+template <class P>
+struct TwiddleRegs
+{
+    // worst case: NS-1 twiddled stages, each needs < R registers
+    float2 w[(P::NS > 1 ? P::NS - 1 : 1)][P::R];
+};
+
+template <class P, int S>
+__device__ __forceinline__ void load_twiddles_stage (TwiddleRegs<P>& tw, const float2* __restrict__ table, int t)
+{
+    constexpr int r = P::radix (S);
+    constexpr int p = P::prod (S);
+    constexpr int Q = P::R / r;
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+    {
+        const int i = t + P::T * q;
+        const int k = i & (p - 1);
+#pragma unroll
+        for (int a = 1; a < r; ++a)
+            tw.w[S - 1][q * (r - 1) + (a - 1)] = table[P::tw_offset (S) + (a - 1) * p + k];
+    }
+}
+
+template <class P>
+__device__ __forceinline__ void load_twiddles (TwiddleRegs<P>& tw, const float2* __restrict__ table, int t)
+{
+    if constexpr (P::NS > 1) load_twiddles_stage<P, 1> (tw, table, t);
+    if constexpr (P::NS > 2) load_twiddles_stage<P, 2> (tw, table, t);
+    if constexpr (P::NS > 3) load_twiddles_stage<P, 3> (tw, table, t);
+}
+
+// ---- one stage ---------------------------------------------------------------------------------
+// compute part: twiddle (S>0) + DFT_r on every butterfly slot of this work-item
+template <class P, int S>
+__device__ __forceinline__ void stage_compute (float2 (&v)[P::R], const TwiddleRegs<P>& tw)
+{
+    constexpr int r = P::radix (S);
+    constexpr int Q = P::R / r;
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+    {
+        float2 u[r];
+#pragma unroll
+        for (int a = 0; a < r; ++a)
+            u[a] = v[q * r + a];
+        if constexpr (S > 0)
+        {
+#pragma unroll
+            for (int a = 1; a < r; ++a)
+                u[a] = cmul (u[a], tw.w[S - 1][q * (r - 1) + (a - 1)]);
+        }
+        fft_reg<r> (u);
+#pragma unroll
+        for (int a = 0; a < r; ++a)
+            v[q * r + a] = u[a];
+    }
+}
+
+// scatter the outputs of stage S into the LDS image (Y[j + b*p])
+template <class P, int S>
+__device__ __forceinline__ void stage_write_lds (const float2 (&v)[P::R], float2* __restrict__ lds, int t)
+{
+    constexpr int r = P::radix (S);
+    constexpr int p = P::prod (S);
+    constexpr int Q = P::R / r;
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+    {
+        const int i = t + P::T * q;
+        const int k = i & (p - 1);
+        const int j = (i - k) * r + k;
+#pragma unroll
+        for (int b = 0; b < r; ++b)
+            lds[lds_phys (j + b * p)] = v[q * r + b];
+    }
+}
+
+// gather the inputs of stage S from the LDS image (X[i + a*N/r])
+template <class P, int S>
+__device__ __forceinline__ void stage_read_lds (float2 (&v)[P::R], const float2* __restrict__ lds, int t)
+{
+    constexpr int r = P::radix (S);
+    constexpr int Q = P::R / r;
+    constexpr int m = P::N / r;
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+    {
+        const int i = t + P::T * q;
+#pragma unroll
+        for (int a = 0; a < r; ++a)
+            v[q * r + a] = lds[lds_phys (i + a * m)];
+    }
+}
+
+// Index (within the frame) of register slot `slot` of work-item t BEFORE stage 0 (input side).
+template <class P>
+__device__ __forceinline__ constexpr int input_index (int t, int slot)
+{
+    constexpr int r = P::radix (0);
+    return (t + P::T * (slot / r)) + (slot % r) * (P::N / r);
+}
+// Index (within the frame) of register slot `slot` of work-item t AFTER the last stage (output side).
+template <class P>
+__device__ __forceinline__ constexpr int output_index (int t, int slot)
+{
+    constexpr int r = P::radix (P::NS - 1);
+    return (t + P::T * (slot / r)) + (slot % r) * (P::N / r);
+}
+
+// Stages 0..NS-1 on registers v (already loaded in input_index order); leaves the result in
+// output_index order.  `lds` is this team's private LDS image.
+template <class P>
+__device__ __forceinline__ void fft_core (float2 (&v)[P::R], const TwiddleRegs<P>& tw, float2* __restrict__ lds, int t)
+{
+    stage_compute<P, 0> (v, tw);
+    if constexpr (P::NS > 1)
+    {
+        stage_write_lds<P, 0> (v, lds, t);
+        team_sync<P::T>();
+        stage_read_lds<P, 1> (v, lds, t);
+        stage_compute<P, 1> (v, tw);
+    }
+    if constexpr (P::NS > 2)
+    {
+        team_sync<P::T>();
+        stage_write_lds<P, 1> (v, lds, t);
+        team_sync<P::T>();
+        stage_read_lds<P, 2> (v, lds, t);
+        stage_compute<P, 2> (v, tw);
+    }
+    if constexpr (P::NS > 3)
+    {
+        team_sync<P::T>();
+        stage_write_lds<P, 2> (v, lds, t);
+        team_sync<P::T>();
+        stage_read_lds<P, 3> (v, lds, t);
+        stage_compute<P, 3> (v, tw);
+    }
+}
+} // namespace cfft

@@ -1,0 +1,102 @@
+// Twiddle-table construction (host, double precision, rounded once to fp32).
+#include "tables.hpp"
+#include "plans.hpp"
+
+#include <cmath>
+
+namespace cfft::host
+{
+namespace
+{
+constexpr int kMaxLog2 = 20;
+
+bool is_pow2 (int n) { return n > 0 && (n & (n - 1)) == 0; }
+
+float2 unit_root (long long num, long long den) // exp(-2*pi*i*num/den)
+{
+    const long long r = ((num % den) + den) % den;
+    const double a = -2.0 * M_PI * (double) r / (double) den;
+    return make_float2 ((float) std::cos (a), (float) std::sin (a));
+}
+
+void append_stage_twiddles (const PlanDesc& d, std::vector<float2>& out)
+{
+    // stage s >= 1 : (r-1) * p entries, [a-1][k] = W_{p*r}^{a*k}
+    int p = d.radix[0];
+    for (int s = 1; s < d.ns; ++s)
+    {
+        const int r = d.radix[s];
+        for (int a = 1; a < r; ++a)
+            for (int k = 0; k < p; ++k)
+                out.push_back (unit_root ((long long) a * k, (long long) p * r));
+        p *= r;
+    }
+}
+} // namespace
+
+void split_large (int n_complex, int& n1, int& n2)
+{
+    n1 = n2 = 0;
+    if (n_complex <= kMaxCoreN)
+        return;
+    int lg = 0;
+    while ((1 << lg) < n_complex)
+        ++lg;
+    const int l2 = lg / 2; // pass A (column) length 2^l2, pass B (row) length 2^(lg-l2)
+    n2 = 1 << l2;
+    n1 = 1 << (lg - l2);
+}
+
+bool size_supported (int N, int transform)
+{
+    if (! is_pow2 (N) || N > (1 << kMaxLog2))
+        return false;
+    // the reference needs N % 16 == 0 (complex) / N % 32 == 0 (real) on its SSE path
+    // (simd/chowdsp_fft_impl_common.hpp:168-177); same lower bounds here.
+    if (transform == 0 /* FFT_REAL */)
+        return N >= 32;
+    return N >= 16;
+}
+
+bool build_host_tables (int N, int transform, HostTables& out)
+{
+    if (! size_supported (N, transform))
+        return false;
+    const bool real = (transform == 0);
+    const int nc = real ? N / 2 : N; // complex length actually transformed
+
+    if (real)
+    {
+        // W_N^k for k = 0 .. N/4 (the pair stage touches k and N/2-k together)
+        out.real_twiddles.reserve ((size_t) N / 4 + 1);
+        for (int k = 0; k <= N / 4; ++k)
+            out.real_twiddles.push_back (unit_root (k, N));
+    }
+
+    PlanDesc d;
+    if (nc <= kMaxCoreN)
+    {
+        out.core_n = nc;
+        if (! core_plan_desc (nc, d))
+            return false;
+        append_stage_twiddles (d, out.stage_twiddles);
+        return true;
+    }
+
+    // multi-pass: nc = n1 * n2.  stage tables of the two cores are stored back to back
+    // (n2 core first), the inter-pass twiddle W_nc^{a*k2}, a < n1, k2 < n2, laid out [k2][a].
+    int n1 = 0, n2 = 0;
+    split_large (nc, n1, n2);
+    out.core_n = 0;
+    PlanDesc d2, d1;
+    if (! core_plan_desc (n2, d2) || ! core_plan_desc (n1, d1))
+        return false;
+    append_stage_twiddles (d2, out.stage_twiddles);
+    append_stage_twiddles (d1, out.stage_twiddles);
+    out.big_twiddles.reserve ((size_t) nc);
+    for (int k2 = 0; k2 < n2; ++k2)
+        for (int a = 0; a < n1; ++a)
+            out.big_twiddles.push_back (unit_root ((long long) a * k2, nc));
+    return true;
+}
+} // namespace cfft::host

@@ -1,0 +1,29 @@
+// Host-side construction of the twiddle tables a plan needs on the device.
+//
+// Counterpart of the table section of the reference's common::fft_new_setup
+// (simd/chowdsp_fft_impl_common.hpp:195-214).  The reference forms its angles in float before calling
+// cosf/sinf (:90-113, :126-151, :201-203); here every angle is formed and evaluated in double and rounded
+// to float once, which is at least as accurate and keeps the result within the 1e-6 parity bound.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+namespace cfft::host
+{
+struct HostTables
+{
+    int core_n = 0;                     // length of the LDS-resident complex core
+    std::vector<float2> stage_twiddles; // Stockham per-stage tables, layout of Plan::tw_offset
+    std::vector<float2> real_twiddles;  // W_N^k, k = 0..N/4   (REAL plans)
+    std::vector<float2> big_twiddles;   // multi-pass plans, see multipass.hpp
+};
+
+// Validates (N, transform) and fills the tables.  false = unsupported size.
+bool build_host_tables (int N, int transform, HostTables& out);
+
+// Size policy shared with the C API.
+bool size_supported (int N, int transform);
+// For multi-pass sizes: N = n1 * n2 with both factors LDS-resident; (0,0) if N is LDS-resident itself.
+void split_large (int n_complex, int& n1, int& n2);
+} // namespace cfft::host

@@ -1,0 +1,94 @@
+/*
+  chowdsp_fft_gpu.h -- batched, device-pointer extension of the chowdsp_fft C interface for MI355X.
+
+  The reference API transforms exactly one frame per call and has no batch argument: every caller
+  loops over frames itself (reference test/test.cpp:47-62, bench/bench.cpp:36-45).  On a GPU the unit
+  of work is a large batch of independent frames, so this header adds, next to the eleven legacy
+  symbols of chowdsp_fft.h, batch variants of the same five operations plus a fused
+  forward -> multiply-accumulate -> backward convolution kernel.  Each entry point names the legacy
+  function (and reference file:line) whose per-frame semantics it repeats `batch` times.
+
+  Conventions
+    * `setup` is a handle from fft_new_setup / fft_new_setup_preallocated (chowdsp_fft.h).
+    * all data pointers are DEVICE pointers (hipMalloc, fft_gpu_malloc, torch tensors ...);
+      frames are contiguous: frame b starts at element b * frame_floats, where frame_floats is
+      2*N (COMPLEX) or N (REAL).  in and out may alias.
+    * `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are asynchronous
+      with respect to the host; nothing in here synchronises unless its name says so.
+    * return value: 0 on success, a negative FFT_GPU_E* code otherwise.  Nothing throws, nothing aborts.
+*/
+#pragma once
+
+#include "chowdsp_fft.h"
+
+#ifdef __cplusplus
+#include <cstddef>
+extern "C"
+{
+namespace chowdsp::fft
+{
+#else
+#include <stddef.h>
+#endif
+
+enum
+{
+    FFT_GPU_OK = 0,
+    FFT_GPU_EINVAL = -1,   /* NULL / malformed argument */
+    FFT_GPU_ENODEV = -2,   /* no usable HIP device */
+    FFT_GPU_ELAUNCH = -3,  /* kernel launch or runtime call failed */
+    FFT_GPU_ENOMEM = -4,   /* device allocation failed */
+    FFT_GPU_ENOTSUP = -5   /* operation not available for this plan */
+};
+
+/* ---- device / memory helpers (thin wrappers so that C callers need no HIP headers) ------------ */
+int fft_gpu_device_count (void);
+int fft_gpu_set_device (int ordinal);
+void* fft_gpu_malloc (size_t nb_bytes);           /* device memory; NULL on failure */
+void fft_gpu_free (void* p);
+void* fft_gpu_host_malloc (size_t nb_bytes);      /* pinned host memory (counterpart of aligned_malloc) */
+void fft_gpu_host_free (void* p);
+/* kind: 0 = host->device, 1 = device->host, 2 = device->device; asynchronous on `stream` */
+int fft_gpu_memcpy (void* dst, const void* src, size_t nb_bytes, int kind, void* stream);
+int fft_gpu_stream_synchronize (void* stream);
+/* Last HIP error string seen by this thread inside the library ("" if none). */
+const char* fft_gpu_last_error (void);
+
+/* ---- plan introspection -------------------------------------------------------------------------- */
+int fft_gpu_setup_size (void* setup);              /* N, or negative error */
+int fft_gpu_setup_is_real (void* setup);           /* 1 REAL, 0 COMPLEX */
+/* scratch the plan needs per launch for N > 4096 (multi-pass through HBM), bytes for `batch` frames;
+   0 for LDS-resident sizes.  The library allocates and caches it internally per (device, stream). */
+size_t fft_gpu_workspace_bytes (void* setup, size_t batch);
+
+/* ---- batched operations -------------------------------------------------------------------------- */
+
+/* `batch` x fft_transform (chowdsp_fft.h; reference chowdsp_fft.h:138,
+   simd/chowdsp_fft_impl_sse.cpp:1518-1601 with ordered = 1). */
+int fft_transform_batch (void* setup, const float* input, float* output, size_t batch, fft_direction_t direction, void* stream);
+
+/* `batch` x fft_transform_unordered (reference chowdsp_fft.h:145; ordered = 0). */
+int fft_transform_unordered_batch (void* setup, const float* input, float* output, size_t batch, fft_direction_t direction, void* stream);
+
+/* `batch` x fft_convolve_unordered: ab[f] += (a[f] * b[f or 0]) * scaling
+   (reference chowdsp_fft.h:154, simd/chowdsp_fft_impl_sse.cpp:1603-1645).
+   b_is_shared != 0: `dft_b` is ONE frame (e.g. a filter spectrum) used for every frame of the batch. */
+int fft_convolve_unordered_batch (void* setup, const float* dft_a, const float* dft_b, float* dft_ab, float scaling, size_t batch, int b_is_shared, void* stream);
+
+/* ab[i] = a[i] + b[i] for i < count floats (reference chowdsp_fft.h:160,
+   simd/chowdsp_fft_impl_sse.cpp:1647-1660); count = batch * N for a batch of frames. */
+int fft_accumulate_batch (void* setup, const float* a, const float* b, float* ab, size_t count, void* stream);
+
+/* Fused frequency-domain convolution of a batch of time-domain frames with one filter:
+       y[f] = BACKWARD( FORWARD(x[f]) * H ) * scaling                       (H = dft_filter, one frame,
+   i.e. the reference call sequence of test/test.cpp:161-166 / :212-215       unordered layout)
+       fft_transform_unordered(x, FORWARD) -> fft_convolve_unordered(X, H, 0-initialised, scaling)
+       -> fft_transform_unordered(BACKWARD)
+   in ONE kernel: the spectrum never leaves the CU, HBM traffic is one read + one write per frame.
+   Available for LDS-resident sizes (N <= 4096 complex, N <= 8192 real); FFT_GPU_ENOTSUP otherwise. */
+int fft_convolve_frames_batch (void* setup, const float* x, const float* dft_filter, float* y, float scaling, size_t batch, void* stream);
+
+#ifdef __cplusplus
+} // namespace chowdsp::fft
+} // extern "C"
+#endif

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Compile a .hip file for gfx950 and print one line per kernel: VGPRs, SGPRs, scratch, occupancy, LDS.
+
+usage: tools/kres.py file.hip [extra hipcc flags...]
+"""
+import re, subprocess, sys
+src = sys.argv[1]
+cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", "/tmp/kres.o",
+       "-Rpass-analysis=kernel-resource-usage"] + sys.argv[2:]
+p = subprocess.run(cmd, capture_output=True, text=True)
+txt = p.stderr
+if p.returncode != 0:
+    print(txt); sys.exit(1)
+cur = None
+rows = []
+for line in txt.splitlines():
+    m = re.search(r"Function Name: (\S+)", line)
+    if m:
+        name = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
+        cur = {"name": name}; rows.append(cur); continue
+    for key in ("VGPRs", "AGPRs", "TotalSGPRs", "ScratchSize [bytes/lane]", "Occupancy [waves/SIMD]", "LDS Size [bytes/block]"):
+        m = re.search(re.escape(key) + r": (\d+)", line)
+        if m and cur is not None and " " + key in " " + line:
+            cur[key.split(" ")[0]] = int(m.group(1))
+for r in rows:
+    n = re.sub(r"HIP_vector_type<float, 2u>", "float2", r["name"])
+    n = re.sub(r"\(.*", "", n)
+    print(f"vgpr={r.get('VGPRs'):4d} sgpr={r.get('TotalSGPRs'):3d} scratch={r.get('ScratchSize'):4d} occ={r.get('Occupancy')} {n}")
