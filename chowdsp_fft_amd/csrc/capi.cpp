@@ -12,7 +12,10 @@
 #include "tables.hpp"
 
 #include <cstdlib>
+#include <map>
+#include <mutex>
 #include <new>
+#include <utility>
 
 using namespace cfft::host;
 namespace cf = chowdsp::fft;
@@ -65,21 +68,121 @@ struct Staging
 };
 thread_local Staging g_staging;
 
+// grow-only scratch for the two-pass sizes, one per (device, stream); bounded by kWorkspaceCap so that the
+// intermediate of one chunk of frames stays inside the 256 MiB Infinity Cache between pass A and pass B.
+constexpr size_t kWorkspaceCap = 128ull << 20;
+struct Workspace
+{
+    float2* ptr = nullptr;
+    size_t bytes = 0;
+};
+std::mutex g_ws_mutex;
+std::map<std::pair<int, hipStream_t>, Workspace> g_workspaces;
+
+float2* get_workspace (int device, hipStream_t stream, size_t bytes)
+{
+    std::lock_guard<std::mutex> lock (g_ws_mutex);
+    Workspace& w = g_workspaces[std::make_pair (device, stream)];
+    if (w.bytes >= bytes)
+        return w.ptr;
+    if (w.ptr != nullptr)
+    {
+        (void) hipStreamSynchronize (stream);
+        (void) hipFree (w.ptr);
+        w.ptr = nullptr;
+        w.bytes = 0;
+    }
+    if (hipMalloc ((void**) &w.ptr, bytes) != hipSuccess)
+    {
+        w.ptr = nullptr;
+        set_last_error ("workspace allocation failed");
+        return nullptr;
+    }
+    w.bytes = bytes;
+    return w.ptr;
+}
+
+// complex length the plan's core transforms
+int complex_len (const Setup* s) { return s->transform == cf::FFT_COMPLEX ? s->N : s->N / 2; }
+
+int big_c2c_chunked (Setup* s, int nc, bool inverse, const float2* in, float2* out, size_t batch, hipStream_t stream)
+{
+    int n1 = 0, n2 = 0;
+    split_large (nc, n1, n2);
+    const size_t frame_bytes = (size_t) nc * sizeof (float2);
+    size_t chunk = kWorkspaceCap / frame_bytes;
+    if (chunk < 1)
+        chunk = 1;
+    if (chunk > batch)
+        chunk = batch;
+    float2* work = get_workspace (s->device, stream, chunk * frame_bytes);
+    if (work == nullptr)
+        return cf::FFT_GPU_ENOMEM;
+    for (size_t f0 = 0; f0 < batch; f0 += chunk)
+    {
+        const size_t nb = (batch - f0 < chunk) ? batch - f0 : chunk;
+        const hipError_t e = launch_big_c2c (n1, n2, inverse, in + f0 * nc, work, out + f0 * nc, s->tables->stage_twiddles,
+                                             s->tables->big_twiddles, nb, stream);
+        if (e != hipSuccess)
+        {
+            set_last_error ("two-pass kernel launch", e);
+            return cf::FFT_GPU_ELAUNCH;
+        }
+    }
+    return cf::FFT_GPU_OK;
+}
+
 int run_transform (Setup* s, const float* in, float* out, size_t batch, cf::fft_direction_t dir, hipStream_t stream)
 {
+    if (batch == 0)
+        return cf::FFT_GPU_OK;
     const bool inverse = (dir == cf::FFT_BACKWARD);
     const DeviceTables* t = s->tables;
-    hipError_t e = hipErrorInvalidValue;
-    if (s->transform == cf::FFT_COMPLEX && t->core_n == s->N)
-        e = launch_c2c (s->N, inverse, (const float2*) in, (float2*) out, t->stage_twiddles, batch, stream);
+    const int nc = complex_len (s);
+    const bool lds_resident = (t->core_n == nc);
+    const float2* cin = (const float2*) in;
+    float2* cout = (float2*) out;
+    hipError_t e = hipSuccess;
+    if (s->transform == cf::FFT_COMPLEX)
+    {
+        if (! lds_resident)
+            return big_c2c_chunked (s, nc, inverse, cin, cout, batch, stream);
+        e = launch_c2c (nc, inverse, cin, cout, t->stage_twiddles, batch, stream);
+    }
+    else if (lds_resident)
+    {
+        e = inverse ? launch_c2r (nc, cin, cout, t->stage_twiddles, t->real_twiddles, batch, stream)
+                    : launch_r2c (nc, cin, cout, t->stage_twiddles, t->real_twiddles, batch, stream);
+    }
+    else if (! inverse)
+    {
+        // long real frames: complex two-pass transform of z[n] = x[2n] + i x[2n+1], then the pair stage in place
+        const int rc = big_c2c_chunked (s, nc, false, cin, cout, batch, stream);
+        if (rc != cf::FFT_GPU_OK)
+            return rc;
+        e = launch_real_pair (true, cout, cout, t->real_twiddles, (unsigned) nc, batch, stream);
+    }
     else
     {
-        set_last_error ("transform kind/size not available in this build");
-        return cf::FFT_GPU_ENOTSUP;
+        e = launch_real_pair (false, cin, cout, t->real_twiddles, (unsigned) nc, batch, stream);
+        if (e == hipSuccess)
+            return big_c2c_chunked (s, nc, true, cout, cout, batch, stream);
     }
     if (e != hipSuccess)
     {
         set_last_error ("kernel launch", e);
+        return cf::FFT_GPU_ELAUNCH;
+    }
+    return cf::FFT_GPU_OK;
+}
+
+int run_convolve (Setup* s, const float* a, const float* b, float* ab, float scaling, size_t batch, bool b_is_shared, hipStream_t stream)
+{
+    const bool real = (s->transform == cf::FFT_REAL);
+    const hipError_t e = launch_conv_mac (real, a, b, ab, scaling, (size_t) complex_len (s), batch, b_is_shared, stream);
+    if (e != hipSuccess)
+    {
+        set_last_error ("convolve kernel launch", e);
         return cf::FFT_GPU_ELAUNCH;
     }
     return cf::FFT_GPU_OK;
@@ -121,8 +224,53 @@ void legacy_transform (void* setup, const float* input, float* output, cf::fft_d
         (void) hipMemcpyAsync (output, dout, nf * sizeof (float), hipMemcpyDeviceToHost, nullptr);
     (void) hipStreamSynchronize (nullptr);
 }
+
+// legacy three-operand entry (convolve / accumulate): stage whichever operands live in host memory.
+// ab_is_input: the destination is also read (ab += ...), so its old contents must be staged too.
+template <class Op>
+void legacy_elementwise (Setup* s, const float* a, const float* b, float* ab, size_t nf, Op&& op, bool ab_is_input)
+{
+    const bool a_dev = is_device_pointer (a), b_dev = is_device_pointer (b), ab_dev = is_device_pointer (ab);
+    float* stage = nullptr;
+    if (! (a_dev && b_dev && ab_dev))
+    {
+        stage = g_staging.get (3 * nf, s->device);
+        if (stage == nullptr)
+        {
+            set_last_error ("staging allocation failed");
+            return;
+        }
+    }
+    const float *da = a, *db = b;
+    float* dab = ab;
+    // the reference allows a, b and ab to alias: stage ab first and reuse it for aliased sources
+    if (! ab_dev)
+    {
+        dab = stage + 2 * nf;
+        if (ab_is_input && hipMemcpyAsync (dab, ab, nf * sizeof (float), hipMemcpyHostToDevice, nullptr) != hipSuccess)
+            return;
+    }
+    if (! a_dev)
+    {
+        if (hipMemcpyAsync (stage, a, nf * sizeof (float), hipMemcpyHostToDevice, nullptr) != hipSuccess)
+            return;
+        da = stage;
+    }
+    if (! b_dev)
+    {
+        if (hipMemcpyAsync (stage + nf, b, nf * sizeof (float), hipMemcpyHostToDevice, nullptr) != hipSuccess)
+            return;
+        db = stage + nf;
+    }
+    if (op (da, db, dab) != cf::FFT_GPU_OK)
+        return;
+    if (! ab_dev)
+        (void) hipMemcpyAsync (ab, dab, nf * sizeof (float), hipMemcpyDeviceToHost, nullptr);
+    (void) hipStreamSynchronize (nullptr);
+}
 } // namespace
 
+#pragma GCC visibility push(default)
 extern "C"
 {
 namespace chowdsp::fft
@@ -219,14 +367,28 @@ void fft_transform_unordered (void* setup, const float* input, float* output, fl
     legacy_transform (setup, input, output, direction);
 }
 
-void fft_convolve_unordered (void*, const float*, const float*, float*, float)
+void fft_convolve_unordered (void* setup, const float* a, const float* b, float* ab, float scaling)
 {
-    set_last_error ("fft_convolve_unordered: not available in this build");
+    Setup* s = as_setup (setup);
+    if (s == nullptr || a == nullptr || b == nullptr || ab == nullptr)
+        return;
+    const size_t nf = frame_floats (s);
+    legacy_elementwise (s, a, b, ab, nf, [&] (const float* da, const float* db, float* dab) {
+        return run_convolve (s, da, db, dab, scaling, 1, false, nullptr);
+    }, true);
 }
 
-void fft_accumulate (void*, const float*, const float*, float*, int)
+void fft_accumulate (void* setup, const float* a, const float* b, float* ab, int N)
 {
-    set_last_error ("fft_accumulate: not available in this build");
+    Setup* s = as_setup (setup);
+    if (s == nullptr || a == nullptr || b == nullptr || ab == nullptr || N <= 0)
+        return;
+    legacy_elementwise (s, a, b, ab, (size_t) N, [&] (const float* da, const float* db, float* dab) {
+        const hipError_t e = launch_accumulate (da, db, dab, (size_t) N, nullptr);
+        if (e != hipSuccess)
+            set_last_error ("accumulate kernel launch", e);
+        return e == hipSuccess ? FFT_GPU_OK : FFT_GPU_ELAUNCH;
+    }, false);
 }
 
 // ---- extension: device / memory helpers ----------------------------------------------------------
@@ -300,7 +462,19 @@ int fft_gpu_setup_is_real (void* setup)
     return s != nullptr ? (s->transform == FFT_REAL ? 1 : 0) : FFT_GPU_EINVAL;
 }
 
-size_t fft_gpu_workspace_bytes (void*, size_t) { return 0; }
+size_t fft_gpu_workspace_bytes (void* setup, size_t batch)
+{
+    Setup* s = as_setup (setup);
+    if (s == nullptr || s->tables->core_n == complex_len (s))
+        return 0;
+    const size_t frame_bytes = (size_t) complex_len (s) * sizeof (float2);
+    size_t chunk = kWorkspaceCap / frame_bytes;
+    if (chunk < 1)
+        chunk = 1;
+    if (chunk > batch)
+        chunk = batch;
+    return chunk * frame_bytes;
+}
 
 // ---- extension: batched operations ---------------------------------------------------------------
 int fft_transform_batch (void* setup, const float* input, float* output, size_t batch, fft_direction_t direction, void* stream)
@@ -316,13 +490,49 @@ int fft_transform_unordered_batch (void* setup, const float* input, float* outpu
     return fft_transform_batch (setup, input, output, batch, direction, stream);
 }
 
-int fft_convolve_unordered_batch (void*, const float*, const float*, float*, float, size_t, int, void*)
+int fft_convolve_unordered_batch (void* setup, const float* dft_a, const float* dft_b, float* dft_ab, float scaling, size_t batch, int b_is_shared, void* stream)
 {
-    return FFT_GPU_ENOTSUP;
+    Setup* s = as_setup (setup);
+    if (s == nullptr || dft_a == nullptr || dft_b == nullptr || dft_ab == nullptr)
+        return FFT_GPU_EINVAL;
+    return run_convolve (s, dft_a, dft_b, dft_ab, scaling, batch, b_is_shared != 0, (hipStream_t) stream);
 }
 
-int fft_accumulate_batch (void*, const float*, const float*, float*, size_t, void*) { return FFT_GPU_ENOTSUP; }
+int fft_accumulate_batch (void* setup, const float* a, const float* b, float* ab, size_t count, void* stream)
+{
+    if (as_setup (setup) == nullptr || a == nullptr || b == nullptr || ab == nullptr)
+        return FFT_GPU_EINVAL;
+    const hipError_t e = launch_accumulate (a, b, ab, count, (hipStream_t) stream);
+    if (e != hipSuccess)
+    {
+        set_last_error ("accumulate kernel launch", e);
+        return FFT_GPU_ELAUNCH;
+    }
+    return FFT_GPU_OK;
+}
 
-int fft_convolve_frames_batch (void*, const float*, const float*, float*, float, size_t, void*) { return FFT_GPU_ENOTSUP; }
+int fft_convolve_frames_batch (void* setup, const float* x, const float* dft_filter, float* y, float scaling, size_t batch, void* stream)
+{
+    Setup* s = as_setup (setup);
+    if (s == nullptr || x == nullptr || dft_filter == nullptr || y == nullptr)
+        return FFT_GPU_EINVAL;
+    const DeviceTables* t = s->tables;
+    const int nc = complex_len (s);
+    if (t->core_n != nc)
+    {
+        set_last_error ("fft_convolve_frames_batch: frame too long for the fused kernel");
+        return FFT_GPU_ENOTSUP;
+    }
+    const hipError_t e = (s->transform == FFT_COMPLEX)
+                             ? launch_conv_frames_c2c (nc, (const float2*) x, (const float2*) dft_filter, (float2*) y, t->stage_twiddles, scaling, batch, (hipStream_t) stream)
+                             : launch_conv_frames_real (nc, (const float2*) x, (const float2*) dft_filter, (float2*) y, t->stage_twiddles, t->real_twiddles, scaling, batch, (hipStream_t) stream);
+    if (e != hipSuccess)
+    {
+        set_last_error ("fused convolution kernel launch", e);
+        return FFT_GPU_ELAUNCH;
+    }
+    return FFT_GPU_OK;
+}
 } // namespace chowdsp::fft
 } // extern "C"
+#pragma GCC visibility pop

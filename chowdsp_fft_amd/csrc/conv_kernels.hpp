@@ -1,0 +1,214 @@
+// Frequency-domain multiply-accumulate, plain accumulate, and the fused convolution kernel.
+//
+// conv_mac_kernel   <-> pffft_convolve_internal   (simd/chowdsp_fft_impl_sse.cpp:1603-1645)
+// accumulate_kernel <-> fft_accumulate_internal   (simd/chowdsp_fft_impl_sse.cpp:1647-1660)
+// The reference multiplies in its SIMD-lane ("unordered") layout; this backend's unordered layout is
+// the canonical one, so the same arithmetic runs on interleaved (re, im) pairs.  Rounding order of the
+// reference SSE path is kept: ab + ((ar*br - ai*bi) * scaling)  (no FMA contraction of the product sum
+// is required for parity; the compiler may fuse, the difference is below 1 ulp of the result).
+#pragma once
+#include "real_kernels.hpp"
+
+namespace cfft
+{
+// ab[f][k] += a[f][k] * b[f or 0][k] * scaling ; frame = `cplx_per_frame` float2 values.
+// REAL: element 0 of every frame packs two purely real bins (DC, Nyquist) and is multiplied per
+// component (reference :1614-1619, :1640-1644).
+template <bool REAL>
+__global__ __launch_bounds__ (256) void conv_mac_kernel (const float4* __restrict__ a,
+                                                        const float4* __restrict__ b,
+                                                        float4* __restrict__ ab,
+                                                        float scaling,
+                                                        unsigned pairs_per_frame, // float4 = 2 complex per element
+                                                        size_t total_pairs,
+                                                        int b_is_shared)
+{
+    const size_t stride = (size_t) gridDim.x * blockDim.x;
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < total_pairs; i += stride)
+    {
+        const unsigned in_frame = (unsigned) (i % pairs_per_frame);
+        const float4 va = a[i];
+        const float4 vb = b[b_is_shared ? (size_t) in_frame : i];
+        float4 acc = ab[i];
+        float r0 = va.x * vb.x - va.y * vb.y;
+        float i0 = va.x * vb.y + va.y * vb.x;
+        const float r1 = va.z * vb.z - va.w * vb.w;
+        const float i1 = va.z * vb.w + va.w * vb.z;
+        if (REAL && in_frame == 0)
+        {
+            r0 = va.x * vb.x;
+            i0 = va.y * vb.y;
+        }
+        acc.x += r0 * scaling;
+        acc.y += i0 * scaling;
+        acc.z += r1 * scaling;
+        acc.w += i1 * scaling;
+        ab[i] = acc;
+    }
+}
+
+__global__ __launch_bounds__ (256) void accumulate_kernel (const float* __restrict__ a,
+                                                          const float* __restrict__ b,
+                                                          float* __restrict__ ab,
+                                                          size_t count)
+{
+    const size_t stride = (size_t) gridDim.x * blockDim.x;
+    const size_t n4 = count / 4;
+    const float4* a4 = (const float4*) a;
+    const float4* b4 = (const float4*) b;
+    float4* o4 = (float4*) ab;
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
+    {
+        const float4 x = a4[i], y = b4[i];
+        o4[i] = make_float4 (x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+    }
+    // tail (count not a multiple of 4)
+    for (size_t i = n4 * 4 + (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride)
+        ab[i] = a[i] + b[i];
+}
+
+// ---- fused: y = BACKWARD( FORWARD(x) * H ) * scaling, one kernel, spectrum never leaves the CU -----
+// COMPLEX plan: P is the N point plan, H has N complex bins in canonical order.
+template <class P, int FPB>
+__global__ __launch_bounds__ (P::T* FPB) void conv_frames_c2c_kernel (const float2* __restrict__ in,
+                                                                     const float2* __restrict__ H,
+                                                                     float2* __restrict__ out,
+                                                                     const float2* __restrict__ twtab,
+                                                                     float scaling,
+                                                                     unsigned batch)
+{
+    extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
+    const int tid = threadIdx.x;
+    const int team = tid / P::T;
+    const int t = tid % P::T;
+    float2* lds = smem + team * LdsFrame<P::N>::floats2;
+
+    TwiddleRegs<P> tw;
+    load_twiddles<P> (tw, twtab, t);
+
+    const unsigned ngroups = (batch + FPB - 1) / FPB;
+    const unsigned team_base = (unsigned) team * P::N;
+    for (unsigned g = blockIdx.x; g < ngroups; g += gridDim.x)
+    {
+        const bool active = g * FPB + team < batch;
+        const float2* __restrict__ src = in + (size_t) g * (FPB * P::N);
+        float2* __restrict__ dst = out + (size_t) g * (FPB * P::N);
+        float2 v[P::R];
+#pragma unroll
+        for (int s = 0; s < P::R; ++s)
+            v[s] = active ? src[team_base + (unsigned) input_index<P> (t, s)] : make_float2 (0.f, 0.f);
+        team_sync<P::T>();
+        fft_core<P> (v, tw, lds, t);
+        // multiply by the filter spectrum (L2-resident, shared by every frame), scale, swap for the inverse
+#pragma unroll
+        for (int s = 0; s < P::R; ++s)
+        {
+            const float2 h = H[output_index<P> (t, s)];
+            const float2 y = cmul (v[s], h);
+            v[s] = make_float2 (y.y * scaling, y.x * scaling);
+        }
+        if constexpr (P::NS > 1)
+            team_sync<P::T>();
+        lds_store_output_order<P> (v, lds, t);
+        team_sync<P::T>();
+        lds_load_input_order<P> (v, lds, t);
+        team_sync<P::T>();
+        fft_core<P> (v, tw, lds, t);
+        if (active)
+        {
+#pragma unroll
+            for (int s = 0; s < P::R; ++s)
+                dst[team_base + (unsigned) output_index<P> (t, s)] = make_float2 (v[s].y, v[s].x);
+        }
+    }
+}
+
+// REAL plan: P is the M = N/2 point plan, H is a packed real spectrum (M float2, element 0 = DC/Nyquist).
+template <class P, int FPB>
+__global__ __launch_bounds__ (P::T* FPB) void conv_frames_real_kernel (const float2* __restrict__ in,
+                                                                      const float2* __restrict__ H,
+                                                                      float2* __restrict__ out,
+                                                                      const float2* __restrict__ twtab,
+                                                                      const float2* __restrict__ wtab,
+                                                                      float scaling,
+                                                                      unsigned batch)
+{
+    extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
+    constexpr int M = P::N;
+    const int tid = threadIdx.x;
+    const int team = tid / P::T;
+    const int t = tid % P::T;
+    float2* lds = smem + team * LdsFrame<M>::floats2;
+
+    TwiddleRegs<P> tw;
+    load_twiddles<P> (tw, twtab, t);
+    PairTwiddles<P> pw;
+    load_pair_twiddles<P> (pw, wtab, t);
+
+    const unsigned ngroups = (batch + FPB - 1) / FPB;
+    const unsigned team_base = (unsigned) team * M;
+    for (unsigned g = blockIdx.x; g < ngroups; g += gridDim.x)
+    {
+        const bool active = g * FPB + team < batch;
+        const float2* __restrict__ src = in + (size_t) g * (FPB * M);
+        float2* __restrict__ dst = out + (size_t) g * (FPB * M);
+        float2 v[P::R];
+#pragma unroll
+        for (int s = 0; s < P::R; ++s)
+            v[s] = active ? src[team_base + (unsigned) input_index<P> (t, s)] : make_float2 (0.f, 0.f);
+        team_sync<P::T>();
+        fft_core<P> (v, tw, lds, t);
+        if constexpr (P::NS > 1)
+            team_sync<P::T>();
+        lds_store_output_order<P> (v, lds, t);
+        team_sync<P::T>();
+
+        // split -> multiply -> merge on each (k, M-k) pair, all in registers
+        float2 zk[P::R / 2], zp[P::R / 2];
+#pragma unroll
+        for (int q = 0; q < P::R / 2; ++q)
+        {
+            const int k = t + P::T * q;
+            const int kp = (k == 0 ? M / 2 : M - k);
+            const float2 A = lds[lds_phys (k)];
+            const float2 Zp = lds[lds_phys (kp)];
+            const float2 hk = H[k], hp = H[kp];
+            float2 Xk, Xp;
+            real_split_pair (A, Zp, pw.w[q], Xk, Xp);
+            float2 Yk = cmul (Xk, hk), Yp = cmul (Xp, hp);
+            if (k == 0)
+            {
+                // packed DC / Nyquist: real products (reference :1640-1644); X[M/2] = conj(Z[M/2])
+                Yk = make_float2 ((A.x + A.y) * hk.x, (A.x - A.y) * hk.y);
+                Yp = cmul (make_float2 (Zp.x, -Zp.y), hp);
+            }
+            Yk = make_float2 (Yk.x * scaling, Yk.y * scaling);
+            Yp = make_float2 (Yp.x * scaling, Yp.y * scaling);
+            real_merge_pair (Yk, Yp, pw.w[q], zk[q], zp[q]);
+            if (k == 0)
+            {
+                zk[q] = make_float2 (Yk.x + Yk.y, Yk.x - Yk.y);
+                zp[q] = make_float2 (2.f * Yp.x, -2.f * Yp.y);
+            }
+        }
+        team_sync<P::T>(); // every pair has been read before the image is rewritten
+#pragma unroll
+        for (int q = 0; q < P::R / 2; ++q)
+        {
+            const int k = t + P::T * q;
+            lds[lds_phys (k)] = make_float2 (zk[q].y, zk[q].x);
+            lds[lds_phys (k == 0 ? M / 2 : M - k)] = make_float2 (zp[q].y, zp[q].x);
+        }
+        team_sync<P::T>();
+        lds_load_input_order<P> (v, lds, t);
+        team_sync<P::T>();
+        fft_core<P> (v, tw, lds, t);
+        if (active)
+        {
+#pragma unroll
+            for (int s = 0; s < P::R; ++s)
+                dst[team_base + (unsigned) output_index<P> (t, s)] = make_float2 (v[s].y, v[s].x);
+        }
+    }
+}
+} // namespace cfft

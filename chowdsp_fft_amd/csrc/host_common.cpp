@@ -1,6 +1,7 @@
 // Error capture, device facts and the process-wide device-table cache (host side, no kernels).
 #include "host_common.hpp"
 #include "tables.hpp"
+#include "launch.hpp"
 
 #include <map>
 #include <mutex>
@@ -66,6 +67,26 @@ bool current_device_info (DeviceInfo& out)
     }
     out = it->second;
     return true;
+}
+
+int blocks_per_cu_cached (const void* kernel, int threads, size_t lds_bytes)
+{
+    int dev = 0;
+    (void) hipGetDevice (&dev);
+    static std::map<std::tuple<const void*, int, size_t>, int> cache;
+    std::lock_guard<std::mutex> lock (g_cache_mutex);
+    const auto key = std::make_tuple (kernel, dev, lds_bytes);
+    auto it = cache.find (key);
+    if (it != cache.end())
+        return it->second;
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, kernel, threads, lds_bytes) != hipSuccess || n < 1)
+    {
+        (void) hipGetLastError();
+        n = 1;
+    }
+    cache.emplace (key, n);
+    return n;
 }
 
 const DeviceTables* acquire_tables (int device, int N, int transform)

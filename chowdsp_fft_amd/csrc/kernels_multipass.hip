@@ -1,0 +1,123 @@
+// Instantiation + launch of the two-pass (N > 4096) kernels and the stand-alone real pair stage.
+#include "launch_util.hpp"
+#include "multipass_kernels.hpp"
+
+namespace cfft::host
+{
+namespace
+{
+template <int N>
+struct TileGeom
+{
+    using P = typename CorePlan<N>::type;
+    static constexpr int FPB = 256 / P::T;
+    // tile width: at least 16 columns (128 contiguous bytes per access), at least one frame per team,
+    // and an LDS image that still lets two workgroups share a CU
+    static constexpr int C = (N >= 1024) ? 8 : (FPB > 16 ? FPB : 16);
+    static constexpr size_t lds_bytes = (size_t) C * TileFrame<N>::stride * sizeof (float2);
+};
+
+template <class K>
+hipError_t ensure_lds (K kernel, size_t bytes)
+{
+    if (bytes > 64 * 1024)
+        return hipFuncSetAttribute ((const void*) kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes);
+    return hipSuccess;
+}
+
+// pass A: n2-point column FFTs (+ inter-pass twiddle), in -> work
+template <int N2, bool INV>
+hipError_t pass_a (int n1, const float2* in, float2* work, const float2* tw2, const float2* big_tw, size_t batch, hipStream_t stream)
+{
+    using TG = TileGeom<N2>;
+    auto kernel = tile_fft_kernel<typename TG::P, TG::C, true, true, INV, false>;
+    hipError_t e = ensure_lds (kernel, TG::lds_bytes);
+    if (e != hipSuccess)
+        return e;
+    const unsigned tiles = (unsigned) (n1 / TG::C);
+    const unsigned grid = persistent_grid (kernel, 256, TG::lds_bytes, batch * tiles);
+    if (grid == 0)
+        return hipErrorNoDevice;
+    hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (256), TG::lds_bytes, stream, in, work, tw2, big_tw, tiles,
+                        1u, (unsigned) n1, (unsigned) n1, (unsigned) (n1 * N2), (unsigned) batch);
+    return hipGetLastError();
+}
+
+// pass B: n1-point row FFTs, transposed store, work -> out
+template <int N1, bool INV>
+hipError_t pass_b (int n2, const float2* work, float2* out, const float2* tw1, size_t batch, hipStream_t stream)
+{
+    using TG = TileGeom<N1>;
+    auto kernel = tile_fft_kernel<typename TG::P, TG::C, false, false, false, INV>;
+    hipError_t e = ensure_lds (kernel, TG::lds_bytes);
+    if (e != hipSuccess)
+        return e;
+    const unsigned tiles = (unsigned) (n2 / TG::C);
+    const unsigned grid = persistent_grid (kernel, 256, TG::lds_bytes, batch * tiles);
+    if (grid == 0)
+        return hipErrorNoDevice;
+    hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (256), TG::lds_bytes, stream, work, out, tw1, (const float2*) nullptr, tiles,
+                        (unsigned) N1, 1u, (unsigned) n2, (unsigned) (N1 * n2), (unsigned) batch);
+    return hipGetLastError();
+}
+
+#define CFFT_DISPATCH_BIG(n, CALL)                           \
+    switch (n)                                               \
+    {                                                        \
+        case 64: { constexpr int N_ = 64; CALL; } break;     \
+        case 128: { constexpr int N_ = 128; CALL; } break;   \
+        case 256: { constexpr int N_ = 256; CALL; } break;   \
+        case 512: { constexpr int N_ = 512; CALL; } break;   \
+        case 1024: { constexpr int N_ = 1024; CALL; } break; \
+        default: return hipErrorInvalidValue;                \
+    }
+
+int stage_table_len (int n)
+{
+    PlanDesc d;
+    return core_plan_desc (n, d) ? d.tw_total : 0;
+}
+} // namespace
+
+hipError_t launch_big_c2c (int n1, int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, size_t batch, hipStream_t stream)
+{
+    if (batch == 0)
+        return hipSuccess;
+    if (batch > 0x7FFFFFFFull)
+        return hipErrorInvalidValue;
+    const float2* tw2 = stage_tw;
+    const float2* tw1 = stage_tw + stage_table_len (n2);
+    hipError_t e = hipErrorInvalidValue;
+    if (inverse)
+    {
+        CFFT_DISPATCH_BIG (n2, e = (pass_a<N_, true> (n1, in, work, tw2, big_tw, batch, stream)));
+        if (e != hipSuccess)
+            return e;
+        CFFT_DISPATCH_BIG (n1, e = (pass_b<N_, true> (n2, work, out, tw1, batch, stream)));
+    }
+    else
+    {
+        CFFT_DISPATCH_BIG (n2, e = (pass_a<N_, false> (n1, in, work, tw2, big_tw, batch, stream)));
+        if (e != hipSuccess)
+            return e;
+        CFFT_DISPATCH_BIG (n1, e = (pass_b<N_, false> (n2, work, out, tw1, batch, stream)));
+    }
+    return e;
+}
+
+hipError_t launch_real_pair (bool forward, const float2* in, float2* out, const float2* real_tw, unsigned m, size_t batch, hipStream_t stream)
+{
+    if (batch == 0)
+        return hipSuccess;
+    DeviceInfo dev;
+    if (! current_device_info (dev))
+        return hipErrorNoDevice;
+    const size_t total = batch * (m / 2);
+    const unsigned grid = (unsigned) std::max<size_t> (1, std::min<size_t> ((total + 255) / 256, (size_t) dev.num_cus * 8));
+    if (forward)
+        hipLaunchKernelGGL (real_pair_kernel<true>, dim3 (grid), dim3 (256), 0, stream, in, out, real_tw, m, (unsigned) batch);
+    else
+        hipLaunchKernelGGL (real_pair_kernel<false>, dim3 (grid), dim3 (256), 0, stream, in, out, real_tw, m, (unsigned) batch);
+    return hipGetLastError();
+}
+} // namespace cfft::host

@@ -9,4 +9,24 @@ namespace cfft::host
 
 // batched complex FFT, interleaved in/out, in may equal out
 hipError_t launch_c2c (int n, bool inverse, const float2* in, float2* out, const float2* stage_tw, size_t batch, hipStream_t stream);
+
+// batched real FFT of N = 2*m real points through the m-point core (m = 16..4096)
+hipError_t launch_r2c (int m, const float2* in, float2* out, const float2* stage_tw, const float2* real_tw, size_t batch, hipStream_t stream);
+hipError_t launch_c2r (int m, const float2* in, float2* out, const float2* stage_tw, const float2* real_tw, size_t batch, hipStream_t stream);
+
+// ab += a*b*scaling on `batch` frames of `cplx_per_frame` complex values; real_packed: bin 0 is (DC, Nyquist)
+hipError_t launch_conv_mac (bool real_packed, const float* a, const float* b, float* ab, float scaling, size_t cplx_per_frame, size_t batch, bool b_is_shared, hipStream_t stream);
+hipError_t launch_accumulate (const float* a, const float* b, float* ab, size_t count, hipStream_t stream);
+
+// fused forward -> *H*scaling -> backward
+hipError_t launch_conv_frames_c2c (int n, const float2* in, const float2* H, float2* out, const float2* stage_tw, float scaling, size_t batch, hipStream_t stream);
+hipError_t launch_conv_frames_real (int m, const float2* in, const float2* H, float2* out, const float2* stage_tw, const float2* real_tw, float scaling, size_t batch, hipStream_t stream);
+
+// multi-pass complex FFT of nc = n1*n2 points: in -> work -> out (work holds `batch` frames)
+// stage_tw holds the n2-core table followed by the n1-core table.
+hipError_t launch_big_c2c (int n1, int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, size_t batch, hipStream_t stream);
+hipError_t launch_real_pair (bool forward, const float2* in, float2* out, const float2* real_tw, unsigned m, size_t batch, hipStream_t stream);
+
+// shared by the kernels_*.hip files
+int blocks_per_cu_cached (const void* kernel, int threads, size_t lds_bytes);
 } // namespace cfft::host
