@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the hot path on MI355X, one JSON line on stdout (rank 0).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): GFFT/s, batched fp32 complex N=4096, plus achieved HBM GB/s vs the roofline.
+Workload at every N: BASELINE configs[1] on EACH GPU -- N=4096 complex, batch 65536 frames per GPU,
+one "step" = one FORWARD launch + one BACKWARD launch over the whole batch (fwd+inv), inputs resident
+in HBM before the timed region.  Frames are independent, so N GPUs = N x the work, no data-path
+collective ("weak" scaling); the per-rank elapsed time is reduced with MAX over ranks.
+
+value        = transforms (2 per frame per step) x frames x GPUs / elapsed / 1e9
+roofline     = algorithmic bytes of ONE launch (16*N bytes per frame: read 8N + write 8N) / average launch
+               duration measured with HIP events on the launch stream over the timed region; peak 8000 GB/s
+cpu_baseline = the REAL reference's AVX path (oracle/_ref, compiled in place from /root/reference) timed on
+               this host by oracle/_ref/ref_bench; rank 0, --gpus 1 only; falls back to the plain-C oracle port.
+Nothing here routes product work through oracle/: the oracle is only the CPU baseline being measured.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
+
+WORKLOADS = {
+    # name: (N, transform, frames per GPU, description)
+    "c2c_n4096_b65536_fwd_inv": (4096, "complex", 65536, "BASELINE configs[1]: N=4096 fp32 complex fwd+inv, batch=65536 per GPU"),
+    "real_n1024_b262144_fwd_inv": (1024, "real", 262144, "BASELINE configs[2]: N=1024 fp32 real r2c+c2r, batch=262144 per GPU"),
+    "c2c_n65536_b8192_fwd_inv": (65536, "complex", 8192, "BASELINE configs[4]: N=65536 fp32 complex (two-pass), batch=8192 per GPU"),
+    "conv_real_n4096_b131072": (4096, "real", 131072, "BASELINE configs[3] per-GPU share: fused fwd->mul->inv frames, N=4096 real, 131072 frames per GPU"),
+}
+
+
+def cpu_baseline(n: int, transform: str, seconds: float) -> dict:
+    """Time the reference on the host CPU (bounded: 3 regimes x `seconds`)."""
+    ref_so = os.path.join(ROOT, "oracle", "_ref", "libchowdsp_fft_ref.so")
+    ref_bench = os.path.join(ROOT, "oracle", "_ref", "ref_bench")
+    ncpu = os.cpu_count() or 1
+    if os.path.exists(ref_so) and os.path.exists(ref_bench):
+        try:
+            out = subprocess.run([ref_bench, ref_so, str(n), transform, "1", f"{seconds:.2f}", str(ncpu), "512"],
+                                 capture_output=True, text=True, timeout=120 + 6 * seconds, check=True).stdout
+            d = json.loads(out.strip().splitlines()[-1])
+            return {
+                "value": d["hot_1t_transforms_per_s"] / 1e9, "unit": "GFFT/s", "cores": 1, "kind": "reference",
+                "sample": f"reference AVX path (simd width {d['simd_width_bytes']} B), N={n} {transform}, in-place "
+                          f"FORWARD+BACKWARD with work buffer, one cache-hot frame repeated for {seconds:.1f} s on one thread",
+                "stream_1t_GFFT_s": d["stream_1t_transforms_per_s"] / 1e9,
+                "allcore_GFFT_s": d["allcore_transforms_per_s"] / 1e9, "allcore_threads": d["allcore_threads"],
+                "stream_sample": f"{d['stream_mib']} MiB of distinct frames, out of place, {seconds:.1f} s per regime",
+            }
+        except Exception as e:  # fall through to the port
+            sys.stderr.write(f"[bench] reference CPU baseline failed ({e}); using the oracle port\n")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib as ol
+
+    oracle = ol.Oracle()
+    s = oracle.new_setup(n, ol.COMPLEX if transform == "complex" else ol.REAL)
+    frame = 2 * n if transform == "complex" else n
+    x = ol.uniform(64 * frame, 1234).reshape(64, frame)
+    done, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        y = oracle.transform_batch(s, x, ol.FORWARD)
+        oracle.transform_batch(s, y, ol.BACKWARD)
+        done += 2 * 64
+    dt = time.perf_counter() - t0
+    del np
+    return {"value": done / dt / 1e9, "unit": "GFFT/s", "cores": 1, "kind": "port",
+            "sample": f"plain-C oracle (scalar restatement of the SSE path), N={n} {transform}, 64 frames fwd+bwd repeated for {seconds:.1f} s"}
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2c_n4096_b65536_fwd_inv", choices=sorted(WORKLOADS))
+    ap.add_argument("--frames-per-gpu", type=int, default=0, help="override the workload's batch (debugging only)")
+    ap.add_argument("--cpu-seconds", type=float, default=4.0, help="seconds per CPU-baseline regime (3 regimes)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", action="store_true", help="also time the final all-gather of results over xGMI (reported separately)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from chowdsp_fft_amd import api, sharding
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            sys.stderr.write(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1\n")
+        if world == 1 and args.gpus > 1:
+            return 2
+    if not torch.cuda.is_available():
+        sys.stderr.write("[bench] no GPU visible: the HIP path cannot run (there is no CPU fallback)\n")
+        return 3
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    n, transform, frames, desc = WORKLOADS[args.workload]
+    if args.frames_per_gpu > 0:
+        frames = args.frames_per_gpu
+    tr = api.FFT_COMPLEX if transform == "complex" else api.FFT_REAL
+    frame_floats = 2 * n if transform == "complex" else n
+    setup = api.fft_new_setup(n, tr)
+    if setup is None:
+        sys.stderr.write("[bench] fft_new_setup returned NULL\n")
+        return 4
+
+    # synthetic uniform(-1, 1) frames, seed 1234 (+rank): every rank owns `frames` frames (weak scaling)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    x = torch.rand((frames, frame_floats), device=dev, generator=g) * 2 - 1
+    y = torch.empty_like(x)
+    z = torch.empty_like(x)
+    fused = args.workload.startswith("conv_")
+    if fused:
+        h = torch.rand((1, frame_floats), device=dev, generator=g) * 2 - 1
+        H = torch.empty_like(h)
+        api.fft_transform_unordered_batch(setup, h, H, api.FFT_FORWARD)
+
+    def step():
+        if fused:
+            api.fft_convolve_frames_batch(setup, x, H, y, 1.0 / n)
+        else:
+            api.fft_transform_batch(setup, x, y, api.FFT_FORWARD)
+            api.fft_transform_batch(setup, y, z, api.FFT_BACKWARD)
+
+    launches_per_step = 1 if fused else 2
+    transforms_per_frame_step = 2  # forward + backward (fused: both inside one kernel)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    elapsed = sharding.max_over_ranks(elapsed, device=dev)
+    event_ms = sharding.max_over_ranks(ev0.elapsed_time(ev1), device=dev)
+
+    # sanity on the timed data: BACKWARD(FORWARD(x)) = N x  (cheap, outside the timed region)
+    if not fused:
+        err = float((z[:256] / n - x[:256]).abs().max())
+        if not err < 5e-6:
+            sys.stderr.write(f"[bench] round-trip check failed: {err}\n")
+            return 5
+
+    gather_info = None
+    if args.gather and world > 1:
+        torch.cuda.synchronize()
+        dist.barrier()
+        tg = time.perf_counter()
+        full = sharding.gather_frames(z if not fused else y, frames * world)
+        torch.cuda.synchronize()
+        dist.barrier()
+        tg = sharding.max_over_ranks(time.perf_counter() - tg, device=dev)
+        gather_info = {"seconds": tg, "bytes_received_per_gpu": int(full.numel() * 4 * (world - 1) / world),
+                       "GB_s_per_gpu": full.numel() * 4 * (world - 1) / world / tg / 1e9}
+        del full
+
+    if rank == 0:
+        total_transforms = transforms_per_frame_step * frames * world * args.steps
+        value = total_transforms / elapsed / 1e9
+        launches = launches_per_step * args.steps
+        avg_launch_s = event_ms * 1e-3 / launches
+        alg_bytes_per_launch = (4 * frame_floats * 2) * frames  # read + write one frame each, per launch
+        achieved = alg_bytes_per_launch / avg_launch_s / 1e9
+        kernel = {"complex": "cfft::c2c_kernel<Plan<4096,256,16,16,16>> (forward and backward instantiations)"}.get(
+            transform if n == 4096 and not fused else "", f"{args.workload} kernels")
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.workload)
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "GFFT/s (batched fp32 complex, N=4096) + achieved HBM GB/s vs roofline" if args.workload == "c2c_n4096_b65536_fwd_inv"
+                      else f"GFFT/s ({args.workload})",
+            "value": value, "unit": "GFFT/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic uniform(-1,1), seed 1234",
+            "config": {"workload": args.workload, "description": desc, "N": n, "transform": transform,
+                       "frames_per_gpu": frames, "global_frames": frames * world,
+                       "transforms_per_frame_per_step": transforms_per_frame_step,
+                       "sharding": f"contiguous batch blocks over {world} GPU(s), no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kernel,
+                         "algorithmic_bytes_per_launch": alg_bytes_per_launch, "avg_launch_ms": avg_launch_s * 1e3,
+                         "launches_timed": launches, "timer": "HIP events on the launch stream"},
+        }
+        if gather_info:
+            line["gather_xgmi"] = gather_info
+        if not args.no_cpu_baseline and world == 1:
+            cb = cpu_baseline(n, transform, args.cpu_seconds)
+            cb["gpu_over_cpu"] = value / cb["value"] if cb["value"] > 0 else None
+            try:
+                with open("/proc/cpuinfo") as f:
+                    cb["host_cpu"] = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "unknown")
+            except OSError:
+                pass
+            cb["host_threads"] = os.cpu_count()
+            line["cpu_baseline"] = cb
+        print(json.dumps(line), flush=True)
+
+    api.fft_destroy_setup(setup)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -166,5 +166,18 @@ def fft_convolve_frames_batch(setup, x, dft_filter, y, scaling: float, batch: in
            "fft_convolve_frames_batch")
 
 
+def size_supported(N: int, transform: int) -> bool:
+    return bool(_lib.lib().fft_gpu_size_supported(N, transform))
+
+
+def plan_describe(N: int, transform: int):
+    """dict(complex_len, passes, n1, n2, radices) or None for an unsupported size (host logic, no GPU)"""
+    buf = (C.c_int * 8)()
+    if _lib.lib().fft_gpu_plan_describe(N, transform, buf) != 0:
+        return None
+    return {"complex_len": buf[0], "passes": buf[1], "n1": buf[2], "n2": buf[3],
+            "radices": [r for r in buf[4:8] if r]}
+
+
 def device_count() -> int:
     return int(_lib.lib().fft_gpu_device_count())

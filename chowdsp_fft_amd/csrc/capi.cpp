@@ -450,6 +450,27 @@ int fft_gpu_stream_synchronize (void* stream)
 
 const char* fft_gpu_last_error (void) { return last_error(); }
 
+int fft_gpu_size_supported (int N, fft_transform_t transform) { return size_supported (N, (int) transform) ? 1 : 0; }
+
+int fft_gpu_plan_describe (int N, fft_transform_t transform, int desc[8])
+{
+    if (desc == nullptr || ! size_supported (N, (int) transform))
+        return FFT_GPU_EINVAL;
+    const int nc = (transform == FFT_COMPLEX) ? N : N / 2;
+    int n1 = 0, n2 = 0;
+    split_large (nc, n1, n2);
+    int radix[4] = { 0, 0, 0, 0 };
+    if (! core_radices (n2 != 0 ? n2 : nc, radix))
+        return FFT_GPU_EINVAL;
+    desc[0] = nc;
+    desc[1] = (n2 != 0) ? 2 : 1;
+    desc[2] = n1;
+    desc[3] = n2;
+    for (int i = 0; i < 4; ++i)
+        desc[4 + i] = radix[i];
+    return FFT_GPU_OK;
+}
+
 int fft_gpu_setup_size (void* setup)
 {
     Setup* s = as_setup (setup);

@@ -34,6 +34,16 @@ void append_stage_twiddles (const PlanDesc& d, std::vector<float2>& out)
 }
 } // namespace
 
+bool core_radices (int n, int radix[4])
+{
+    PlanDesc d;
+    if (! core_plan_desc (n, d))
+        return false;
+    for (int i = 0; i < 4; ++i)
+        radix[i] = i < d.ns ? d.radix[i] : 0;
+    return true;
+}
+
 void split_large (int n_complex, int& n1, int& n2)
 {
     n1 = n2 = 0;

@@ -24,6 +24,8 @@ bool build_host_tables (int N, int transform, HostTables& out);
 
 // Size policy shared with the C API.
 bool size_supported (int N, int transform);
+// stage radices of the LDS-resident core of length n (0-padded); false if n has no core plan
+bool core_radices (int n, int radix[4]);
 // For multi-pass sizes: N = n1 * n2 with both factors LDS-resident; (0,0) if N is LDS-resident itself.
 void split_large (int n_complex, int& n1, int& n2);
 } // namespace cfft::host

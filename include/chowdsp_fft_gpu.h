@@ -55,6 +55,15 @@ int fft_gpu_stream_synchronize (void* stream);
 const char* fft_gpu_last_error (void);
 
 /* ---- plan introspection -------------------------------------------------------------------------- */
+/* 1 if fft_new_setup would accept (N, transform) on a machine with a usable device, else 0.  Pure host
+   logic (no GPU needed); the rule is the reference's SSE size rule restricted to powers of two
+   (reference simd/chowdsp_fft_impl_common.hpp:168-177, 216-225). */
+int fft_gpu_size_supported (int N, fft_transform_t transform);
+/* How (N, transform) is executed.  Fills desc[0..7] = { complex length transformed, number of passes
+   through device memory (1 = LDS-resident, 2 = two-pass), n1, n2 (two-pass split, else 0), then up to
+   four stage radices of the LDS-resident core (of the n2 core for two-pass plans), 0-padded }.
+   Returns 0, or FFT_GPU_EINVAL for an unsupported size.  Pure host logic. */
+int fft_gpu_plan_describe (int N, fft_transform_t transform, int desc[8]);
 int fft_gpu_setup_size (void* setup);              /* N, or negative error */
 int fft_gpu_setup_is_real (void* setup);           /* 1 REAL, 0 COMPLEX */
 /* scratch the plan needs per launch for N > 4096 (multi-pass through HBM), bytes for `batch` frames;

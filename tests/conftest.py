@@ -1,0 +1,73 @@
+"""pytest configuration: the `gpu` marker, the CPU checkers (oracle / compiled reference) and golden data.
+
+  -m "not gpu" : oracle vs golden vectors / compiled reference, host logic, C-ABI surface (no GPU needed)
+  -m gpu       : parity of the HIP path (through the C ABI) against the oracle -- needs one MI355X
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import oracle_lib  # noqa: E402
+
+# parity bound of the north star: results match the reference SSE path within 1e-6 relative fp32,
+# normalised per frame (relative L2, and max-abs error over the frame's max-abs value)
+PARITY_TOL = 1.0e-6
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    return oracle_lib.Oracle()
+
+
+@pytest.fixture(scope="session")
+def reflib():
+    if not oracle_lib.ref_available():
+        pytest.skip("oracle/_ref/libchowdsp_fft_ref.so not built (needs /root/reference; `make -C oracle ref`)")
+    return oracle_lib.RefLib()
+
+
+@pytest.fixture(scope="session")
+def golden():
+    path = os.path.join(HERE, "golden", "reference_sse.npz")
+    with np.load(path) as z:
+        return {k: z[k] for k in z.files}
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    """(api module, torch, device) -- fails loudly if the HIP library or the GPU is missing."""
+    import torch
+
+    assert torch.cuda.is_available(), "gpu tests need a visible MI355X"
+    from chowdsp_fft_amd import api
+
+    assert api.device_count() >= 1, "libchowdsp_fft_hip.so sees no HIP device"
+    return api, torch, torch.device("cuda:0")
+
+
+def assert_frames_close(got, want, tol=PARITY_TOL, what=""):
+    """per-frame relative L2 and max-abs/frame-max, both <= tol"""
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape, f"{what}: shape {got.shape} vs {want.shape}"
+    g2 = got.reshape(-1, got.shape[-1]) if got.ndim > 1 else got[None, :]
+    w2 = want.reshape(-1, want.shape[-1]) if want.ndim > 1 else want[None, :]
+    num = np.linalg.norm(g2 - w2, axis=1)
+    den = np.maximum(np.linalg.norm(w2, axis=1), 1e-300)
+    l2 = float((num / den).max())
+    mx = float((np.abs(g2 - w2).max(axis=1) / np.maximum(np.abs(w2).max(axis=1), 1e-300)).max())
+    assert l2 <= tol, f"{what}: relative L2 {l2:.3e} > {tol:.1e}"
+    assert mx <= tol, f"{what}: max-abs/frame-max {mx:.3e} > {tol:.1e}"
+    return l2, mx

@@ -1,0 +1,177 @@
+"""The drop-in boundary without a GPU: the shared library loads, exports every symbol the headers
+declare (and nothing else public), the header is consumable from C11 and from C++ under its
+chowdsp::fft namespace, and the host-side plan logic (size rule, pass split, byte sizes) is right.
+No compute call is made here.
+"""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INCLUDE = os.path.join(ROOT, "include")
+sys.path.insert(0, ROOT)
+
+from chowdsp_fft_amd import _lib, api  # noqa: E402
+
+LEGACY = ["fft_bytes_required", "fft_new_setup", "fft_new_setup_preallocated", "fft_destroy_setup",
+          "fft_simd_width_bytes", "fft_transform", "fft_transform_unordered", "fft_convolve_unordered",
+          "fft_accumulate", "aligned_malloc", "aligned_free"]  # reference chowdsp_fft.h:81-163
+
+
+def _declared(header):
+    txt = open(os.path.join(INCLUDE, header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"//[^\n]*", "", txt)
+    return re.findall(r"\b([a-z_0-9]+)\s*\(", " ".join(l for l in txt.splitlines() if not l.strip().startswith("#")))
+
+
+def test_headers_declare_expected_symbols():
+    legacy = [n for n in _declared("chowdsp_fft.h") if n.startswith(("fft_", "aligned_"))]
+    assert sorted(set(legacy)) == sorted(LEGACY)
+    ext = [n for n in _declared("chowdsp_fft_gpu.h") if n.startswith("fft_")]
+    assert set(ext) <= set(_lib.PROTOTYPES), set(ext) - set(_lib.PROTOTYPES)
+    assert set(_lib.PROTOTYPES) == set(legacy) | set(ext)
+
+
+def test_library_exports_every_declared_symbol_and_only_those():
+    lib = _lib.lib()
+    for name in _lib.PROTOTYPES:
+        assert getattr(lib, name) is not None
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    assert set(_lib.PROTOTYPES) <= exported
+    extra = {s for s in exported - set(_lib.PROTOTYPES) if not s.startswith(("_init", "_fini", "__"))}
+    assert not extra, f"unexpected public symbols: {sorted(extra)[:8]}"
+
+
+def test_enum_values_match_reference():
+    # reference chowdsp_fft.h:64-75
+    assert (_lib.FFT_FORWARD, _lib.FFT_BACKWARD, _lib.FFT_REAL, _lib.FFT_COMPLEX) == (0, 1, 0, 1)
+
+
+def test_aligned_malloc_is_64_byte_aligned():
+    lib = _lib.lib()
+    for nbytes in (1, 63, 64, 4096, 1 << 20):
+        p = lib.aligned_malloc(nbytes)
+        assert p and p % 64 == 0  # reference chowdsp_fft.cpp:63-72
+        C.memset(p, 0xAB, nbytes)
+        lib.aligned_free(p)
+    lib.aligned_free(None)  # reference chowdsp_fft.cpp:74-78: NULL is a no-op
+
+
+def test_bytes_required_is_never_below_the_reference_figure():
+    # reference simd/chowdsp_fft_impl_sse.cpp:67-72: 8N+96 (complex) / 4N+96 (real)
+    for n in (16, 64, 4096, 65536):
+        assert api.fft_bytes_required(n, api.FFT_COMPLEX) >= 8 * n + 96
+        assert api.fft_bytes_required(n, api.FFT_REAL, False) >= 4 * n + 96
+    assert api.fft_bytes_required(16, api.FFT_REAL) >= 128  # room for the plan header even for tiny N
+
+
+def test_size_rule_host_logic():
+    """powers of two, complex >= 16, real >= 32 (reference common.hpp:168-177), up to 2^20"""
+    ok_c = [1 << k for k in range(4, 21)]
+    for n in range(1, 70):
+        assert api.size_supported(n, api.FFT_COMPLEX) == (n in ok_c)
+        assert api.size_supported(n, api.FFT_REAL) == (n in ok_c and n >= 32)
+    for n in (0, -16, 96, 480, 9216, 1 << 21):
+        assert not api.size_supported(n, api.FFT_COMPLEX)
+    assert api.size_supported(1 << 20, api.FFT_REAL)
+
+
+def test_plan_describe_host_logic():
+    d = api.plan_describe(4096, api.FFT_COMPLEX)
+    assert d == {"complex_len": 4096, "passes": 1, "n1": 0, "n2": 0, "radices": [16, 16, 16]}
+    d = api.plan_describe(1024, api.FFT_REAL)  # real N=1024 rides the 512-point complex core
+    assert d["complex_len"] == 512 and d["passes"] == 1
+    d = api.plan_describe(65536, api.FFT_COMPLEX)  # BASELINE config 5: two passes, 256 x 256
+    assert (d["passes"], d["n1"], d["n2"]) == (2, 256, 256)
+    for lg in range(4, 21):
+        d = api.plan_describe(1 << lg, api.FFT_COMPLEX)
+        prod = 1
+        for r in d["radices"]:
+            assert r in (2, 4, 8, 16)
+            prod *= r
+        assert prod == (d["n2"] if d["passes"] == 2 else d["complex_len"])
+        if d["passes"] == 2:
+            assert d["n1"] * d["n2"] == 1 << lg and 64 <= d["n2"] <= d["n1"] <= 1024
+    assert api.plan_describe(24, api.FFT_COMPLEX) is None
+
+
+def test_misuse_returns_codes_not_crashes():
+    lib = _lib.lib()
+    assert lib.fft_transform_batch(None, None, None, 4, 0, None) == -1  # FFT_GPU_EINVAL
+    assert lib.fft_convolve_frames_batch(None, None, None, None, 1.0, 1, None) == -1
+    assert lib.fft_gpu_setup_size(None) == -1
+    lib.fft_destroy_setup(None)  # tolerated (the reference dereferences NULL here)
+    lib.fft_transform(None, None, None, None, 0)
+    assert isinstance(lib.fft_gpu_last_error(), bytes)
+
+
+C_PROGRAM = r"""
+#include "chowdsp_fft.h"
+#include "chowdsp_fft_gpu.h"
+#include <stdio.h>
+#include <string.h>
+int main (void)
+{
+    float* x = (float*) aligned_malloc (sizeof (float) * 64 * 2);
+    if (! x || ((size_t) x) % 64) return 2;
+    memset (x, 0, sizeof (float) * 128);
+    x[2] = 1.0f; /* unit impulse at n = 1 */
+    if (fft_bytes_required (64, FFT_COMPLEX, false) < 8 * 64 + 96) return 3;
+    if (fft_new_setup (24, FFT_COMPLEX, true) != NULL) return 4; /* unsupported size -> NULL */
+    void* s = fft_new_setup (64, FFT_COMPLEX, false);
+    if (s != NULL) /* only with a usable GPU */
+    {
+        if (fft_simd_width_bytes (s) != 16) return 5;
+        fft_transform (s, x, x, NULL, FFT_FORWARD);
+        /* |X[k]| = 1 for an impulse */
+        for (int k = 0; k < 64; ++k)
+        {
+            float m = x[2 * k] * x[2 * k] + x[2 * k + 1] * x[2 * k + 1];
+            if (m < 0.9999f || m > 1.0001f) return 6;
+        }
+        fft_destroy_setup (s);
+        puts ("gpu-ok");
+    }
+    else
+        puts ("no-gpu");
+    aligned_free (x);
+    return fft_gpu_size_supported (4096, FFT_COMPLEX) == 1 ? 0 : 7;
+}
+"""
+
+CPP_PROGRAM = r"""
+#include "chowdsp_fft.h"
+#include "chowdsp_fft_gpu.h"
+int main()
+{
+    // C++ callers use the namespace and the `= true` default argument (reference chowdsp_fft.h:82-85)
+    auto bytes = chowdsp::fft::fft_bytes_required (1024, chowdsp::fft::FFT_REAL);
+    void* p = chowdsp::fft::aligned_malloc (bytes);
+    void* s = chowdsp::fft::fft_new_setup_preallocated (1024, chowdsp::fft::FFT_REAL, p);
+    (void) s; // NULL without a GPU; caller-owned memory either way
+    chowdsp::fft::aligned_free (p);
+    return chowdsp::fft::fft_gpu_size_supported (1024, chowdsp::fft::FFT_REAL) == 1 ? 0 : 1;
+}
+"""
+
+
+@pytest.mark.parametrize("lang,compiler,std,src", [("c", "gcc", "-std=c11", C_PROGRAM), ("cpp", "g++", "-std=c++17", CPP_PROGRAM)])
+def test_header_is_consumable_and_links(tmp_path, lang, compiler, std, src):
+    """counterpart of the reference's test/test.c: the header compiles as C11 and as C++, and a program
+    linked against the drop-in library runs (with or without a GPU)"""
+    f = tmp_path / f"smoke.{lang}"
+    f.write_text(src)
+    exe = tmp_path / f"smoke_{lang}"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    cmd = [compiler, std, "-Wall", "-Werror", "-I", INCLUDE, str(f), "-o", str(exe), "-L", libdir,
+           "-lchowdsp_fft_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
