@@ -92,14 +92,27 @@ def main() -> int:
     ap.add_argument("--gather", action="store_true", help="also time the final all-gather of results over xGMI (reported separately)")
     args = ap.parse_args()
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    # The CPU baseline runs a child process (oracle/_ref/ref_bench): do it BEFORE anything touches the GPU
+    # (a process that has initialised HIP must not fork+exec on this pool).
+    cb = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        n0, transform0 = WORKLOADS[args.workload][0], WORKLOADS[args.workload][1]
+        cb = cpu_baseline(n0, transform0, args.cpu_seconds)
+        try:
+            with open("/proc/cpuinfo") as f:
+                cb["host_cpu"] = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "unknown")
+        except OSError:
+            pass
+        cb["host_threads"] = os.cpu_count()
+
     import torch
     import torch.distributed as dist
 
     from chowdsp_fft_amd import api, sharding
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
             sys.stderr.write(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1\n")
@@ -218,15 +231,8 @@ def main() -> int:
         }
         if gather_info:
             line["gather_xgmi"] = gather_info
-        if not args.no_cpu_baseline and world == 1:
-            cb = cpu_baseline(n, transform, args.cpu_seconds)
+        if cb is not None:
             cb["gpu_over_cpu"] = value / cb["value"] if cb["value"] > 0 else None
-            try:
-                with open("/proc/cpuinfo") as f:
-                    cb["host_cpu"] = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "unknown")
-            except OSError:
-                pass
-            cb["host_threads"] = os.cpu_count()
             line["cpu_baseline"] = cb
         print(json.dumps(line), flush=True)
 
