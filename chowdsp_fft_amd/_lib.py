@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libchowdsp_fft_hip.so")
+# CHOWDSP_FFT_LIB: developer override used by tools/time_variants.py to A/B differently built libraries
+LIB_PATH = os.environ.get("CHOWDSP_FFT_LIB") or os.path.join(_HERE, "libchowdsp_fft_hip.so")
 
 # enums of include/chowdsp_fft.h (reference chowdsp_fft.h:64-75)
 FFT_FORWARD, FFT_BACKWARD = 0, 1

@@ -41,7 +41,7 @@ __global__ __launch_bounds__ (P::T* FPB) void c2c_kernel (const float2* __restri
 #pragma unroll
             for (int s = 0; s < P::R; ++s)
             {
-                const float2 x = src[team_base + (unsigned) input_index<P> (t, s)];
+                const float2 x = gload (&src[team_base + (unsigned) input_index<P> (t, s)]);
                 v[s] = INV ? make_float2 (x.y, x.x) : x;
             }
         }
@@ -60,9 +60,91 @@ __global__ __launch_bounds__ (P::T* FPB) void c2c_kernel (const float2* __restri
             for (int s = 0; s < P::R; ++s)
             {
                 const float2 y = v[s];
-                dst[team_base + (unsigned) output_index<P> (t, s)] = INV ? make_float2 (y.y, y.x) : y;
+                gstore (&dst[team_base + (unsigned) output_index<P> (t, s)], INV ? make_float2 (y.y, y.x) : y);
             }
         }
     }
+}
+
+// Software-pipelined variant: the loads of the NEXT frame are issued before the current frame is computed and
+// stored.  Besides hiding the load latency behind this frame's arithmetic, it puts the loads AHEAD of the
+// stores in the wave's in-order vmcnt queue, so waiting for them (s_waitcnt vmcnt(R)) no longer has to wait
+// for the previous frame's stores to be acknowledged by memory.  Costs 2*R more VGPRs.
+template <class P, int FPB, bool INV>
+__global__ __launch_bounds__ (P::T* FPB) void c2c_kernel_pf (const float2* __restrict__ in,
+                                                            float2* __restrict__ out,
+                                                            const float2* __restrict__ twtab,
+                                                            unsigned batch)
+{
+    extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
+    const int tid = threadIdx.x;
+    const int team = tid / P::T;
+    const int t = tid % P::T;
+    float2* lds = smem + team * LdsFrame<P::N>::floats2;
+
+    TwiddleRegs<P> tw;
+    load_twiddles<P> (tw, twtab, t);
+
+    const unsigned ngroups = (batch + FPB - 1) / FPB;
+    const unsigned team_base = (unsigned) team * P::N;
+
+    // One frame: v holds it (already swapped for INV); the next frame's loads go out first, then the
+    // arithmetic, then the stores.  The very first frame is peeled so that BOTH ways into the steady-state
+    // loop carry the same queue shape (R loads, then R stores) and the loop-top wait is vmcnt(R), not vmcnt(0).
+    // (The body is a macro, not a lambda: with a by-reference closure the INV instantiation keeps `v` in scratch.)
+    float nre[P::R], nim[P::R]; // prefetch registers (re, im already swapped for INV)
+#define CFFT_PF_BODY(G, V)                                                                                          \
+    {                                                                                                               \
+        const bool active_ = (G) * FPB + team < batch;                                                              \
+        float2* __restrict__ dst_ = out + (size_t) (G) * (FPB * P::N);                                              \
+        const unsigned gn_ = (G) + gridDim.x;                                                                       \
+        if (gn_ < ngroups)                                                                                          \
+        {                                                                                                           \
+            const bool actn_ = gn_ * FPB + team < batch;                                                            \
+            const float2* __restrict__ srcn_ = in + (size_t) gn_ * (FPB * P::N);                                    \
+            if (FPB == 1 || actn_)                                                                                  \
+            {                                                                                                       \
+                _Pragma ("unroll") for (int s = 0; s < P::R; ++s)                                                   \
+                {                                                                                                   \
+                    const float2 x_ = gload (&srcn_[team_base + (unsigned) input_index<P> (t, s)]);                 \
+                    nre[s] = INV ? x_.y : x_.x;                                                                     \
+                    nim[s] = INV ? x_.x : x_.y;                                                                     \
+                }                                                                                                   \
+            }                                                                                                       \
+        }                                                                                                           \
+        team_sync<P::T>();                                                                                          \
+        fft_core<P> (V, tw, lds, t);                                                                                \
+        if (FPB == 1 || active_) /* FPB == 1: the store count per iteration is a compile-time constant */           \
+        {                                                                                                           \
+            _Pragma ("unroll") for (int s = 0; s < P::R; ++s)                                                       \
+                gstore (&dst_[team_base + (unsigned) output_index<P> (t, s)],                                       \
+                        INV ? make_float2 (V[s].y, V[s].x) : V[s]);                                                 \
+        }                                                                                                           \
+    }
+
+    unsigned g = blockIdx.x;
+    if (g >= ngroups)
+        return;
+    {
+        const bool act0 = g * FPB + team < batch;
+        const float2* __restrict__ src0 = in + (size_t) g * (FPB * P::N);
+        float2 v[P::R];
+#pragma unroll
+        for (int s = 0; s < P::R; ++s)
+        {
+            const float2 x = (FPB == 1 || act0) ? gload (&src0[team_base + (unsigned) input_index<P> (t, s)]) : make_float2 (0.f, 0.f);
+            v[s] = INV ? make_float2 (x.y, x.x) : x;
+        }
+        CFFT_PF_BODY (g, v)
+    }
+    for (g += gridDim.x; g < ngroups; g += gridDim.x)
+    {
+        float2 v[P::R];
+#pragma unroll
+        for (int s = 0; s < P::R; ++s)
+            v[s] = make_float2 (nre[s], nim[s]);
+        CFFT_PF_BODY (g, v)
+    }
+#undef CFFT_PF_BODY
 }
 } // namespace cfft

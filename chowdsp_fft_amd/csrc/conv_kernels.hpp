@@ -27,9 +27,9 @@ __global__ __launch_bounds__ (256) void conv_mac_kernel (const float4* __restric
     for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < total_pairs; i += stride)
     {
         const unsigned in_frame = (unsigned) (i % pairs_per_frame);
-        const float4 va = a[i];
-        const float4 vb = b[b_is_shared ? (size_t) in_frame : i];
-        float4 acc = ab[i];
+        const float4 va = gload4 (&a[i]);
+        const float4 vb = b_is_shared ? b[in_frame] : gload4 (&b[i]);
+        float4 acc = gload4 (&ab[i]);
         float r0 = va.x * vb.x - va.y * vb.y;
         float i0 = va.x * vb.y + va.y * vb.x;
         const float r1 = va.z * vb.z - va.w * vb.w;
@@ -43,7 +43,7 @@ __global__ __launch_bounds__ (256) void conv_mac_kernel (const float4* __restric
         acc.y += i0 * scaling;
         acc.z += r1 * scaling;
         acc.w += i1 * scaling;
-        ab[i] = acc;
+        gstore4 (&ab[i], acc);
     }
 }
 
@@ -59,8 +59,8 @@ __global__ __launch_bounds__ (256) void accumulate_kernel (const float* __restri
     float4* o4 = (float4*) ab;
     for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
     {
-        const float4 x = a4[i], y = b4[i];
-        o4[i] = make_float4 (x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+        const float4 x = gload4 (&a4[i]), y = gload4 (&b4[i]);
+        gstore4 (&o4[i], make_float4 (x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w));
     }
     // tail (count not a multiple of 4)
     for (size_t i = n4 * 4 + (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride)
@@ -96,7 +96,7 @@ __global__ __launch_bounds__ (P::T* FPB) void conv_frames_c2c_kernel (const floa
         float2 v[P::R];
 #pragma unroll
         for (int s = 0; s < P::R; ++s)
-            v[s] = active ? src[team_base + (unsigned) input_index<P> (t, s)] : make_float2 (0.f, 0.f);
+            v[s] = active ? gload (&src[team_base + (unsigned) input_index<P> (t, s)]) : make_float2 (0.f, 0.f);
         team_sync<P::T>();
         fft_core<P> (v, tw, lds, t);
         // multiply by the filter spectrum (L2-resident, shared by every frame), scale, swap for the inverse
@@ -118,7 +118,7 @@ __global__ __launch_bounds__ (P::T* FPB) void conv_frames_c2c_kernel (const floa
         {
 #pragma unroll
             for (int s = 0; s < P::R; ++s)
-                dst[team_base + (unsigned) output_index<P> (t, s)] = make_float2 (v[s].y, v[s].x);
+                gstore (&dst[team_base + (unsigned) output_index<P> (t, s)], make_float2 (v[s].y, v[s].x));
         }
     }
 }
@@ -155,7 +155,7 @@ __global__ __launch_bounds__ (P::T* FPB) void conv_frames_real_kernel (const flo
         float2 v[P::R];
 #pragma unroll
         for (int s = 0; s < P::R; ++s)
-            v[s] = active ? src[team_base + (unsigned) input_index<P> (t, s)] : make_float2 (0.f, 0.f);
+            v[s] = active ? gload (&src[team_base + (unsigned) input_index<P> (t, s)]) : make_float2 (0.f, 0.f);
         team_sync<P::T>();
         fft_core<P> (v, tw, lds, t);
         if constexpr (P::NS > 1)
@@ -207,7 +207,7 @@ __global__ __launch_bounds__ (P::T* FPB) void conv_frames_real_kernel (const flo
         {
 #pragma unroll
             for (int s = 0; s < P::R; ++s)
-                dst[team_base + (unsigned) output_index<P> (t, s)] = make_float2 (v[s].y, v[s].x);
+                gstore (&dst[team_base + (unsigned) output_index<P> (t, s)], make_float2 (v[s].y, v[s].x));
         }
     }
 }

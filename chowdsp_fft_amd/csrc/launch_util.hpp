@@ -14,6 +14,9 @@ inline unsigned persistent_grid (K kernel, int threads, size_t lds_bytes, size_t
     DeviceInfo dev;
     if (! current_device_info (dev))
         return 0;
+#if defined(CFFT_PERSISTENT) && CFFT_PERSISTENT == 0
+    return (unsigned) std::max<size_t> (1, work_items); // experiment: one workgroup per work item
+#endif
     const int per_cu = blocks_per_cu_cached ((const void*) kernel, threads, lds_bytes);
     const size_t resident = (size_t) dev.num_cus * (size_t) per_cu;
     return (unsigned) std::max<size_t> (1, std::min (work_items, resident));

@@ -132,7 +132,7 @@ __global__ __launch_bounds__ (256) void real_pair_kernel (const float2* __restri
         const unsigned kp = (k == 0 ? half : M - k);
         const float2* __restrict__ src = in + (size_t) f * M;
         float2* __restrict__ dst = out + (size_t) f * M;
-        const float2 A = src[k], Bp = src[kp];
+        const float2 A = gload (&src[k]), Bp = gload (&src[kp]);
         const float2 w = wtab[k];
         float2 rk, rp;
         if (FORWARD)
@@ -153,8 +153,8 @@ __global__ __launch_bounds__ (256) void real_pair_kernel (const float2* __restri
                 rp = make_float2 (2.f * Bp.x, -2.f * Bp.y);
             }
         }
-        dst[k] = rk;
-        dst[kp] = rp;
+        gstore (&dst[k], rk);
+        gstore (&dst[kp], rp);
     }
 }
 } // namespace cfft

@@ -106,7 +106,7 @@ __global__ __launch_bounds__ (P::T* FPB) void r2c_kernel (const float2* __restri
         float2 v[P::R];
 #pragma unroll
         for (int s = 0; s < P::R; ++s)
-            v[s] = active ? src[team_base + (unsigned) input_index<P> (t, s)] : make_float2 (0.f, 0.f);
+            v[s] = active ? gload (&src[team_base + (unsigned) input_index<P> (t, s)]) : make_float2 (0.f, 0.f);
 
         team_sync<P::T>();
         fft_core<P> (v, tw, lds, t);
@@ -131,8 +131,8 @@ __global__ __launch_bounds__ (P::T* FPB) void r2c_kernel (const float2* __restri
             }
             if (active)
             {
-                dst[team_base + (unsigned) k] = Xk;
-                dst[team_base + (unsigned) (k == 0 ? M / 2 : M - k)] = Xp;
+                gstore (&dst[team_base + (unsigned) k], Xk);
+                gstore (&dst[team_base + (unsigned) (k == 0 ? M / 2 : M - k)], Xp);
             }
         }
     }
@@ -172,8 +172,8 @@ __global__ __launch_bounds__ (P::T* FPB) void c2r_kernel (const float2* __restri
         for (int q = 0; q < P::R / 2; ++q)
         {
             const int k = t + P::T * q;
-            const float2 A = active ? src[team_base + (unsigned) k] : make_float2 (0.f, 0.f);
-            const float2 Xp = active ? src[team_base + (unsigned) (k == 0 ? M / 2 : M - k)] : make_float2 (0.f, 0.f);
+            const float2 A = active ? gload (&src[team_base + (unsigned) k]) : make_float2 (0.f, 0.f);
+            const float2 Xp = active ? gload (&src[team_base + (unsigned) (k == 0 ? M / 2 : M - k)]) : make_float2 (0.f, 0.f);
             real_merge_pair (A, Xp, pw.w[q], zk[q], zp[q]);
             if (k == 0)
             {
@@ -199,7 +199,7 @@ __global__ __launch_bounds__ (P::T* FPB) void c2r_kernel (const float2* __restri
         {
 #pragma unroll
             for (int s = 0; s < P::R; ++s)
-                dst[team_base + (unsigned) output_index<P> (t, s)] = make_float2 (v[s].y, v[s].x);
+                gstore (&dst[team_base + (unsigned) output_index<P> (t, s)], make_float2 (v[s].y, v[s].x));
         }
     }
 }

@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""A/B timing of differently built libchowdsp_fft_hip variants in ONE process, interleaved rounds
+(cdna_hip_programming.md rule 24).  Each variant is its own dlopen handle (RTLD_LOCAL), so the same
+symbol names coexist.
+
+usage: python tools/time_variants.py [--workloads c4096,r1024,c65536,conv4096,c64,c256,c1024] [--rounds 7] lib1.so lib2.so ...
+       (default libs: chowdsp_fft_amd/libchowdsp_fft_hip.so + chowdsp_fft_amd/variants/*.so)
+"""
+import argparse
+import glob
+import os
+import statistics
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from chowdsp_fft_amd import _lib  # noqa: E402
+
+WORK = {
+    # name: (N, transform(1=complex), frames, fused)
+    "c4096": (4096, 1, 65536, False),
+    "r1024": (1024, 0, 262144, False),
+    "c65536": (65536, 1, 8192, False),
+    "conv4096": (4096, 0, 131072, True),
+    "c64": (64, 1, 4194304, False),
+    "c256": (256, 1, 1048576, False),
+    "c1024": (1024, 1, 262144, False),
+    "c2048": (2048, 1, 131072, False),
+    "r4096": (4096, 0, 131072, False),
+    "r8192": (8192, 0, 65536, False),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workloads", default="c4096,r1024,conv4096,c65536")
+    ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("libs", nargs="*")
+    args = ap.parse_args()
+    libs = args.libs or ([os.path.join(ROOT, "chowdsp_fft_amd", "libchowdsp_fft_hip.so")]
+                         + sorted(glob.glob(os.path.join(ROOT, "chowdsp_fft_amd", "variants", "*.so"))))
+    handles = [(os.path.basename(p).replace("lib_", "").replace(".so", ""), _lib.load(p)) for p in libs]
+    dev = torch.device("cuda:0")
+    stream = int(torch.cuda.current_stream().cuda_stream)
+    for wname in args.workloads.split(","):
+        n, tr, frames, fused = WORK[wname]
+        ff = 2 * n if tr == 1 else n
+        x = torch.rand((frames, ff), device=dev) * 2 - 1
+        y = torch.empty_like(x)
+        z = torch.empty_like(x)
+        H = torch.rand((1, ff), device=dev)
+        setups = [(name, L, L.fft_new_setup(n, tr, True)) for name, L in handles]
+
+        def step(L, s):
+            if fused:
+                rc = L.fft_convolve_frames_batch(s, x.data_ptr(), H.data_ptr(), y.data_ptr(), 1.0 / n, frames, stream)
+            else:
+                rc = L.fft_transform_batch(s, x.data_ptr(), y.data_ptr(), frames, 0, stream)
+                rc |= L.fft_transform_batch(s, y.data_ptr(), z.data_ptr(), frames, 1, stream)
+            assert rc == 0, L.fft_gpu_last_error()
+
+        times = {name: [] for name, _, _ in setups}
+        for name, L, s in setups:  # warm-up
+            step(L, s)
+        torch.cuda.synchronize()
+        for _ in range(args.rounds):
+            for name, L, s in setups:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.iters):
+                    step(L, s)
+                e1.record()
+                torch.cuda.synchronize()
+                times[name].append(e0.elapsed_time(e1) / args.iters)
+        launches = 1 if fused else 2
+        alg = 2 * 4 * ff * frames  # bytes per launch
+        print(f"--- {wname}: N={n} {'complex' if tr else 'real'} frames={frames} {'fused conv' if fused else 'fwd+bwd'}")
+        for name, ts in times.items():
+            med, best = statistics.median(ts), min(ts)
+            print(f"{name:28s} median {med:8.4f} ms/step  min {best:8.4f}  -> {alg * launches / med * 1e-6:7.0f} GB/s  "
+                  f"{2 * frames / med * 1e-6:8.4f} GFFT/s")
+        for name, L, s in setups:
+            L.fft_destroy_setup(s)
+        del x, y, z
+        torch.cuda.empty_cache()
+        sys.stdout.flush()
+
+
+if __name__ == "__main__":
+    main()
