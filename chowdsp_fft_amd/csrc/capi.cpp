@@ -68,38 +68,86 @@ struct Staging
 };
 thread_local Staging g_staging;
 
-// grow-only scratch for the two-pass sizes, one per (device, stream); bounded by kWorkspaceCap so that the
+// grow-only scratch for the two-pass sizes, one per (device, stream); bounded by workspace_cap() so that the
 // intermediate of one chunk of frames stays inside the 256 MiB Infinity Cache between pass A and pass B.
-constexpr size_t kWorkspaceCap = 128ull << 20;
-struct Workspace
+constexpr size_t kWorkspaceCapDefault = 256ull << 20;
+// developer knob for the cap sweep in tools/ (MiB); read once
+size_t workspace_cap()
 {
-    float2* ptr = nullptr;
-    size_t bytes = 0;
+    static const size_t cap = [] {
+        const char* e = std::getenv ("CHOWDSP_FFT_WORKSPACE_MIB");
+        const long v = e != nullptr ? std::atol (e) : 0;
+        return v > 0 ? (size_t) v << 20 : kWorkspaceCapDefault;
+    }();
+    return cap;
+}
+// Two-pass plans run as a two-lane software pipeline: chunk i goes to lane i%2 (its own internal stream and
+// workspace), so pass B of one chunk (workspace -> HBM writes) overlaps pass A of the next (HBM reads -> workspace).
+// Lanes fork from / join back into the caller's stream with events, so the call stays asynchronous and ordered
+// on the caller's stream (and capturable into a hipGraph).
+struct Lanes
+{
+    hipStream_t lane[2] = { nullptr, nullptr };
+    hipEvent_t start = nullptr, done[2] = { nullptr, nullptr };
+    float2* ws[2] = { nullptr, nullptr };
+    size_t bytes = 0; // per workspace
+    bool ok = false;
 };
 std::mutex g_ws_mutex;
-std::map<std::pair<int, hipStream_t>, Workspace> g_workspaces;
+std::map<std::pair<int, hipStream_t>, Lanes> g_lanes;
 
-float2* get_workspace (int device, hipStream_t stream, size_t bytes)
+int lane_count()
+{
+    static const int n = [] {
+        const char* e = std::getenv ("CHOWDSP_FFT_LANES");
+        const int v = e != nullptr ? std::atoi (e) : 2;
+        return v == 1 ? 1 : 2;
+    }();
+    return n;
+}
+
+Lanes* get_lanes (int device, hipStream_t stream, size_t bytes_each)
 {
     std::lock_guard<std::mutex> lock (g_ws_mutex);
-    Workspace& w = g_workspaces[std::make_pair (device, stream)];
-    if (w.bytes >= bytes)
-        return w.ptr;
-    if (w.ptr != nullptr)
+    Lanes& L = g_lanes[std::make_pair (device, stream)];
+    if (! L.ok)
     {
-        (void) hipStreamSynchronize (stream);
-        (void) hipFree (w.ptr);
-        w.ptr = nullptr;
-        w.bytes = 0;
+        bool good = hipEventCreateWithFlags (&L.start, hipEventDisableTiming) == hipSuccess;
+        for (int k = 0; k < 2 && good; ++k)
+            good = hipStreamCreateWithFlags (&L.lane[k], hipStreamNonBlocking) == hipSuccess
+                   && hipEventCreateWithFlags (&L.done[k], hipEventDisableTiming) == hipSuccess;
+        if (! good)
+        {
+            set_last_error ("could not create the two-pass pipeline streams");
+            return nullptr;
+        }
+        L.ok = true;
     }
-    if (hipMalloc ((void**) &w.ptr, bytes) != hipSuccess)
+    if (L.bytes < bytes_each)
     {
-        w.ptr = nullptr;
-        set_last_error ("workspace allocation failed");
-        return nullptr;
+        for (int k = 0; k < 2; ++k)
+        {
+            if (L.ws[k] != nullptr)
+            {
+                (void) hipStreamSynchronize (L.lane[k]);
+                (void) hipStreamSynchronize (stream);
+                (void) hipFree (L.ws[k]);
+                L.ws[k] = nullptr;
+            }
+        }
+        L.bytes = 0;
+        for (int k = 0; k < 2; ++k)
+        {
+            if (hipMalloc ((void**) &L.ws[k], bytes_each) != hipSuccess)
+            {
+                L.ws[k] = nullptr;
+                set_last_error ("workspace allocation failed");
+                return nullptr;
+            }
+        }
+        L.bytes = bytes_each;
     }
-    w.bytes = bytes;
-    return w.ptr;
+    return &L;
 }
 
 // complex length the plan's core transforms
@@ -110,23 +158,44 @@ int big_c2c_chunked (Setup* s, int nc, bool inverse, const float2* in, float2* o
     int n1 = 0, n2 = 0;
     split_large (nc, n1, n2);
     const size_t frame_bytes = (size_t) nc * sizeof (float2);
-    size_t chunk = kWorkspaceCap / frame_bytes;
+    const int want_lanes = lane_count();
+    // the cap covers BOTH workspaces, so that they fit the Infinity Cache together
+    size_t chunk = workspace_cap() / (size_t) want_lanes / frame_bytes;
     if (chunk < 1)
         chunk = 1;
     if (chunk > batch)
         chunk = batch;
-    float2* work = get_workspace (s->device, stream, chunk * frame_bytes);
-    if (work == nullptr)
+    Lanes* L = get_lanes (s->device, stream, chunk * frame_bytes);
+    if (L == nullptr)
         return cf::FFT_GPU_ENOMEM;
-    for (size_t f0 = 0; f0 < batch; f0 += chunk)
+    const size_t nchunks = (batch + chunk - 1) / chunk;
+    const int lanes = (nchunks >= 2) ? want_lanes : 1;
+    if (lanes == 2)
+    {
+        CFFT_HIP_TRY (hipEventRecord (L->start, stream), cf::FFT_GPU_ELAUNCH);
+        for (int k = 0; k < 2; ++k)
+            CFFT_HIP_TRY (hipStreamWaitEvent (L->lane[k], L->start, 0), cf::FFT_GPU_ELAUNCH);
+    }
+    size_t i = 0;
+    for (size_t f0 = 0; f0 < batch; f0 += chunk, ++i)
     {
         const size_t nb = (batch - f0 < chunk) ? batch - f0 : chunk;
-        const hipError_t e = launch_big_c2c (n1, n2, inverse, in + f0 * nc, work, out + f0 * nc, s->tables->stage_twiddles,
-                                             s->tables->big_twiddles, nb, stream);
+        const int k = (lanes == 2) ? (int) (i & 1) : 0;
+        const hipStream_t st = (lanes == 2) ? L->lane[k] : stream;
+        const hipError_t e = launch_big_c2c (n1, n2, inverse, in + f0 * nc, L->ws[k], out + f0 * nc, s->tables->stage_twiddles,
+                                             s->tables->big_twiddles, nb, lanes, st);
         if (e != hipSuccess)
         {
             set_last_error ("two-pass kernel launch", e);
             return cf::FFT_GPU_ELAUNCH;
+        }
+    }
+    if (lanes == 2)
+    {
+        for (int k = 0; k < 2; ++k)
+        {
+            CFFT_HIP_TRY (hipEventRecord (L->done[k], L->lane[k]), cf::FFT_GPU_ELAUNCH);
+            CFFT_HIP_TRY (hipStreamWaitEvent (stream, L->done[k], 0), cf::FFT_GPU_ELAUNCH);
         }
     }
     return cf::FFT_GPU_OK;
@@ -489,12 +558,12 @@ size_t fft_gpu_workspace_bytes (void* setup, size_t batch)
     if (s == nullptr || s->tables->core_n == complex_len (s))
         return 0;
     const size_t frame_bytes = (size_t) complex_len (s) * sizeof (float2);
-    size_t chunk = kWorkspaceCap / frame_bytes;
+    size_t chunk = workspace_cap() / (size_t) lane_count() / frame_bytes;
     if (chunk < 1)
         chunk = 1;
     if (chunk > batch)
         chunk = batch;
-    return chunk * frame_bytes;
+    return (size_t) lane_count() * chunk * frame_bytes;
 }
 
 // ---- extension: batched operations ---------------------------------------------------------------

@@ -10,10 +10,7 @@ template <int N>
 struct TileGeom
 {
     using P = typename CorePlan<N>::type;
-    static constexpr int FPB = 256 / P::T;
-    // tile width: at least 16 columns (128 contiguous bytes per access), at least one frame per team,
-    // and an LDS image that still lets two workgroups share a CU
-    static constexpr int C = (N >= 1024) ? 8 : (FPB > 16 ? FPB : 16);
+    static constexpr int C = tile_width (N, P::T);
     static constexpr size_t lds_bytes = (size_t) C * TileFrame<N>::stride * sizeof (float2);
 };
 
@@ -25,39 +22,42 @@ hipError_t ensure_lds (K kernel, size_t bytes)
     return hipSuccess;
 }
 
-// pass A: n2-point column FFTs (+ inter-pass twiddle), in -> work
+// pass A: n2-point column FFTs (+ inter-pass twiddle), in -> work (tile-major)
 template <int N2, bool INV>
-hipError_t pass_a (int n1, const float2* in, float2* work, const float2* tw2, const float2* big_tw, size_t batch, hipStream_t stream)
+hipError_t pass_a (int n1, const float2* in, float2* work, const float2* tw2, const float2* big_tw, size_t batch, int div, hipStream_t stream)
 {
     using TG = TileGeom<N2>;
-    auto kernel = tile_fft_kernel<typename TG::P, TG::C, true, true, INV, false>;
+    auto kernel = pass_a_kernel<typename TG::P, TG::C, INV>;
     hipError_t e = ensure_lds (kernel, TG::lds_bytes);
     if (e != hipSuccess)
         return e;
-    const unsigned tiles = (unsigned) (n1 / TG::C);
-    const unsigned grid = persistent_grid (kernel, 256, TG::lds_bytes, batch * tiles);
+    const size_t tiles = (size_t) (n1 / TG::C);
+    unsigned grid = persistent_grid (kernel, 256, TG::lds_bytes, batch * tiles);
     if (grid == 0)
         return hipErrorNoDevice;
-    hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (256), TG::lds_bytes, stream, in, work, tw2, big_tw, tiles,
-                        1u, (unsigned) n1, (unsigned) n1, (unsigned) (n1 * N2), (unsigned) batch);
+    grid = std::max (1u, grid / (unsigned) div);
+    hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (256), TG::lds_bytes, stream, in, work, tw2, big_tw, (unsigned) n1, (unsigned) batch);
     return hipGetLastError();
 }
 
 // pass B: n1-point row FFTs, transposed store, work -> out
 template <int N1, bool INV>
-hipError_t pass_b (int n2, const float2* work, float2* out, const float2* tw1, size_t batch, hipStream_t stream)
+hipError_t pass_b (int n2, const float2* work, float2* out, const float2* tw1, size_t batch, int div, hipStream_t stream)
 {
     using TG = TileGeom<N1>;
-    auto kernel = tile_fft_kernel<typename TG::P, TG::C, false, false, false, INV>;
+    auto kernel = pass_b_kernel<typename TG::P, TG::C, INV>;
     hipError_t e = ensure_lds (kernel, TG::lds_bytes);
     if (e != hipSuccess)
         return e;
-    const unsigned tiles = (unsigned) (n2 / TG::C);
-    const unsigned grid = persistent_grid (kernel, 256, TG::lds_bytes, batch * tiles);
+    const size_t tiles = (size_t) (n2 / TG::C);
+    unsigned grid = persistent_grid (kernel, 256, TG::lds_bytes, batch * tiles);
     if (grid == 0)
         return hipErrorNoDevice;
-    hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (256), TG::lds_bytes, stream, work, out, tw1, (const float2*) nullptr, tiles,
-                        (unsigned) N1, 1u, (unsigned) n2, (unsigned) (N1 * n2), (unsigned) batch);
+    grid = std::max (1u, grid / (unsigned) div);
+    unsigned ca_log2 = 0;
+    while ((1 << ca_log2) < tile_width_for (n2))
+        ++ca_log2;
+    hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (256), TG::lds_bytes, stream, work, out, tw1, (unsigned) n2, ca_log2, (unsigned) batch);
     return hipGetLastError();
 }
 
@@ -72,6 +72,27 @@ hipError_t pass_b (int n2, const float2* work, float2* out, const float2* tw1, s
         default: return hipErrorInvalidValue;                \
     }
 
+// N = 65536 = 256 x 256 fast path (register-direct, software-pipelined; multipass_kernels.hpp)
+template <bool INV>
+hipError_t big256 (const float2* in, float2* work, float2* out, const float2* tw256, const float2* big_tw, size_t batch, int div, hipStream_t stream)
+{
+    constexpr size_t lds = (size_t) 16 * TileFrame<256>::stride * sizeof (float2);
+    auto ka = pass_a256_kernel<INV>;
+    auto kb = pass_b256_kernel<INV>;
+    unsigned ga = persistent_grid (ka, 256, lds, batch * 16);
+    unsigned gb = persistent_grid (kb, 256, lds, batch * 16);
+    if (ga == 0 || gb == 0)
+        return hipErrorNoDevice;
+    ga = std::max (1u, ga / (unsigned) div);
+    gb = std::max (1u, gb / (unsigned) div);
+    hipLaunchKernelGGL (ka, dim3 (ga), dim3 (256), lds, stream, in, work, tw256, big_tw, (unsigned) batch);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return e;
+    hipLaunchKernelGGL (kb, dim3 (gb), dim3 (256), lds, stream, (const float2*) work, out, tw256, (unsigned) batch);
+    return hipGetLastError();
+}
+
 int stage_table_len (int n)
 {
     PlanDesc d;
@@ -79,7 +100,7 @@ int stage_table_len (int n)
 }
 } // namespace
 
-hipError_t launch_big_c2c (int n1, int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, size_t batch, hipStream_t stream)
+hipError_t launch_big_c2c (int n1, int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, size_t batch, int grid_divisor, hipStream_t stream)
 {
     if (batch == 0)
         return hipSuccess;
@@ -87,20 +108,23 @@ hipError_t launch_big_c2c (int n1, int n2, bool inverse, const float2* in, float
         return hipErrorInvalidValue;
     const float2* tw2 = stage_tw;
     const float2* tw1 = stage_tw + stage_table_len (n2);
+    if (n1 == 256 && n2 == 256 && batch * 16 <= 0x7FFFFFFFull)
+        return inverse ? big256<true> (in, work, out, tw2, big_tw, batch, grid_divisor, stream)
+                       : big256<false> (in, work, out, tw2, big_tw, batch, grid_divisor, stream);
     hipError_t e = hipErrorInvalidValue;
     if (inverse)
     {
-        CFFT_DISPATCH_BIG (n2, e = (pass_a<N_, true> (n1, in, work, tw2, big_tw, batch, stream)));
+        CFFT_DISPATCH_BIG (n2, e = (pass_a<N_, true> (n1, in, work, tw2, big_tw, batch, grid_divisor, stream)));
         if (e != hipSuccess)
             return e;
-        CFFT_DISPATCH_BIG (n1, e = (pass_b<N_, true> (n2, work, out, tw1, batch, stream)));
+        CFFT_DISPATCH_BIG (n1, e = (pass_b<N_, true> (n2, work, out, tw1, batch, grid_divisor, stream)));
     }
     else
     {
-        CFFT_DISPATCH_BIG (n2, e = (pass_a<N_, false> (n1, in, work, tw2, big_tw, batch, stream)));
+        CFFT_DISPATCH_BIG (n2, e = (pass_a<N_, false> (n1, in, work, tw2, big_tw, batch, grid_divisor, stream)));
         if (e != hipSuccess)
             return e;
-        CFFT_DISPATCH_BIG (n1, e = (pass_b<N_, false> (n2, work, out, tw1, batch, stream)));
+        CFFT_DISPATCH_BIG (n1, e = (pass_b<N_, false> (n2, work, out, tw1, batch, grid_divisor, stream)));
     }
     return e;
 }

@@ -23,8 +23,9 @@ hipError_t launch_conv_frames_c2c (int n, const float2* in, const float2* H, flo
 hipError_t launch_conv_frames_real (int m, const float2* in, const float2* H, float2* out, const float2* stage_tw, const float2* real_tw, float scaling, size_t batch, hipStream_t stream);
 
 // multi-pass complex FFT of nc = n1*n2 points: in -> work -> out (work holds `batch` frames)
-// stage_tw holds the n2-core table followed by the n1-core table.
-hipError_t launch_big_c2c (int n1, int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, size_t batch, hipStream_t stream);
+// stage_tw holds the n2-core table followed by the n1-core table.  grid_divisor: 2 when two launches are meant
+// to share the GPU (two-lane pipeline), else 1.
+hipError_t launch_big_c2c (int n1, int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, size_t batch, int grid_divisor, hipStream_t stream);
 hipError_t launch_real_pair (bool forward, const float2* in, float2* out, const float2* real_tw, unsigned m, size_t batch, hipStream_t stream);
 
 // shared by the kernels_*.hip files

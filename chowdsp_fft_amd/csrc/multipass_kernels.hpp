@@ -4,10 +4,8 @@
 //   n = a + n1*b   (a < n1, b < n2)        k = n2*ka + kb   (ka < n1, kb < n2)
 //   X[n2*ka + kb] = sum_a W_n1^{a ka} [ W_N^{a kb} sum_b x[a + n1 b] W_n2^{b kb} ]
 //
-//   pass A ("columns"): for every a, the n2-point DFT over b (stride n1), times W_N^{a kb},
-//                       written back to the same positions  I[kb*n1 + a]
-//   pass B ("rows")   : for every kb, the n1-point DFT over a on the contiguous row I[kb*n1 + .],
-//                       written transposed to X[n2*ka + kb]
+//   pass A ("columns"): for every a, the n2-point DFT over b (stride n1), times W_N^{a kb} -> I[kb][a]
+//   pass B ("rows")   : for every kb, the n1-point DFT over a of I[kb][.], written transposed to X[n2*ka + kb]
 //
 // The reference handles any N with the same in-cache pass loop (cfftf1_ps,
 // simd/chowdsp_fft_impl_sse.cpp:372-432) and only changes the scratch strategy for large N
@@ -29,86 +27,136 @@ struct TileFrame
     static constexpr int stride = LdsFrame<N>::floats2 + 1;
 };
 
-// CONTIG_IN_C : global input is contiguous along the frame index c (pass A), else along the element index (pass B)
-template <class P, int C, bool CONTIG_IN_C, bool TWIDDLE, bool SWAP_IN, bool SWAP_OUT>
-__global__ __launch_bounds__ (256) void tile_fft_kernel (const float2* __restrict__ in,
-                                                        float2* __restrict__ out,
-                                                        const float2* __restrict__ stage_tw,
-                                                        const float2* __restrict__ big_tw,
-                                                        unsigned tiles_per_frame,
-                                                        unsigned in_cstride, unsigned in_jstride,
-                                                        unsigned out_kstride,
-                                                        unsigned frame_len, // N (complex points per frame)
-                                                        unsigned batch)
+// phase 2 of both passes: LDS-resident FFT of each of the C frames of the tile image (FS floats2 apart)
+template <class P, int C>
+__device__ __forceinline__ void tile_fft_frames (float2* __restrict__ smem, const TwiddleRegs<P>& tw, int team, int t)
 {
-    extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
-    constexpr int n = P::N;
-    constexpr int FS = TileFrame<n>::stride;
+    constexpr int FS = TileFrame<P::N>::stride;
     constexpr int FPB = 256 / P::T;
     static_assert (C % FPB == 0 || FPB % C == 0, "tile width vs teams per workgroup");
     constexpr int ROUNDS = (C + FPB - 1) / FPB;
+#pragma unroll 1
+    for (int r = 0; r < ROUNDS; ++r)
+    {
+        const int c = r * FPB + team;
+        const bool have = (c < C); // only false when FPB > C (then T <= 64 and fft_core uses wave-local sync only)
+        float2* lds = smem + (have ? c : 0) * FS;
+        float2 v[P::R];
+        if (have)
+            lds_load_input_order<P> (v, lds, t);
+        __syncthreads();
+        if (have)
+            fft_core<P> (v, tw, lds, t); // T > 64: its workgroup barriers are reached by every team (have is uniform)
+        __syncthreads();
+        if (have)
+            lds_store_output_order<P> (v, lds, t);
+    }
+}
+
+// Workspace layout between the passes ("tile-major"): frame f, pass-A tile tA (CA adjacent columns),
+// output row kb, column c inside the tile:   W[f*N + (tA*n2 + kb)*CA + c]
+// -> pass A stores one fully contiguous n2*CA block per tile, pass B gathers CB*CA-element (2 KiB) runs.
+// The inter-pass twiddle table uses the same order, so its reads are contiguous as well.
+
+// ---- pass A: n2-point column FFTs of CA adjacent columns, times W_N^{a*kb} ----------------------------
+template <class P, int CA, bool SWAP_IN>
+__global__ __launch_bounds__ (256) void pass_a_kernel (const float2* __restrict__ in,
+                                                      float2* __restrict__ work,
+                                                      const float2* __restrict__ stage_tw,
+                                                      const float2* __restrict__ big_tw,
+                                                      unsigned n1,
+                                                      unsigned batch)
+{
+    extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
+    constexpr int n2 = P::N;
+    constexpr int FS = TileFrame<n2>::stride;
     const int tid = threadIdx.x;
     const int team = tid / P::T;
     const int t = tid % P::T;
-
     TwiddleRegs<P> tw;
     load_twiddles<P> (tw, stage_tw, t);
 
-    const size_t nwork = (size_t) batch * tiles_per_frame;
+    const unsigned tiles = n1 / CA;
+    const size_t frame_len = (size_t) n1 * n2;
+    const size_t nwork = (size_t) batch * tiles;
     for (size_t w = blockIdx.x; w < nwork; w += gridDim.x)
     {
-        const unsigned f = (unsigned) (w / tiles_per_frame);
-        const unsigned tile = (unsigned) (w % tiles_per_frame);
-        const float2* __restrict__ src = in + (size_t) f * frame_len + (size_t) tile * C * in_cstride;
-        float2* __restrict__ dst = out + (size_t) f * frame_len + (size_t) tile * C;
-        const float2* __restrict__ twp = big_tw + (size_t) tile * C;
+        const unsigned f = (unsigned) (w / tiles);
+        const unsigned tile = (unsigned) (w % tiles);
+        const float2* __restrict__ src = in + (size_t) f * frame_len + (size_t) tile * CA;
+        float2* __restrict__ dst = work + (size_t) f * frame_len + (size_t) tile * (n2 * CA);
+        const float2* __restrict__ twp = big_tw + (size_t) tile * (n2 * CA);
 
-        // ---- phase 1: coalesced tile load into the LDS image --------------------------------
         __syncthreads(); // previous tile fully stored
 #pragma unroll 4
-        for (int e = tid; e < C * n; e += 256)
+        for (int e = tid; e < CA * n2; e += 256)
         {
-            const int c = CONTIG_IN_C ? (e % C) : (e / n);
-            const int j = CONTIG_IN_C ? (e / C) : (e % n);
-            const float2 x = src[(size_t) c * in_cstride + (size_t) j * in_jstride];
+            const int c = e % CA, j = e / CA;
+            const float2 x = gload (&src[(size_t) j * n1 + c]); // caller's input: streamed once
             smem[c * FS + lds_phys (j)] = SWAP_IN ? make_float2 (x.y, x.x) : x;
         }
         __syncthreads();
-
-        // ---- phase 2: LDS-resident FFT of every frame of the tile ---------------------------
-#pragma unroll 1
-        for (int r = 0; r < ROUNDS; ++r)
+        tile_fft_frames<P, CA> (smem, tw, team, t);
+        __syncthreads();
+#pragma unroll 4
+        for (int e = tid; e < CA * n2; e += 256)
         {
-            const int c = r * FPB + team;
-            const bool have = (c < C); // only false when FPB > C
-            float2* lds = smem + (have ? c : 0) * FS;
-            float2 v[P::R];
-            if (have)
-                lds_load_input_order<P> (v, lds, t);
-            __syncthreads();
-            if (have)
-            {
-                // fft_core synchronises with team_sync<T>(): whole-workgroup barriers when T > 64, wave-local otherwise.
-                // With T > 64 every team must reach the barriers, which holds because have is workgroup-uniform then.
-                fft_core<P> (v, tw, lds, t);
-            }
-            __syncthreads();
-            if (have)
-                lds_store_output_order<P> (v, lds, t);
+            const int c = e % CA, k = e / CA;
+            dst[e] = cmul (smem[c * FS + lds_phys (k)], twp[e]); // plain store: the workspace should stay cached
+        }
+    }
+}
+
+// ---- pass B: n1-point row FFTs of CB adjacent rows, transposed store X[n2*ka + kb] -------------------
+template <class P, int CB, bool SWAP_OUT>
+__global__ __launch_bounds__ (256) void pass_b_kernel (const float2* __restrict__ work,
+                                                      float2* __restrict__ out,
+                                                      const float2* __restrict__ stage_tw,
+                                                      unsigned n2,
+                                                      unsigned ca_log2, // log2 of pass A's tile width
+                                                      unsigned batch)
+{
+    extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
+    constexpr int n1 = P::N;
+    constexpr int FS = TileFrame<n1>::stride;
+    const int tid = threadIdx.x;
+    const int team = tid / P::T;
+    const int t = tid % P::T;
+    TwiddleRegs<P> tw;
+    load_twiddles<P> (tw, stage_tw, t);
+
+    const unsigned tiles = n2 / CB;
+    const size_t frame_len = (size_t) n1 * n2;
+    const size_t nwork = (size_t) batch * tiles;
+    const unsigned ca = 1u << ca_log2;
+    for (size_t w = blockIdx.x; w < nwork; w += gridDim.x)
+    {
+        const unsigned f = (unsigned) (w / tiles);
+        const unsigned tile = (unsigned) (w % tiles);
+        const unsigned kb0 = tile * CB;
+        const float2* __restrict__ src = work + (size_t) f * frame_len;
+        float2* __restrict__ dst = out + (size_t) f * frame_len + kb0;
+
+        __syncthreads();
+#pragma unroll 4
+        for (int e = tid; e < CB * n1; e += 256)
+        {
+            // c fastest (ca), then the tile's row kbl (CB), then pass A's tile index tA
+            const unsigned c = (unsigned) e & (ca - 1);
+            const unsigned kbl = ((unsigned) e >> ca_log2) % CB;
+            const unsigned tA = ((unsigned) e >> ca_log2) / CB;
+            const float2 x = src[((size_t) tA * n2 + kb0 + kbl) * ca + c];
+            smem[kbl * FS + lds_phys ((int) (tA * ca + c))] = x;
         }
         __syncthreads();
-
-        // ---- phase 3: coalesced (twiddled) store, contiguous along c -------------------------
+        tile_fft_frames<P, CB> (smem, tw, team, t);
+        __syncthreads();
 #pragma unroll 4
-        for (int e = tid; e < C * n; e += 256)
+        for (int e = tid; e < CB * n1; e += 256)
         {
-            const int c = e % C;
-            const int k = e / C;
-            float2 y = smem[c * FS + lds_phys (k)];
-            const size_t o = (size_t) k * out_kstride + c;
-            if (TWIDDLE)
-                y = cmul (y, twp[o]);
-            dst[o] = SWAP_OUT ? make_float2 (y.y, y.x) : y;
+            const int c = e % CB, k = e / CB;
+            const float2 y = smem[c * FS + lds_phys (k)];
+            gstore (&dst[(size_t) k * n2 + c], SWAP_OUT ? make_float2 (y.y, y.x) : y); // result: streamed once
         }
     }
 }
@@ -156,5 +204,175 @@ __global__ __launch_bounds__ (256) void real_pair_kernel (const float2* __restri
         gstore (&dst[k], rk);
         gstore (&dst[kp], rp);
     }
+}
+
+
+// =====================================================================================================
+// Fast path for N = 65536 = 256 x 256 (BASELINE configuration 5; also the core of real N = 131072).
+//
+// Both passes are built like the single-pass kernel: 16 global loads per work-item straight into VGPRs, radix-16,
+// ONE LDS exchange, radix-16, 16 global stores -- no staging copies, two workgroup barriers per tile, and the next
+// tile's loads are issued before this tile's arithmetic (software pipeline, loop-top wait vmcnt(16)).
+// A tile is 16 adjacent columns (pass A) / rows (pass B); the 256 work-items are 16 teams x 16 butterflies with the
+// teams INTERLEAVED across lanes (lane = column + 16 * butterfly) so that one wave-instruction touches 4 x 128
+// contiguous bytes of the strided side, and 512 contiguous bytes of the workspace side.
+//
+// Workspace ("block") layout between the passes: 16 x 16 blocks,
+//     W[f*N + ((a >> 4) * 16 + (kb >> 4)) * 256 + (a & 15) * 16 + (kb & 15)]
+// (a = column / pass-B element index, kb = pass-A output index / pass-B row).  Pass A writes it with lanes
+// (kb&15 fastest, a&15 next) -- it re-maps its work-items across the LDS exchange to get there -- and pass B reads
+// it with lane = (kb&15) + 16*(a&15): both sides move 2 KiB contiguous per workgroup instruction.  The inter-pass
+// twiddle table is stored in the same order.
+// =====================================================================================================
+using Plan256 = Plan<256, 16, 16, 16>;
+static constexpr int kFS256 = TileFrame<256>::stride;
+
+__device__ __forceinline__ void load_stage1_twiddles_256 (float2 (&w)[15], const float2* __restrict__ stage_tw, int k)
+{
+#pragma unroll
+    for (int a = 1; a < 16; ++a)
+        w[a - 1] = stage_tw[Plan256::tw_offset (1) + (a - 1) * 16 + k];
+}
+
+// radix-16 stage 0 on v (no twiddle), exchange through the tile image, radix-16 stage 1 with twiddles w.
+// Stage 0 role: team c0, butterfly t0.  Stage 1 role: team c1, butterfly i1.  Result: v[b] = Y_{c1}[i1 + 16 b].
+__device__ __forceinline__ void fft256_two_stage (float2 (&v)[16], const float2 (&w)[15], float2* __restrict__ smem,
+                                                  int c0, int t0, int c1, int i1)
+{
+    fft_reg<16> (v);
+    __syncthreads(); // the previous tile's stage-1 reads are finished
+#pragma unroll
+    for (int b = 0; b < 16; ++b)
+        smem[c0 * kFS256 + 17 * t0 + b] = v[b]; // lds_phys (16*t0 + b) = 17*t0 + b
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 16; ++a)
+        v[a] = smem[c1 * kFS256 + i1 + 17 * a]; // lds_phys (i1 + 16*a) = i1 + 17*a
+#pragma unroll
+    for (int a = 1; a < 16; ++a)
+        v[a] = cmul (v[a], w[a - 1]);
+    fft_reg<16> (v);
+}
+
+template <bool SWAP_IN>
+__global__ __launch_bounds__ (256) void pass_a256_kernel (const float2* __restrict__ in,
+                                                         float2* __restrict__ work,
+                                                         const float2* __restrict__ stage_tw,
+                                                         const float2* __restrict__ big_tw,
+                                                         unsigned batch)
+{
+    extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
+    constexpr unsigned n1 = 256, N = 65536, tiles = 16;
+    const int tid = threadIdx.x;
+    const int c0 = tid & 15, t0 = tid >> 4; // stage 0: lanes run along the 16 columns of the tile
+    const int i1 = tid & 15, c1 = tid >> 4; // stage 1: lanes run along the butterfly index
+    float2 w[15];
+    load_stage1_twiddles_256 (w, stage_tw, i1);
+
+    const unsigned nwork = batch * tiles;
+    unsigned wk = blockIdx.x;
+    if (wk >= nwork)
+        return;
+    float nre[16], nim[16];
+#define CFFT_A256_LOAD(W, RE, IM)                                                                  \
+    {                                                                                              \
+        const float2* __restrict__ src_ = in + (size_t) ((W) / tiles) * N + ((W) % tiles) * 16;    \
+        _Pragma ("unroll") for (int s = 0; s < 16; ++s)                                            \
+        {                                                                                          \
+            const float2 x_ = gload (&src_[(unsigned) (t0 + 16 * s) * n1 + c0]);                   \
+            RE[s] = SWAP_IN ? x_.y : x_.x;                                                         \
+            IM[s] = SWAP_IN ? x_.x : x_.y;                                                         \
+        }                                                                                          \
+    }
+#define CFFT_A256_BODY(W, V)                                                                       \
+    {                                                                                              \
+        const unsigned wn_ = (W) + gridDim.x;                                                      \
+        if (wn_ < nwork)                                                                           \
+            CFFT_A256_LOAD (wn_, nre, nim)                                                         \
+        fft256_two_stage (V, w, smem, c0, t0, c1, i1);                                             \
+        const size_t base_ = (size_t) (((W) % tiles) * 16) * 256 + c1 * 16 + i1;                   \
+        float2* __restrict__ dst_ = work + (size_t) ((W) / tiles) * N + base_;                     \
+        const float2* __restrict__ twp_ = big_tw + base_;                                          \
+        _Pragma ("unroll") for (int b = 0; b < 16; ++b)                                            \
+            dst_[b * 256] = cmul (V[b], twp_[b * 256]);                                            \
+    }
+    {
+        float2 v[16];
+        float re[16], im[16];
+        CFFT_A256_LOAD (wk, re, im)
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+            v[s] = make_float2 (re[s], im[s]);
+        CFFT_A256_BODY (wk, v)
+    }
+    for (wk += gridDim.x; wk < nwork; wk += gridDim.x)
+    {
+        float2 v[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+            v[s] = make_float2 (nre[s], nim[s]);
+        CFFT_A256_BODY (wk, v)
+    }
+#undef CFFT_A256_BODY
+#undef CFFT_A256_LOAD
+}
+
+template <bool SWAP_OUT>
+__global__ __launch_bounds__ (256) void pass_b256_kernel (const float2* __restrict__ work,
+                                                         float2* __restrict__ out,
+                                                         const float2* __restrict__ stage_tw,
+                                                         unsigned batch)
+{
+    extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
+    constexpr unsigned n2 = 256, N = 65536, tiles = 16;
+    const int tid = threadIdx.x;
+    const int kbl = tid & 15, t = tid >> 4; // both stages: lanes run along the 16 rows of the tile
+    float2 w[15];
+    load_stage1_twiddles_256 (w, stage_tw, t);
+
+    const unsigned nwork = batch * tiles;
+    unsigned wk = blockIdx.x;
+    if (wk >= nwork)
+        return;
+    float nre[16], nim[16];
+#define CFFT_B256_LOAD(W, RE, IM)                                                                  \
+    {                                                                                              \
+        const float2* __restrict__ src_ = work + (size_t) ((W) / tiles) * N + ((W) % tiles) * 256 + tid; \
+        _Pragma ("unroll") for (int s = 0; s < 16; ++s)                                            \
+        {                                                                                          \
+            const float2 x_ = src_[s * 16 * 256]; /* block (a_hi = s, kb_hi = tile), element tid */ \
+            RE[s] = x_.x;                                                                          \
+            IM[s] = x_.y;                                                                          \
+        }                                                                                          \
+    }
+#define CFFT_B256_BODY(W, V)                                                                       \
+    {                                                                                              \
+        const unsigned wn_ = (W) + gridDim.x;                                                      \
+        if (wn_ < nwork)                                                                           \
+            CFFT_B256_LOAD (wn_, nre, nim)                                                         \
+        fft256_two_stage (V, w, smem, kbl, t, kbl, t);                                             \
+        float2* __restrict__ dst_ = out + (size_t) ((W) / tiles) * N + ((W) % tiles) * 16 + kbl;   \
+        _Pragma ("unroll") for (int b = 0; b < 16; ++b)                                            \
+            gstore (&dst_[(unsigned) (t + 16 * b) * n2], SWAP_OUT ? make_float2 (V[b].y, V[b].x) : V[b]); \
+    }
+    {
+        float2 v[16];
+        float re[16], im[16];
+        CFFT_B256_LOAD (wk, re, im)
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+            v[s] = make_float2 (re[s], im[s]);
+        CFFT_B256_BODY (wk, v)
+    }
+    for (wk += gridDim.x; wk < nwork; wk += gridDim.x)
+    {
+        float2 v[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+            v[s] = make_float2 (nre[s], nim[s]);
+        CFFT_B256_BODY (wk, v)
+    }
+#undef CFFT_B256_BODY
+#undef CFFT_B256_LOAD
 }
 } // namespace cfft

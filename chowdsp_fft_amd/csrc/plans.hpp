@@ -40,6 +40,16 @@ struct Geometry
     static constexpr size_t lds_bytes = (size_t) FPB * LdsFrame<P::N>::floats2 * sizeof (float2);
 };
 
+// Width (adjacent columns / rows) of the tiles the two-pass kernels work on, for a core of length n:
+// at least 16 (128 contiguous bytes per global access), at least one frame per team of the 256-thread workgroup,
+// and an LDS image small enough for two workgroups per CU.
+constexpr int tile_width (int n, int team_threads)
+{
+    const int fpb = 256 / team_threads;
+    return n >= 1024 ? 8 : (fpb > 16 ? fpb : 16);
+}
+inline int tile_width_for (int n); // run-time version, defined after core_plan_desc
+
 // Run-time mirror of a Plan, for the host-side table builder.
 struct PlanDesc
 {
@@ -76,5 +86,10 @@ inline bool core_plan_desc (int n, PlanDesc& d)
         case 4096: d = describe<CorePlan<4096>::type>(); return true;
         default: return false;
     }
+}
+inline int tile_width_for (int n)
+{
+    PlanDesc d;
+    return core_plan_desc (n, d) ? tile_width (d.N, d.T) : 0;
 }
 } // namespace cfft

@@ -94,7 +94,7 @@ bool build_host_tables (int N, int transform, HostTables& out)
     }
 
     // multi-pass: nc = n1 * n2.  stage tables of the two cores are stored back to back
-    // (n2 core first), the inter-pass twiddle W_nc^{a*k2}, a < n1, k2 < n2, laid out [k2][a].
+    // (n2 core first), the inter-pass twiddle W_nc^{a*k2}, a < n1, k2 < n2, in tile-major order.
     int n1 = 0, n2 = 0;
     split_large (nc, n1, n2);
     out.core_n = 0;
@@ -104,9 +104,22 @@ bool build_host_tables (int N, int transform, HostTables& out)
     append_stage_twiddles (d2, out.stage_twiddles);
     append_stage_twiddles (d1, out.stage_twiddles);
     out.big_twiddles.reserve ((size_t) nc);
-    for (int k2 = 0; k2 < n2; ++k2)
-        for (int a = 0; a < n1; ++a)
-            out.big_twiddles.push_back (unit_root ((long long) a * k2, nc));
+    if (n1 == 256 && n2 == 256)
+    {
+        // 65536 = 256 x 256 fast path: 16 x 16 block order [a>>4][k2>>4][a&15][k2&15] (multipass_kernels.hpp)
+        for (int ah = 0; ah < 16; ++ah)
+            for (int kh = 0; kh < 16; ++kh)
+                for (int al = 0; al < 16; ++al)
+                    for (int kl = 0; kl < 16; ++kl)
+                        out.big_twiddles.push_back (unit_root ((long long) (ah * 16 + al) * (kh * 16 + kl), nc));
+        return true;
+    }
+    // W_nc^{a*k2} in the workspace's tile-major order: [tile tA][k2][c], a = tA*CA + c (multipass_kernels.hpp)
+    const int ca = tile_width_for (n2);
+    for (int ta = 0; ta < n1 / ca; ++ta)
+        for (int k2 = 0; k2 < n2; ++k2)
+            for (int c = 0; c < ca; ++c)
+                out.big_twiddles.push_back (unit_root ((long long) (ta * ca + c) * k2, nc));
     return true;
 }
 } // namespace cfft::host
