@@ -20,7 +20,11 @@ template <> struct CorePlan<128>  { using type = Plan<128,  8,  16, 8>;         
 template <> struct CorePlan<256>  { using type = Plan<256,  16, 16, 16>;         };
 template <> struct CorePlan<512>  { using type = Plan<512,  64,  8, 8, 8>;       };
 template <> struct CorePlan<1024> { using type = Plan<1024, 64, 16, 16, 4>;      };
+#if defined(CFFT_PLAN2048_ALT) && CFFT_PLAN2048_ALT == 1
+template <> struct CorePlan<2048> { using type = Plan<2048, 256, 8, 8, 8, 4>;    }; // experiment: 8 points per work-item
+#else
 template <> struct CorePlan<2048> { using type = Plan<2048, 128, 16, 16, 8>;     };
+#endif
 #if defined(CFFT_PLAN4096_ALT) && CFFT_PLAN4096_ALT == 1
 template <> struct CorePlan<4096> { using type = Plan<4096, 512, 8, 8, 8, 8>;    }; // experiment: 8 waves per frame
 #else
