@@ -38,6 +38,8 @@ WORKLOADS = {
     "real_n1024_b262144_fwd_inv": (1024, "real", 262144, "BASELINE configs[2]: N=1024 fp32 real r2c+c2r, batch=262144 per GPU"),
     "c2c_n65536_b8192_fwd_inv": (65536, "complex", 8192, "BASELINE configs[4]: N=65536 fp32 complex (two-pass), batch=8192 per GPU"),
     "conv_real_n4096_b131072": (4096, "real", 131072, "BASELINE configs[3] per-GPU share: fused fwd->mul->inv frames, N=4096 real, 131072 frames per GPU"),
+    # streaming partitioned overlap-save engine; one step = one block of 2048 samples on every channel
+    "ols_engine_b2048_p16_c8192": (4096, "real", 8192, "partitioned overlap-save engine: block 2048 (N=4096 real), 16 partitions, 8192 channels per GPU"),
 }
 
 
@@ -143,19 +145,28 @@ def main() -> int:
     y = torch.empty_like(x)
     z = torch.empty_like(x)
     fused = args.workload.startswith("conv_")
+    engine = None
+    if args.workload.startswith("ols_engine"):
+        block, parts = n // 2, 16
+        ir = torch.rand((block * parts,), device=dev, generator=g) * 2 - 1
+        engine = api.ConvEngine(block, frames, ir, shared=True)
+        x = torch.rand((frames, block), device=dev, generator=g) * 2 - 1
+        y = torch.empty_like(x)
     if fused:
         h = torch.rand((1, frame_floats), device=dev, generator=g) * 2 - 1
         H = torch.empty_like(h)
         api.fft_transform_unordered_batch(setup, h, H, api.FFT_FORWARD)
 
     def step():
-        if fused:
+        if engine is not None:
+            engine.process(x, y)
+        elif fused:
             api.fft_convolve_frames_batch(setup, x, H, y, 1.0 / n)
         else:
             api.fft_transform_batch(setup, x, y, api.FFT_FORWARD)
             api.fft_transform_batch(setup, y, z, api.FFT_BACKWARD)
 
-    launches_per_step = 1 if fused else 2
+    launches_per_step = 1 if (fused or engine is not None) else 2
     transforms_per_frame_step = 2  # forward + backward (fused: both inside one kernel)
 
     for _ in range(args.warmup):
@@ -179,7 +190,7 @@ def main() -> int:
     event_ms = sharding.max_over_ranks(ev0.elapsed_time(ev1), device=dev)
 
     # sanity on the timed data: BACKWARD(FORWARD(x)) = N x  (cheap, outside the timed region)
-    if not fused:
+    if not fused and engine is None:
         err = float((z[:256] / n - x[:256]).abs().max())
         if not err < 5e-6:
             sys.stderr.write(f"[bench] round-trip check failed: {err}\n")
@@ -204,6 +215,10 @@ def main() -> int:
         launches = launches_per_step * args.steps
         avg_launch_s = event_ms * 1e-3 / launches
         alg_bytes_per_launch = (4 * frame_floats * 2) * frames  # read + write one frame each, per launch
+        if engine is not None:
+            # per channel and block: new samples in + out (2*L), the delay line re-read (P*N) and its new slot written (N)
+            alg_bytes_per_launch = 4 * frames * (2 * (n // 2) + 16 * n + n)
+            transforms_per_frame_step = 2
         achieved = alg_bytes_per_launch / avg_launch_s / 1e9
         kernel = {"complex": "cfft::c2c_kernel<Plan<4096,256,16,16,16>> (forward and backward instantiations)"}.get(
             transform if n == 4096 and not fused else "", f"{args.workload} kernels")

@@ -166,6 +166,38 @@ def fft_convolve_frames_batch(setup, x, dft_filter, y, scaling: float, batch: in
            "fft_convolve_frames_batch")
 
 
+class ConvEngine:
+    """Streaming partitioned overlap-save convolver (include/chowdsp_fft_gpu.h, fft_conv_engine_*)."""
+
+    def __init__(self, block: int, channels: int, ir, shared: bool = True, stream=None):
+        ir_len = ir.shape[-1]
+        self.block, self.channels = block, channels
+        self._h = _lib.lib().fft_conv_engine_create(block, channels, _ptr(ir), ir_len, 1 if shared else 0, _stream_handle(stream))
+        if not self._h:
+            raise FFTError("fft_conv_engine_create failed: " + _lib.lib().fft_gpu_last_error().decode(errors="replace"))
+
+    @property
+    def partitions(self) -> int:
+        return int(_lib.lib().fft_conv_engine_partitions(self._h))
+
+    def process(self, x, y, stream=None) -> None:
+        _check(_lib.lib().fft_conv_engine_process(self._h, _ptr(x), _ptr(y), _stream_handle(stream)), "fft_conv_engine_process")
+
+    def reset(self, stream=None) -> None:
+        _check(_lib.lib().fft_conv_engine_reset(self._h, _stream_handle(stream)), "fft_conv_engine_reset")
+
+    def close(self) -> None:
+        if self._h:
+            _lib.lib().fft_conv_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def size_supported(N: int, transform: int) -> bool:
     return bool(_lib.lib().fft_gpu_size_supported(N, transform))
 

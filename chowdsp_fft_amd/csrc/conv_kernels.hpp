@@ -67,6 +67,79 @@ __global__ __launch_bounds__ (256) void accumulate_kernel (const float* __restri
         ab[i] = a[i] + b[i];
 }
 
+// ---- streaming partitioned convolution engine: frequency-domain delay line kernels -------------
+// Y[c][k] = sum_{p<P} FDL[(head - p) mod P][c][k] * H[p][c or 0][k] * scale, accumulated in partition order
+// (= P successive fft_convolve_unordered calls into a zeroed ab; reference sse.cpp:1621-1644 for one of them).
+__global__ __launch_bounds__ (256) void fdl_mac_kernel (const float4* __restrict__ fdl,
+                                                       const float4* __restrict__ H,
+                                                       float4* __restrict__ Y,
+                                                       float scale,
+                                                       unsigned pairs_per_frame,
+                                                       unsigned channels,
+                                                       unsigned P,
+                                                       unsigned head,
+                                                       int h_shared)
+{
+    const size_t total = (size_t) channels * pairs_per_frame;
+    const size_t stride = (size_t) gridDim.x * blockDim.x;
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride)
+    {
+        const unsigned c = (unsigned) (i / pairs_per_frame);
+        const unsigned k = (unsigned) (i % pairs_per_frame);
+        float4 acc = make_float4 (0.f, 0.f, 0.f, 0.f);
+        for (unsigned p = 0; p < P; ++p)
+        {
+            const unsigned slot = (head + P - p) % P;
+            const float4 a = fdl[((size_t) slot * channels + c) * pairs_per_frame + k];
+            const float4 b = H[((size_t) p * (h_shared ? 1u : channels) + (h_shared ? 0u : c)) * pairs_per_frame + k];
+            float r0 = a.x * b.x - a.y * b.y;
+            float i0 = a.x * b.y + a.y * b.x;
+            const float r1 = a.z * b.z - a.w * b.w;
+            const float i1 = a.z * b.w + a.w * b.z;
+            if (k == 0)
+            {
+                r0 = a.x * b.x; // packed DC and Nyquist bins are purely real
+                i0 = a.y * b.y;
+            }
+            acc.x += r0 * scale;
+            acc.y += i0 * scale;
+            acc.z += r1 * scale;
+            acc.w += i1 * scale;
+        }
+        gstore4 (&Y[i], acc);
+    }
+}
+
+// frame[c] = [prev[c] | in[c]] ; prev[c] = in[c]      (L = block floats, multiples of 4)
+__global__ __launch_bounds__ (256) void ols_assemble_kernel (const float4* __restrict__ in, float4* __restrict__ prev,
+                                                            float4* __restrict__ frame, unsigned quads_per_block, unsigned channels)
+{
+    const size_t total = (size_t) channels * quads_per_block;
+    const size_t stride = (size_t) gridDim.x * blockDim.x;
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride)
+    {
+        const size_t c = i / quads_per_block, q = i % quads_per_block;
+        const float4 x = in[i];
+        const float4 old = prev[i];
+        frame[c * 2 * quads_per_block + q] = old;
+        frame[c * 2 * quads_per_block + quads_per_block + q] = x;
+        prev[i] = x;
+    }
+}
+
+// out[c] = second half of y[c]
+__global__ __launch_bounds__ (256) void ols_extract_kernel (const float4* __restrict__ y, float4* __restrict__ out,
+                                                           unsigned quads_per_block, unsigned channels)
+{
+    const size_t total = (size_t) channels * quads_per_block;
+    const size_t stride = (size_t) gridDim.x * blockDim.x;
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride)
+    {
+        const size_t c = i / quads_per_block, q = i % quads_per_block;
+        out[i] = y[c * 2 * quads_per_block + quads_per_block + q];
+    }
+}
+
 // ---- fused: y = BACKWARD( FORWARD(x) * H ) * scaling, one kernel, spectrum never leaves the CU -----
 // COMPLEX plan: P is the N point plan, H has N complex bins in canonical order.
 template <class P, int FPB>

@@ -70,6 +70,34 @@ hipError_t launch_accumulate (const float* a, const float* b, float* ab, size_t 
     return hipGetLastError();
 }
 
+hipError_t launch_fdl_mac (const float* fdl, const float* H, float* Y, float scale, size_t frame_floats, unsigned channels, unsigned P, unsigned head, bool h_shared, hipStream_t stream)
+{
+    const unsigned ppf = (unsigned) (frame_floats / 4);
+    const unsigned grid = stream_grid ((size_t) channels * ppf);
+    if (grid == 0)
+        return hipErrorNoDevice;
+    hipLaunchKernelGGL (fdl_mac_kernel, dim3 (grid), dim3 (256), 0, stream, (const float4*) fdl, (const float4*) H, (float4*) Y, scale, ppf, channels, P, head, h_shared ? 1 : 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_ols_assemble (const float* in, float* prev, float* frame, size_t block, unsigned channels, hipStream_t stream)
+{
+    const unsigned grid = stream_grid ((size_t) channels * block / 4);
+    if (grid == 0)
+        return hipErrorNoDevice;
+    hipLaunchKernelGGL (ols_assemble_kernel, dim3 (grid), dim3 (256), 0, stream, (const float4*) in, (float4*) prev, (float4*) frame, (unsigned) (block / 4), channels);
+    return hipGetLastError();
+}
+
+hipError_t launch_ols_extract (const float* y, float* out, size_t block, unsigned channels, hipStream_t stream)
+{
+    const unsigned grid = stream_grid ((size_t) channels * block / 4);
+    if (grid == 0)
+        return hipErrorNoDevice;
+    hipLaunchKernelGGL (ols_extract_kernel, dim3 (grid), dim3 (256), 0, stream, (const float4*) y, (float4*) out, (unsigned) (block / 4), channels);
+    return hipGetLastError();
+}
+
 hipError_t launch_conv_frames_c2c (int n, const float2* in, const float2* H, float2* out, const float2* stage_tw, float scaling, size_t batch, hipStream_t stream)
 {
     if (batch == 0)

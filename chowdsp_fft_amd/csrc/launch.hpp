@@ -18,6 +18,11 @@ hipError_t launch_c2r (int m, const float2* in, float2* out, const float2* stage
 hipError_t launch_conv_mac (bool real_packed, const float* a, const float* b, float* ab, float scaling, size_t cplx_per_frame, size_t batch, bool b_is_shared, hipStream_t stream);
 hipError_t launch_accumulate (const float* a, const float* b, float* ab, size_t count, hipStream_t stream);
 
+// streaming partitioned convolution engine (conv_engine.cpp)
+hipError_t launch_fdl_mac (const float* fdl, const float* H, float* Y, float scale, size_t frame_floats, unsigned channels, unsigned P, unsigned head, bool h_shared, hipStream_t stream);
+hipError_t launch_ols_assemble (const float* in, float* prev, float* frame, size_t block, unsigned channels, hipStream_t stream);
+hipError_t launch_ols_extract (const float* y, float* out, size_t block, unsigned channels, hipStream_t stream);
+
 // fused forward -> *H*scaling -> backward
 hipError_t launch_conv_frames_c2c (int n, const float2* in, const float2* H, float2* out, const float2* stage_tw, float scaling, size_t batch, hipStream_t stream);
 hipError_t launch_conv_frames_real (int m, const float2* in, const float2* H, float2* out, const float2* stage_tw, const float2* real_tw, float scaling, size_t batch, hipStream_t stream);

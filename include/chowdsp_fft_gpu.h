@@ -97,6 +97,26 @@ int fft_accumulate_batch (void* setup, const float* a, const float* b, float* ab
    Available for LDS-resident sizes (N <= 4096 complex, N <= 8192 real); FFT_GPU_ENOTSUP otherwise. */
 int fft_convolve_frames_batch (void* setup, const float* x, const float* dft_filter, float* y, float scaling, size_t batch, void* stream);
 
+/* ---- streaming partitioned convolution engine -----------------------------------
+   The caller-side structure that fft_convolve_unordered's "ab += a*b*scaling" and fft_accumulate exist for
+   (reference chowdsp_fft.h:147-160, usage test/test.cpp:212-218), which the reference leaves to its callers:
+   a uniformly partitioned overlap-save convolver for `channels` independent streams.  An impulse response of
+   ir_len taps is cut into P = ceil(ir_len / block) partitions of `block` taps, each kept as the (unordered) REAL
+   spectrum of a 2*block frame.  Every fft_conv_engine_process() call consumes `block` new samples per channel and
+   produces `block` output samples per channel:
+       frame = [previous block | new block]                      (2*block samples)
+       X_t   = fft_transform_unordered (frame, FORWARD)            -> pushed into a frequency-domain delay line
+       Y     = sum_{p<P} X_{t-p} * H_p * (1 / (2*block))          (P x fft_convolve_unordered)
+       y     = fft_transform_unordered (Y, BACKWARD), last `block` samples are the output
+   All state (delay line, filter spectra, previous block) lives on the device.  `block` must be a power of two,
+   16 <= block <= 2^19.  ir: host or device pointer, [ir_len] if ir_is_shared else [channels][ir_len].
+   in / out: device pointers, [channels][block] floats each.  Returns NULL / negative codes on failure. */
+void* fft_conv_engine_create (int block, int channels, const float* ir, int ir_len, int ir_is_shared, void* stream);
+int fft_conv_engine_process (void* engine, const float* in, float* out, void* stream);
+int fft_conv_engine_reset (void* engine, void* stream);
+int fft_conv_engine_partitions (void* engine);
+void fft_conv_engine_destroy (void* engine);
+
 #ifdef __cplusplus
 } // namespace chowdsp::fft
 } // extern "C"
