@@ -16,6 +16,7 @@
 #include <mutex>
 #include <new>
 #include <utility>
+#include <vector>
 
 using namespace cfft::host;
 namespace cf = chowdsp::fft;
@@ -212,7 +213,13 @@ int run_transform (Setup* s, const float* in, float* out, size_t batch, cf::fft_
     const float2* cin = (const float2*) in;
     float2* cout = (float2*) out;
     hipError_t e = hipSuccess;
-    if (s->transform == cf::FFT_COMPLEX)
+    if (t->gen_ns > 0)
+    {
+        // N = 2^a 3^b 5^c, not a power of two: generic mixed-radix kernel
+        const int mode = (s->transform == cf::FFT_COMPLEX) ? 0 : (inverse ? 2 : 1);
+        e = launch_generic (mode, inverse, nc, *t, cin, cout, batch, stream);
+    }
+    else if (s->transform == cf::FFT_COMPLEX)
     {
         if (! lds_resident)
             return big_c2c_chunked (s, nc, inverse, cin, cout, batch, stream);
@@ -526,6 +533,18 @@ int fft_gpu_plan_describe (int N, fft_transform_t transform, int desc[8])
     if (desc == nullptr || ! size_supported (N, (int) transform))
         return FFT_GPU_EINVAL;
     const int nc = (transform == FFT_COMPLEX) ? N : N / 2;
+    if ((nc & (nc - 1)) != 0)
+    {
+        // mixed-radix plan of the generic kernel: one pass, first four stage radices reported
+        std::vector<int> r;
+        generic_plan_radices (nc, r);
+        desc[0] = nc;
+        desc[1] = 1;
+        desc[2] = desc[3] = 0;
+        for (int i = 0; i < 4; ++i)
+            desc[4 + i] = i < (int) r.size() ? r[(size_t) i] : 0;
+        return FFT_GPU_OK;
+    }
     int n1 = 0, n2 = 0;
     split_large (nc, n1, n2);
     int radix[4] = { 0, 0, 0, 0 };
@@ -555,7 +574,7 @@ int fft_gpu_setup_is_real (void* setup)
 size_t fft_gpu_workspace_bytes (void* setup, size_t batch)
 {
     Setup* s = as_setup (setup);
-    if (s == nullptr || s->tables->core_n == complex_len (s))
+    if (s == nullptr || s->tables->core_n == complex_len (s) || s->tables->gen_ns > 0)
         return 0;
     const size_t frame_bytes = (size_t) complex_len (s) * sizeof (float2);
     size_t chunk = workspace_cap() / (size_t) lane_count() / frame_bytes;

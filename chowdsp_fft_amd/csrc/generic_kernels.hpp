@@ -1,0 +1,203 @@
+// Mixed-radix (2, 3, 4, 5, 8) frames that are not powers of two: N = 2^a * 3^b * 5^c, the rest of the reference's
+// accepted size set (simd/chowdsp_fft_impl_common.hpp:51-82, 216-225; exercised by the reference's "Other sizes"
+// tests, test/test.cpp:279-285: 96, 192, 384, 480, 640, 768, 9216).  SURVEY section 8 row f2.
+//
+// Replaces passf3_ps / passf5_ps (simd/chowdsp_fft_impl_sse.cpp:182-219, 298-370) and, through the same
+// half-length-complex + pair-stage scheme as real_kernels.hpp, radf3/5 and radb3/5 (:588-625, :704-786, :1126-1170,
+// :1262-1356).  One 256-work-item workgroup per frame, the whole frame ping-pongs between two LDS images, one
+// Stockham stage per radix with a RUN-TIME radix list (these sizes are an open set, so there is no per-size template
+// plan); per-stage twiddles come from a table in L2.  This path favours generality over the last 20 % of bandwidth:
+// the power-of-two sizes -- the hot path -- never take it.
+#pragma once
+#include "real_kernels.hpp"
+
+namespace cfft
+{
+static constexpr int kGenericMaxStages = 10;
+static constexpr int kGenericMaxN = 9216; // two LDS images of 8*N bytes must fit the CU's 160 KiB
+
+struct GenericPlan
+{
+    int n;                           // complex points per frame
+    int ns;                          // number of stages
+    int radix[kGenericMaxStages];    // each in {2, 3, 4, 5, 8}
+    int tw_offset[kGenericMaxStages]; // float2 offset of the stage's table: (radix-1) * p entries, [a-1][k]
+};
+
+template <>
+__device__ __forceinline__ void fft_reg<3> (float2 (&u)[3])
+{
+    constexpr float s60 = 0.86602540378443864676f;
+    const float2 t = cadd (u[1], u[2]);
+    const float2 d = csub (u[1], u[2]);
+    const float2 m = make_float2 (u[0].x - 0.5f * t.x, u[0].y - 0.5f * t.y);
+    const float2 rot = make_float2 (s60 * d.y, -s60 * d.x); // -i * s60 * d
+    u[0] = cadd (u[0], t);
+    u[1] = cadd (m, rot);
+    u[2] = csub (m, rot);
+}
+
+template <>
+__device__ __forceinline__ void fft_reg<5> (float2 (&u)[5])
+{
+    constexpr float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
+    constexpr float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
+    const float2 a1 = cadd (u[1], u[4]), b1 = csub (u[1], u[4]);
+    const float2 a2 = cadd (u[2], u[3]), b2 = csub (u[2], u[3]);
+    const float2 m1 = make_float2 (u[0].x + c1 * a1.x + c2 * a2.x, u[0].y + c1 * a1.y + c2 * a2.y);
+    const float2 m2 = make_float2 (u[0].x + c2 * a1.x + c1 * a2.x, u[0].y + c2 * a1.y + c1 * a2.y);
+    // forward: X1 = m1 - i (s1 b1 + s2 b2),  X2 = m2 - i (s2 b1 - s1 b2)
+    const float2 q1 = make_float2 (s1 * b1.x + s2 * b2.x, s1 * b1.y + s2 * b2.y);
+    const float2 q2 = make_float2 (s2 * b1.x - s1 * b2.x, s2 * b1.y - s1 * b2.y);
+    u[0] = make_float2 (u[0].x + a1.x + a2.x, u[0].y + a1.y + a2.y);
+    u[1] = make_float2 (m1.x + q1.y, m1.y - q1.x);
+    u[4] = make_float2 (m1.x - q1.y, m1.y + q1.x);
+    u[2] = make_float2 (m2.x + q2.y, m2.y - q2.x);
+    u[3] = make_float2 (m2.x - q2.y, m2.y + q2.x);
+}
+
+// one Stockham stage of radix R over the whole frame: src -> dst
+template <int R>
+__device__ __forceinline__ void generic_stage (const float2* __restrict__ src, float2* __restrict__ dst,
+                                               const float2* __restrict__ tw, int n, int p, int tid)
+{
+    const int m = n / R;
+    for (int i = tid; i < m; i += 256)
+    {
+        const int k = i % p;
+        const int j = (i - k) * R + k;
+        float2 u[R];
+#pragma unroll
+        for (int a = 0; a < R; ++a)
+            u[a] = src[i + a * m];
+        if (p > 1)
+        {
+#pragma unroll
+            for (int a = 1; a < R; ++a)
+                u[a] = cmul (u[a], tw[(a - 1) * p + k]);
+        }
+        fft_reg<R> (u);
+#pragma unroll
+        for (int b = 0; b < R; ++b)
+            dst[j + b * p] = u[b];
+    }
+}
+
+// all stages; the frame starts in `a`, returns the image that holds the result
+__device__ __forceinline__ float2* generic_core (const GenericPlan& plan, const float2* __restrict__ twtab, float2* a, float2* b, int tid)
+{
+    float2 *src = a, *dst = b;
+    int p = 1;
+    for (int s = 0; s < plan.ns; ++s)
+    {
+        const int r = plan.radix[s];
+        const float2* tw = twtab + plan.tw_offset[s];
+        switch (r)
+        {
+            case 2: generic_stage<2> (src, dst, tw, plan.n, p, tid); break;
+            case 3: generic_stage<3> (src, dst, tw, plan.n, p, tid); break;
+            case 4: generic_stage<4> (src, dst, tw, plan.n, p, tid); break;
+            case 5: generic_stage<5> (src, dst, tw, plan.n, p, tid); break;
+            default: generic_stage<8> (src, dst, tw, plan.n, p, tid); break;
+        }
+        __syncthreads();
+        float2* t = src;
+        src = dst;
+        dst = t;
+        p *= r;
+    }
+    return src;
+}
+
+// MODE 0: complex <-> complex (INV: backward).  MODE 1: real forward (packed spectrum out).  MODE 2: real backward.
+// For the real modes plan.n = N/2 and wtab holds W_N^k, k <= N/4 (pair stage formulas: real_kernels.hpp).
+template <int MODE, bool INV>
+__global__ __launch_bounds__ (256) void generic_kernel (const float2* __restrict__ in,
+                                                       float2* __restrict__ out,
+                                                       const float2* __restrict__ twtab,
+                                                       const float2* __restrict__ wtab,
+                                                       GenericPlan plan,
+                                                       unsigned batch)
+{
+    extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
+    const int tid = threadIdx.x;
+    const int n = plan.n;
+    float2* bufA = smem;
+    float2* bufB = smem + n;
+    for (unsigned f = blockIdx.x; f < batch; f += gridDim.x)
+    {
+        const float2* __restrict__ src = in + (size_t) f * n;
+        float2* __restrict__ dst = out + (size_t) f * n;
+        __syncthreads(); // previous frame's reads of the images are finished
+        if (MODE == 2)
+        {
+            // merge pairs straight from global memory (k and n-k), stored re<->im swapped for the inverse core
+            for (int k = tid; k <= n / 2; k += 256)
+            {
+                const int kp = (k == 0) ? 0 : n - k;
+                const float2 A = gload (&src[k]);
+                const float2 Xp = gload (&src[kp]);
+                float2 zk, zp;
+                if (k == 0)
+                {
+                    zk = make_float2 (A.x + A.y, A.x - A.y); // Z[0] = (X0 + XM) + i (X0 - XM)
+                    zp = zk;
+                }
+                else if (2 * k == n)
+                {
+                    zk = make_float2 (2.f * A.x, -2.f * A.y); // Z[n/2] = 2 conj(X[n/2])
+                    zp = zk;
+                }
+                else
+                    real_merge_pair (A, Xp, wtab[k], zk, zp);
+                bufA[k] = make_float2 (zk.y, zk.x);
+                if (kp != k)
+                    bufA[kp] = make_float2 (zp.y, zp.x);
+            }
+        }
+        else
+        {
+            for (int e = tid; e < n; e += 256)
+            {
+                const float2 x = gload (&src[e]);
+                bufA[e] = (MODE == 0 && INV) ? make_float2 (x.y, x.x) : x;
+            }
+        }
+        __syncthreads();
+        const float2* res = generic_core (plan, twtab, bufA, bufB, tid);
+        if (MODE == 1)
+        {
+            for (int k = tid; k <= n / 2; k += 256)
+            {
+                const int kp = (k == 0) ? 0 : n - k;
+                const float2 A = res[k];
+                const float2 Zp = res[kp];
+                float2 Xk, Xp;
+                if (k == 0)
+                {
+                    Xk = make_float2 (A.x + A.y, A.x - A.y); // [X0.re, X(N/2).re]
+                    Xp = Xk;
+                }
+                else if (2 * k == n)
+                {
+                    Xk = make_float2 (A.x, -A.y); // X[n/2] = conj(Z[n/2])
+                    Xp = Xk;
+                }
+                else
+                    real_split_pair (A, Zp, wtab[k], Xk, Xp);
+                gstore (&dst[k], Xk);
+                if (kp != k)
+                    gstore (&dst[kp], Xp);
+            }
+        }
+        else
+        {
+            for (int e = tid; e < n; e += 256)
+            {
+                const float2 y = res[e];
+                gstore (&dst[e], (MODE == 2 || INV) ? make_float2 (y.y, y.x) : y);
+            }
+        }
+    }
+}
+} // namespace cfft

@@ -105,6 +105,12 @@ const DeviceTables* acquire_tables (int device, int N, int transform)
     }
     auto* t = new DeviceTables();
     t->core_n = h.core_n;
+    t->gen_ns = (int) h.generic_radix.size();
+    for (int i = 0; i < t->gen_ns; ++i)
+    {
+        t->gen_radix[i] = h.generic_radix[(size_t) i];
+        t->gen_tw_offset[i] = h.generic_tw_offset[(size_t) i];
+    }
     t->stage_twiddles = upload (h.stage_twiddles);
     t->real_twiddles = upload (h.real_twiddles);
     t->big_twiddles = upload (h.big_twiddles);

@@ -43,6 +43,10 @@ struct DeviceTables
     float2* real_twiddles = nullptr;  // W_N^k, k < N/4+1, for the real <-> half-length complex split
     float2* big_twiddles = nullptr;   // W_N^{a*b} table for the multi-pass (N > 4096) decomposition
     int core_n = 0;                   // length handled by the LDS-resident core (N, N/2 for REAL, or N2)
+    // mixed-radix (not a power of two) plans: run-time stage list of the generic kernel, else gen_ns == 0
+    int gen_ns = 0;
+    int gen_radix[10] = { 0 };
+    int gen_tw_offset[10] = { 0 };
 };
 
 // The plan header.  Lives either in a block we allocated (fft_new_setup) or in caller memory

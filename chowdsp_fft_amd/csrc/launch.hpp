@@ -33,6 +33,9 @@ hipError_t launch_conv_frames_real (int m, const float2* in, const float2* H, fl
 hipError_t launch_big_c2c (int n1, int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, size_t batch, int grid_divisor, hipStream_t stream);
 hipError_t launch_real_pair (bool forward, const float2* in, float2* out, const float2* real_tw, unsigned m, size_t batch, hipStream_t stream);
 
+// mixed-radix (non power of two) frames: mode 0 c2c, 1 real forward, 2 real backward; nc = complex length
+hipError_t launch_generic (int mode, bool inverse, int nc, const DeviceTables& t, const float2* in, float2* out, size_t batch, hipStream_t stream);
+
 // shared by the kernels_*.hip files
 int blocks_per_cu_cached (const void* kernel, int threads, size_t lds_bytes);
 } // namespace cfft::host

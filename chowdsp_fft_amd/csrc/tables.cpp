@@ -6,6 +6,7 @@
 
 namespace cfft::host
 {
+static void generic_radices (int n, std::vector<int>& radix);
 namespace
 {
 constexpr int kMaxLog2 = 20;
@@ -34,6 +35,8 @@ void append_stage_twiddles (const PlanDesc& d, std::vector<float2>& out)
 }
 } // namespace
 
+void generic_plan_radices (int n_complex, std::vector<int>& radix) { generic_radices (n_complex, radix); }
+
 bool core_radices (int n, int radix[4])
 {
     PlanDesc d;
@@ -57,15 +60,43 @@ void split_large (int n_complex, int& n1, int& n2)
     n1 = 1 << (lg - l2);
 }
 
+// 2^a 3^b 5^c ?  (the reference's accepted prime factors, simd/chowdsp_fft_impl_common.hpp:51-82)
+static bool is_235_smooth (int n)
+{
+    if (n < 1)
+        return false;
+    for (int f : { 2, 3, 5 })
+        while (n % f == 0)
+            n /= f;
+    return n == 1;
+}
+
+static constexpr int kGenericMaxComplexLen = 9216; // = cfft::kGenericMaxN (two LDS images per workgroup)
+
 bool size_supported (int N, int transform)
 {
-    if (! is_pow2 (N) || N > (1 << kMaxLog2))
-        return false;
     // the reference needs N % 16 == 0 (complex) / N % 32 == 0 (real) on its SSE path
-    // (simd/chowdsp_fft_impl_common.hpp:168-177); same lower bounds here.
-    if (transform == 0 /* FFT_REAL */)
-        return N >= 32;
-    return N >= 16;
+    // (simd/chowdsp_fft_impl_common.hpp:168-177) and N/4 free of primes other than 2, 3, 5 (:216-225).
+    const bool real = (transform == 0 /* FFT_REAL */);
+    if (N <= 0 || N % (real ? 32 : 16) != 0)
+        return false;
+    if (is_pow2 (N))
+        return N <= (1 << kMaxLog2);
+    // mixed-radix sizes run LDS-resident in the generic kernel: bounded by what two frame images need
+    return is_235_smooth (N) && (real ? N / 2 : N) <= kGenericMaxComplexLen;
+}
+
+// stage radices of the generic kernel for a 2^a 3^b 5^c length: fives, threes, then the power of two as 8s/4s/2
+static void generic_radices (int n, std::vector<int>& radix)
+{
+    radix.clear();
+    while (n % 5 == 0) { radix.push_back (5); n /= 5; }
+    while (n % 3 == 0) { radix.push_back (3); n /= 3; }
+    int e = 0;
+    while (n % 2 == 0) { ++e; n /= 2; }
+    if (e % 2 == 1 && e >= 3) { radix.push_back (8); e -= 3; }
+    while (e >= 2) { radix.push_back (4); e -= 2; }
+    if (e == 1) radix.push_back (2);
 }
 
 bool build_host_tables (int N, int transform, HostTables& out)
@@ -81,6 +112,23 @@ bool build_host_tables (int N, int transform, HostTables& out)
         out.real_twiddles.reserve ((size_t) N / 4 + 1);
         for (int k = 0; k <= N / 4; ++k)
             out.real_twiddles.push_back (unit_root (k, N));
+    }
+
+    if (! is_pow2 (nc))
+    {
+        // generic mixed-radix plan: per stage (r-1)*p entries [a-1][k] = W_{p*r}^{a*k}
+        out.core_n = 0;
+        generic_radices (nc, out.generic_radix);
+        int p = 1;
+        for (int r : out.generic_radix)
+        {
+            out.generic_tw_offset.push_back ((int) out.stage_twiddles.size());
+            for (int a = 1; a < r; ++a)
+                for (int k = 0; k < p; ++k)
+                    out.stage_twiddles.push_back (unit_root ((long long) a * k, (long long) p * r));
+            p *= r;
+        }
+        return p == nc && out.generic_radix.size() <= 10;
     }
 
     PlanDesc d;

@@ -17,6 +17,8 @@ struct HostTables
     std::vector<float2> stage_twiddles; // Stockham per-stage tables, layout of Plan::tw_offset
     std::vector<float2> real_twiddles;  // W_N^k, k = 0..N/4   (REAL plans)
     std::vector<float2> big_twiddles;   // multi-pass plans, see multipass.hpp
+    std::vector<int> generic_radix;     // non-power-of-two plans: stage radices of the generic kernel
+    std::vector<int> generic_tw_offset; // ... and the offset of each stage's table inside stage_twiddles
 };
 
 // Validates (N, transform) and fills the tables.  false = unsupported size.
@@ -26,6 +28,8 @@ bool build_host_tables (int N, int transform, HostTables& out);
 bool size_supported (int N, int transform);
 // stage radices of the LDS-resident core of length n (0-padded); false if n has no core plan
 bool core_radices (int n, int radix[4]);
+// stage radices of the generic mixed-radix kernel for a complex length that is not a power of two
+void generic_plan_radices (int n_complex, std::vector<int>& radix);
 // For multi-pass sizes: N = n1 * n2 with both factors LDS-resident; (0,0) if N is LDS-resident itself.
 void split_large (int n_complex, int& n1, int& n2);
 } // namespace cfft::host

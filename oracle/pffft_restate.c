@@ -15,8 +15,10 @@
  *   z-domain reorder                        simd/chowdsp_fft_impl_sse.cpp:1420-1515
  *   transform driver                        simd/chowdsp_fft_impl_sse.cpp:1518-1601
  *   multiply-accumulate, accumulate         simd/chowdsp_fft_impl_sse.cpp:1603-1660
- * Radix-3 and radix-5 passes (:182-219, :298-370, :588-625, :704-786, :1126-1170, :1262-1356) are NOT
- * restated: the hot path is power-of-two sizes only, and oracle_new_setup() rejects everything else.
+ *   radix-3 / radix-5 passes (sizes 2^a 3^b 5^c) simd/chowdsp_fft_impl_sse.cpp:182-219, 298-370 (complex),
+ *                                            :588-625, :704-786 (real forward), :1126-1170, :1262-1356 (real backward)
+ * The restatement is faithful to the point of reproducing a defect of the reference: its REAL FORWARD transform
+ * is wrong for every size divisible by 25 (radf5_ps with ido > 1, :747-782) -- see tests/test_gpu_other_sizes.py.
  *
  * How it is restated.  The reference treats a length-N transform as V = 4 interleaved transforms of
  * length N/4: element e of lane l lives at float index 4*e + l of a buffer, every butterfly pass is
@@ -61,23 +63,28 @@ struct oracle_setup
 
 /* ---- plan (common.hpp:51-82 decompose, :84-160 rffti1_ps / cffti1_ps, :162-228 fft_new_setup) ---- */
 
-/* For a power of two n both try-orders of the reference ({5,3,4,2} complex, {4,2,3,5} real) give
-   radix-4 factors and, when log2(n) is odd, a single radix-2 factor that is moved to the front. */
-static int factor_pow2 (int n, int* fac)
+/* common.hpp:51-82 decompose: divide out the candidate radices in the given order (complex {5,3,4,2},
+   real {4,2,3,5}); a factor 2 found after other factors is moved to the front.  Returns the number of
+   factors, or -1 when n has a prime factor other than 2, 3, 5 (common.hpp:216-225 rejects the size). */
+static int factor_like_reference (int n, int* fac, const int* tries)
 {
     int nf = 0, left = n;
-    while (left % 4 == 0)
+    for (int t = 0; tries[t] != 0; ++t)
     {
-        fac[nf++] = 4;
-        left /= 4;
-    }
-    if (left == 2)
-    {
-        for (int i = nf; i > 0; --i)
-            fac[i] = fac[i - 1];
-        fac[0] = 2;
-        ++nf;
-        left = 1;
+        const int r = tries[t];
+        while (left != 1 && left % r == 0)
+        {
+            if (nf >= 15)
+                return -1;
+            fac[nf++] = r;
+            left /= r;
+            if (r == 2 && nf != 1)
+            {
+                for (int i = nf - 1; i > 0; --i)
+                    fac[i] = fac[i - 1];
+                fac[0] = 2;
+            }
+        }
     }
     return left == 1 ? nf : -1;
 }
@@ -139,8 +146,10 @@ static void fill_real_pass_twiddles (int n, float* wa, const int* fac, int nf)
 
 oracle_setup* oracle_new_setup (int N, int transform)
 {
-    if (N <= 0 || (N & (N - 1)) != 0)
-        return NULL; /* power-of-two path only */
+    static const int tries_complex[] = { 5, 3, 4, 2, 0 }; /* common.hpp:122 */
+    static const int tries_real[] = { 4, 2, 3, 5, 0 };    /* common.hpp:86 */
+    if (N <= 0)
+        return NULL;
     if (transform == ORACLE_REAL && N % (2 * LANES * LANES) != 0)
         return NULL; /* common.hpp:168-172 */
     if (transform == ORACLE_COMPLEX && N % (LANES * LANES) != 0)
@@ -154,7 +163,7 @@ oracle_setup* oracle_new_setup (int N, int transform)
     s->Ncvec = (transform == ORACLE_REAL ? N / 2 : N) / LANES;
     s->e = (float*) calloc ((size_t) 6 * s->Ncvec + 8, sizeof (float));
     s->twiddle = (float*) calloc ((size_t) 2 * s->Ncvec + 16, sizeof (float));
-    s->nfac = factor_pow2 (N / LANES, s->fac);
+    s->nfac = factor_like_reference (N / LANES, s->fac, transform == ORACLE_REAL ? tries_real : tries_complex);
     if (! s->e || ! s->twiddle || s->nfac < 0)
     {
         oracle_destroy_setup (s);
@@ -289,6 +298,88 @@ static void cpass4_lane (int ido, int l1, const float* cc, float* ch, const floa
     }
 }
 
+/* sse.cpp:182-219 passf3_ps (only reached for sizes with a factor 3) */
+static void cpass3_lane (int ido, int l1, const float* cc, float* ch, const float* wa1, const float* wa2, float fsign)
+{
+    const float taur = -0.5f;
+    const float taui = 0.866025403784439f * fsign;
+    const int span = l1 * ido;
+    for (int blk = 0; blk < l1; ++blk)
+    {
+        const float* c = cc + LANES * (3 * ido * blk);
+        float* h = ch + LANES * (ido * blk);
+        for (int i = 0; i < ido - 1; i += 2)
+        {
+            const float tr2 = AT (c, i + ido) + AT (c, i + 2 * ido);
+            const float cr2 = AT (c, i) + tr2 * taur;
+            AT (h, i) = AT (c, i) + tr2;
+            const float ti2 = AT (c, i + ido + 1) + AT (c, i + 2 * ido + 1);
+            const float ci2 = AT (c, i + 1) + ti2 * taur;
+            AT (h, i + 1) = AT (c, i + 1) + ti2;
+            const float cr3 = (AT (c, i + ido) - AT (c, i + 2 * ido)) * taui;
+            const float ci3 = (AT (c, i + ido + 1) - AT (c, i + 2 * ido + 1)) * taui;
+            float dr2 = cr2 - ci3, dr3 = cr2 + ci3;
+            float di2 = ci2 + cr3, di3 = ci2 - cr3;
+            CMUL (dr2, di2, wa1[i], fsign * wa1[i + 1]);
+            AT (h, i + span) = dr2;
+            AT (h, i + span + 1) = di2;
+            CMUL (dr3, di3, wa2[i], fsign * wa2[i + 1]);
+            AT (h, i + 2 * span) = dr3;
+            AT (h, i + 2 * span + 1) = di3;
+        }
+    }
+}
+
+/* sse.cpp:298-370 passf5_ps (only reached for sizes with a factor 5) */
+static void cpass5_lane (int ido, int l1, const float* cc, float* ch, const float* wa1, const float* wa2, const float* wa3, const float* wa4, float fsign)
+{
+    const float tr11 = .309016994374947f, tr12 = -.809016994374947f;
+    const float ti11 = .951056516295154f * fsign, ti12 = .587785252292473f * fsign;
+    const int span = l1 * ido;
+    for (int blk = 0; blk < l1; ++blk)
+    {
+        const float* c = cc + LANES * (5 * ido * blk);
+        float* h = ch + LANES * (ido * blk);
+        for (int i = 0; i < ido - 1; i += 2)
+        {
+#define RE(j) AT (c, (j) * ido + i)
+#define IM(j) AT (c, (j) * ido + i + 1)
+            const float ti5 = IM (1) - IM (4), ti2 = IM (1) + IM (4);
+            const float ti4 = IM (2) - IM (3), ti3 = IM (2) + IM (3);
+            const float tr5 = RE (1) - RE (4), tr2 = RE (1) + RE (4);
+            const float tr4 = RE (2) - RE (3), tr3 = RE (2) + RE (3);
+            AT (h, i) = RE (0) + (tr2 + tr3);
+            AT (h, i + 1) = IM (0) + (ti2 + ti3);
+            const float cr2 = RE (0) + (tr2 * tr11 + tr3 * tr12);
+            const float ci2 = IM (0) + (ti2 * tr11 + ti3 * tr12);
+            const float cr3 = RE (0) + (tr2 * tr12 + tr3 * tr11);
+            const float ci3 = IM (0) + (ti2 * tr12 + ti3 * tr11);
+            const float cr5 = tr5 * ti11 + tr4 * ti12;
+            const float ci5 = ti5 * ti11 + ti4 * ti12;
+            const float cr4 = tr5 * ti12 - tr4 * ti11;
+            const float ci4 = ti5 * ti12 - ti4 * ti11;
+#undef RE
+#undef IM
+            float dr3 = cr3 - ci4, dr4 = cr3 + ci4;
+            float di3 = ci3 + cr4, di4 = ci3 - cr4;
+            float dr5 = cr2 + ci5, dr2 = cr2 - ci5;
+            float di5 = ci2 - cr5, di2 = ci2 + cr5;
+            CMUL (dr2, di2, wa1[i], fsign * wa1[i + 1]);
+            AT (h, i + span) = dr2;
+            AT (h, i + span + 1) = di2;
+            CMUL (dr3, di3, wa2[i], fsign * wa2[i + 1]);
+            AT (h, i + 2 * span) = dr3;
+            AT (h, i + 2 * span + 1) = di3;
+            CMUL (dr4, di4, wa3[i], fsign * wa3[i + 1]);
+            AT (h, i + 3 * span) = dr4;
+            AT (h, i + 3 * span + 1) = di4;
+            CMUL (dr5, di5, wa4[i], fsign * wa4[i + 1]);
+            AT (h, i + 4 * span) = dr5;
+            AT (h, i + 4 * span + 1) = di5;
+        }
+    }
+}
+
 /* pass driver, sse.cpp:372-432 (cfftf1_ps).  n = Ncvec.  Returns the buffer holding the result. */
 static float* complex_passes (const oracle_setup* s, float* a, float* b, float fsign)
 {
@@ -306,6 +397,10 @@ static float* complex_passes (const oracle_setup* s, float* a, float* b, float f
         {
             if (ip == 4)
                 cpass4_lane (idot, l1, in + lane, out + lane, wa + iw, wa + iw + idot, wa + iw + 2 * idot, fsign);
+            else if (ip == 3)
+                cpass3_lane (idot, l1, in + lane, out + lane, wa + iw, wa + iw + idot, fsign);
+            else if (ip == 5)
+                cpass5_lane (idot, l1, in + lane, out + lane, wa + iw, wa + iw + idot, wa + iw + 2 * idot, wa + iw + 3 * idot, fsign);
             else
                 cpass2_lane (idot, l1, in + lane, out + lane, wa + iw, fsign);
         }
@@ -487,6 +582,100 @@ static void rfwd4_lane (int ido, int l1, const float* cc, float* ch, const float
     }
 }
 
+/* sse.cpp:588-625 radf3_ps (sizes with a factor 3) */
+static void rfwd3_lane (int ido, int l1, const float* cc, float* ch, const float* wa1, const float* wa2)
+{
+    const float taur = -0.5f, taui = 0.866025403784439f;
+    for (int k = 0; k < l1; ++k)
+    {
+        const float cr2 = AT (cc, (k + l1) * ido) + AT (cc, (k + 2 * l1) * ido);
+        AT (ch, 3 * k * ido) = AT (cc, k * ido) + cr2;
+        AT (ch, (3 * k + 2) * ido) = (AT (cc, (k + l1 * 2) * ido) - AT (cc, (k + l1) * ido)) * taui;
+        AT (ch, ido - 1 + (3 * k + 1) * ido) = AT (cc, k * ido) + cr2 * taur;
+    }
+    if (ido == 1)
+        return;
+    for (int k = 0; k < l1; ++k)
+        for (int i = 2; i < ido; i += 2)
+        {
+            const int ic = ido - i;
+            float dr2 = AT (cc, i - 1 + (k + l1) * ido), di2 = AT (cc, i + (k + l1) * ido);
+            float dr3 = AT (cc, i - 1 + (k + l1 * 2) * ido), di3 = AT (cc, i + (k + l1 * 2) * ido);
+            CMUL_CONJ (dr2, di2, wa1[i - 2], wa1[i - 1]);
+            CMUL_CONJ (dr3, di3, wa2[i - 2], wa2[i - 1]);
+            const float cr2 = dr2 + dr3, ci2 = di2 + di3;
+            AT (ch, i - 1 + 3 * k * ido) = AT (cc, i - 1 + k * ido) + cr2;
+            AT (ch, i + 3 * k * ido) = AT (cc, i + k * ido) + ci2;
+            const float tr2 = AT (cc, i - 1 + k * ido) + cr2 * taur;
+            const float ti2 = AT (cc, i + k * ido) + ci2 * taur;
+            const float tr3 = (di2 - di3) * taui;
+            const float ti3 = (dr3 - dr2) * taui;
+            AT (ch, i - 1 + (3 * k + 2) * ido) = tr2 + tr3;
+            AT (ch, ic - 1 + (3 * k + 1) * ido) = tr2 - tr3;
+            AT (ch, i + (3 * k + 2) * ido) = ti2 + ti3;
+            AT (ch, ic + (3 * k + 1) * ido) = ti3 - ti2;
+        }
+}
+
+/* sse.cpp:704-786 radf5_ps (sizes with a factor 5).  0-based views of the reference's 1-based macros:
+   CC(a, k, j) = cc[(j*l1 + k)*ido + a],  CH(a, j, k) = ch[(k*5 + j)*ido + a] */
+static void rfwd5_lane (int ido, int l1, const float* cc, float* ch, const float* wa1, const float* wa2, const float* wa3, const float* wa4)
+{
+    const float tr11 = .309016994374947f, ti11 = .951056516295154f;
+    const float tr12 = -.809016994374947f, ti12 = .587785252292473f;
+#define CC(a, k, j) AT (cc, ((j) * l1 + (k)) * ido + (a))
+#define CH(a, j, k) AT (ch, ((k) * 5 + (j)) * ido + (a))
+    for (int k = 0; k < l1; ++k)
+    {
+        const float cr2 = CC (0, k, 4) + CC (0, k, 1), ci5 = CC (0, k, 4) - CC (0, k, 1);
+        const float cr3 = CC (0, k, 3) + CC (0, k, 2), ci4 = CC (0, k, 3) - CC (0, k, 2);
+        CH (0, 0, k) = CC (0, k, 0) + (cr2 + cr3);
+        CH (ido - 1, 1, k) = CC (0, k, 0) + (cr2 * tr11 + cr3 * tr12);
+        CH (0, 2, k) = ci5 * ti11 + ci4 * ti12;
+        CH (ido - 1, 3, k) = CC (0, k, 0) + (cr2 * tr12 + cr3 * tr11);
+        CH (0, 4, k) = ci5 * ti12 - ci4 * ti11;
+    }
+    if (ido == 1)
+        return;
+    for (int k = 0; k < l1; ++k)
+        for (int ii = 2; ii < ido; ii += 2) /* ii = the reference's i - 1 (imaginary slot), ii - 1 the real slot */
+        {
+            const int icc = ido - ii;
+            float dr2 = CC (ii - 1, k, 1), di2 = CC (ii, k, 1);
+            float dr3 = CC (ii - 1, k, 2), di3 = CC (ii, k, 2);
+            float dr4 = CC (ii - 1, k, 3), di4 = CC (ii, k, 3);
+            float dr5 = CC (ii - 1, k, 4), di5 = CC (ii, k, 4);
+            CMUL_CONJ (dr2, di2, wa1[ii - 2], wa1[ii - 1]);
+            CMUL_CONJ (dr3, di3, wa2[ii - 2], wa2[ii - 1]);
+            CMUL_CONJ (dr4, di4, wa3[ii - 2], wa3[ii - 1]);
+            CMUL_CONJ (dr5, di5, wa4[ii - 2], wa4[ii - 1]);
+            const float cr2 = dr2 + dr5, ci5 = dr5 - dr2;
+            const float cr5 = di2 - di5, ci2 = di2 + di5;
+            const float cr3 = dr3 + dr4, ci4 = dr4 - dr3;
+            const float cr4 = di3 - di4, ci3 = di3 + di4;
+            CH (ii - 1, 0, k) = CC (ii - 1, k, 0) + (cr2 + cr3);
+            CH (ii, 0, k) = CC (ii, k, 0) - (ci2 + ci3);
+            const float tr2 = CC (ii - 1, k, 0) + (cr2 * tr11 + cr3 * tr12);
+            const float ti2 = CC (ii, k, 0) - (ci2 * tr11 + ci3 * tr12);
+            const float tr3 = CC (ii - 1, k, 0) + (cr2 * tr12 + cr3 * tr11);
+            const float ti3 = CC (ii, k, 0) - (ci2 * tr12 + ci3 * tr11);
+            const float tr5 = cr5 * ti11 + cr4 * ti12;
+            const float ti5 = ci5 * ti11 + ci4 * ti12;
+            const float tr4 = cr5 * ti12 - cr4 * ti11;
+            const float ti4 = ci5 * ti12 - ci4 * ti11;
+            CH (ii - 1, 2, k) = tr2 - tr5;
+            CH (icc - 1, 1, k) = tr2 + tr5;
+            CH (ii, 2, k) = ti2 + ti5;
+            CH (icc, 1, k) = ti5 - ti2;
+            CH (ii - 1, 4, k) = tr3 - tr4;
+            CH (icc - 1, 3, k) = tr3 + tr4;
+            CH (ii, 4, k) = ti3 + ti4;
+            CH (icc, 3, k) = ti4 - ti3;
+        }
+#undef CC
+#undef CH
+}
+
 /* sse.cpp:788-846 rfftf1_ps: factors consumed last to first.  n = 2*Ncvec. */
 static float* real_forward_passes (const oracle_setup* s, float* a, float* b)
 {
@@ -504,6 +693,10 @@ static float* real_forward_passes (const oracle_setup* s, float* a, float* b)
         {
             if (ip == 4)
                 rfwd4_lane (ido, l1, in + lane, out + lane, wa + iw, wa + iw + ido, wa + iw + 2 * ido);
+            else if (ip == 3)
+                rfwd3_lane (ido, l1, in + lane, out + lane, wa + iw, wa + iw + ido);
+            else if (ip == 5)
+                rfwd5_lane (ido, l1, in + lane, out + lane, wa + iw, wa + iw + ido, wa + iw + 2 * ido, wa + iw + 3 * ido);
             else
                 rfwd2_lane (ido, l1, in + lane, out + lane, wa + iw);
         }
@@ -624,6 +817,111 @@ static void rbwd4_lane (int ido, int l1, const float* cc, float* ch, const float
     }
 }
 
+/* sse.cpp:1126-1170 radb3_ps (sizes with a factor 3) */
+static void rbwd3_lane (int ido, int l1, const float* cc, float* ch, const float* wa1, const float* wa2)
+{
+    const float taur = -0.5f, taui = 0.866025403784439f;
+    const float taui_2 = 0.866025403784439f * 2;
+    for (int k = 0; k < l1; ++k)
+    {
+        float tr2 = AT (cc, ido - 1 + (3 * k + 1) * ido);
+        tr2 = tr2 + tr2;
+        const float cr2 = AT (cc, 3 * k * ido) + tr2 * taur;
+        AT (ch, k * ido) = AT (cc, 3 * k * ido) + tr2;
+        const float ci3 = AT (cc, (3 * k + 2) * ido) * taui_2;
+        AT (ch, (k + l1) * ido) = cr2 - ci3;
+        AT (ch, (k + 2 * l1) * ido) = cr2 + ci3;
+    }
+    if (ido == 1)
+        return;
+    for (int k = 0; k < l1; ++k)
+        for (int i = 2; i < ido; i += 2)
+        {
+            const int ic = ido - i;
+            const float tr2 = AT (cc, i - 1 + (3 * k + 2) * ido) + AT (cc, ic - 1 + (3 * k + 1) * ido);
+            const float cr2 = AT (cc, i - 1 + 3 * k * ido) + tr2 * taur;
+            AT (ch, i - 1 + k * ido) = AT (cc, i - 1 + 3 * k * ido) + tr2;
+            const float ti2 = AT (cc, i + (3 * k + 2) * ido) - AT (cc, ic + (3 * k + 1) * ido);
+            const float ci2 = AT (cc, i + 3 * k * ido) + ti2 * taur;
+            AT (ch, i + k * ido) = AT (cc, i + 3 * k * ido) + ti2;
+            const float cr3 = (AT (cc, i - 1 + (3 * k + 2) * ido) - AT (cc, ic - 1 + (3 * k + 1) * ido)) * taui;
+            const float ci3 = (AT (cc, i + (3 * k + 2) * ido) + AT (cc, ic + (3 * k + 1) * ido)) * taui;
+            float dr2 = cr2 - ci3, dr3 = cr2 + ci3;
+            float di2 = ci2 + cr3, di3 = ci2 - cr3;
+            CMUL (dr2, di2, wa1[i - 2], wa1[i - 1]);
+            AT (ch, i - 1 + (k + l1) * ido) = dr2;
+            AT (ch, i + (k + l1) * ido) = di2;
+            CMUL (dr3, di3, wa2[i - 2], wa2[i - 1]);
+            AT (ch, i - 1 + (k + 2 * l1) * ido) = dr3;
+            AT (ch, i + (k + 2 * l1) * ido) = di3;
+        }
+}
+
+/* sse.cpp:1262-1356 radb5_ps (sizes with a factor 5).  0-based views of the reference's 1-based macros:
+   CC(a, j, k) = cc[(k*5 + j)*ido + a],  CH(a, k, j) = ch[(j*l1 + k)*ido + a] */
+static void rbwd5_lane (int ido, int l1, const float* cc, float* ch, const float* wa1, const float* wa2, const float* wa3, const float* wa4)
+{
+    const float tr11 = .309016994374947f, ti11 = .951056516295154f;
+    const float tr12 = -.809016994374947f, ti12 = .587785252292473f;
+#define CC(a, j, k) AT (cc, ((k) * 5 + (j)) * ido + (a))
+#define CH(a, k, j) AT (ch, ((j) * l1 + (k)) * ido + (a))
+    for (int k = 0; k < l1; ++k)
+    {
+        const float ti5 = CC (0, 2, k) + CC (0, 2, k);
+        const float ti4 = CC (0, 4, k) + CC (0, 4, k);
+        const float tr2 = CC (ido - 1, 1, k) + CC (ido - 1, 1, k);
+        const float tr3 = CC (ido - 1, 3, k) + CC (ido - 1, 3, k);
+        CH (0, k, 0) = CC (0, 0, k) + (tr2 + tr3);
+        const float cr2 = CC (0, 0, k) + (tr2 * tr11 + tr3 * tr12);
+        const float cr3 = CC (0, 0, k) + (tr2 * tr12 + tr3 * tr11);
+        const float ci5 = ti5 * ti11 + ti4 * ti12;
+        const float ci4 = ti5 * ti12 - ti4 * ti11;
+        CH (0, k, 1) = cr2 - ci5;
+        CH (0, k, 2) = cr3 - ci4;
+        CH (0, k, 3) = cr3 + ci4;
+        CH (0, k, 4) = cr2 + ci5;
+    }
+    if (ido == 1)
+        return;
+    for (int k = 0; k < l1; ++k)
+        for (int ii = 2; ii < ido; ii += 2)
+        {
+            const int icc = ido - ii;
+            const float ti5 = CC (ii, 2, k) + CC (icc, 1, k), ti2 = CC (ii, 2, k) - CC (icc, 1, k);
+            const float ti4 = CC (ii, 4, k) + CC (icc, 3, k), ti3 = CC (ii, 4, k) - CC (icc, 3, k);
+            const float tr5 = CC (ii - 1, 2, k) - CC (icc - 1, 1, k), tr2 = CC (ii - 1, 2, k) + CC (icc - 1, 1, k);
+            const float tr4 = CC (ii - 1, 4, k) - CC (icc - 1, 3, k), tr3 = CC (ii - 1, 4, k) + CC (icc - 1, 3, k);
+            CH (ii - 1, k, 0) = CC (ii - 1, 0, k) + (tr2 + tr3);
+            CH (ii, k, 0) = CC (ii, 0, k) + (ti2 + ti3);
+            const float cr2 = CC (ii - 1, 0, k) + (tr2 * tr11 + tr3 * tr12);
+            const float ci2 = CC (ii, 0, k) + (ti2 * tr11 + ti3 * tr12);
+            const float cr3 = CC (ii - 1, 0, k) + (tr2 * tr12 + tr3 * tr11);
+            const float ci3 = CC (ii, 0, k) + (ti2 * tr12 + ti3 * tr11);
+            const float cr5 = tr5 * ti11 + tr4 * ti12;
+            const float ci5 = ti5 * ti11 + ti4 * ti12;
+            const float cr4 = tr5 * ti12 - tr4 * ti11;
+            const float ci4 = ti5 * ti12 - ti4 * ti11;
+            float dr3 = cr3 - ci4, dr4 = cr3 + ci4;
+            float di3 = ci3 + cr4, di4 = ci3 - cr4;
+            float dr5 = cr2 + ci5, dr2 = cr2 - ci5;
+            float di5 = ci2 - cr5, di2 = ci2 + cr5;
+            CMUL (dr2, di2, wa1[ii - 2], wa1[ii - 1]);
+            CMUL (dr3, di3, wa2[ii - 2], wa2[ii - 1]);
+            CMUL (dr4, di4, wa3[ii - 2], wa3[ii - 1]);
+            CMUL (dr5, di5, wa4[ii - 2], wa4[ii - 1]);
+            CH (ii - 1, k, 1) = dr2;
+            CH (ii, k, 1) = di2;
+            CH (ii - 1, k, 2) = dr3;
+            CH (ii, k, 2) = di3;
+            CH (ii - 1, k, 3) = dr4;
+            CH (ii, k, 3) = di4;
+            CH (ii - 1, k, 4) = dr5;
+            CH (ii, k, 4) = di5;
+        }
+#undef CC
+#undef CH
+}
+
 /* sse.cpp:1358-1416 rfftb1_ps */
 static float* real_backward_passes (const oracle_setup* s, float* a, float* b)
 {
@@ -640,6 +938,10 @@ static float* real_backward_passes (const oracle_setup* s, float* a, float* b)
         {
             if (ip == 4)
                 rbwd4_lane (ido, l1, in + lane, out + lane, wa + iw, wa + iw + ido, wa + iw + 2 * ido);
+            else if (ip == 3)
+                rbwd3_lane (ido, l1, in + lane, out + lane, wa + iw, wa + iw + ido);
+            else if (ip == 5)
+                rbwd5_lane (ido, l1, in + lane, out + lane, wa + iw, wa + iw + ido, wa + iw + 2 * ido, wa + iw + 3 * ido);
             else
                 rbwd2_lane (ido, l1, in + lane, out + lane, wa + iw);
         }

@@ -18,8 +18,7 @@ enum { ORACLE_REAL = 0, ORACLE_COMPLEX = 1 };     /* = fft_transform_t */
 
 typedef struct oracle_setup oracle_setup;
 
-/* NULL when the reference's SSE path would return NULL (size rules) or when N is not a power of two
-   (radix-3/5 passes are not restated). */
+/* NULL exactly when the reference's SSE path returns NULL: N % 16 (complex) / N % 32 (real), N/4 = 2^a 3^b 5^c. */
 oracle_setup* oracle_new_setup (int N, int transform);
 void oracle_destroy_setup (oracle_setup* s);
 

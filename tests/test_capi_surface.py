@@ -72,14 +72,26 @@ def test_bytes_required_is_never_below_the_reference_figure():
 
 
 def test_size_rule_host_logic():
-    """powers of two, complex >= 16, real >= 32 (reference common.hpp:168-177), up to 2^20"""
-    ok_c = [1 << k for k in range(4, 21)]
-    for n in range(1, 70):
-        assert api.size_supported(n, api.FFT_COMPLEX) == (n in ok_c)
-        assert api.size_supported(n, api.FFT_REAL) == (n in ok_c and n >= 32)
-    for n in (0, -16, 96, 480, 9216, 1 << 21):
+    """the reference's rule (common.hpp:168-177, 216-225): N % 16 (complex) / N % 32 (real) and no prime
+    factor other than 2, 3, 5; powers of two up to 2^20, mixed-radix sizes while the complex length <= 9216"""
+
+    def smooth(n):
+        for f in (2, 3, 5):
+            while n % f == 0:
+                n //= f
+        return n == 1
+
+    for n in range(1, 2000):
+        assert api.size_supported(n, api.FFT_COMPLEX) == (n % 16 == 0 and smooth(n)), n
+        assert api.size_supported(n, api.FFT_REAL) == (n % 32 == 0 and smooth(n)), n
+    for n in (0, -16, 24, 112, 176, 1 << 21, 3 << 19):
         assert not api.size_supported(n, api.FFT_COMPLEX)
+    # the reference's "Other sizes" test list (test/test.cpp:279-285)
+    for n in (96, 192, 384, 480, 640, 768, 9216):
+        assert api.size_supported(n, api.FFT_COMPLEX) and api.size_supported(n, api.FFT_REAL)
     assert api.size_supported(1 << 20, api.FFT_REAL)
+    assert not api.size_supported(9216 + 1024, api.FFT_COMPLEX)  # 10240 = 2^11 * 5: too long for the LDS-resident generic kernel
+    assert api.size_supported(2 * 9216, api.FFT_REAL)
 
 
 def test_plan_describe_host_logic():
@@ -99,6 +111,10 @@ def test_plan_describe_host_logic():
         if d["passes"] == 2:
             assert d["n1"] * d["n2"] == 1 << lg and 64 <= d["n2"] <= d["n1"] <= 1024
     assert api.plan_describe(24, api.FFT_COMPLEX) is None
+    # mixed-radix sizes: one pass of the generic kernel, radices 5 / 3 first, then the power of two
+    d = api.plan_describe(480, api.FFT_COMPLEX)
+    assert d == {"complex_len": 480, "passes": 1, "n1": 0, "n2": 0, "radices": [5, 3, 8, 4]}
+    assert api.plan_describe(96, api.FFT_REAL)["complex_len"] == 48
 
 
 def test_misuse_returns_codes_not_crashes():

@@ -1,0 +1,133 @@
+"""sizes N = 2^a 3^b 5^c that are not powers of two -- the rest of the reference's
+accepted set, exercised by its "Other sizes" tests (test/test.cpp:279-285: 96, 192, 384, 480, 640, 768, 9216,
+run WITHOUT the convolution cases, like here).  The oracle runs the reference's radix-3 / radix-5 passes
+(bit-identical to the compiled reference, tests/test_oracle_vs_reference.py); bound 1e-6 relative L2 per frame.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from conftest import assert_frames_close
+from oracle_lib import BACKWARD, COMPLEX, FORWARD, REAL
+
+pytestmark = pytest.mark.gpu
+
+REFERENCE_OTHER_SIZES = [96, 192, 384, 480, 640, 768, 9216]
+MORE_SIZES = [48, 80, 160, 240, 320, 720, 1440, 2000, 3072, 5120, 6400, 7680, 8640]
+
+
+def _gpu(gpu, s, x, direction):
+    api, torch, dev = gpu
+    xd = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    yd = torch.empty_like(xd)
+    api.fft_transform_batch(s, xd, yd, direction)
+    torch.cuda.synchronize()
+    return yd.cpu().numpy()
+
+
+@pytest.mark.parametrize("n", REFERENCE_OTHER_SIZES + MORE_SIZES)
+@pytest.mark.parametrize("tr", [COMPLEX, REAL])
+def test_other_sizes_batch_vs_oracle(gpu, oracle, n, tr):
+    api = gpu[0]
+    so = oracle.new_setup(n, tr)
+    s = api.fft_new_setup(n, tr)
+    assert (s is None) == (so is None), "accepted-size rule differs from the reference's"
+    if s is None:
+        return
+    nf = 2 * n if tr == COMPLEX else n
+    batch = 11
+    x = ol.uniform(batch * nf, 7 + n).reshape(batch, nf)
+    want_f = oracle.transform_batch(so, x, FORWARD)
+    got_f = _gpu(gpu, s, x, api.FFT_FORWARD)
+    if tr == REAL and n % 25 == 0:
+        # REFERENCE DEFECT (found while pinning this row): the reference's REAL FORWARD transform is wrong whenever
+        # radf5_ps runs with ido > 1, i.e. for every real size divisible by 25 (simd/chowdsp_fft_impl_sse.cpp:747-782;
+        # SSE and AVX alike, BACKWARD(FORWARD(x)) != N x, ~80 % of the bins off by O(1)).  The oracle reproduces it
+        # bit for bit.  Nothing can be "in parity" with that, so the forward result is checked against the exact
+        # (float64) packed spectrum instead, and the defect itself is asserted so that this note stays honest.
+        spec = np.fft.rfft(x.astype(np.float64), axis=1)
+        exact = np.empty((batch, n))
+        exact[:, 0], exact[:, 1] = spec[:, 0].real, spec[:, n // 2].real
+        exact[:, 2::2], exact[:, 3::2] = spec[:, 1:n // 2].real, spec[:, 1:n // 2].imag
+        assert max(ol.rel_l2(got_f[i], exact[i]) for i in range(batch)) <= 5e-7
+        assert ol.rel_l2(want_f[0], exact[0]) > 0.1, "the reference defect seems to be gone: drop this special case"
+        want_f = exact.astype(np.float32)  # the reference's BACKWARD path is correct: feed both the true spectrum
+    else:
+        assert_frames_close(got_f, want_f, what=f"N={n} fwd")
+    want_b = oracle.transform_batch(so, want_f, BACKWARD)
+    assert_frames_close(_gpu(gpu, s, want_f, api.FFT_BACKWARD), want_b, what=f"N={n} bwd")
+    api.fft_destroy_setup(s)
+    oracle.destroy_setup(so)
+
+
+@pytest.mark.parametrize("n", REFERENCE_OTHER_SIZES)
+@pytest.mark.parametrize("tr", [COMPLEX, REAL])
+@pytest.mark.parametrize("preallocate", [False, True])
+def test_reference_other_sizes_sequence_host_pointers(gpu, oracle, n, tr, preallocate):
+    """reference test/test.cpp:236-258 run_tests_for_size(fft_size, test_convolution = false): complex, real,
+    preallocated complex, preallocated real -- in place, host pointers, tone input.  The reference's own tolerance
+    (2e-7 * len, absolute, against upstream pffft) is applied against the EXACT float64 result here: at N = 9216 the
+    reference algorithm itself is 4.7e-3 away from the exact spectrum (its float-angle twiddles), more than that
+    tolerance, so it only passes its own test because pffft shares the error."""
+    api = gpu[0]
+    nf = 2 * n if tr == COMPLEX else n
+    data, dp = api.aligned_array(nf)
+    work, wp = api.aligned_array(nf)
+    data[:] = ol.tone(n, tr == COMPLEX)
+    x0 = data.copy()
+    prealloc = None
+    if preallocate:
+        prealloc = api.aligned_malloc(api.fft_bytes_required(n, tr, False))
+        s = api.fft_new_setup_preallocated(n, tr, prealloc, False)
+    else:
+        s = api.fft_new_setup(n, tr, False)
+    assert s is not None and api.fft_simd_width_bytes(s) == 16
+    so = oracle.new_setup(n, tr)
+    api.fft_transform(s, data, data, work, api.FFT_FORWARD)
+    want_f = oracle.transform(so, x0, FORWARD)
+    if tr == COMPLEX:
+        t = np.fft.fft(x0[0::2].astype(np.float64) + 1j * x0[1::2])
+        exact = np.empty(nf)
+        exact[0::2], exact[1::2] = t.real, t.imag
+    else:
+        t = np.fft.rfft(x0.astype(np.float64))
+        exact = np.empty(nf)
+        exact[0], exact[1] = t[0].real, t[n // 2].real
+        exact[2::2], exact[3::2] = t[1:n // 2].real, t[1:n // 2].imag
+    assert np.abs(data - exact).max() <= 2.0e-7 * nf
+    assert_frames_close(data, want_f, what="other size fwd")
+    api.fft_transform(s, data, data, work, api.FFT_BACKWARD)
+    assert np.abs(data / n - x0).max() <= 2.0e-7 * nf  # BACKWARD(FORWARD(x)) = N x
+    want_b = oracle.transform(so, oracle.transform(so, x0, FORWARD), BACKWARD)
+    assert_frames_close(data, want_b, what="other size round trip")
+    if preallocate:
+        api.aligned_free(prealloc)
+    else:
+        api.fft_destroy_setup(s)
+    oracle.destroy_setup(so)
+    api.aligned_free(dp)
+    api.aligned_free(wp)
+
+
+def test_other_size_convolution_ops(gpu, oracle):
+    """multiply-accumulate / accumulate work on any supported size; the fused kernel is power-of-two only"""
+    api, torch, dev = gpu
+    n, tr = 480, REAL
+    s, so = api.fft_new_setup(n, tr), oracle.new_setup(n, tr)
+    x, h = ol.uniform(3 * n, 1).reshape(3, n), ol.uniform(n, 2).reshape(1, n)
+    xd, hd = torch.from_numpy(x).to(dev), torch.from_numpy(h).to(dev)
+    X, H = torch.empty_like(xd), torch.empty_like(hd)
+    api.fft_transform_unordered_batch(s, xd, X, api.FFT_FORWARD)
+    api.fft_transform_unordered_batch(s, hd, H, api.FFT_FORWARD)
+    acc = torch.zeros_like(xd)
+    api.fft_convolve_unordered_batch(s, X, H, acc, 1.0 / n, b_is_shared=True)
+    y = torch.empty_like(xd)
+    api.fft_transform_unordered_batch(s, acc, y, api.FFT_BACKWARD)
+    torch.cuda.synchronize()
+    hb = oracle.transform(so, h[0], FORWARD, False)
+    want = np.stack([oracle.transform(so, oracle.convolve(so, oracle.transform(so, x[i], FORWARD, False), hb, np.zeros(n, np.float32), 1.0 / n), BACKWARD, False) for i in range(3)])
+    assert_frames_close(y.cpu().numpy(), want, what="N=480 convolution pipeline")
+    with pytest.raises(api.FFTError):
+        api.fft_convolve_frames_batch(s, xd, H, y, 1.0 / n)
+    api.fft_destroy_setup(s)
+    oracle.destroy_setup(so)

@@ -102,7 +102,7 @@ def test_one_million_point_frames(gpu, oracle):
         oracle.destroy_setup(so)
 
 
-@pytest.mark.parametrize("key_n", [16, 32, 64, 1024, 4096])
+@pytest.mark.parametrize("key_n", [16, 32, 64, 1024, 4096, 96, 480])
 @pytest.mark.parametrize("tag", ["c", "r"])
 @pytest.mark.parametrize("name", ["tone", "uniform", "impulse"])
 def test_golden_vectors(gpu, golden, key_n, tag, name):
@@ -327,8 +327,9 @@ def test_in_place_and_device_pointer_legacy_calls(gpu, oracle):
 
 def test_edge_cases(gpu):
     api, torch, dev = gpu
-    # sizes the reference rejects, or that are outside the power-of-two hot path -> NULL, no crash
-    for n, tr in ((0, COMPLEX), (-64, COMPLEX), (8, COMPLEX), (16, REAL), (24, COMPLEX), (96, COMPLEX), (1 << 21, COMPLEX)):
+    # sizes the reference rejects, or that are too long for this backend -> NULL, no crash
+    for n, tr in ((0, COMPLEX), (-64, COMPLEX), (8, COMPLEX), (16, REAL), (24, COMPLEX), (112, COMPLEX), (48, REAL),
+                  (1 << 21, COMPLEX), (10240, COMPLEX)):
         assert api.fft_new_setup(n, tr) is None
     s = api.fft_new_setup(256, api.FFT_COMPLEX)
     x = torch.zeros(512, device=dev)

@@ -25,7 +25,7 @@ def _input(golden, tag, n, name):
     return ol.impulse(n, cplx, 1)
 
 
-@pytest.mark.parametrize("n", [16, 32, 64, 1024, 4096])
+@pytest.mark.parametrize("n", [16, 32, 64, 1024, 4096, 96, 480])
 @pytest.mark.parametrize("tag", ["c", "r"])
 @pytest.mark.parametrize("name", ["tone", "uniform", "impulse"])
 def test_oracle_matches_golden_ordered(oracle, golden, n, tag, name):
@@ -112,12 +112,13 @@ def test_oracle_real_packed_format_vs_float64(oracle, n):
 
 
 def test_oracle_size_rules(oracle):
-    """reference simd/chowdsp_fft_impl_common.hpp:168-177: complex N % 16, real N % 32; powers of two only here"""
+    """reference simd/chowdsp_fft_impl_common.hpp:168-177, 216-225: complex N % 16, real N % 32, N/4 = 2^a 3^b 5^c"""
     assert oracle.new_setup(8, COMPLEX) is None
     assert oracle.new_setup(16, REAL) is None
     assert oracle.new_setup(0, COMPLEX) is None
-    assert oracle.new_setup(96, COMPLEX) is None  # accepted by the reference, not restated (radix 3)
-    for n, tr in ((16, COMPLEX), (32, REAL)):
+    assert oracle.new_setup(112, COMPLEX) is None  # 7 is not an accepted factor
+    assert oracle.new_setup(48, REAL) is None
+    for n, tr in ((16, COMPLEX), (32, REAL), (96, COMPLEX), (96, REAL), (480, COMPLEX), (9216, REAL)):
         s = oracle.new_setup(n, tr)
         assert s is not None
         oracle.destroy_setup(s)

@@ -15,13 +15,15 @@ from oracle_lib import BACKWARD, COMPLEX, FORWARD, REAL
 
 SIZES_FAST = [1 << k for k in range(4, 15)]
 SIZES_SLOW = [1 << k for k in range(15, 20)]
+# the reference's "Other sizes" (test/test.cpp:279-285) and more 2^a 3^b 5^c sizes: radix-3 / radix-5 passes
+SIZES_OTHER = [96, 192, 384, 480, 640, 768, 9216, 48, 80, 160, 240, 320, 720, 1440, 2000, 3072, 5120, 15360, 24000]
 
 
 def _bits(a):
     return np.ascontiguousarray(a).view(np.uint32)
 
 
-@pytest.mark.parametrize("n", SIZES_FAST + SIZES_SLOW)
+@pytest.mark.parametrize("n", SIZES_FAST + SIZES_SLOW + SIZES_OTHER)
 @pytest.mark.parametrize("tr", [COMPLEX, REAL])
 def test_bit_identical_to_reference_sse(oracle, reflib, n, tr):
     so, sr = oracle.new_setup(n, tr), reflib.new_setup(n, tr, False)
