@@ -18,7 +18,7 @@ tail -1 "$OUT/smoke.log"
 echo "== bench (default workload)"
 timeout 600 python bench.py --steps 20 --warmup 3 > "$OUT/bench_c2c4096.json" 2> "$OUT/bench_c2c4096.err"
 cat "$OUT/bench_c2c4096.json"
-for W in real_n1024_b262144_fwd_inv conv_real_n4096_b131072 c2c_n65536_b8192_fwd_inv; do
+for W in real_n1024_b262144_fwd_inv conv_real_n4096_b131072 c2c_n65536_b8192_fwd_inv ols_engine_b2048_p16_c8192; do
   timeout 600 python bench.py --steps 20 --warmup 3 --workload $W --no-cpu-baseline > "$OUT/bench_$W.json" 2> "$OUT/bench_$W.err"
   python - "$OUT/bench_$W.json" <<'EOF'
 import json, sys
@@ -29,6 +29,9 @@ except Exception as e:
     print("bench parse failed", sys.argv[1], e)
 EOF
 done
+
+echo "== legacy host-pointer call rate (PCIe inclusive)"
+timeout 300 python tools/legacy_rate.py 2>/dev/null | tee "$OUT/legacy_rate.txt"
 
 echo "== rocprofv3 kernel stats (same command as the bench line)"
 cd /tmp
