@@ -107,9 +107,9 @@ int lane_count()
     return n;
 }
 
+// caller holds g_ws_mutex
 Lanes* get_lanes (int device, hipStream_t stream, size_t bytes_each)
 {
-    std::lock_guard<std::mutex> lock (g_ws_mutex);
     Lanes& L = g_lanes[std::make_pair (device, stream)];
     if (! L.ok)
     {
@@ -166,6 +166,10 @@ int big_c2c_chunked (Setup* s, int nc, bool inverse, const float2* in, float2* o
         chunk = 1;
     if (chunk > batch)
         chunk = batch;
+    // One enqueue sequence at a time per process: concurrent host threads sharing a stream (e.g. legacy calls on the
+    // default stream) must not interleave "pass A -> workspace -> pass B" of different calls on the same workspace.
+    // Only the (microseconds of) enqueueing is serialised; execution order then follows from stream order.
+    std::lock_guard<std::mutex> lock (g_ws_mutex);
     Lanes* L = get_lanes (s->device, stream, chunk * frame_bytes);
     if (L == nullptr)
         return cf::FFT_GPU_ENOMEM;
@@ -202,10 +206,28 @@ int big_c2c_chunked (Setup* s, int nc, bool inverse, const float2* in, float2* o
     return cf::FFT_GPU_OK;
 }
 
+// RAII: run on the device the plan's tables live on, whatever device the calling thread has current
+struct DeviceGuard
+{
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard (int want)
+    {
+        if (hipGetDevice (&prev) == hipSuccess && prev != want)
+            switched = hipSetDevice (want) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        if (switched)
+            (void) hipSetDevice (prev);
+    }
+};
+
 int run_transform (Setup* s, const float* in, float* out, size_t batch, cf::fft_direction_t dir, hipStream_t stream)
 {
     if (batch == 0)
         return cf::FFT_GPU_OK;
+    const DeviceGuard guard (s->device);
     const bool inverse = (dir == cf::FFT_BACKWARD);
     const DeviceTables* t = s->tables;
     const int nc = complex_len (s);
