@@ -14,7 +14,13 @@ hipError_t launch_real_m (const float2* in, float2* out, const float2* tw, const
     const size_t ngroups = (batch + G::FPB - 1) / G::FPB;
     if constexpr (FWD)
     {
-        auto kernel = r2c_kernel<P, G::FPB>;
+        // CFFT_REAL_PREFETCH: 0 never, 1 always, default 2 = only one-frame-per-workgroup plans (measured on MI355X:
+        // N=8192 +2 %, N=1024 / N=4096 -2 % -- same picture as the complex kernels)
+#ifndef CFFT_REAL_PREFETCH
+#define CFFT_REAL_PREFETCH 2
+#endif
+        constexpr bool use_pf = (CFFT_REAL_PREFETCH == 1) || (CFFT_REAL_PREFETCH == 2 && G::FPB == 1);
+        auto kernel = use_pf ? r2c_kernel_pf<P, G::FPB> : r2c_kernel<P, G::FPB>;
         const unsigned grid = persistent_grid (kernel, G::threads, G::lds_bytes, ngroups);
         if (grid == 0)
             return hipErrorNoDevice;

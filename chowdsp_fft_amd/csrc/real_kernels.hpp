@@ -138,6 +138,121 @@ __global__ __launch_bounds__ (P::T* FPB) void r2c_kernel (const float2* __restri
     }
 }
 
+// ---- software-pipelined variants ------------------------------------------------------------------------
+// Same scheme as c2c_kernel_pf: the next group's loads are issued before this group's arithmetic and stores, and the
+// first group is peeled so that the steady-state loop-top wait is vmcnt(#stores), never vmcnt(0).  To keep the load and
+// store counts compile-time constants with several frames per workgroup, the main loop only walks FULL groups
+// (batch / FPB of them); a ragged last group is handled once, predicated, by the workgroup whose turn it would be.
+template <class P, bool PRED>
+__device__ __forceinline__ void r2c_finish (float2 (&v)[P::R], const TwiddleRegs<P>& tw, const PairTwiddles<P>& pw,
+                                            float2* __restrict__ lds, float2* __restrict__ dst, unsigned team_base, int t, bool active)
+{
+    constexpr int M = P::N;
+    team_sync<P::T>();
+    fft_core<P> (v, tw, lds, t);
+    if constexpr (P::NS > 1)
+        team_sync<P::T>();
+    lds_store_output_order<P> (v, lds, t);
+    team_sync<P::T>();
+#pragma unroll
+    for (int q = 0; q < P::R / 2; ++q)
+    {
+        const int k = t + P::T * q;
+        const float2 A = lds[lds_phys (k)];
+        const float2 Zp = lds[lds_phys (k == 0 ? M / 2 : M - k)];
+        float2 Xk, Xp;
+        real_split_pair (A, Zp, pw.w[q], Xk, Xp);
+        if (k == 0)
+        {
+            Xk = make_float2 (A.x + A.y, A.x - A.y);
+            Xp = make_float2 (Zp.x, -Zp.y);
+        }
+        if (! PRED || active)
+        {
+            gstore (&dst[team_base + (unsigned) k], Xk);
+            gstore (&dst[team_base + (unsigned) (k == 0 ? M / 2 : M - k)], Xp);
+        }
+    }
+}
+
+template <class P, int FPB>
+__global__ __launch_bounds__ (P::T* FPB) void r2c_kernel_pf (const float2* __restrict__ in,
+                                                            float2* __restrict__ out,
+                                                            const float2* __restrict__ twtab,
+                                                            const float2* __restrict__ wtab,
+                                                            unsigned batch)
+{
+    extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
+    constexpr int M = P::N;
+    const int tid = threadIdx.x;
+    const int team = tid / P::T;
+    const int t = tid % P::T;
+    float2* lds = smem + team * LdsFrame<M>::floats2;
+    TwiddleRegs<P> tw;
+    load_twiddles<P> (tw, twtab, t);
+    PairTwiddles<P> pw;
+    load_pair_twiddles<P> (pw, wtab, t);
+
+    const unsigned nfull = batch / FPB;
+    const unsigned team_base = (unsigned) team * M;
+    float nre[P::R], nim[P::R];
+    unsigned g = blockIdx.x;
+    if (g < nfull)
+    {
+        {
+            const float2* __restrict__ src = in + (size_t) g * (FPB * M);
+            float2 v[P::R];
+#pragma unroll
+            for (int s = 0; s < P::R; ++s)
+                v[s] = gload (&src[team_base + (unsigned) input_index<P> (t, s)]);
+            const unsigned gn = g + gridDim.x;
+            if (gn < nfull)
+            {
+                const float2* __restrict__ srcn = in + (size_t) gn * (FPB * M);
+#pragma unroll
+                for (int s = 0; s < P::R; ++s)
+                {
+                    const float2 x = gload (&srcn[team_base + (unsigned) input_index<P> (t, s)]);
+                    nre[s] = x.x;
+                    nim[s] = x.y;
+                }
+            }
+            r2c_finish<P, false> (v, tw, pw, lds, out + (size_t) g * (FPB * M), team_base, t, true);
+        }
+        for (g += gridDim.x; g < nfull; g += gridDim.x)
+        {
+            float2 v[P::R];
+#pragma unroll
+            for (int s = 0; s < P::R; ++s)
+                v[s] = make_float2 (nre[s], nim[s]);
+            const unsigned gn = g + gridDim.x;
+            if (gn < nfull)
+            {
+                const float2* __restrict__ srcn = in + (size_t) gn * (FPB * M);
+#pragma unroll
+                for (int s = 0; s < P::R; ++s)
+                {
+                    const float2 x = gload (&srcn[team_base + (unsigned) input_index<P> (t, s)]);
+                    nre[s] = x.x;
+                    nim[s] = x.y;
+                }
+            }
+            r2c_finish<P, false> (v, tw, pw, lds, out + (size_t) g * (FPB * M), team_base, t, true);
+        }
+    }
+    // ragged last group
+    if (FPB > 1 && nfull * FPB < batch && blockIdx.x == nfull % gridDim.x)
+    {
+        const bool active = nfull * FPB + team < batch;
+        const float2* __restrict__ src = in + (size_t) nfull * (FPB * M);
+        float2 v[P::R];
+#pragma unroll
+        for (int s = 0; s < P::R; ++s)
+            v[s] = active ? gload (&src[team_base + (unsigned) input_index<P> (t, s)]) : make_float2 (0.f, 0.f);
+        r2c_finish<P, true> (v, tw, pw, lds, out + (size_t) nfull * (FPB * M), team_base, t, active);
+    }
+}
+
 // ---- c2r -----------------------------------------------------------------------------------------
 template <class P, int FPB>
 __global__ __launch_bounds__ (P::T* FPB) void c2r_kernel (const float2* __restrict__ in,
