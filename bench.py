@@ -38,6 +38,8 @@ WORKLOADS = {
     "real_n1024_b262144_fwd_inv": (1024, "real", 262144, "BASELINE configs[2]: N=1024 fp32 real r2c+c2r, batch=262144 per GPU"),
     "c2c_n65536_b8192_fwd_inv": (65536, "complex", 8192, "BASELINE configs[4]: N=65536 fp32 complex (two-pass), batch=8192 per GPU"),
     "conv_real_n4096_b131072": (4096, "real", 131072, "BASELINE configs[3] per-GPU share: fused fwd->mul->inv frames, N=4096 real, 131072 frames per GPU"),
+    # a mixed-radix size from the reference's "Other sizes" list (9216 = 2^10 * 3^2), generic kernel
+    "c2c_n9216_b16384_fwd_inv": (9216, "complex", 16384, "mixed-radix N=9216 fp32 complex fwd+inv (generic kernel), batch=16384 per GPU"),
     # streaming partitioned overlap-save engine; one step = one block of 2048 samples on every channel
     "ols_engine_b2048_p16_c8192": (4096, "real", 8192, "partitioned overlap-save engine: block 2048 (N=4096 real), 16 partitions, 8192 channels per GPU"),
 }

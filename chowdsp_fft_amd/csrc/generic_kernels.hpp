@@ -4,10 +4,12 @@
 //
 // Replaces passf3_ps / passf5_ps (simd/chowdsp_fft_impl_sse.cpp:182-219, 298-370) and, through the same
 // half-length-complex + pair-stage scheme as real_kernels.hpp, radf3/5 and radb3/5 (:588-625, :704-786, :1126-1170,
-// :1262-1356).  One 256-work-item workgroup per frame, the whole frame ping-pongs between two LDS images, one
-// Stockham stage per radix with a RUN-TIME radix list (these sizes are an open set, so there is no per-size template
-// plan); per-stage twiddles come from a table in L2.  This path favours generality over the last 20 % of bandwidth:
-// the power-of-two sizes -- the hot path -- never take it.
+// :1262-1356).  A workgroup owns F whole frames at a time (F > 1 for short frames so that every work-item has a
+// butterfly to do); the frames ping-pong between two LDS images, one Stockham stage per radix with a RUN-TIME radix
+// list (these sizes are an open set, so there is no per-size template plan); per-stage twiddles come from a table in
+// L2.  Long frames (two images > 64 KiB) run with 1024 work-items per workgroup because only one workgroup fits a CU.
+// This path favours generality over the last factor of two in bandwidth: the power-of-two sizes -- the hot path --
+// never take it.
 #pragma once
 #include "real_kernels.hpp"
 
@@ -18,9 +20,10 @@ static constexpr int kGenericMaxN = 9216; // two LDS images of 8*N bytes must fi
 
 struct GenericPlan
 {
-    int n;                           // complex points per frame
-    int ns;                          // number of stages
-    int radix[kGenericMaxStages];    // each in {2, 3, 4, 5, 8}
+    int n;                            // complex points per frame
+    int ns;                           // number of stages
+    int frames;                       // frames per workgroup pass (F)
+    int radix[kGenericMaxStages];     // each in {2, 3, 4, 5, 8}
     int tw_offset[kGenericMaxStages]; // float2 offset of the stage's table: (radix-1) * p entries, [a-1][k]
 };
 
@@ -56,20 +59,24 @@ __device__ __forceinline__ void fft_reg<5> (float2 (&u)[5])
     u[3] = make_float2 (m2.x - q2.y, m2.y + q2.x);
 }
 
-// one Stockham stage of radix R over the whole frame: src -> dst
-template <int R>
+// one Stockham stage of radix R over `nframes` frames of n points: src -> dst (frame f at offset f*n)
+template <int R, int BLOCK>
 __device__ __forceinline__ void generic_stage (const float2* __restrict__ src, float2* __restrict__ dst,
-                                               const float2* __restrict__ tw, int n, int p, int tid)
+                                               const float2* __restrict__ tw, int n, int p, int nframes, int tid)
 {
     const int m = n / R;
-    for (int i = tid; i < m; i += 256)
+    for (int idx = tid; idx < nframes * m; idx += BLOCK)
     {
+        const int f = idx / m;
+        const int i = idx - f * m;
         const int k = i % p;
         const int j = (i - k) * R + k;
+        const float2* s = src + f * n;
+        float2* d = dst + f * n;
         float2 u[R];
 #pragma unroll
         for (int a = 0; a < R; ++a)
-            u[a] = src[i + a * m];
+            u[a] = s[i + a * m];
         if (p > 1)
         {
 #pragma unroll
@@ -79,12 +86,13 @@ __device__ __forceinline__ void generic_stage (const float2* __restrict__ src, f
         fft_reg<R> (u);
 #pragma unroll
         for (int b = 0; b < R; ++b)
-            dst[j + b * p] = u[b];
+            d[j + b * p] = u[b];
     }
 }
 
-// all stages; the frame starts in `a`, returns the image that holds the result
-__device__ __forceinline__ float2* generic_core (const GenericPlan& plan, const float2* __restrict__ twtab, float2* a, float2* b, int tid)
+// all stages; the frames start in `a`, returns the image that holds the result
+template <int BLOCK>
+__device__ __forceinline__ float2* generic_core (const GenericPlan& plan, const float2* __restrict__ twtab, float2* a, float2* b, int nframes, int tid)
 {
     float2 *src = a, *dst = b;
     int p = 1;
@@ -94,11 +102,11 @@ __device__ __forceinline__ float2* generic_core (const GenericPlan& plan, const 
         const float2* tw = twtab + plan.tw_offset[s];
         switch (r)
         {
-            case 2: generic_stage<2> (src, dst, tw, plan.n, p, tid); break;
-            case 3: generic_stage<3> (src, dst, tw, plan.n, p, tid); break;
-            case 4: generic_stage<4> (src, dst, tw, plan.n, p, tid); break;
-            case 5: generic_stage<5> (src, dst, tw, plan.n, p, tid); break;
-            default: generic_stage<8> (src, dst, tw, plan.n, p, tid); break;
+            case 2: generic_stage<2, BLOCK> (src, dst, tw, plan.n, p, nframes, tid); break;
+            case 3: generic_stage<3, BLOCK> (src, dst, tw, plan.n, p, nframes, tid); break;
+            case 4: generic_stage<4, BLOCK> (src, dst, tw, plan.n, p, nframes, tid); break;
+            case 5: generic_stage<5, BLOCK> (src, dst, tw, plan.n, p, nframes, tid); break;
+            default: generic_stage<8, BLOCK> (src, dst, tw, plan.n, p, nframes, tid); break;
         }
         __syncthreads();
         float2* t = src;
@@ -111,32 +119,37 @@ __device__ __forceinline__ float2* generic_core (const GenericPlan& plan, const 
 
 // MODE 0: complex <-> complex (INV: backward).  MODE 1: real forward (packed spectrum out).  MODE 2: real backward.
 // For the real modes plan.n = N/2 and wtab holds W_N^k, k <= N/4 (pair stage formulas: real_kernels.hpp).
-template <int MODE, bool INV>
-__global__ __launch_bounds__ (256) void generic_kernel (const float2* __restrict__ in,
-                                                       float2* __restrict__ out,
-                                                       const float2* __restrict__ twtab,
-                                                       const float2* __restrict__ wtab,
-                                                       GenericPlan plan,
-                                                       unsigned batch)
+template <int MODE, bool INV, int BLOCK>
+__global__ __launch_bounds__ (BLOCK) void generic_kernel (const float2* __restrict__ in,
+                                                         float2* __restrict__ out,
+                                                         const float2* __restrict__ twtab,
+                                                         const float2* __restrict__ wtab,
+                                                         GenericPlan plan,
+                                                         unsigned batch)
 {
     extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
     const int tid = threadIdx.x;
     const int n = plan.n;
+    const int F = plan.frames;
+    const int half = n / 2 + 1; // pair-stage work items per frame: k = 0 .. n/2
     float2* bufA = smem;
-    float2* bufB = smem + n;
-    for (unsigned f = blockIdx.x; f < batch; f += gridDim.x)
+    float2* bufB = smem + (size_t) F * n;
+    const unsigned ngroups = (batch + F - 1) / F;
+    for (unsigned g = blockIdx.x; g < ngroups; g += gridDim.x)
     {
-        const float2* __restrict__ src = in + (size_t) f * n;
-        float2* __restrict__ dst = out + (size_t) f * n;
-        __syncthreads(); // previous frame's reads of the images are finished
+        const int nframes = (int) min ((unsigned) F, batch - g * F);
+        const float2* __restrict__ src = in + (size_t) g * F * n;
+        float2* __restrict__ dst = out + (size_t) g * F * n;
+        __syncthreads(); // previous group's reads of the images are finished
         if (MODE == 2)
         {
             // merge pairs straight from global memory (k and n-k), stored re<->im swapped for the inverse core
-            for (int k = tid; k <= n / 2; k += 256)
+            for (int idx = tid; idx < nframes * half; idx += BLOCK)
             {
+                const int f = idx / half, k = idx - f * half;
                 const int kp = (k == 0) ? 0 : n - k;
-                const float2 A = gload (&src[k]);
-                const float2 Xp = gload (&src[kp]);
+                const float2 A = gload (&src[f * n + k]);
+                const float2 Xp = gload (&src[f * n + kp]);
                 float2 zk, zp;
                 if (k == 0)
                 {
@@ -150,28 +163,29 @@ __global__ __launch_bounds__ (256) void generic_kernel (const float2* __restrict
                 }
                 else
                     real_merge_pair (A, Xp, wtab[k], zk, zp);
-                bufA[k] = make_float2 (zk.y, zk.x);
+                bufA[f * n + k] = make_float2 (zk.y, zk.x);
                 if (kp != k)
-                    bufA[kp] = make_float2 (zp.y, zp.x);
+                    bufA[f * n + kp] = make_float2 (zp.y, zp.x);
             }
         }
         else
         {
-            for (int e = tid; e < n; e += 256)
+            for (int e = tid; e < nframes * n; e += BLOCK)
             {
                 const float2 x = gload (&src[e]);
                 bufA[e] = (MODE == 0 && INV) ? make_float2 (x.y, x.x) : x;
             }
         }
         __syncthreads();
-        const float2* res = generic_core (plan, twtab, bufA, bufB, tid);
+        const float2* res = generic_core<BLOCK> (plan, twtab, bufA, bufB, nframes, tid);
         if (MODE == 1)
         {
-            for (int k = tid; k <= n / 2; k += 256)
+            for (int idx = tid; idx < nframes * half; idx += BLOCK)
             {
+                const int f = idx / half, k = idx - f * half;
                 const int kp = (k == 0) ? 0 : n - k;
-                const float2 A = res[k];
-                const float2 Zp = res[kp];
+                const float2 A = res[f * n + k];
+                const float2 Zp = res[f * n + kp];
                 float2 Xk, Xp;
                 if (k == 0)
                 {
@@ -185,14 +199,14 @@ __global__ __launch_bounds__ (256) void generic_kernel (const float2* __restrict
                 }
                 else
                     real_split_pair (A, Zp, wtab[k], Xk, Xp);
-                gstore (&dst[k], Xk);
+                gstore (&dst[f * n + k], Xk);
                 if (kp != k)
-                    gstore (&dst[kp], Xp);
+                    gstore (&dst[f * n + kp], Xp);
             }
         }
         else
         {
-            for (int e = tid; e < n; e += 256)
+            for (int e = tid; e < nframes * n; e += BLOCK)
             {
                 const float2 y = res[e];
                 gstore (&dst[e], (MODE == 2 || INV) ? make_float2 (y.y, y.x) : y);

@@ -6,22 +6,37 @@ namespace cfft::host
 {
 namespace
 {
-template <int MODE, bool INV>
-hipError_t launch_generic_m (const GenericPlan& plan, const DeviceTables& t, const float2* in, float2* out, size_t batch, hipStream_t stream)
+template <int MODE, bool INV, int BLOCK>
+hipError_t launch_generic_mb (const GenericPlan& plan, const DeviceTables& t, const float2* in, float2* out, size_t batch, hipStream_t stream)
 {
-    auto kernel = generic_kernel<MODE, INV>;
-    const size_t lds = (size_t) 2 * plan.n * sizeof (float2);
+    auto kernel = generic_kernel<MODE, INV, BLOCK>;
+    const size_t lds = (size_t) 2 * plan.frames * plan.n * sizeof (float2);
     if (lds > 64 * 1024)
     {
         const hipError_t e = hipFuncSetAttribute ((const void*) kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
         if (e != hipSuccess)
             return e;
     }
-    const unsigned grid = persistent_grid (kernel, 256, lds, batch);
+    const size_t ngroups = (batch + plan.frames - 1) / plan.frames;
+    const unsigned grid = persistent_grid (kernel, BLOCK, lds, ngroups);
     if (grid == 0)
         return hipErrorNoDevice;
-    hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (256), lds, stream, in, out, (const float2*) t.stage_twiddles, (const float2*) t.real_twiddles, plan, (unsigned) batch);
+    hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (BLOCK), lds, stream, in, out, (const float2*) t.stage_twiddles, (const float2*) t.real_twiddles, plan, (unsigned) batch);
     return hipGetLastError();
+}
+
+template <int MODE, bool INV>
+hipError_t launch_generic_m (GenericPlan& plan, const DeviceTables& t, const float2* in, float2* out, size_t batch, hipStream_t stream)
+{
+    // Short frames: several per workgroup so that each of the 256 work-items has butterflies (about 2048 points in
+    // flight).  Long frames: the two LDS images allow one workgroup per CU, so it gets 1024 work-items.
+    if (2 * (size_t) plan.n * sizeof (float2) > 64 * 1024)
+    {
+        plan.frames = 1;
+        return launch_generic_mb<MODE, INV, 1024> (plan, t, in, out, batch, stream);
+    }
+    plan.frames = plan.n <= 512 ? std::max (1, 2048 / plan.n) : 1; // measured: N=480 +4 % with 4 frames, N=768 -13 % with 2
+    return launch_generic_mb<MODE, INV, 256> (plan, t, in, out, batch, stream);
 }
 } // namespace
 

@@ -30,6 +30,11 @@ WORK = {
     "c2048": (2048, 1, 131072, False),
     "r4096": (4096, 0, 131072, False),
     "r8192": (8192, 0, 65536, False),
+    "c9216": (9216, 1, 16384, False),
+    "c3072": (3072, 1, 65536, False),
+    "c768": (768, 1, 262144, False),
+    "c480": (480, 1, 524288, False),
+    "r9216": (9216, 0, 32768, False),
 }
 
 
