@@ -28,15 +28,30 @@ __global__ __launch_bounds__ (P::T* FPB) void c2c_kernel (const float2* __restri
 
     const unsigned ngroups = (batch + FPB - 1) / FPB;
     const unsigned team_base = (unsigned) team * P::N; // element offset of this team's frame inside the group
+    constexpr bool STAGED = (P::T < 16);
+    float2* stage = smem + FPB * LdsFrame<P::N>::floats2; // staging area (STAGED only): FPB frames, natural order
     for (unsigned g = blockIdx.x; g < ngroups; g += gridDim.x)
     {
         const bool active = g * FPB + team < batch; // uniform per team
         // group base is workgroup-uniform (SGPR pair); everything per work-item is a 32-bit offset
         const float2* __restrict__ src = in + (size_t) g * (FPB * P::N);
         float2* __restrict__ dst = out + (size_t) g * (FPB * P::N);
+        const unsigned valid = min ((unsigned) FPB, batch - g * FPB) * P::N; // elements of this group that exist
 
         float2 v[P::R];
-        if (active)
+        if constexpr (STAGED)
+        {
+            __syncthreads(); // previous group's copy-out has read the staging area
+            stage_in<P::T * FPB, FPB * P::N> (src, stage, valid, tid);
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < P::R; ++s)
+            {
+                const float2 x = stage[team_base + (unsigned) input_index<P> (t, s)];
+                v[s] = INV ? make_float2 (x.y, x.x) : x;
+            }
+        }
+        else if (active)
         {
 #pragma unroll
             for (int s = 0; s < P::R; ++s)
@@ -54,7 +69,16 @@ __global__ __launch_bounds__ (P::T* FPB) void c2c_kernel (const float2* __restri
         // the previous frame's last-stage LDS reads must be finished before stage 0 overwrites the image
         team_sync<P::T>();
         fft_core<P> (v, tw, lds, t);
-        if (active)
+        if constexpr (STAGED)
+        {
+            // the team's own slice of the staging area: every input was read (and synchronised inside fft_core)
+#pragma unroll
+            for (int s = 0; s < P::R; ++s)
+                stage[team_base + (unsigned) output_index<P> (t, s)] = INV ? make_float2 (v[s].y, v[s].x) : v[s];
+            __syncthreads();
+            stage_out<P::T * FPB, FPB * P::N> (dst, stage, valid, tid);
+        }
+        else if (active)
         {
 #pragma unroll
             for (int s = 0; s < P::R; ++s)

@@ -79,6 +79,9 @@ int blocks_per_cu_cached (const void* kernel, int threads, size_t lds_bytes)
     auto it = cache.find (key);
     if (it != cache.end())
         return it->second;
+    // first use of this kernel on this device: raise the dynamic-LDS cap when the launch needs more than 64 KiB
+    if (lds_bytes > 64 * 1024 && hipFuncSetAttribute (kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes) != hipSuccess)
+        (void) hipGetLastError();
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, kernel, threads, lds_bytes) != hipSuccess || n < 1)
     {

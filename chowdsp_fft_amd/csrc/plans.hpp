@@ -16,7 +16,11 @@ struct CorePlan;
 template <> struct CorePlan<16>   { using type = Plan<16,   4,   4, 4>;          };
 template <> struct CorePlan<32>   { using type = Plan<32,   4,   8, 4>;          };
 template <> struct CorePlan<64>   { using type = Plan<64,   8,   8, 8>;          };
+#if defined(CFFT_PLAN128_ALT) && CFFT_PLAN128_ALT == 1
+template <> struct CorePlan<128>  { using type = Plan<128,  16, 8, 4, 4>;        }; // experiment: 16-lane teams, 8 points each
+#else
 template <> struct CorePlan<128>  { using type = Plan<128,  8,  16, 8>;          };
+#endif
 template <> struct CorePlan<256>  { using type = Plan<256,  16, 16, 16>;         };
 template <> struct CorePlan<512>  { using type = Plan<512,  64,  8, 8, 8>;       };
 template <> struct CorePlan<1024> { using type = Plan<1024, 64, 16, 16, 4>;      };
@@ -41,7 +45,12 @@ struct Geometry
 {
     static constexpr int FPB = (kBlockThreads / P::T) > 0 ? (kBlockThreads / P::T) : 1; // frames per workgroup
     static constexpr int threads = P::T * FPB;
-    static constexpr size_t lds_bytes = (size_t) FPB * LdsFrame<P::N>::floats2 * sizeof (float2);
+    // Teams narrower than 16 lanes (N <= 128) would touch less than one 128-byte line per team and instruction:
+    // their workgroup instead copies its FPB contiguous frames between HBM and a staging area in LDS with
+    // full-width accesses ("coalesced HBM loads of many independent frames at once") and the teams work from there.
+    static constexpr bool staged = (P::T < 16);
+    static constexpr size_t image_floats2 = (size_t) FPB * LdsFrame<P::N>::floats2;
+    static constexpr size_t lds_bytes = (image_floats2 + (staged ? (size_t) FPB * P::N : 0)) * sizeof (float2);
 };
 
 // Width (adjacent columns / rows) of the tiles the two-pass kernels work on, for a core of length n:

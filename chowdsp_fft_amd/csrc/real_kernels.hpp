@@ -97,16 +97,31 @@ __global__ __launch_bounds__ (P::T* FPB) void r2c_kernel (const float2* __restri
 
     const unsigned ngroups = (batch + FPB - 1) / FPB;
     const unsigned team_base = (unsigned) team * M;
+    constexpr bool STAGED = (P::T < 16); // narrow teams: whole-workgroup coalesced copies through LDS (plans.hpp)
+    float2* stage = smem + FPB * LdsFrame<M>::floats2;
     for (unsigned g = blockIdx.x; g < ngroups; g += gridDim.x)
     {
         const bool active = g * FPB + team < batch;
         const float2* __restrict__ src = in + (size_t) g * (FPB * M);
         float2* __restrict__ dst = out + (size_t) g * (FPB * M);
+        const unsigned valid = min ((unsigned) FPB, batch - g * FPB) * M;
 
         float2 v[P::R];
+        if constexpr (STAGED)
+        {
+            __syncthreads();
+            stage_in<P::T * FPB, FPB * M> (src, stage, valid, tid);
+            __syncthreads();
 #pragma unroll
-        for (int s = 0; s < P::R; ++s)
-            v[s] = active ? gload (&src[team_base + (unsigned) input_index<P> (t, s)]) : make_float2 (0.f, 0.f);
+            for (int s = 0; s < P::R; ++s)
+                v[s] = stage[team_base + (unsigned) input_index<P> (t, s)];
+        }
+        else
+        {
+#pragma unroll
+            for (int s = 0; s < P::R; ++s)
+                v[s] = active ? gload (&src[team_base + (unsigned) input_index<P> (t, s)]) : make_float2 (0.f, 0.f);
+        }
 
         team_sync<P::T>();
         fft_core<P> (v, tw, lds, t);
@@ -129,11 +144,21 @@ __global__ __launch_bounds__ (P::T* FPB) void r2c_kernel (const float2* __restri
                 Xk = make_float2 (A.x + A.y, A.x - A.y); // [X0.re, X(N/2).re]
                 Xp = make_float2 (Zp.x, -Zp.y);          // X[M/2] = conj(Z[M/2])
             }
-            if (active)
+            if constexpr (STAGED)
+            {
+                stage[team_base + (unsigned) k] = Xk;
+                stage[team_base + (unsigned) (k == 0 ? M / 2 : M - k)] = Xp;
+            }
+            else if (active)
             {
                 gstore (&dst[team_base + (unsigned) k], Xk);
                 gstore (&dst[team_base + (unsigned) (k == 0 ? M / 2 : M - k)], Xp);
             }
+        }
+        if constexpr (STAGED)
+        {
+            __syncthreads();
+            stage_out<P::T * FPB, FPB * M> (dst, stage, valid, tid);
         }
     }
 }
@@ -275,11 +300,20 @@ __global__ __launch_bounds__ (P::T* FPB) void c2r_kernel (const float2* __restri
 
     const unsigned ngroups = (batch + FPB - 1) / FPB;
     const unsigned team_base = (unsigned) team * M;
+    constexpr bool STAGED = (P::T < 16); // narrow teams: whole-workgroup coalesced copies through LDS (plans.hpp)
+    float2* stage = smem + FPB * LdsFrame<M>::floats2;
     for (unsigned g = blockIdx.x; g < ngroups; g += gridDim.x)
     {
         const bool active = g * FPB + team < batch;
         const float2* __restrict__ src = in + (size_t) g * (FPB * M);
         float2* __restrict__ dst = out + (size_t) g * (FPB * M);
+        const unsigned valid = min ((unsigned) FPB, batch - g * FPB) * M;
+        if constexpr (STAGED)
+        {
+            __syncthreads();
+            stage_in<P::T * FPB, FPB * M> (src, stage, valid, tid);
+            __syncthreads();
+        }
 
         // pair stage straight from global memory (ascending k and descending M-k, both lane-contiguous)
         float2 zk[P::R / 2], zp[P::R / 2];
@@ -287,8 +321,11 @@ __global__ __launch_bounds__ (P::T* FPB) void c2r_kernel (const float2* __restri
         for (int q = 0; q < P::R / 2; ++q)
         {
             const int k = t + P::T * q;
-            const float2 A = active ? gload (&src[team_base + (unsigned) k]) : make_float2 (0.f, 0.f);
-            const float2 Xp = active ? gload (&src[team_base + (unsigned) (k == 0 ? M / 2 : M - k)]) : make_float2 (0.f, 0.f);
+            const int kq = (k == 0 ? M / 2 : M - k);
+            const float2 A = STAGED ? stage[team_base + (unsigned) k]
+                                    : (active ? gload (&src[team_base + (unsigned) k]) : make_float2 (0.f, 0.f));
+            const float2 Xp = STAGED ? stage[team_base + (unsigned) kq]
+                                     : (active ? gload (&src[team_base + (unsigned) kq]) : make_float2 (0.f, 0.f));
             real_merge_pair (A, Xp, pw.w[q], zk[q], zp[q]);
             if (k == 0)
             {
@@ -310,7 +347,15 @@ __global__ __launch_bounds__ (P::T* FPB) void c2r_kernel (const float2* __restri
         lds_load_input_order<P> (v, lds, t);
         team_sync<P::T>();
         fft_core<P> (v, tw, lds, t);
-        if (active)
+        if constexpr (STAGED)
+        {
+#pragma unroll
+            for (int s = 0; s < P::R; ++s)
+                stage[team_base + (unsigned) output_index<P> (t, s)] = make_float2 (v[s].y, v[s].x);
+            __syncthreads();
+            stage_out<P::T * FPB, FPB * M> (dst, stage, valid, tid);
+        }
+        else if (active)
         {
 #pragma unroll
             for (int s = 0; s < P::R; ++s)

@@ -192,6 +192,27 @@ __device__ __forceinline__ constexpr int output_index (int t, int slot)
     return (t + P::T * (slot / r)) + (slot % r) * (P::N / r);
 }
 
+// ---- staged global I/O for narrow teams (T < 16): the workgroup's FPB contiguous frames <-> LDS, 16 B per lane ----
+template <int THREADS, int ELEMS>
+__device__ __forceinline__ void stage_in (const float2* __restrict__ src, float2* __restrict__ stage, unsigned valid, int tid)
+{
+    const float4* __restrict__ s4 = reinterpret_cast<const float4*> (src);
+    float4* __restrict__ d4 = reinterpret_cast<float4*> (stage);
+#pragma unroll 4
+    for (int e = tid; e < ELEMS / 2; e += THREADS)
+        d4[e] = (2u * (unsigned) e < valid) ? gload4 (&s4[e]) : make_float4 (0.f, 0.f, 0.f, 0.f);
+}
+template <int THREADS, int ELEMS>
+__device__ __forceinline__ void stage_out (float2* __restrict__ dst, const float2* __restrict__ stage, unsigned valid, int tid)
+{
+    float4* __restrict__ d4 = reinterpret_cast<float4*> (dst);
+    const float4* __restrict__ s4 = reinterpret_cast<const float4*> (stage);
+#pragma unroll 4
+    for (int e = tid; e < ELEMS / 2; e += THREADS)
+        if (2u * (unsigned) e < valid)
+            gstore4 (&d4[e], s4[e]);
+}
+
 // Stages 0..NS-1 on registers v (already loaded in input_index order); leaves the result in
 // output_index order.  `lds` is this team's private LDS image.
 template <class P>

@@ -30,6 +30,14 @@ WORK = {
     "c2048": (2048, 1, 131072, False),
     "r4096": (4096, 0, 131072, False),
     "r8192": (8192, 0, 65536, False),
+    "c16": (16, 1, 16777216, False),
+    "c32": (32, 1, 8388608, False),
+    "c128": (128, 1, 2097152, False),
+    "c512": (512, 1, 524288, False),
+    "r32": (32, 0, 16777216, False),
+    "r64": (64, 0, 8388608, False),
+    "r256": (256, 0, 2097152, False),
+    "r2048": (2048, 0, 262144, False),
     "c9216": (9216, 1, 16384, False),
     "c3072": (3072, 1, 65536, False),
     "c768": (768, 1, 262144, False),
