@@ -16,10 +16,10 @@ struct CorePlan;
 template <> struct CorePlan<16>   { using type = Plan<16,   4,   4, 4>;          };
 template <> struct CorePlan<32>   { using type = Plan<32,   4,   8, 4>;          };
 template <> struct CorePlan<64>   { using type = Plan<64,   8,   8, 8>;          };
-#if defined(CFFT_PLAN128_ALT) && CFFT_PLAN128_ALT == 1
-template <> struct CorePlan<128>  { using type = Plan<128,  16, 8, 4, 4>;        }; // experiment: 16-lane teams, 8 points each
+#if defined(CFFT_PLAN128_ALT) && CFFT_PLAN128_ALT == 0
+template <> struct CorePlan<128>  { using type = Plan<128,  8,  16, 8>;          }; // first version: 4.3 TB/s (8 lanes x 16 points, 102 VGPRs)
 #else
-template <> struct CorePlan<128>  { using type = Plan<128,  8,  16, 8>;          };
+template <> struct CorePlan<128>  { using type = Plan<128,  16, 8, 4, 4>;        }; // 16-lane teams x 8 points: 5.5 TB/s
 #endif
 template <> struct CorePlan<256>  { using type = Plan<256,  16, 16, 16>;         };
 template <> struct CorePlan<512>  { using type = Plan<512,  64,  8, 8, 8>;       };
