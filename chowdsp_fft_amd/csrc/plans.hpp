@@ -21,9 +21,17 @@ template <> struct CorePlan<128>  { using type = Plan<128,  8,  16, 8>;         
 #else
 template <> struct CorePlan<128>  { using type = Plan<128,  16, 8, 4, 4>;        }; // 16-lane teams x 8 points: 5.5 TB/s
 #endif
-template <> struct CorePlan<256>  { using type = Plan<256,  16, 16, 16>;         };
+#if defined(CFFT_PLAN256_ALT) && CFFT_PLAN256_ALT == 0
+template <> struct CorePlan<256>  { using type = Plan<256,  16, 16, 16>;         }; // first version: 5.42 TB/s
+#else
+template <> struct CorePlan<256>  { using type = Plan<256,  32, 8, 8, 4>;        }; // 32-lane teams x 8 points: 5.74 TB/s
+#endif
 template <> struct CorePlan<512>  { using type = Plan<512,  64,  8, 8, 8>;       };
+#if defined(CFFT_PLAN1024_ALT) && CFFT_PLAN1024_ALT == 1
+template <> struct CorePlan<1024> { using type = Plan<1024, 128, 8, 8, 4, 4>;    }; // experiment
+#else
 template <> struct CorePlan<1024> { using type = Plan<1024, 64, 16, 16, 4>;      };
+#endif
 #if defined(CFFT_PLAN2048_ALT) && CFFT_PLAN2048_ALT == 1
 template <> struct CorePlan<2048> { using type = Plan<2048, 256, 8, 8, 8, 4>;    }; // experiment: 8 points per work-item
 #else
