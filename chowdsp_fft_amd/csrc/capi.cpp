@@ -570,7 +570,9 @@ int fft_gpu_plan_describe (int N, fft_transform_t transform, int desc[8])
     int n1 = 0, n2 = 0;
     split_large (nc, n1, n2);
     int radix[4] = { 0, 0, 0, 0 };
-    if (! core_radices (n2 != 0 ? n2 : nc, radix))
+    if (n1 == 256 && n2 == 256)
+        radix[0] = radix[1] = 16; // the 65536 fast path has its own radix-16 x 16 plan
+    else if (! core_radices (n2 != 0 ? n2 : nc, radix))
         return FFT_GPU_EINVAL;
     desc[0] = nc;
     desc[1] = (n2 != 0) ? 2 : 1;

@@ -224,7 +224,7 @@ __global__ __launch_bounds__ (256) void real_pair_kernel (const float2* __restri
 // it with lane = (kb&15) + 16*(a&15): both sides move 2 KiB contiguous per workgroup instruction.  The inter-pass
 // twiddle table is stored in the same order.
 // =====================================================================================================
-using Plan256 = Plan<256, 16, 16, 16>;
+// Plan256 (= Plan<256, 16, 16, 16>, fixed for this path whatever CorePlan<256> is) lives in plans.hpp
 static constexpr int kFS256 = TileFrame<256>::stride;
 
 __device__ __forceinline__ void load_stage1_twiddles_256 (float2 (&w)[15], const float2* __restrict__ stage_tw, int k)

@@ -44,6 +44,9 @@ template <> struct CorePlan<4096> { using type = Plan<4096, 256, 16, 16, 16>;   
 #endif
 // clang-format on
 
+// the 65536 = 256 x 256 fast path (multipass_kernels.hpp) is written for this plan, independent of CorePlan<256>
+using Plan256 = Plan<256, 16, 16, 16>;
+
 static constexpr int kMaxCoreN = 4096;
 static constexpr int kMinCoreN = 16;
 static constexpr int kBlockThreads = 256;

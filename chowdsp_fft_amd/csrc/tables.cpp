@@ -147,7 +147,9 @@ bool build_host_tables (int N, int transform, HostTables& out)
     split_large (nc, n1, n2);
     out.core_n = 0;
     PlanDesc d2, d1;
-    if (! core_plan_desc (n2, d2) || ! core_plan_desc (n1, d1))
+    if (n1 == 256 && n2 == 256)
+        d2 = d1 = describe<Plan256>(); // the fast path's own radix-16 x 16 plan
+    else if (! core_plan_desc (n2, d2) || ! core_plan_desc (n1, d1))
         return false;
     append_stage_twiddles (d2, out.stage_twiddles);
     append_stage_twiddles (d1, out.stage_twiddles);
