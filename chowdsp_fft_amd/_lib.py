@@ -52,6 +52,7 @@ PROTOTYPES = {
     "fft_convolve_unordered_batch": (_i, [_vp, _fp, _fp, _fp, _f, _sz, _i, _vp]),
     "fft_accumulate_batch": (_i, [_vp, _fp, _fp, _fp, _sz, _vp]),
     "fft_convolve_frames_batch": (_i, [_vp, _fp, _fp, _fp, _f, _sz, _vp]),
+    "fft_transform_host_batch": (_i, [_vp, _fp, _fp, _sz, _i]),
     "fft_conv_engine_create": (_vp, [_i, _i, _fp, _i, _i, _vp]),
     "fft_conv_engine_process": (_i, [_vp, _fp, _fp, _vp]),
     "fft_conv_engine_reset": (_i, [_vp, _vp]),

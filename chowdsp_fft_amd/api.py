@@ -166,6 +166,12 @@ def fft_convolve_frames_batch(setup, x, dft_filter, y, scaling: float, batch: in
            "fft_convolve_frames_batch")
 
 
+def fft_transform_host_batch(setup, input, output, direction: int, batch: int | None = None) -> None:
+    """numpy (host) buffers of `batch` frames; pinned in place and pipelined over PCIe (synchronous)."""
+    b = _batch_of(setup, input) if batch is None else batch
+    _check(_lib.lib().fft_transform_host_batch(setup, _ptr(input), _ptr(output), b, direction), "fft_transform_host_batch")
+
+
 class ConvEngine:
     """Streaming partitioned overlap-save convolver (include/chowdsp_fft_gpu.h, fft_conv_engine_*)."""
 

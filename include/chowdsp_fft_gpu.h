@@ -97,6 +97,15 @@ int fft_accumulate_batch (void* setup, const float* a, const float* b, float* ab
    Available for LDS-resident sizes (N <= 4096 complex, N <= 8192 real); FFT_GPU_ENOTSUP otherwise. */
 int fft_convolve_frames_batch (void* setup, const float* x, const float* dft_filter, float* y, float scaling, size_t batch, void* stream);
 
+/* ---- host-memory streaming mode ------------------------------------------------
+   `batch` x fft_transform for callers whose frames live in HOST memory (what every reference caller has:
+   test/test.cpp:18-21, bench/bench.cpp:22-29, chowdsp_fft_juce.cpp:32-46) without paying one staged copy, one
+   launch and one synchronisation per frame like the legacy symbols do.  The host buffers are pinned in place for
+   the duration of the call, cut into chunks, and chunk i's host->device copy, transform and device->host copy
+   run on stream i%2, so that the PCIe transfers of one chunk overlap the other chunk's.  Synchronous: the result
+   is in `output` on return.  input == output is allowed.  PCIe-bound by construction. */
+int fft_transform_host_batch (void* setup, const float* input, float* output, size_t batch, fft_direction_t direction);
+
 /* ---- streaming partitioned convolution engine -----------------------------------
    The caller-side structure that fft_convolve_unordered's "ab += a*b*scaling" and fft_accumulate exist for
    (reference chowdsp_fft.h:147-160, usage test/test.cpp:212-218), which the reference leaves to its callers:
