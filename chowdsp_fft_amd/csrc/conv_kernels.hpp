@@ -142,6 +142,44 @@ __global__ __launch_bounds__ (256) void ols_extract_kernel (const float4* __rest
 
 // ---- fused: y = BACKWARD( FORWARD(x) * H ) * scaling, one kernel, spectrum never leaves the CU -----
 // COMPLEX plan: P is the N point plan, H has N complex bins in canonical order.
+// The bins a work-item multiplies (its output_index positions) are the same for every frame: kept in VGPRs.
+template <class P, bool PREDICATED>
+__device__ __forceinline__ void conv_c2c_finish (float2 (&v)[P::R],
+                                                 const TwiddleRegs<P>& tw,
+                                                 const float2 (&h)[P::R],
+                                                 float2* lds,
+                                                 float2* __restrict__ dst,
+                                                 unsigned team_base,
+                                                 int t,
+                                                 float scaling,
+                                                 bool active)
+{
+    team_sync<P::T>();
+    fft_core<P> (v, tw, lds, t);
+    // multiply by the filter spectrum, scale, swap re/im for the inverse
+    float2 w[P::R];
+#pragma unroll
+    for (int s = 0; s < P::R; ++s)
+    {
+        const float2 y = cmul (v[s], h[s]);
+        w[s] = make_float2 (y.y * scaling, y.x * scaling);
+    }
+    if constexpr (P::NS > 1)
+        team_sync<P::T>();
+    lds_store_output_order<P> (w, lds, t);
+    team_sync<P::T>();
+    float2 u[P::R]; // fresh arrays: reusing the caller's `v` through the reference leaves it in scratch memory
+    lds_load_input_order<P> (u, lds, t);
+    team_sync<P::T>();
+    fft_core<P> (u, tw, lds, t);
+    if (! PREDICATED || active)
+    {
+#pragma unroll
+        for (int s = 0; s < P::R; ++s)
+            gstore (&dst[team_base + (unsigned) output_index<P> (t, s)], make_float2 (u[s].y, u[s].x));
+    }
+}
+
 template <class P, int FPB>
 __global__ __launch_bounds__ (P::T* FPB) void conv_frames_c2c_kernel (const float2* __restrict__ in,
                                                                      const float2* __restrict__ H,
@@ -158,6 +196,10 @@ __global__ __launch_bounds__ (P::T* FPB) void conv_frames_c2c_kernel (const floa
 
     TwiddleRegs<P> tw;
     load_twiddles<P> (tw, twtab, t);
+    float2 h[P::R];
+#pragma unroll
+    for (int s = 0; s < P::R; ++s)
+        h[s] = H[output_index<P> (t, s)];
 
     const unsigned ngroups = (batch + FPB - 1) / FPB;
     const unsigned team_base = (unsigned) team * P::N;
@@ -165,39 +207,196 @@ __global__ __launch_bounds__ (P::T* FPB) void conv_frames_c2c_kernel (const floa
     {
         const bool active = g * FPB + team < batch;
         const float2* __restrict__ src = in + (size_t) g * (FPB * P::N);
-        float2* __restrict__ dst = out + (size_t) g * (FPB * P::N);
         float2 v[P::R];
 #pragma unroll
         for (int s = 0; s < P::R; ++s)
             v[s] = active ? gload (&src[team_base + (unsigned) input_index<P> (t, s)]) : make_float2 (0.f, 0.f);
-        team_sync<P::T>();
-        fft_core<P> (v, tw, lds, t);
-        // multiply by the filter spectrum (L2-resident, shared by every frame), scale, swap for the inverse
+        conv_c2c_finish<P, true> (v, tw, h, lds, out + (size_t) g * (FPB * P::N), team_base, t, scaling, active);
+    }
+}
+
+// software-pipelined variant: the next group's loads are in flight while this group's two FFT cores run; full
+// groups store unconditionally, a ragged last group is handled once by the workgroup whose turn it would be
+template <class P, int FPB>
+__global__ __launch_bounds__ (P::T* FPB) void conv_frames_c2c_kernel_pf (const float2* __restrict__ in,
+                                                                        const float2* __restrict__ H,
+                                                                        float2* __restrict__ out,
+                                                                        const float2* __restrict__ twtab,
+                                                                        float scaling,
+                                                                        unsigned batch)
+{
+    extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
+    const int tid = threadIdx.x;
+    const int team = tid / P::T;
+    const int t = tid % P::T;
+    float2* lds = smem + team * LdsFrame<P::N>::floats2;
+
+    TwiddleRegs<P> tw;
+    load_twiddles<P> (tw, twtab, t);
+    float2 h[P::R];
 #pragma unroll
-        for (int s = 0; s < P::R; ++s)
+    for (int s = 0; s < P::R; ++s)
+        h[s] = H[output_index<P> (t, s)];
+
+    const unsigned nfull = batch / FPB;
+    const unsigned team_base = (unsigned) team * P::N;
+    float nre[P::R], nim[P::R];
+    unsigned g = blockIdx.x;
+    if (g < nfull)
+    {
         {
-            const float2 h = H[output_index<P> (t, s)];
-            const float2 y = cmul (v[s], h);
-            v[s] = make_float2 (y.y * scaling, y.x * scaling);
-        }
-        if constexpr (P::NS > 1)
-            team_sync<P::T>();
-        lds_store_output_order<P> (v, lds, t);
-        team_sync<P::T>();
-        lds_load_input_order<P> (v, lds, t);
-        team_sync<P::T>();
-        fft_core<P> (v, tw, lds, t);
-        if (active)
-        {
+            const float2* __restrict__ src = in + (size_t) g * (FPB * P::N);
+            float2 v[P::R];
 #pragma unroll
             for (int s = 0; s < P::R; ++s)
-                gstore (&dst[team_base + (unsigned) output_index<P> (t, s)], make_float2 (v[s].y, v[s].x));
+                v[s] = gload (&src[team_base + (unsigned) input_index<P> (t, s)]);
+            const unsigned gn = g + gridDim.x;
+            if (gn < nfull)
+            {
+                const float2* __restrict__ srcn = in + (size_t) gn * (FPB * P::N);
+#pragma unroll
+                for (int s = 0; s < P::R; ++s)
+                {
+                    const float2 x = gload (&srcn[team_base + (unsigned) input_index<P> (t, s)]);
+                    nre[s] = x.x;
+                    nim[s] = x.y;
+                }
+            }
+            conv_c2c_finish<P, false> (v, tw, h, lds, out + (size_t) g * (FPB * P::N), team_base, t, scaling, true);
         }
+        for (g += gridDim.x; g < nfull; g += gridDim.x)
+        {
+            float2 v[P::R];
+#pragma unroll
+            for (int s = 0; s < P::R; ++s)
+                v[s] = make_float2 (nre[s], nim[s]);
+            const unsigned gn = g + gridDim.x;
+            if (gn < nfull)
+            {
+                const float2* __restrict__ srcn = in + (size_t) gn * (FPB * P::N);
+#pragma unroll
+                for (int s = 0; s < P::R; ++s)
+                {
+                    const float2 x = gload (&srcn[team_base + (unsigned) input_index<P> (t, s)]);
+                    nre[s] = x.x;
+                    nim[s] = x.y;
+                }
+            }
+            conv_c2c_finish<P, false> (v, tw, h, lds, out + (size_t) g * (FPB * P::N), team_base, t, scaling, true);
+        }
+    }
+    if (FPB > 1 && nfull * FPB < batch && blockIdx.x == nfull % gridDim.x)
+    {
+        const bool active = nfull * FPB + team < batch;
+        const float2* __restrict__ src = in + (size_t) nfull * (FPB * P::N);
+        float2 v[P::R];
+#pragma unroll
+        for (int s = 0; s < P::R; ++s)
+            v[s] = active ? gload (&src[team_base + (unsigned) input_index<P> (t, s)]) : make_float2 (0.f, 0.f);
+        conv_c2c_finish<P, true> (v, tw, h, lds, out + (size_t) nfull * (FPB * P::N), team_base, t, scaling, active);
     }
 }
 
 // REAL plan: P is the M = N/2 point plan, H is a packed real spectrum (M float2, element 0 = DC/Nyquist).
-template <class P, int FPB>
+// The filter bins a work-item multiplies are the same for every frame, so the persistent workgroup keeps them in
+// VGPRs (R float2) instead of re-reading them from L2 for each frame.
+template <class P, bool REGS>
+struct PairFilter
+{
+    float2 k[REGS ? P::R / 2 : 1], p[REGS ? P::R / 2 : 1];
+    const float2* __restrict__ H; // REGS == false: read per frame from L2 (kernels at the VGPR limit)
+    __device__ __forceinline__ float2 bin_k (int q, int k) const { return REGS ? this->k[REGS ? q : 0] : H[k]; }
+    __device__ __forceinline__ float2 bin_p (int q, int kp) const { return REGS ? this->p[REGS ? q : 0] : H[kp]; }
+};
+
+template <class P, bool REGS>
+__device__ __forceinline__ void load_pair_filter (PairFilter<P, REGS>& h, const float2* __restrict__ H, int t)
+{
+    constexpr int M = P::N;
+    h.H = H;
+    if constexpr (REGS)
+    {
+#pragma unroll
+        for (int q = 0; q < P::R / 2; ++q)
+        {
+            const int k = t + P::T * q;
+            h.k[q] = H[k];
+            h.p[q] = H[k == 0 ? M / 2 : M - k];
+        }
+    }
+}
+
+// everything after the frame is in registers: forward core, pair split * H merge, inverse core, store
+template <class P, bool PREDICATED, bool HREGS>
+__device__ __forceinline__ void conv_real_finish (float2 (&v)[P::R],
+                                                  const TwiddleRegs<P>& tw,
+                                                  const PairTwiddles<P>& pw,
+                                                  const PairFilter<P, HREGS>& h,
+                                                  float2* lds,
+                                                  float2* __restrict__ dst,
+                                                  unsigned team_base,
+                                                  int t,
+                                                  float scaling,
+                                                  bool active)
+{
+    constexpr int M = P::N;
+    team_sync<P::T>();
+    fft_core<P> (v, tw, lds, t);
+    if constexpr (P::NS > 1)
+        team_sync<P::T>();
+    lds_store_output_order<P> (v, lds, t);
+    team_sync<P::T>();
+
+    // split -> multiply -> merge on each (k, M-k) pair, all in registers
+    float2 zk[P::R / 2], zp[P::R / 2];
+#pragma unroll
+    for (int q = 0; q < P::R / 2; ++q)
+    {
+        const int k = t + P::T * q;
+        const int kp = (k == 0 ? M / 2 : M - k);
+        const float2 A = lds[lds_phys (k)];
+        const float2 Zp = lds[lds_phys (kp)];
+        const float2 hk = h.bin_k (q, k), hp = h.bin_p (q, kp);
+        float2 Xk, Xp;
+        real_split_pair (A, Zp, pw.w[q], Xk, Xp);
+        float2 Yk = cmul (Xk, hk), Yp = cmul (Xp, hp);
+        if (k == 0)
+        {
+            // packed DC / Nyquist: real products (reference :1640-1644); X[M/2] = conj(Z[M/2])
+            Yk = make_float2 ((A.x + A.y) * hk.x, (A.x - A.y) * hk.y);
+            Yp = cmul (make_float2 (Zp.x, -Zp.y), hp);
+        }
+        Yk = make_float2 (Yk.x * scaling, Yk.y * scaling);
+        Yp = make_float2 (Yp.x * scaling, Yp.y * scaling);
+        real_merge_pair (Yk, Yp, pw.w[q], zk[q], zp[q]);
+        if (k == 0)
+        {
+            zk[q] = make_float2 (Yk.x + Yk.y, Yk.x - Yk.y);
+            zp[q] = make_float2 (2.f * Yp.x, -2.f * Yp.y);
+        }
+    }
+    team_sync<P::T>(); // every pair has been read before the image is rewritten
+#pragma unroll
+    for (int q = 0; q < P::R / 2; ++q)
+    {
+        const int k = t + P::T * q;
+        lds[lds_phys (k)] = make_float2 (zk[q].y, zk[q].x);
+        lds[lds_phys (k == 0 ? M / 2 : M - k)] = make_float2 (zp[q].y, zp[q].x);
+    }
+    team_sync<P::T>();
+    float2 u[P::R]; // a fresh array: reusing the caller's `v` through the reference leaves it in scratch memory
+    lds_load_input_order<P> (u, lds, t);
+    team_sync<P::T>();
+    fft_core<P> (u, tw, lds, t);
+    if (!PREDICATED || active)
+    {
+#pragma unroll
+        for (int s = 0; s < P::R; ++s)
+            gstore (&dst[team_base + (unsigned) output_index<P> (t, s)], make_float2 (u[s].y, u[s].x));
+    }
+}
+
+template <class P, int FPB, bool HREGS>
 __global__ __launch_bounds__ (P::T* FPB) void conv_frames_real_kernel (const float2* __restrict__ in,
                                                                       const float2* __restrict__ H,
                                                                       float2* __restrict__ out,
@@ -217,6 +416,8 @@ __global__ __launch_bounds__ (P::T* FPB) void conv_frames_real_kernel (const flo
     load_twiddles<P> (tw, twtab, t);
     PairTwiddles<P> pw;
     load_pair_twiddles<P> (pw, wtab, t);
+    PairFilter<P, HREGS> h;
+    load_pair_filter<P> (h, H, t);
 
     const unsigned ngroups = (batch + FPB - 1) / FPB;
     const unsigned team_base = (unsigned) team * M;
@@ -224,64 +425,95 @@ __global__ __launch_bounds__ (P::T* FPB) void conv_frames_real_kernel (const flo
     {
         const bool active = g * FPB + team < batch;
         const float2* __restrict__ src = in + (size_t) g * (FPB * M);
-        float2* __restrict__ dst = out + (size_t) g * (FPB * M);
         float2 v[P::R];
 #pragma unroll
         for (int s = 0; s < P::R; ++s)
             v[s] = active ? gload (&src[team_base + (unsigned) input_index<P> (t, s)]) : make_float2 (0.f, 0.f);
-        team_sync<P::T>();
-        fft_core<P> (v, tw, lds, t);
-        if constexpr (P::NS > 1)
-            team_sync<P::T>();
-        lds_store_output_order<P> (v, lds, t);
-        team_sync<P::T>();
+        conv_real_finish<P, true, HREGS> (v, tw, pw, h, lds, out + (size_t) g * (FPB * M), team_base, t, scaling, active);
+    }
+}
 
-        // split -> multiply -> merge on each (k, M-k) pair, all in registers
-        float2 zk[P::R / 2], zp[P::R / 2];
-#pragma unroll
-        for (int q = 0; q < P::R / 2; ++q)
+// software-pipelined variant (same scheme as r2c_kernel_pf): the next group's loads are in flight while this
+// group's two FFT cores run; full groups store unconditionally, the ragged last group is handled separately
+template <class P, int FPB, bool HREGS>
+__global__ __launch_bounds__ (P::T* FPB) void conv_frames_real_kernel_pf (const float2* __restrict__ in,
+                                                                         const float2* __restrict__ H,
+                                                                         float2* __restrict__ out,
+                                                                         const float2* __restrict__ twtab,
+                                                                         const float2* __restrict__ wtab,
+                                                                         float scaling,
+                                                                         unsigned batch)
+{
+    extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
+    constexpr int M = P::N;
+    const int tid = threadIdx.x;
+    const int team = tid / P::T;
+    const int t = tid % P::T;
+    float2* lds = smem + team * LdsFrame<M>::floats2;
+
+    TwiddleRegs<P> tw;
+    load_twiddles<P> (tw, twtab, t);
+    PairTwiddles<P> pw;
+    load_pair_twiddles<P> (pw, wtab, t);
+    PairFilter<P, HREGS> h;
+    load_pair_filter<P> (h, H, t);
+
+    const unsigned nfull = batch / FPB;
+    const unsigned team_base = (unsigned) team * M;
+    float nre[P::R], nim[P::R];
+    unsigned g = blockIdx.x;
+    if (g < nfull)
+    {
         {
-            const int k = t + P::T * q;
-            const int kp = (k == 0 ? M / 2 : M - k);
-            const float2 A = lds[lds_phys (k)];
-            const float2 Zp = lds[lds_phys (kp)];
-            const float2 hk = H[k], hp = H[kp];
-            float2 Xk, Xp;
-            real_split_pair (A, Zp, pw.w[q], Xk, Xp);
-            float2 Yk = cmul (Xk, hk), Yp = cmul (Xp, hp);
-            if (k == 0)
-            {
-                // packed DC / Nyquist: real products (reference :1640-1644); X[M/2] = conj(Z[M/2])
-                Yk = make_float2 ((A.x + A.y) * hk.x, (A.x - A.y) * hk.y);
-                Yp = cmul (make_float2 (Zp.x, -Zp.y), hp);
-            }
-            Yk = make_float2 (Yk.x * scaling, Yk.y * scaling);
-            Yp = make_float2 (Yp.x * scaling, Yp.y * scaling);
-            real_merge_pair (Yk, Yp, pw.w[q], zk[q], zp[q]);
-            if (k == 0)
-            {
-                zk[q] = make_float2 (Yk.x + Yk.y, Yk.x - Yk.y);
-                zp[q] = make_float2 (2.f * Yp.x, -2.f * Yp.y);
-            }
-        }
-        team_sync<P::T>(); // every pair has been read before the image is rewritten
-#pragma unroll
-        for (int q = 0; q < P::R / 2; ++q)
-        {
-            const int k = t + P::T * q;
-            lds[lds_phys (k)] = make_float2 (zk[q].y, zk[q].x);
-            lds[lds_phys (k == 0 ? M / 2 : M - k)] = make_float2 (zp[q].y, zp[q].x);
-        }
-        team_sync<P::T>();
-        lds_load_input_order<P> (v, lds, t);
-        team_sync<P::T>();
-        fft_core<P> (v, tw, lds, t);
-        if (active)
-        {
+            const float2* __restrict__ src = in + (size_t) g * (FPB * M);
+            float2 v[P::R];
 #pragma unroll
             for (int s = 0; s < P::R; ++s)
-                gstore (&dst[team_base + (unsigned) output_index<P> (t, s)], make_float2 (v[s].y, v[s].x));
+                v[s] = gload (&src[team_base + (unsigned) input_index<P> (t, s)]);
+            const unsigned gn = g + gridDim.x;
+            if (gn < nfull)
+            {
+                const float2* __restrict__ srcn = in + (size_t) gn * (FPB * M);
+#pragma unroll
+                for (int s = 0; s < P::R; ++s)
+                {
+                    const float2 x = gload (&srcn[team_base + (unsigned) input_index<P> (t, s)]);
+                    nre[s] = x.x;
+                    nim[s] = x.y;
+                }
+            }
+            conv_real_finish<P, false, HREGS> (v, tw, pw, h, lds, out + (size_t) g * (FPB * M), team_base, t, scaling, true);
         }
+        for (g += gridDim.x; g < nfull; g += gridDim.x)
+        {
+            float2 v[P::R];
+#pragma unroll
+            for (int s = 0; s < P::R; ++s)
+                v[s] = make_float2 (nre[s], nim[s]);
+            const unsigned gn = g + gridDim.x;
+            if (gn < nfull)
+            {
+                const float2* __restrict__ srcn = in + (size_t) gn * (FPB * M);
+#pragma unroll
+                for (int s = 0; s < P::R; ++s)
+                {
+                    const float2 x = gload (&srcn[team_base + (unsigned) input_index<P> (t, s)]);
+                    nre[s] = x.x;
+                    nim[s] = x.y;
+                }
+            }
+            conv_real_finish<P, false, HREGS> (v, tw, pw, h, lds, out + (size_t) g * (FPB * M), team_base, t, scaling, true);
+        }
+    }
+    if (FPB > 1 && nfull * FPB < batch && blockIdx.x == nfull % gridDim.x)
+    {
+        const bool active = nfull * FPB + team < batch;
+        const float2* __restrict__ src = in + (size_t) nfull * (FPB * M);
+        float2 v[P::R];
+#pragma unroll
+        for (int s = 0; s < P::R; ++s)
+            v[s] = active ? gload (&src[team_base + (unsigned) input_index<P> (t, s)]) : make_float2 (0.f, 0.f);
+        conv_real_finish<P, true, HREGS> (v, tw, pw, h, lds, out + (size_t) nfull * (FPB * M), team_base, t, scaling, active);
     }
 }
 } // namespace cfft

@@ -20,12 +20,25 @@ hipError_t launch_cf_c2c_n (const float2* in, const float2* H, float2* out, cons
 {
     using P = typename CorePlan<N>::type;
     using G = Geometry<P>;
-    auto kernel = conv_frames_c2c_kernel<P, G::FPB>;
-    const size_t ngroups = (batch + G::FPB - 1) / G::FPB;
-    const unsigned grid = persistent_grid (kernel, G::threads, G::lds_bytes, ngroups);
+    // CFFT_CCONV_PF_MIN: smallest N that takes the software-pipelined kernel; CFFT_CCONV_FPB2048: frames per workgroup
+    // of the N = 2048 plan (see launch_cf_real_m).  Measured on MI355X (profiles/r01_variants_cconv_pf.txt):
+    // N=4096 4.89 -> 5.20 TB/s, N=2048 with 128-thread workgroups 4.97 -> 5.53 TB/s, N <= 1024 unchanged or slower.
+#ifndef CFFT_CCONV_PF_MIN
+#define CFFT_CCONV_PF_MIN 2048
+#endif
+#ifndef CFFT_CCONV_FPB2048
+#define CFFT_CCONV_FPB2048 1
+#endif
+    constexpr int FPB = (N == 2048) ? CFFT_CCONV_FPB2048 : G::FPB;
+    constexpr int threads = P::T * FPB;
+    constexpr size_t lds_bytes = G::lds_bytes / G::FPB * FPB;
+    constexpr bool use_pf = N >= CFFT_CCONV_PF_MIN;
+    auto kernel = use_pf ? conv_frames_c2c_kernel_pf<P, FPB> : conv_frames_c2c_kernel<P, FPB>;
+    const size_t ngroups = (batch + FPB - 1) / FPB;
+    const unsigned grid = persistent_grid (kernel, threads, lds_bytes, ngroups);
     if (grid == 0)
         return hipErrorNoDevice;
-    hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (G::threads), G::lds_bytes, stream, in, H, out, tw, scaling, (unsigned) batch);
+    hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (threads), lds_bytes, stream, in, H, out, tw, scaling, (unsigned) batch);
     return hipGetLastError();
 }
 
@@ -34,12 +47,31 @@ hipError_t launch_cf_real_m (const float2* in, const float2* H, float2* out, con
 {
     using P = typename CorePlan<M>::type;
     using G = Geometry<P>;
-    auto kernel = conv_frames_real_kernel<P, G::FPB>;
-    const size_t ngroups = (batch + G::FPB - 1) / G::FPB;
-    const unsigned grid = persistent_grid (kernel, G::threads, G::lds_bytes, ngroups);
+    // Variant per plan, from A/B timing on MI355X (profiles/r01_variants_conv_hregs_pf.txt):
+    //  - software prefetch of the next group (conv_frames_real_kernel_pf) pays for M = 1024 (+10 %) and M = 4096 (+6 %),
+    //    costs 2 % for M <= 512, and needs more than 256 VGPRs for M = 2048 unless the filter stays in L2;
+    //  - CFFT_CONV_FPB2048: frames per workgroup of the M = 2048 plan (T = 128): 1 -> 128-thread workgroups, so that a
+    //    barrier stalls two waves instead of four.
+#ifndef CFFT_CONV_PREFETCH
+#define CFFT_CONV_PREFETCH 2
+#endif
+#ifndef CFFT_CONV_PF2048
+#define CFFT_CONV_PF2048 1
+#endif
+#ifndef CFFT_CONV_FPB2048
+#define CFFT_CONV_FPB2048 1
+#endif
+    constexpr int FPB = (M == 2048) ? CFFT_CONV_FPB2048 : G::FPB;
+    constexpr bool use_pf = (CFFT_CONV_PREFETCH == 1) || (CFFT_CONV_PREFETCH == 2 && (M == 1024 || M == 4096 || (M == 2048 && CFFT_CONV_PF2048)));
+    constexpr bool hregs = ! (use_pf && M == 2048);
+    constexpr int threads = P::T * FPB;
+    constexpr size_t lds_bytes = G::lds_bytes / G::FPB * FPB; // no staging area for T >= 16
+    auto kernel = use_pf ? conv_frames_real_kernel_pf<P, FPB, hregs> : conv_frames_real_kernel<P, FPB, hregs>;
+    const size_t ngroups = (batch + FPB - 1) / FPB;
+    const unsigned grid = persistent_grid (kernel, threads, lds_bytes, ngroups);
     if (grid == 0)
         return hipErrorNoDevice;
-    hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (G::threads), G::lds_bytes, stream, in, H, out, tw, rtw, scaling, (unsigned) batch);
+    hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (threads), lds_bytes, stream, in, H, out, tw, rtw, scaling, (unsigned) batch);
     return hipGetLastError();
 }
 } // namespace

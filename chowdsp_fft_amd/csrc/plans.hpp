@@ -54,7 +54,12 @@ static constexpr int kBlockThreads = 256;
 template <class P>
 struct Geometry
 {
-    static constexpr int FPB = (kBlockThreads / P::T) > 0 ? (kBlockThreads / P::T) : 1; // frames per workgroup
+    // frames per workgroup.  CFFT_FPB_T128: the 128-lane teams (N = 2048) either share a 256-thread workgroup (2) or
+    // get a 128-thread workgroup each (1), where a barrier stalls two waves instead of four.
+#ifndef CFFT_FPB_T128
+#define CFFT_FPB_T128 2
+#endif
+    static constexpr int FPB = P::T == 128 ? CFFT_FPB_T128 : ((kBlockThreads / P::T) > 0 ? (kBlockThreads / P::T) : 1);
     static constexpr int threads = P::T * FPB;
     // Teams narrower than 16 lanes (N <= 128) would touch less than one 128-byte line per team and instruction:
     // their workgroup instead copies its FPB contiguous frames between HBM and a staging area in LDS with

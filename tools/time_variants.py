@@ -24,6 +24,13 @@ WORK = {
     "r1024": (1024, 0, 262144, False),
     "c65536": (65536, 1, 8192, False),
     "conv4096": (4096, 0, 131072, True),
+    "conv1024": (1024, 0, 524288, True),
+    "conv2048": (2048, 0, 262144, True),
+    "conv8192": (8192, 0, 65536, True),
+    "cconv4096": (4096, 1, 65536, True),
+    "cconv1024": (1024, 1, 262144, True),
+    "cconv2048": (2048, 1, 131072, True),
+    "cconv512": (512, 1, 524288, True),
     "c64": (64, 1, 4194304, False),
     "c256": (256, 1, 1048576, False),
     "c1024": (1024, 1, 262144, False),
