@@ -48,6 +48,7 @@ PROTOTYPES = {
     "fft_gpu_setup_is_real": (_i, [_vp]),
     "fft_gpu_workspace_bytes": (_sz, [_vp, _sz]),
     "fft_transform_batch": (_i, [_vp, _fp, _fp, _sz, _i, _vp]),
+    "fft_transform_batch_strided": (_i, [_vp, _fp, _sz, _fp, _sz, _sz, _i, _vp]),
     "fft_transform_unordered_batch": (_i, [_vp, _fp, _fp, _sz, _i, _vp]),
     "fft_convolve_unordered_batch": (_i, [_vp, _fp, _fp, _fp, _f, _sz, _i, _vp]),
     "fft_accumulate_batch": (_i, [_vp, _fp, _fp, _fp, _sz, _vp]),
@@ -61,8 +62,9 @@ PROTOTYPES = {
 }
 
 
-def load(path: str = LIB_PATH) -> C.CDLL:
-    """dlopen the library (RTLD_LOCAL) and attach prototypes.  Raises OSError if it is not built."""
+def load(path: str = LIB_PATH, strict: bool = True) -> C.CDLL:
+    """dlopen the library (RTLD_LOCAL) and attach prototypes.  Raises OSError if it is not built.
+    strict=False (tools/time_variants.py only): tolerate older builds that lack newer entry points."""
     if not os.path.exists(path):
         raise OSError(
             f"{path} not found: build it with `make -C chowdsp_fft_amd/csrc` "
@@ -70,6 +72,8 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         )
     lib = C.CDLL(path, mode=getattr(os, "RTLD_LOCAL", 0) | getattr(os, "RTLD_NOW", 2))
     for name, (res, args) in PROTOTYPES.items():
+        if not strict and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)  # AttributeError if the symbol is missing -> loud failure
         fn.restype = res
         fn.argtypes = args

@@ -139,6 +139,14 @@ def fft_transform_batch(setup, input, output, direction: int, batch: int | None 
            "fft_transform_batch")
 
 
+def fft_transform_batch_strided(setup, input, in_stride: int, output, out_stride: int, batch: int, direction: int,
+                                stream=None) -> None:
+    """frames embedded in larger buffers: frame b at input[b*in_stride:], output[b*out_stride:] (strides in floats)"""
+    _check(_lib.lib().fft_transform_batch_strided(setup, _ptr(input), in_stride, _ptr(output), out_stride, batch,
+                                                  direction, _stream_handle(stream)),
+           "fft_transform_batch_strided")
+
+
 def fft_transform_unordered_batch(setup, input, output, direction: int, batch: int | None = None, stream=None) -> None:
     b = _batch_of(setup, input) if batch is None else batch
     _check(_lib.lib().fft_transform_unordered_batch(setup, _ptr(input), _ptr(output), b, direction, _stream_handle(stream)),

@@ -11,12 +11,15 @@ namespace cfft
 {
 // FPB = frames (teams) per workgroup.  Persistent: each workgroup walks the batch with a grid stride so
 // that the per-work-item twiddle registers are loaded once per workgroup, not once per frame.
-template <class P, int FPB, bool INV>
+template <class P, int FPB, bool INV, bool STRIDED>
 __global__ __launch_bounds__ (P::T* FPB) void c2c_kernel (const float2* __restrict__ in,
                                                          float2* __restrict__ out,
                                                          const float2* __restrict__ twtab,
-                                                         unsigned batch)
+                                                         unsigned batch,
+                                                         unsigned in_stride_arg,
+                                                         unsigned out_stride_arg)
 {
+    CFFT_FRAME_STRIDES (STRIDED, P::N);
     extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
     const int tid = threadIdx.x;
     const int team = tid / P::T;
@@ -27,22 +30,24 @@ __global__ __launch_bounds__ (P::T* FPB) void c2c_kernel (const float2* __restri
     load_twiddles<P> (tw, twtab, t);
 
     const unsigned ngroups = (batch + FPB - 1) / FPB;
-    const unsigned team_base = (unsigned) team * P::N; // element offset of this team's frame inside the group
+    // strides: distance between consecutive frames in float2 (N for packed batches; SURVEY 8 f4 strided batches)
+    const unsigned team_base = (unsigned) team * P::N; // element offset of this team's frame inside the LDS staging area
+    const unsigned team_in = (unsigned) team * in_stride, team_out = (unsigned) team * out_stride;
     constexpr bool STAGED = (P::T < 16);
     float2* stage = smem + FPB * LdsFrame<P::N>::floats2; // staging area (STAGED only): FPB frames, natural order
     for (unsigned g = blockIdx.x; g < ngroups; g += gridDim.x)
     {
         const bool active = g * FPB + team < batch; // uniform per team
         // group base is workgroup-uniform (SGPR pair); everything per work-item is a 32-bit offset
-        const float2* __restrict__ src = in + (size_t) g * (FPB * P::N);
-        float2* __restrict__ dst = out + (size_t) g * (FPB * P::N);
+        const float2* __restrict__ src = in + (size_t) g * FPB * in_stride;
+        float2* __restrict__ dst = out + (size_t) g * FPB * out_stride;
         const unsigned valid = min ((unsigned) FPB, batch - g * FPB) * P::N; // elements of this group that exist
 
         float2 v[P::R];
         if constexpr (STAGED)
         {
             __syncthreads(); // previous group's copy-out has read the staging area
-            stage_in<P::T * FPB, FPB * P::N> (src, stage, valid, tid);
+            stage_in_strided<P::T * FPB, FPB * P::N, P::N> (src, in_stride, stage, valid, tid);
             __syncthreads();
 #pragma unroll
             for (int s = 0; s < P::R; ++s)
@@ -56,7 +61,7 @@ __global__ __launch_bounds__ (P::T* FPB) void c2c_kernel (const float2* __restri
 #pragma unroll
             for (int s = 0; s < P::R; ++s)
             {
-                const float2 x = gload (&src[team_base + (unsigned) input_index<P> (t, s)]);
+                const float2 x = gload (&src[team_in + (unsigned) input_index<P> (t, s)]);
                 v[s] = INV ? make_float2 (x.y, x.x) : x;
             }
         }
@@ -76,7 +81,7 @@ __global__ __launch_bounds__ (P::T* FPB) void c2c_kernel (const float2* __restri
             for (int s = 0; s < P::R; ++s)
                 stage[team_base + (unsigned) output_index<P> (t, s)] = INV ? make_float2 (v[s].y, v[s].x) : v[s];
             __syncthreads();
-            stage_out<P::T * FPB, FPB * P::N> (dst, stage, valid, tid);
+            stage_out_strided<P::T * FPB, FPB * P::N, P::N> (dst, out_stride, stage, valid, tid);
         }
         else if (active)
         {
@@ -84,7 +89,7 @@ __global__ __launch_bounds__ (P::T* FPB) void c2c_kernel (const float2* __restri
             for (int s = 0; s < P::R; ++s)
             {
                 const float2 y = v[s];
-                gstore (&dst[team_base + (unsigned) output_index<P> (t, s)], INV ? make_float2 (y.y, y.x) : y);
+                gstore (&dst[team_out + (unsigned) output_index<P> (t, s)], INV ? make_float2 (y.y, y.x) : y);
             }
         }
     }
@@ -94,12 +99,15 @@ __global__ __launch_bounds__ (P::T* FPB) void c2c_kernel (const float2* __restri
 // stored.  Besides hiding the load latency behind this frame's arithmetic, it puts the loads AHEAD of the
 // stores in the wave's in-order vmcnt queue, so waiting for them (s_waitcnt vmcnt(R)) no longer has to wait
 // for the previous frame's stores to be acknowledged by memory.  Costs 2*R more VGPRs.
-template <class P, int FPB, bool INV>
+template <class P, int FPB, bool INV, bool STRIDED>
 __global__ __launch_bounds__ (P::T* FPB) void c2c_kernel_pf (const float2* __restrict__ in,
                                                             float2* __restrict__ out,
                                                             const float2* __restrict__ twtab,
-                                                            unsigned batch)
+                                                            unsigned batch,
+                                                            unsigned in_stride_arg,
+                                                            unsigned out_stride_arg)
 {
+    CFFT_FRAME_STRIDES (STRIDED, P::N);
     extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
     const int tid = threadIdx.x;
     const int team = tid / P::T;
@@ -110,7 +118,7 @@ __global__ __launch_bounds__ (P::T* FPB) void c2c_kernel_pf (const float2* __res
     load_twiddles<P> (tw, twtab, t);
 
     const unsigned ngroups = (batch + FPB - 1) / FPB;
-    const unsigned team_base = (unsigned) team * P::N;
+    const unsigned team_in = (unsigned) team * in_stride, team_out = (unsigned) team * out_stride;
 
     // One frame: v holds it (already swapped for INV); the next frame's loads go out first, then the
     // arithmetic, then the stores.  The very first frame is peeled so that BOTH ways into the steady-state
@@ -120,17 +128,17 @@ __global__ __launch_bounds__ (P::T* FPB) void c2c_kernel_pf (const float2* __res
 #define CFFT_PF_BODY(G, V)                                                                                          \
     {                                                                                                               \
         const bool active_ = (G) * FPB + team < batch;                                                              \
-        float2* __restrict__ dst_ = out + (size_t) (G) * (FPB * P::N);                                              \
+        float2* __restrict__ dst_ = out + (size_t) (G) * FPB * out_stride;                                          \
         const unsigned gn_ = (G) + gridDim.x;                                                                       \
         if (gn_ < ngroups)                                                                                          \
         {                                                                                                           \
             const bool actn_ = gn_ * FPB + team < batch;                                                            \
-            const float2* __restrict__ srcn_ = in + (size_t) gn_ * (FPB * P::N);                                    \
+            const float2* __restrict__ srcn_ = in + (size_t) gn_ * FPB * in_stride;                                 \
             if (FPB == 1 || actn_)                                                                                  \
             {                                                                                                       \
                 _Pragma ("unroll") for (int s = 0; s < P::R; ++s)                                                   \
                 {                                                                                                   \
-                    const float2 x_ = gload (&srcn_[team_base + (unsigned) input_index<P> (t, s)]);                 \
+                    const float2 x_ = gload (&srcn_[team_in + (unsigned) input_index<P> (t, s)]);                   \
                     nre[s] = INV ? x_.y : x_.x;                                                                     \
                     nim[s] = INV ? x_.x : x_.y;                                                                     \
                 }                                                                                                   \
@@ -141,7 +149,7 @@ __global__ __launch_bounds__ (P::T* FPB) void c2c_kernel_pf (const float2* __res
         if (FPB == 1 || active_) /* FPB == 1: the store count per iteration is a compile-time constant */           \
         {                                                                                                           \
             _Pragma ("unroll") for (int s = 0; s < P::R; ++s)                                                       \
-                gstore (&dst_[team_base + (unsigned) output_index<P> (t, s)],                                       \
+                gstore (&dst_[team_out + (unsigned) output_index<P> (t, s)],                                        \
                         INV ? make_float2 (V[s].y, V[s].x) : V[s]);                                                 \
         }                                                                                                           \
     }
@@ -151,12 +159,12 @@ __global__ __launch_bounds__ (P::T* FPB) void c2c_kernel_pf (const float2* __res
         return;
     {
         const bool act0 = g * FPB + team < batch;
-        const float2* __restrict__ src0 = in + (size_t) g * (FPB * P::N);
+        const float2* __restrict__ src0 = in + (size_t) g * FPB * in_stride;
         float2 v[P::R];
 #pragma unroll
         for (int s = 0; s < P::R; ++s)
         {
-            const float2 x = (FPB == 1 || act0) ? gload (&src0[team_base + (unsigned) input_index<P> (t, s)]) : make_float2 (0.f, 0.f);
+            const float2 x = (FPB == 1 || act0) ? gload (&src0[team_in + (unsigned) input_index<P> (t, s)]) : make_float2 (0.f, 0.f);
             v[s] = INV ? make_float2 (x.y, x.x) : x;
         }
         CFFT_PF_BODY (g, v)

@@ -154,7 +154,7 @@ Lanes* get_lanes (int device, hipStream_t stream, size_t bytes_each)
 // complex length the plan's core transforms
 int complex_len (const Setup* s) { return s->transform == cf::FFT_COMPLEX ? s->N : s->N / 2; }
 
-int big_c2c_chunked (Setup* s, int nc, bool inverse, const float2* in, float2* out, size_t batch, hipStream_t stream)
+int big_c2c_chunked (Setup* s, int nc, bool inverse, const float2* in, float2* out, size_t batch, hipStream_t stream, size_t is2, size_t os2)
 {
     int n1 = 0, n2 = 0;
     split_large (nc, n1, n2);
@@ -187,8 +187,8 @@ int big_c2c_chunked (Setup* s, int nc, bool inverse, const float2* in, float2* o
         const size_t nb = (batch - f0 < chunk) ? batch - f0 : chunk;
         const int k = (lanes == 2) ? (int) (i & 1) : 0;
         const hipStream_t st = (lanes == 2) ? L->lane[k] : stream;
-        const hipError_t e = launch_big_c2c (n1, n2, inverse, in + f0 * nc, L->ws[k], out + f0 * nc, s->tables->stage_twiddles,
-                                             s->tables->big_twiddles, nb, lanes, st);
+        const hipError_t e = launch_big_c2c (n1, n2, inverse, in + f0 * is2, L->ws[k], out + f0 * os2, s->tables->stage_twiddles,
+                                             s->tables->big_twiddles, nb, lanes, st, is2, os2);
         if (e != hipSuccess)
         {
             set_last_error ("two-pass kernel launch", e);
@@ -223,7 +223,8 @@ struct DeviceGuard
     }
 };
 
-int run_transform (Setup* s, const float* in, float* out, size_t batch, cf::fft_direction_t dir, hipStream_t stream)
+// in_stride / out_stride: floats between consecutive frames (0 = packed); validated by the caller
+int run_transform (Setup* s, const float* in, float* out, size_t batch, cf::fft_direction_t dir, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0)
 {
     if (batch == 0)
         return cf::FFT_GPU_OK;
@@ -234,37 +235,39 @@ int run_transform (Setup* s, const float* in, float* out, size_t batch, cf::fft_
     const bool lds_resident = (t->core_n == nc);
     const float2* cin = (const float2*) in;
     float2* cout = (float2*) out;
+    // strides in float2, always explicit from here on
+    const size_t is2 = in_stride ? in_stride / 2 : (size_t) nc, os2 = out_stride ? out_stride / 2 : (size_t) nc;
     hipError_t e = hipSuccess;
     if (t->gen_ns > 0)
     {
         // N = 2^a 3^b 5^c, not a power of two: generic mixed-radix kernel
         const int mode = (s->transform == cf::FFT_COMPLEX) ? 0 : (inverse ? 2 : 1);
-        e = launch_generic (mode, inverse, nc, *t, cin, cout, batch, stream);
+        e = launch_generic (mode, inverse, nc, *t, cin, cout, batch, stream, is2, os2);
     }
     else if (s->transform == cf::FFT_COMPLEX)
     {
         if (! lds_resident)
-            return big_c2c_chunked (s, nc, inverse, cin, cout, batch, stream);
-        e = launch_c2c (nc, inverse, cin, cout, t->stage_twiddles, batch, stream);
+            return big_c2c_chunked (s, nc, inverse, cin, cout, batch, stream, is2, os2);
+        e = launch_c2c (nc, inverse, cin, cout, t->stage_twiddles, batch, stream, is2, os2);
     }
     else if (lds_resident)
     {
-        e = inverse ? launch_c2r (nc, cin, cout, t->stage_twiddles, t->real_twiddles, batch, stream)
-                    : launch_r2c (nc, cin, cout, t->stage_twiddles, t->real_twiddles, batch, stream);
+        e = inverse ? launch_c2r (nc, cin, cout, t->stage_twiddles, t->real_twiddles, batch, stream, is2, os2)
+                    : launch_r2c (nc, cin, cout, t->stage_twiddles, t->real_twiddles, batch, stream, is2, os2);
     }
     else if (! inverse)
     {
         // long real frames: complex two-pass transform of z[n] = x[2n] + i x[2n+1], then the pair stage in place
-        const int rc = big_c2c_chunked (s, nc, false, cin, cout, batch, stream);
+        const int rc = big_c2c_chunked (s, nc, false, cin, cout, batch, stream, is2, os2);
         if (rc != cf::FFT_GPU_OK)
             return rc;
-        e = launch_real_pair (true, cout, cout, t->real_twiddles, (unsigned) nc, batch, stream);
+        e = launch_real_pair (true, cout, cout, t->real_twiddles, (unsigned) nc, batch, stream, os2, os2);
     }
     else
     {
-        e = launch_real_pair (false, cin, cout, t->real_twiddles, (unsigned) nc, batch, stream);
+        e = launch_real_pair (false, cin, cout, t->real_twiddles, (unsigned) nc, batch, stream, is2, os2);
         if (e == hipSuccess)
-            return big_c2c_chunked (s, nc, true, cout, cout, batch, stream);
+            return big_c2c_chunked (s, nc, true, cout, cout, batch, stream, os2, os2);
     }
     if (e != hipSuccess)
     {
@@ -616,6 +619,35 @@ int fft_transform_batch (void* setup, const float* input, float* output, size_t 
     if (s == nullptr || input == nullptr || output == nullptr)
         return FFT_GPU_EINVAL;
     return run_transform (s, input, output, batch, direction, (hipStream_t) stream);
+}
+
+// frames embedded in larger buffers.  Strides in floats.
+int fft_transform_batch_strided (void* setup, const float* input, size_t in_stride, float* output, size_t out_stride, size_t batch, fft_direction_t direction, void* stream)
+{
+    Setup* s = as_setup (setup);
+    if (s == nullptr || input == nullptr || output == nullptr)
+        return FFT_GPU_EINVAL;
+    const size_t nf = frame_floats (s);
+    const auto bad_stride = [nf] (size_t st) { return st < nf || (st % 4) != 0 || st > 2 * kMaxFrameStride; };
+    if (bad_stride (in_stride) || bad_stride (out_stride)
+        || (reinterpret_cast<uintptr_t> (input) % 16) != 0 || (reinterpret_cast<uintptr_t> (output) % 16) != 0)
+    {
+        set_last_error ("fft_transform_batch_strided: strides must be multiples of 4 floats, >= the frame length, buffers 16-byte aligned");
+        return FFT_GPU_EINVAL;
+    }
+    if (batch > 0)
+    {
+        // overlapping buffers are only meaningful as the same frames in place
+        const float* in_end = input + (batch - 1) * in_stride + nf;
+        const float* out_end = output + (batch - 1) * out_stride + nf;
+        const bool overlap = input < out_end && output < in_end;
+        if (overlap && ! (input == output && in_stride == out_stride))
+        {
+            set_last_error ("fft_transform_batch_strided: input and output overlap without being the same frames");
+            return FFT_GPU_EINVAL;
+        }
+    }
+    return run_transform (s, input, output, batch, direction, (hipStream_t) stream, in_stride, out_stride);
 }
 
 int fft_transform_unordered_batch (void* setup, const float* input, float* output, size_t batch, fft_direction_t direction, void* stream)

@@ -23,6 +23,7 @@ struct GenericPlan
     int n;                            // complex points per frame
     int ns;                           // number of stages
     int frames;                       // frames per workgroup pass (F)
+    unsigned in_stride, out_stride;   // float2 between consecutive frames in global memory (n for packed batches)
     int radix[kGenericMaxStages];     // each in {2, 3, 4, 5, 8}
     int tw_offset[kGenericMaxStages]; // float2 offset of the stage's table: (radix-1) * p entries, [a-1][k]
 };
@@ -138,8 +139,9 @@ __global__ __launch_bounds__ (BLOCK) void generic_kernel (const float2* __restri
     for (unsigned g = blockIdx.x; g < ngroups; g += gridDim.x)
     {
         const int nframes = (int) min ((unsigned) F, batch - g * F);
-        const float2* __restrict__ src = in + (size_t) g * F * n;
-        float2* __restrict__ dst = out + (size_t) g * F * n;
+        const unsigned is = plan.in_stride, os = plan.out_stride;
+        const float2* __restrict__ src = in + (size_t) g * F * is;
+        float2* __restrict__ dst = out + (size_t) g * F * os;
         __syncthreads(); // previous group's reads of the images are finished
         if (MODE == 2)
         {
@@ -148,8 +150,8 @@ __global__ __launch_bounds__ (BLOCK) void generic_kernel (const float2* __restri
             {
                 const int f = idx / half, k = idx - f * half;
                 const int kp = (k == 0) ? 0 : n - k;
-                const float2 A = gload (&src[f * n + k]);
-                const float2 Xp = gload (&src[f * n + kp]);
+                const float2 A = gload (&src[f * is + k]);
+                const float2 Xp = gload (&src[f * is + kp]);
                 float2 zk, zp;
                 if (k == 0)
                 {
@@ -172,7 +174,8 @@ __global__ __launch_bounds__ (BLOCK) void generic_kernel (const float2* __restri
         {
             for (int e = tid; e < nframes * n; e += BLOCK)
             {
-                const float2 x = gload (&src[e]);
+                const unsigned ge = (is == (unsigned) n) ? (unsigned) e : (unsigned) (e / n) * is + (unsigned) (e % n);
+                const float2 x = gload (&src[ge]);
                 bufA[e] = (MODE == 0 && INV) ? make_float2 (x.y, x.x) : x;
             }
         }
@@ -199,9 +202,9 @@ __global__ __launch_bounds__ (BLOCK) void generic_kernel (const float2* __restri
                 }
                 else
                     real_split_pair (A, Zp, wtab[k], Xk, Xp);
-                gstore (&dst[f * n + k], Xk);
+                gstore (&dst[f * os + k], Xk);
                 if (kp != k)
-                    gstore (&dst[f * n + kp], Xp);
+                    gstore (&dst[f * os + kp], Xp);
             }
         }
         else
@@ -209,7 +212,8 @@ __global__ __launch_bounds__ (BLOCK) void generic_kernel (const float2* __restri
             for (int e = tid; e < nframes * n; e += BLOCK)
             {
                 const float2 y = res[e];
-                gstore (&dst[e], (MODE == 2 || INV) ? make_float2 (y.y, y.x) : y);
+                const unsigned ge = (os == (unsigned) n) ? (unsigned) e : (unsigned) (e / n) * os + (unsigned) (e % n);
+                gstore (&dst[ge], (MODE == 2 || INV) ? make_float2 (y.y, y.x) : y);
             }
         }
     }

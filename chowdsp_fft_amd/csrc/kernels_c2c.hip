@@ -7,7 +7,7 @@ namespace cfft::host
 namespace
 {
 template <int N, bool INV>
-hipError_t launch_c2c_n (const float2* in, float2* out, const float2* tw, size_t batch, hipStream_t stream)
+hipError_t launch_c2c_n (const float2* in, float2* out, const float2* tw, size_t batch, hipStream_t stream, unsigned in_stride, unsigned out_stride)
 {
     using P = typename CorePlan<N>::type;
     using G = Geometry<P>;
@@ -18,29 +18,37 @@ hipError_t launch_c2c_n (const float2* in, float2* out, const float2* tw, size_t
 #define CFFT_C2C_PREFETCH 2
 #endif
     constexpr bool use_pf = (CFFT_C2C_PREFETCH == 1) || (CFFT_C2C_PREFETCH == 2 && G::FPB == 1);
-    auto kernel = use_pf ? c2c_kernel_pf<P, G::FPB, INV> : c2c_kernel<P, G::FPB, INV>;
     const size_t ngroups = (batch + G::FPB - 1) / G::FPB;
+    const bool strided = (in_stride != 0 && in_stride != (unsigned) N) || (out_stride != 0 && out_stride != (unsigned) N);
+    auto kernel = [] { // only the variant in use is instantiated
+        if constexpr (use_pf)
+            return &c2c_kernel_pf<P, G::FPB, INV, false>;
+        else
+            return &c2c_kernel<P, G::FPB, INV, false>;
+    }();
+    if (strided) // frames embedded in larger buffers: run-time strides, plain kernel
+        kernel = &c2c_kernel<P, G::FPB, INV, true>;
     const unsigned grid = persistent_grid (kernel, G::threads, G::lds_bytes, ngroups);
     if (grid == 0)
         return hipErrorNoDevice;
-    hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (G::threads), G::lds_bytes, stream, in, out, tw, (unsigned) batch);
+    hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (G::threads), G::lds_bytes, stream, in, out, tw, (unsigned) batch, in_stride ? in_stride : (unsigned) N, out_stride ? out_stride : (unsigned) N);
     return hipGetLastError();
 }
 } // namespace
 
-hipError_t launch_c2c (int n, bool inverse, const float2* in, float2* out, const float2* stage_tw, size_t batch, hipStream_t stream)
+hipError_t launch_c2c (int n, bool inverse, const float2* in, float2* out, const float2* stage_tw, size_t batch, hipStream_t stream, size_t in_stride, size_t out_stride)
 {
     if (batch == 0)
         return hipSuccess;
-    if (batch > 0x7FFFFFFFull)
+    if (batch > 0x7FFFFFFFull || in_stride > kMaxFrameStride || out_stride > kMaxFrameStride)
         return hipErrorInvalidValue;
     if (inverse)
     {
-        CFFT_DISPATCH_N (n, return (launch_c2c_n<N_, true> (in, out, stage_tw, batch, stream)));
+        CFFT_DISPATCH_N (n, return (launch_c2c_n<N_, true> (in, out, stage_tw, batch, stream, (unsigned) in_stride, (unsigned) out_stride)));
     }
     else
     {
-        CFFT_DISPATCH_N (n, return (launch_c2c_n<N_, false> (in, out, stage_tw, batch, stream)));
+        CFFT_DISPATCH_N (n, return (launch_c2c_n<N_, false> (in, out, stage_tw, batch, stream, (unsigned) in_stride, (unsigned) out_stride)));
     }
     return hipErrorInvalidValue;
 }

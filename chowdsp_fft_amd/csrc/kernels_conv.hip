@@ -33,7 +33,12 @@ hipError_t launch_cf_c2c_n (const float2* in, const float2* H, float2* out, cons
     constexpr int threads = P::T * FPB;
     constexpr size_t lds_bytes = G::lds_bytes / G::FPB * FPB;
     constexpr bool use_pf = N >= CFFT_CCONV_PF_MIN;
-    auto kernel = use_pf ? conv_frames_c2c_kernel_pf<P, FPB> : conv_frames_c2c_kernel<P, FPB>;
+    auto kernel = [] { // only the variant in use is instantiated
+        if constexpr (use_pf)
+            return &conv_frames_c2c_kernel_pf<P, FPB>;
+        else
+            return &conv_frames_c2c_kernel<P, FPB>;
+    }();
     const size_t ngroups = (batch + FPB - 1) / FPB;
     const unsigned grid = persistent_grid (kernel, threads, lds_bytes, ngroups);
     if (grid == 0)
@@ -66,7 +71,12 @@ hipError_t launch_cf_real_m (const float2* in, const float2* H, float2* out, con
     constexpr bool hregs = ! (use_pf && M == 2048);
     constexpr int threads = P::T * FPB;
     constexpr size_t lds_bytes = G::lds_bytes / G::FPB * FPB; // no staging area for T >= 16
-    auto kernel = use_pf ? conv_frames_real_kernel_pf<P, FPB, hregs> : conv_frames_real_kernel<P, FPB, hregs>;
+    auto kernel = [] { // only the variant in use is instantiated
+        if constexpr (use_pf)
+            return &conv_frames_real_kernel_pf<P, FPB, hregs>;
+        else
+            return &conv_frames_real_kernel<P, FPB, hregs>;
+    }();
     const size_t ngroups = (batch + FPB - 1) / FPB;
     const unsigned grid = persistent_grid (kernel, threads, lds_bytes, ngroups);
     if (grid == 0)

@@ -40,15 +40,19 @@ hipError_t launch_generic_m (GenericPlan& plan, const DeviceTables& t, const flo
 }
 } // namespace
 
-hipError_t launch_generic (int mode, bool inverse, int nc, const DeviceTables& t, const float2* in, float2* out, size_t batch, hipStream_t stream)
+hipError_t launch_generic (int mode, bool inverse, int nc, const DeviceTables& t, const float2* in, float2* out, size_t batch, hipStream_t stream, size_t in_stride, size_t out_stride)
 {
     if (batch == 0)
         return hipSuccess;
+    if (in_stride > kMaxFrameStride || out_stride > kMaxFrameStride)
+        return hipErrorInvalidValue;
     if (batch > 0x7FFFFFFFull || nc > kGenericMaxN || t.gen_ns < 1 || t.gen_ns > kGenericMaxStages)
         return hipErrorInvalidValue;
     GenericPlan plan {};
     plan.n = nc;
     plan.ns = t.gen_ns;
+    plan.in_stride = in_stride ? (unsigned) in_stride : (unsigned) nc;
+    plan.out_stride = out_stride ? (unsigned) out_stride : (unsigned) nc;
     for (int i = 0; i < t.gen_ns; ++i)
     {
         plan.radix[i] = t.gen_radix[i];

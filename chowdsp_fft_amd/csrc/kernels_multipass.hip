@@ -24,7 +24,7 @@ hipError_t ensure_lds (K kernel, size_t bytes)
 
 // pass A: n2-point column FFTs (+ inter-pass twiddle), in -> work (tile-major)
 template <int N2, bool INV>
-hipError_t pass_a (int n1, const float2* in, float2* work, const float2* tw2, const float2* big_tw, size_t batch, int div, hipStream_t stream)
+hipError_t pass_a (int n1, const float2* in, float2* work, const float2* tw2, const float2* big_tw, size_t batch, int div, hipStream_t stream, size_t in_stride)
 {
     using TG = TileGeom<N2>;
     auto kernel = pass_a_kernel<typename TG::P, TG::C, INV>;
@@ -36,13 +36,13 @@ hipError_t pass_a (int n1, const float2* in, float2* work, const float2* tw2, co
     if (grid == 0)
         return hipErrorNoDevice;
     grid = std::max (1u, grid / (unsigned) div);
-    hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (256), TG::lds_bytes, stream, in, work, tw2, big_tw, (unsigned) n1, (unsigned) batch);
+    hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (256), TG::lds_bytes, stream, in, work, tw2, big_tw, (unsigned) n1, (unsigned) batch, in_stride);
     return hipGetLastError();
 }
 
 // pass B: n1-point row FFTs, transposed store, work -> out
 template <int N1, bool INV>
-hipError_t pass_b (int n2, const float2* work, float2* out, const float2* tw1, size_t batch, int div, hipStream_t stream)
+hipError_t pass_b (int n2, const float2* work, float2* out, const float2* tw1, size_t batch, int div, hipStream_t stream, size_t out_stride)
 {
     using TG = TileGeom<N1>;
     auto kernel = pass_b_kernel<typename TG::P, TG::C, INV>;
@@ -57,7 +57,7 @@ hipError_t pass_b (int n2, const float2* work, float2* out, const float2* tw1, s
     unsigned ca_log2 = 0;
     while ((1 << ca_log2) < tile_width_for (n2))
         ++ca_log2;
-    hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (256), TG::lds_bytes, stream, work, out, tw1, (unsigned) n2, ca_log2, (unsigned) batch);
+    hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (256), TG::lds_bytes, stream, work, out, tw1, (unsigned) n2, ca_log2, (unsigned) batch, out_stride);
     return hipGetLastError();
 }
 
@@ -74,7 +74,7 @@ hipError_t pass_b (int n2, const float2* work, float2* out, const float2* tw1, s
 
 // N = 65536 = 256 x 256 fast path (register-direct, software-pipelined; multipass_kernels.hpp)
 template <bool INV>
-hipError_t big256 (const float2* in, float2* work, float2* out, const float2* tw256, const float2* big_tw, size_t batch, int div, hipStream_t stream)
+hipError_t big256 (const float2* in, float2* work, float2* out, const float2* tw256, const float2* big_tw, size_t batch, int div, hipStream_t stream, size_t in_stride, size_t out_stride)
 {
     constexpr size_t lds = (size_t) 16 * TileFrame<256>::stride * sizeof (float2);
     auto ka = pass_a256_kernel<INV>;
@@ -85,11 +85,11 @@ hipError_t big256 (const float2* in, float2* work, float2* out, const float2* tw
         return hipErrorNoDevice;
     ga = std::max (1u, ga / (unsigned) div);
     gb = std::max (1u, gb / (unsigned) div);
-    hipLaunchKernelGGL (ka, dim3 (ga), dim3 (256), lds, stream, in, work, tw256, big_tw, (unsigned) batch);
+    hipLaunchKernelGGL (ka, dim3 (ga), dim3 (256), lds, stream, in, work, tw256, big_tw, (unsigned) batch, in_stride);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return e;
-    hipLaunchKernelGGL (kb, dim3 (gb), dim3 (256), lds, stream, (const float2*) work, out, tw256, (unsigned) batch);
+    hipLaunchKernelGGL (kb, dim3 (gb), dim3 (256), lds, stream, (const float2*) work, out, tw256, (unsigned) batch, out_stride);
     return hipGetLastError();
 }
 
@@ -100,48 +100,53 @@ int stage_table_len (int n)
 }
 } // namespace
 
-hipError_t launch_big_c2c (int n1, int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, size_t batch, int grid_divisor, hipStream_t stream)
+hipError_t launch_big_c2c (int n1, int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, size_t batch, int grid_divisor, hipStream_t stream, size_t in_stride, size_t out_stride)
 {
     if (batch == 0)
         return hipSuccess;
     if (batch > 0x7FFFFFFFull)
         return hipErrorInvalidValue;
+    const size_t frame_len = (size_t) n1 * (size_t) n2;
+    in_stride = in_stride ? in_stride : frame_len;
+    out_stride = out_stride ? out_stride : frame_len;
     const float2* tw2 = stage_tw;
     const float2* tw1 = stage_tw + stage_table_len (n2);
     if (n1 == 256 && n2 == 256 && batch * 16 <= 0x7FFFFFFFull)
-        return inverse ? big256<true> (in, work, out, tw2, big_tw, batch, grid_divisor, stream)
-                       : big256<false> (in, work, out, tw2, big_tw, batch, grid_divisor, stream);
+        return inverse ? big256<true> (in, work, out, tw2, big_tw, batch, grid_divisor, stream, in_stride, out_stride)
+                       : big256<false> (in, work, out, tw2, big_tw, batch, grid_divisor, stream, in_stride, out_stride);
     hipError_t e = hipErrorInvalidValue;
     if (inverse)
     {
-        CFFT_DISPATCH_BIG (n2, e = (pass_a<N_, true> (n1, in, work, tw2, big_tw, batch, grid_divisor, stream)));
+        CFFT_DISPATCH_BIG (n2, e = (pass_a<N_, true> (n1, in, work, tw2, big_tw, batch, grid_divisor, stream, in_stride)));
         if (e != hipSuccess)
             return e;
-        CFFT_DISPATCH_BIG (n1, e = (pass_b<N_, true> (n2, work, out, tw1, batch, grid_divisor, stream)));
+        CFFT_DISPATCH_BIG (n1, e = (pass_b<N_, true> (n2, work, out, tw1, batch, grid_divisor, stream, out_stride)));
     }
     else
     {
-        CFFT_DISPATCH_BIG (n2, e = (pass_a<N_, false> (n1, in, work, tw2, big_tw, batch, grid_divisor, stream)));
+        CFFT_DISPATCH_BIG (n2, e = (pass_a<N_, false> (n1, in, work, tw2, big_tw, batch, grid_divisor, stream, in_stride)));
         if (e != hipSuccess)
             return e;
-        CFFT_DISPATCH_BIG (n1, e = (pass_b<N_, false> (n2, work, out, tw1, batch, grid_divisor, stream)));
+        CFFT_DISPATCH_BIG (n1, e = (pass_b<N_, false> (n2, work, out, tw1, batch, grid_divisor, stream, out_stride)));
     }
     return e;
 }
 
-hipError_t launch_real_pair (bool forward, const float2* in, float2* out, const float2* real_tw, unsigned m, size_t batch, hipStream_t stream)
+hipError_t launch_real_pair (bool forward, const float2* in, float2* out, const float2* real_tw, unsigned m, size_t batch, hipStream_t stream, size_t in_stride, size_t out_stride)
 {
     if (batch == 0)
         return hipSuccess;
+    in_stride = in_stride ? in_stride : (size_t) m;
+    out_stride = out_stride ? out_stride : (size_t) m;
     DeviceInfo dev;
     if (! current_device_info (dev))
         return hipErrorNoDevice;
     const size_t total = batch * (m / 2);
     const unsigned grid = (unsigned) std::max<size_t> (1, std::min<size_t> ((total + 255) / 256, (size_t) dev.num_cus * 8));
     if (forward)
-        hipLaunchKernelGGL (real_pair_kernel<true>, dim3 (grid), dim3 (256), 0, stream, in, out, real_tw, m, (unsigned) batch);
+        hipLaunchKernelGGL (real_pair_kernel<true>, dim3 (grid), dim3 (256), 0, stream, in, out, real_tw, m, (unsigned) batch, in_stride, out_stride);
     else
-        hipLaunchKernelGGL (real_pair_kernel<false>, dim3 (grid), dim3 (256), 0, stream, in, out, real_tw, m, (unsigned) batch);
+        hipLaunchKernelGGL (real_pair_kernel<false>, dim3 (grid), dim3 (256), 0, stream, in, out, real_tw, m, (unsigned) batch, in_stride, out_stride);
     return hipGetLastError();
 }
 } // namespace cfft::host

@@ -7,11 +7,12 @@ namespace cfft::host
 namespace
 {
 template <int M, bool FWD>
-hipError_t launch_real_m (const float2* in, float2* out, const float2* tw, const float2* rtw, size_t batch, hipStream_t stream)
+hipError_t launch_real_m (const float2* in, float2* out, const float2* tw, const float2* rtw, size_t batch, hipStream_t stream, unsigned in_stride, unsigned out_stride)
 {
     using P = typename CorePlan<M>::type;
     using G = Geometry<P>;
     const size_t ngroups = (batch + G::FPB - 1) / G::FPB;
+    const bool strided = (in_stride != 0 && in_stride != (unsigned) M) || (out_stride != 0 && out_stride != (unsigned) M);
     if constexpr (FWD)
     {
         // CFFT_REAL_PREFETCH: 0 never, 1 always, default 2 = only one-frame-per-workgroup plans (measured on MI355X:
@@ -20,41 +21,48 @@ hipError_t launch_real_m (const float2* in, float2* out, const float2* tw, const
 #define CFFT_REAL_PREFETCH 2
 #endif
         constexpr bool use_pf = (CFFT_REAL_PREFETCH == 1) || (CFFT_REAL_PREFETCH == 2 && G::FPB == 1);
-        auto kernel = use_pf ? r2c_kernel_pf<P, G::FPB> : r2c_kernel<P, G::FPB>;
+        auto kernel = [] { // only the variant in use is instantiated
+            if constexpr (use_pf)
+                return &r2c_kernel_pf<P, G::FPB, false>;
+            else
+                return &r2c_kernel<P, G::FPB, false>;
+        }();
+        if (strided) // frames embedded in larger buffers: run-time strides, plain kernel
+            kernel = &r2c_kernel<P, G::FPB, true>;
         const unsigned grid = persistent_grid (kernel, G::threads, G::lds_bytes, ngroups);
         if (grid == 0)
             return hipErrorNoDevice;
-        hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (G::threads), G::lds_bytes, stream, in, out, tw, rtw, (unsigned) batch);
+        hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (G::threads), G::lds_bytes, stream, in, out, tw, rtw, (unsigned) batch, in_stride ? in_stride : (unsigned) M, out_stride ? out_stride : (unsigned) M);
     }
     else
     {
-        auto kernel = c2r_kernel<P, G::FPB>;
+        auto kernel = strided ? &c2r_kernel<P, G::FPB, true> : &c2r_kernel<P, G::FPB, false>;
         const unsigned grid = persistent_grid (kernel, G::threads, G::lds_bytes, ngroups);
         if (grid == 0)
             return hipErrorNoDevice;
-        hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (G::threads), G::lds_bytes, stream, in, out, tw, rtw, (unsigned) batch);
+        hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (G::threads), G::lds_bytes, stream, in, out, tw, rtw, (unsigned) batch, in_stride ? in_stride : (unsigned) M, out_stride ? out_stride : (unsigned) M);
     }
     return hipGetLastError();
 }
 } // namespace
 
-hipError_t launch_r2c (int m, const float2* in, float2* out, const float2* stage_tw, const float2* real_tw, size_t batch, hipStream_t stream)
+hipError_t launch_r2c (int m, const float2* in, float2* out, const float2* stage_tw, const float2* real_tw, size_t batch, hipStream_t stream, size_t in_stride, size_t out_stride)
 {
     if (batch == 0)
         return hipSuccess;
-    if (batch > 0x7FFFFFFFull)
+    if (batch > 0x7FFFFFFFull || in_stride > kMaxFrameStride || out_stride > kMaxFrameStride)
         return hipErrorInvalidValue;
-    CFFT_DISPATCH_N (m, return (launch_real_m<N_, true> (in, out, stage_tw, real_tw, batch, stream)));
+    CFFT_DISPATCH_N (m, return (launch_real_m<N_, true> (in, out, stage_tw, real_tw, batch, stream, (unsigned) in_stride, (unsigned) out_stride)));
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_c2r (int m, const float2* in, float2* out, const float2* stage_tw, const float2* real_tw, size_t batch, hipStream_t stream)
+hipError_t launch_c2r (int m, const float2* in, float2* out, const float2* stage_tw, const float2* real_tw, size_t batch, hipStream_t stream, size_t in_stride, size_t out_stride)
 {
     if (batch == 0)
         return hipSuccess;
-    if (batch > 0x7FFFFFFFull)
+    if (batch > 0x7FFFFFFFull || in_stride > kMaxFrameStride || out_stride > kMaxFrameStride)
         return hipErrorInvalidValue;
-    CFFT_DISPATCH_N (m, return (launch_real_m<N_, false> (in, out, stage_tw, real_tw, batch, stream)));
+    CFFT_DISPATCH_N (m, return (launch_real_m<N_, false> (in, out, stage_tw, real_tw, batch, stream, (unsigned) in_stride, (unsigned) out_stride)));
     return hipErrorInvalidValue;
 }
 } // namespace cfft::host

@@ -7,12 +7,18 @@ namespace cfft::host
 // All launchers: asynchronous on `stream`, return hipSuccess or the launch error.
 // n = complex frame length handled by the LDS-resident core (16..4096).
 
+// largest frame stride in float2: 64 teams * stride must stay a 32-bit element offset
+static constexpr size_t kMaxFrameStride = (size_t) 1 << 24;
+
+// Frame strides: distance between consecutive frames in float2 units, even, >= the frame length;
+// 0 = packed.  With in == out both strides must be equal.
+
 // batched complex FFT, interleaved in/out, in may equal out
-hipError_t launch_c2c (int n, bool inverse, const float2* in, float2* out, const float2* stage_tw, size_t batch, hipStream_t stream);
+hipError_t launch_c2c (int n, bool inverse, const float2* in, float2* out, const float2* stage_tw, size_t batch, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
 
 // batched real FFT of N = 2*m real points through the m-point core (m = 16..4096)
-hipError_t launch_r2c (int m, const float2* in, float2* out, const float2* stage_tw, const float2* real_tw, size_t batch, hipStream_t stream);
-hipError_t launch_c2r (int m, const float2* in, float2* out, const float2* stage_tw, const float2* real_tw, size_t batch, hipStream_t stream);
+hipError_t launch_r2c (int m, const float2* in, float2* out, const float2* stage_tw, const float2* real_tw, size_t batch, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
+hipError_t launch_c2r (int m, const float2* in, float2* out, const float2* stage_tw, const float2* real_tw, size_t batch, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
 
 // ab += a*b*scaling on `batch` frames of `cplx_per_frame` complex values; real_packed: bin 0 is (DC, Nyquist)
 hipError_t launch_conv_mac (bool real_packed, const float* a, const float* b, float* ab, float scaling, size_t cplx_per_frame, size_t batch, bool b_is_shared, hipStream_t stream);
@@ -30,11 +36,11 @@ hipError_t launch_conv_frames_real (int m, const float2* in, const float2* H, fl
 // multi-pass complex FFT of nc = n1*n2 points: in -> work -> out (work holds `batch` frames)
 // stage_tw holds the n2-core table followed by the n1-core table.  grid_divisor: 2 when two launches are meant
 // to share the GPU (two-lane pipeline), else 1.
-hipError_t launch_big_c2c (int n1, int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, size_t batch, int grid_divisor, hipStream_t stream);
-hipError_t launch_real_pair (bool forward, const float2* in, float2* out, const float2* real_tw, unsigned m, size_t batch, hipStream_t stream);
+hipError_t launch_big_c2c (int n1, int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, size_t batch, int grid_divisor, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
+hipError_t launch_real_pair (bool forward, const float2* in, float2* out, const float2* real_tw, unsigned m, size_t batch, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
 
 // mixed-radix (non power of two) frames: mode 0 c2c, 1 real forward, 2 real backward; nc = complex length
-hipError_t launch_generic (int mode, bool inverse, int nc, const DeviceTables& t, const float2* in, float2* out, size_t batch, hipStream_t stream);
+hipError_t launch_generic (int mode, bool inverse, int nc, const DeviceTables& t, const float2* in, float2* out, size_t batch, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
 
 // shared by the kernels_*.hip files
 int blocks_per_cu_cached (const void* kernel, int threads, size_t lds_bytes);

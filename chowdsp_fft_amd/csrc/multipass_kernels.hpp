@@ -65,7 +65,8 @@ __global__ __launch_bounds__ (256) void pass_a_kernel (const float2* __restrict_
                                                       const float2* __restrict__ stage_tw,
                                                       const float2* __restrict__ big_tw,
                                                       unsigned n1,
-                                                      unsigned batch)
+                                                      unsigned batch,
+                                                      size_t in_stride) // float2 between consecutive input frames
 {
     extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
     constexpr int n2 = P::N;
@@ -83,7 +84,7 @@ __global__ __launch_bounds__ (256) void pass_a_kernel (const float2* __restrict_
     {
         const unsigned f = (unsigned) (w / tiles);
         const unsigned tile = (unsigned) (w % tiles);
-        const float2* __restrict__ src = in + (size_t) f * frame_len + (size_t) tile * CA;
+        const float2* __restrict__ src = in + (size_t) f * in_stride + (size_t) tile * CA;
         float2* __restrict__ dst = work + (size_t) f * frame_len + (size_t) tile * (n2 * CA);
         const float2* __restrict__ twp = big_tw + (size_t) tile * (n2 * CA);
 
@@ -114,7 +115,8 @@ __global__ __launch_bounds__ (256) void pass_b_kernel (const float2* __restrict_
                                                       const float2* __restrict__ stage_tw,
                                                       unsigned n2,
                                                       unsigned ca_log2, // log2 of pass A's tile width
-                                                      unsigned batch)
+                                                      unsigned batch,
+                                                      size_t out_stride) // float2 between consecutive output frames
 {
     extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
     constexpr int n1 = P::N;
@@ -135,7 +137,7 @@ __global__ __launch_bounds__ (256) void pass_b_kernel (const float2* __restrict_
         const unsigned tile = (unsigned) (w % tiles);
         const unsigned kb0 = tile * CB;
         const float2* __restrict__ src = work + (size_t) f * frame_len;
-        float2* __restrict__ dst = out + (size_t) f * frame_len + kb0;
+        float2* __restrict__ dst = out + (size_t) f * out_stride + kb0;
 
         __syncthreads();
 #pragma unroll 4
@@ -168,7 +170,9 @@ __global__ __launch_bounds__ (256) void real_pair_kernel (const float2* __restri
                                                          float2* __restrict__ out,
                                                          const float2* __restrict__ wtab,
                                                          unsigned M,
-                                                         unsigned batch)
+                                                         unsigned batch,
+                                                         size_t in_stride,
+                                                         size_t out_stride)
 {
     const unsigned half = M / 2; // pairs per frame, k = 0 .. M/2-1
     const size_t total = (size_t) batch * half;
@@ -178,8 +182,8 @@ __global__ __launch_bounds__ (256) void real_pair_kernel (const float2* __restri
         const unsigned f = (unsigned) (i / half);
         const unsigned k = (unsigned) (i % half);
         const unsigned kp = (k == 0 ? half : M - k);
-        const float2* __restrict__ src = in + (size_t) f * M;
-        float2* __restrict__ dst = out + (size_t) f * M;
+        const float2* __restrict__ src = in + (size_t) f * in_stride;
+        float2* __restrict__ dst = out + (size_t) f * out_stride;
         const float2 A = gload (&src[k]), Bp = gload (&src[kp]);
         const float2 w = wtab[k];
         float2 rk, rp;
@@ -259,7 +263,8 @@ __global__ __launch_bounds__ (256) void pass_a256_kernel (const float2* __restri
                                                          float2* __restrict__ work,
                                                          const float2* __restrict__ stage_tw,
                                                          const float2* __restrict__ big_tw,
-                                                         unsigned batch)
+                                                         unsigned batch,
+                                                         size_t in_stride)
 {
     extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
     constexpr unsigned n1 = 256, N = 65536, tiles = 16;
@@ -276,7 +281,7 @@ __global__ __launch_bounds__ (256) void pass_a256_kernel (const float2* __restri
     float nre[16], nim[16];
 #define CFFT_A256_LOAD(W, RE, IM)                                                                  \
     {                                                                                              \
-        const float2* __restrict__ src_ = in + (size_t) ((W) / tiles) * N + ((W) % tiles) * 16;    \
+        const float2* __restrict__ src_ = in + (size_t) ((W) / tiles) * in_stride + ((W) % tiles) * 16; \
         _Pragma ("unroll") for (int s = 0; s < 16; ++s)                                            \
         {                                                                                          \
             const float2 x_ = gload (&src_[(unsigned) (t0 + 16 * s) * n1 + c0]);                   \
@@ -321,7 +326,8 @@ template <bool SWAP_OUT>
 __global__ __launch_bounds__ (256) void pass_b256_kernel (const float2* __restrict__ work,
                                                          float2* __restrict__ out,
                                                          const float2* __restrict__ stage_tw,
-                                                         unsigned batch)
+                                                         unsigned batch,
+                                                         size_t out_stride)
 {
     extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
     constexpr unsigned n2 = 256, N = 65536, tiles = 16;
@@ -351,7 +357,7 @@ __global__ __launch_bounds__ (256) void pass_b256_kernel (const float2* __restri
         if (wn_ < nwork)                                                                           \
             CFFT_B256_LOAD (wn_, nre, nim)                                                         \
         fft256_two_stage (V, w, smem, kbl, t, kbl, t);                                             \
-        float2* __restrict__ dst_ = out + (size_t) ((W) / tiles) * N + ((W) % tiles) * 16 + kbl;   \
+        float2* __restrict__ dst_ = out + (size_t) ((W) / tiles) * out_stride + ((W) % tiles) * 16 + kbl; \
         _Pragma ("unroll") for (int b = 0; b < 16; ++b)                                            \
             gstore (&dst_[(unsigned) (t + 16 * b) * n2], SWAP_OUT ? make_float2 (V[b].y, V[b].x) : V[b]); \
     }

@@ -76,13 +76,16 @@ __device__ __forceinline__ void real_merge_pair (float2 A, float2 Xmk, float2 w,
 
 // ---- r2c -----------------------------------------------------------------------------------------
 // P is the plan of the M = N/2 point complex core.
-template <class P, int FPB>
+template <class P, int FPB, bool STRIDED>
 __global__ __launch_bounds__ (P::T* FPB) void r2c_kernel (const float2* __restrict__ in,
                                                          float2* __restrict__ out,
                                                          const float2* __restrict__ twtab,
                                                          const float2* __restrict__ wtab,
-                                                         unsigned batch)
+                                                         unsigned batch,
+                                                         unsigned in_stride_arg,
+                                                         unsigned out_stride_arg)
 {
+    CFFT_FRAME_STRIDES (STRIDED, P::N);
     extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
     constexpr int M = P::N;
     const int tid = threadIdx.x;
@@ -96,21 +99,22 @@ __global__ __launch_bounds__ (P::T* FPB) void r2c_kernel (const float2* __restri
     load_pair_twiddles<P> (pw, wtab, t);
 
     const unsigned ngroups = (batch + FPB - 1) / FPB;
-    const unsigned team_base = (unsigned) team * M;
+    const unsigned team_base = (unsigned) team * M; // inside the LDS staging area
+    const unsigned team_in = (unsigned) team * in_stride, team_out = (unsigned) team * out_stride; // in global memory
     constexpr bool STAGED = (P::T < 16); // narrow teams: whole-workgroup coalesced copies through LDS (plans.hpp)
     float2* stage = smem + FPB * LdsFrame<M>::floats2;
     for (unsigned g = blockIdx.x; g < ngroups; g += gridDim.x)
     {
         const bool active = g * FPB + team < batch;
-        const float2* __restrict__ src = in + (size_t) g * (FPB * M);
-        float2* __restrict__ dst = out + (size_t) g * (FPB * M);
+        const float2* __restrict__ src = in + (size_t) g * FPB * in_stride;
+        float2* __restrict__ dst = out + (size_t) g * FPB * out_stride;
         const unsigned valid = min ((unsigned) FPB, batch - g * FPB) * M;
 
         float2 v[P::R];
         if constexpr (STAGED)
         {
             __syncthreads();
-            stage_in<P::T * FPB, FPB * M> (src, stage, valid, tid);
+            stage_in_strided<P::T * FPB, FPB * M, M> (src, in_stride, stage, valid, tid);
             __syncthreads();
 #pragma unroll
             for (int s = 0; s < P::R; ++s)
@@ -120,7 +124,7 @@ __global__ __launch_bounds__ (P::T* FPB) void r2c_kernel (const float2* __restri
         {
 #pragma unroll
             for (int s = 0; s < P::R; ++s)
-                v[s] = active ? gload (&src[team_base + (unsigned) input_index<P> (t, s)]) : make_float2 (0.f, 0.f);
+                v[s] = active ? gload (&src[team_in + (unsigned) input_index<P> (t, s)]) : make_float2 (0.f, 0.f);
         }
 
         team_sync<P::T>();
@@ -151,14 +155,14 @@ __global__ __launch_bounds__ (P::T* FPB) void r2c_kernel (const float2* __restri
             }
             else if (active)
             {
-                gstore (&dst[team_base + (unsigned) k], Xk);
-                gstore (&dst[team_base + (unsigned) (k == 0 ? M / 2 : M - k)], Xp);
+                gstore (&dst[team_out + (unsigned) k], Xk);
+                gstore (&dst[team_out + (unsigned) (k == 0 ? M / 2 : M - k)], Xp);
             }
         }
         if constexpr (STAGED)
         {
             __syncthreads();
-            stage_out<P::T * FPB, FPB * M> (dst, stage, valid, tid);
+            stage_out_strided<P::T * FPB, FPB * M, M> (dst, out_stride, stage, valid, tid);
         }
     }
 }
@@ -170,7 +174,7 @@ __global__ __launch_bounds__ (P::T* FPB) void r2c_kernel (const float2* __restri
 // (batch / FPB of them); a ragged last group is handled once, predicated, by the workgroup whose turn it would be.
 template <class P, bool PRED>
 __device__ __forceinline__ void r2c_finish (float2 (&v)[P::R], const TwiddleRegs<P>& tw, const PairTwiddles<P>& pw,
-                                            float2* __restrict__ lds, float2* __restrict__ dst, unsigned team_base, int t, bool active)
+                                            float2* __restrict__ lds, float2* __restrict__ dst, unsigned team_out, int t, bool active)
 {
     constexpr int M = P::N;
     team_sync<P::T>();
@@ -194,19 +198,22 @@ __device__ __forceinline__ void r2c_finish (float2 (&v)[P::R], const TwiddleRegs
         }
         if (! PRED || active)
         {
-            gstore (&dst[team_base + (unsigned) k], Xk);
-            gstore (&dst[team_base + (unsigned) (k == 0 ? M / 2 : M - k)], Xp);
+            gstore (&dst[team_out + (unsigned) k], Xk);
+            gstore (&dst[team_out + (unsigned) (k == 0 ? M / 2 : M - k)], Xp);
         }
     }
 }
 
-template <class P, int FPB>
+template <class P, int FPB, bool STRIDED>
 __global__ __launch_bounds__ (P::T* FPB) void r2c_kernel_pf (const float2* __restrict__ in,
                                                             float2* __restrict__ out,
                                                             const float2* __restrict__ twtab,
                                                             const float2* __restrict__ wtab,
-                                                            unsigned batch)
+                                                            unsigned batch,
+                                                            unsigned in_stride_arg,
+                                                            unsigned out_stride_arg)
 {
+    CFFT_FRAME_STRIDES (STRIDED, P::N);
     extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
     constexpr int M = P::N;
     const int tid = threadIdx.x;
@@ -219,30 +226,30 @@ __global__ __launch_bounds__ (P::T* FPB) void r2c_kernel_pf (const float2* __res
     load_pair_twiddles<P> (pw, wtab, t);
 
     const unsigned nfull = batch / FPB;
-    const unsigned team_base = (unsigned) team * M;
+    const unsigned team_in = (unsigned) team * in_stride, team_out = (unsigned) team * out_stride; // in global memory
     float nre[P::R], nim[P::R];
     unsigned g = blockIdx.x;
     if (g < nfull)
     {
         {
-            const float2* __restrict__ src = in + (size_t) g * (FPB * M);
+            const float2* __restrict__ src = in + (size_t) g * FPB * in_stride;
             float2 v[P::R];
 #pragma unroll
             for (int s = 0; s < P::R; ++s)
-                v[s] = gload (&src[team_base + (unsigned) input_index<P> (t, s)]);
+                v[s] = gload (&src[team_in + (unsigned) input_index<P> (t, s)]);
             const unsigned gn = g + gridDim.x;
             if (gn < nfull)
             {
-                const float2* __restrict__ srcn = in + (size_t) gn * (FPB * M);
+                const float2* __restrict__ srcn = in + (size_t) gn * FPB * in_stride;
 #pragma unroll
                 for (int s = 0; s < P::R; ++s)
                 {
-                    const float2 x = gload (&srcn[team_base + (unsigned) input_index<P> (t, s)]);
+                    const float2 x = gload (&srcn[team_in + (unsigned) input_index<P> (t, s)]);
                     nre[s] = x.x;
                     nim[s] = x.y;
                 }
             }
-            r2c_finish<P, false> (v, tw, pw, lds, out + (size_t) g * (FPB * M), team_base, t, true);
+            r2c_finish<P, false> (v, tw, pw, lds, out + (size_t) g * FPB * out_stride, team_out, t, true);
         }
         for (g += gridDim.x; g < nfull; g += gridDim.x)
         {
@@ -253,39 +260,42 @@ __global__ __launch_bounds__ (P::T* FPB) void r2c_kernel_pf (const float2* __res
             const unsigned gn = g + gridDim.x;
             if (gn < nfull)
             {
-                const float2* __restrict__ srcn = in + (size_t) gn * (FPB * M);
+                const float2* __restrict__ srcn = in + (size_t) gn * FPB * in_stride;
 #pragma unroll
                 for (int s = 0; s < P::R; ++s)
                 {
-                    const float2 x = gload (&srcn[team_base + (unsigned) input_index<P> (t, s)]);
+                    const float2 x = gload (&srcn[team_in + (unsigned) input_index<P> (t, s)]);
                     nre[s] = x.x;
                     nim[s] = x.y;
                 }
             }
-            r2c_finish<P, false> (v, tw, pw, lds, out + (size_t) g * (FPB * M), team_base, t, true);
+            r2c_finish<P, false> (v, tw, pw, lds, out + (size_t) g * FPB * out_stride, team_out, t, true);
         }
     }
     // ragged last group
     if (FPB > 1 && nfull * FPB < batch && blockIdx.x == nfull % gridDim.x)
     {
         const bool active = nfull * FPB + team < batch;
-        const float2* __restrict__ src = in + (size_t) nfull * (FPB * M);
+        const float2* __restrict__ src = in + (size_t) nfull * FPB * in_stride;
         float2 v[P::R];
 #pragma unroll
         for (int s = 0; s < P::R; ++s)
-            v[s] = active ? gload (&src[team_base + (unsigned) input_index<P> (t, s)]) : make_float2 (0.f, 0.f);
-        r2c_finish<P, true> (v, tw, pw, lds, out + (size_t) nfull * (FPB * M), team_base, t, active);
+            v[s] = active ? gload (&src[team_in + (unsigned) input_index<P> (t, s)]) : make_float2 (0.f, 0.f);
+        r2c_finish<P, true> (v, tw, pw, lds, out + (size_t) nfull * FPB * out_stride, team_out, t, active);
     }
 }
 
 // ---- c2r -----------------------------------------------------------------------------------------
-template <class P, int FPB>
+template <class P, int FPB, bool STRIDED>
 __global__ __launch_bounds__ (P::T* FPB) void c2r_kernel (const float2* __restrict__ in,
                                                          float2* __restrict__ out,
                                                          const float2* __restrict__ twtab,
                                                          const float2* __restrict__ wtab,
-                                                         unsigned batch)
+                                                         unsigned batch,
+                                                         unsigned in_stride_arg,
+                                                         unsigned out_stride_arg)
 {
+    CFFT_FRAME_STRIDES (STRIDED, P::N);
     extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
     constexpr int M = P::N;
     const int tid = threadIdx.x;
@@ -299,19 +309,20 @@ __global__ __launch_bounds__ (P::T* FPB) void c2r_kernel (const float2* __restri
     load_pair_twiddles<P> (pw, wtab, t);
 
     const unsigned ngroups = (batch + FPB - 1) / FPB;
-    const unsigned team_base = (unsigned) team * M;
+    const unsigned team_base = (unsigned) team * M; // inside the LDS staging area
+    const unsigned team_in = (unsigned) team * in_stride, team_out = (unsigned) team * out_stride; // in global memory
     constexpr bool STAGED = (P::T < 16); // narrow teams: whole-workgroup coalesced copies through LDS (plans.hpp)
     float2* stage = smem + FPB * LdsFrame<M>::floats2;
     for (unsigned g = blockIdx.x; g < ngroups; g += gridDim.x)
     {
         const bool active = g * FPB + team < batch;
-        const float2* __restrict__ src = in + (size_t) g * (FPB * M);
-        float2* __restrict__ dst = out + (size_t) g * (FPB * M);
+        const float2* __restrict__ src = in + (size_t) g * FPB * in_stride;
+        float2* __restrict__ dst = out + (size_t) g * FPB * out_stride;
         const unsigned valid = min ((unsigned) FPB, batch - g * FPB) * M;
         if constexpr (STAGED)
         {
             __syncthreads();
-            stage_in<P::T * FPB, FPB * M> (src, stage, valid, tid);
+            stage_in_strided<P::T * FPB, FPB * M, M> (src, in_stride, stage, valid, tid);
             __syncthreads();
         }
 
@@ -323,9 +334,9 @@ __global__ __launch_bounds__ (P::T* FPB) void c2r_kernel (const float2* __restri
             const int k = t + P::T * q;
             const int kq = (k == 0 ? M / 2 : M - k);
             const float2 A = STAGED ? stage[team_base + (unsigned) k]
-                                    : (active ? gload (&src[team_base + (unsigned) k]) : make_float2 (0.f, 0.f));
+                                    : (active ? gload (&src[team_in + (unsigned) k]) : make_float2 (0.f, 0.f));
             const float2 Xp = STAGED ? stage[team_base + (unsigned) kq]
-                                     : (active ? gload (&src[team_base + (unsigned) kq]) : make_float2 (0.f, 0.f));
+                                     : (active ? gload (&src[team_in + (unsigned) kq]) : make_float2 (0.f, 0.f));
             real_merge_pair (A, Xp, pw.w[q], zk[q], zp[q]);
             if (k == 0)
             {
@@ -353,13 +364,13 @@ __global__ __launch_bounds__ (P::T* FPB) void c2r_kernel (const float2* __restri
             for (int s = 0; s < P::R; ++s)
                 stage[team_base + (unsigned) output_index<P> (t, s)] = make_float2 (v[s].y, v[s].x);
             __syncthreads();
-            stage_out<P::T * FPB, FPB * M> (dst, stage, valid, tid);
+            stage_out_strided<P::T * FPB, FPB * M, M> (dst, out_stride, stage, valid, tid);
         }
         else if (active)
         {
 #pragma unroll
             for (int s = 0; s < P::R; ++s)
-                gstore (&dst[team_base + (unsigned) output_index<P> (t, s)], make_float2 (v[s].y, v[s].x));
+                gstore (&dst[team_out + (unsigned) output_index<P> (t, s)], make_float2 (v[s].y, v[s].x));
         }
     }
 }

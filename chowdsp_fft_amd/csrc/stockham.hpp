@@ -213,6 +213,46 @@ __device__ __forceinline__ void stage_out (float2* __restrict__ dst, const float
             gstore4 (&d4[e], s4[e]);
 }
 
+// Frame strides of a kernel.  Packed batches (STRIDED == false) use the compile-time frame length, so
+// their code is exactly the packed-only kernel.  For strided batches the launchers guarantee stride <= kMaxFrameStride
+// (2^24 float2, launch.hpp); telling the compiler lets it prove that team * stride + index cannot wrap in 32 bits, so
+// that per-access constants fold into the instruction's immediate offset instead of costing one address VGPR each.
+#define CFFT_FRAME_STRIDES(STRIDED_, N_)                                               \
+    __builtin_assume (in_stride_arg <= (1u << 24));                                    \
+    __builtin_assume (out_stride_arg <= (1u << 24));                                   \
+    const unsigned in_stride = (STRIDED_) ? in_stride_arg : (unsigned) (N_);           \
+    const unsigned out_stride = (STRIDED_) ? out_stride_arg : (unsigned) (N_)
+
+// Strided batches: consecutive frames are `stride` float2 apart in global memory (stride >= N, even)
+// while the staging area keeps them packed.  N is a power of two >= 16, so a float4 never straddles two frames.
+template <int THREADS, int ELEMS, int N>
+__device__ __forceinline__ void stage_in_strided (const float2* __restrict__ src, unsigned stride, float2* __restrict__ stage, unsigned valid, int tid)
+{
+    if (stride == (unsigned) N)
+        return stage_in<THREADS, ELEMS> (src, stage, valid, tid);
+    float4* __restrict__ d4 = reinterpret_cast<float4*> (stage);
+#pragma unroll 4
+    for (int e = tid; e < ELEMS / 2; e += THREADS)
+    {
+        const unsigned e2 = 2u * (unsigned) e, f = e2 / (unsigned) N, o = e2 % (unsigned) N;
+        d4[e] = (e2 < valid) ? gload4 (reinterpret_cast<const float4*> (src + (size_t) f * stride + o)) : make_float4 (0.f, 0.f, 0.f, 0.f);
+    }
+}
+template <int THREADS, int ELEMS, int N>
+__device__ __forceinline__ void stage_out_strided (float2* __restrict__ dst, unsigned stride, const float2* __restrict__ stage, unsigned valid, int tid)
+{
+    if (stride == (unsigned) N)
+        return stage_out<THREADS, ELEMS> (dst, stage, valid, tid);
+    const float4* __restrict__ s4 = reinterpret_cast<const float4*> (stage);
+#pragma unroll 4
+    for (int e = tid; e < ELEMS / 2; e += THREADS)
+    {
+        const unsigned e2 = 2u * (unsigned) e, f = e2 / (unsigned) N, o = e2 % (unsigned) N;
+        if (e2 < valid)
+            gstore4 (reinterpret_cast<float4*> (dst + (size_t) f * stride + o), s4[e]);
+    }
+}
+
 // Stages 0..NS-1 on registers v (already loaded in input_index order); leaves the result in
 // output_index order.  `lds` is this team's private LDS image.
 template <class P>

@@ -76,6 +76,13 @@ size_t fft_gpu_workspace_bytes (void* setup, size_t batch);
    simd/chowdsp_fft_impl_sse.cpp:1518-1601 with ordered = 1). */
 int fft_transform_batch (void* setup, const float* input, float* output, size_t batch, fft_direction_t direction, void* stream);
 
+/* Strided batch: the same transform on frames embedded in larger buffers, frame b
+   starting at input + b*in_stride / output + b*out_stride (strides in FLOATS, multiples of 4, >= the frame
+   length; buffers 16-byte aligned).  The reference's counterpart is the caller's loop over fft_transform with
+   advancing pointers (e.g. chowdsp_fft_juce/chowdsp_fft_juce.cpp:47-55, one 2N-float JUCE buffer per frame).
+   In place (input == output) needs in_stride == out_stride; any other overlap is FFT_GPU_EINVAL. */
+int fft_transform_batch_strided (void* setup, const float* input, size_t in_stride, float* output, size_t out_stride, size_t batch, fft_direction_t direction, void* stream);
+
 /* `batch` x fft_transform_unordered (reference chowdsp_fft.h:145; ordered = 0). */
 int fft_transform_unordered_batch (void* setup, const float* input, float* output, size_t batch, fft_direction_t direction, void* stream);
 

@@ -62,7 +62,7 @@ def main():
     args = ap.parse_args()
     libs = args.libs or ([os.path.join(ROOT, "chowdsp_fft_amd", "libchowdsp_fft_hip.so")]
                          + sorted(glob.glob(os.path.join(ROOT, "chowdsp_fft_amd", "variants", "*.so"))))
-    handles = [(os.path.basename(p).replace("lib_", "").replace(".so", ""), _lib.load(p)) for p in libs]
+    handles = [(os.path.basename(p).replace("lib_", "").replace(".so", ""), _lib.load(p, strict=False)) for p in libs]
     dev = torch.device("cuda:0")
     stream = int(torch.cuda.current_stream().cuda_stream)
     for wname in args.workloads.split(","):
