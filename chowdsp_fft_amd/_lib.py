@@ -46,7 +46,11 @@ PROTOTYPES = {
     "fft_gpu_plan_describe": (_i, [_i, _i, C.POINTER(C.c_int)]),
     "fft_gpu_setup_size": (_i, [_vp]),
     "fft_gpu_setup_is_real": (_i, [_vp]),
+    "fft_gpu_setup_device": (_i, [_vp]),
     "fft_gpu_workspace_bytes": (_sz, [_vp, _sz]),
+    "fft_juce_perform_batch": (_i, [_vp, _fp, _fp, _sz, _i, _vp]),
+    "fft_juce_real_forward_batch": (_i, [_vp, _fp, _sz, _i, _vp]),
+    "fft_juce_real_inverse_batch": (_i, [_vp, _fp, _sz, _vp]),
     "fft_transform_batch": (_i, [_vp, _fp, _fp, _sz, _i, _vp]),
     "fft_transform_batch_strided": (_i, [_vp, _fp, _sz, _fp, _sz, _sz, _i, _vp]),
     "fft_transform_unordered_batch": (_i, [_vp, _fp, _fp, _sz, _i, _vp]),

@@ -180,6 +180,51 @@ def fft_transform_host_batch(setup, input, output, direction: int, batch: int | 
     _check(_lib.lib().fft_transform_host_batch(setup, _ptr(input), _ptr(output), b, direction), "fft_transform_host_batch")
 
 
+class JuceFFT:
+    """Batched mirror of the reference's JUCE engine adapter `juce::dsp::ChowDSP_FFT`
+    (chowdsp_fft_juce/chowdsp_fft_juce.cpp:13-126): one real and one complex plan of size 2**order, the three
+    transform methods with JUCE's buffer shapes, applied to `batch` device buffers per call."""
+
+    def __init__(self, order: int):
+        if order < 5:  # :20-29, pffft needs N >= 32 for real transforms
+            raise ValueError("order < 5 is not supported")
+        self.order, self.size = order, 1 << order
+        self.setup_real = fft_new_setup(self.size, FFT_REAL)
+        self.setup_complex = fft_new_setup(self.size, FFT_COMPLEX)
+        if self.setup_real is None or self.setup_complex is None:
+            raise FFTError("no plan for this size / no device")
+
+    def perform(self, input, output, inverse: bool, stream=None) -> None:
+        """[batch, 2N] interleaved complex in -> out; the inverse is scaled by 1/N"""
+        b = _batch_of(self.setup_complex, input)
+        _check(_lib.lib().fft_juce_perform_batch(self.setup_complex, _ptr(input), _ptr(output), b, 1 if inverse else 0,
+                                                 _stream_handle(stream)), "fft_juce_perform_batch")
+
+    def perform_real_only_forward_transform(self, inout, ignore_negative_freqs: bool = False, stream=None) -> None:
+        """[batch, 2N] buffers, N samples at the start of each -> N/2+1 (or N) interleaved complex bins"""
+        b = (inout.numel() if hasattr(inout, "numel") else inout.size) // (2 * self.size)
+        _check(_lib.lib().fft_juce_real_forward_batch(self.setup_real, _ptr(inout), b, 1 if ignore_negative_freqs else 0,
+                                                      _stream_handle(stream)), "fft_juce_real_forward_batch")
+
+    def perform_real_only_inverse_transform(self, inout, stream=None) -> None:
+        b = (inout.numel() if hasattr(inout, "numel") else inout.size) // (2 * self.size)
+        _check(_lib.lib().fft_juce_real_inverse_batch(self.setup_real, _ptr(inout), b, _stream_handle(stream)),
+               "fft_juce_real_inverse_batch")
+
+    def close(self) -> None:
+        for name in ("setup_real", "setup_complex"):
+            h = getattr(self, name, None)
+            if h:
+                fft_destroy_setup(h)
+                setattr(self, name, None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ConvEngine:
     """Streaming partitioned overlap-save convolver (include/chowdsp_fft_gpu.h, fft_conv_engine_*)."""
 

@@ -206,23 +206,6 @@ int big_c2c_chunked (Setup* s, int nc, bool inverse, const float2* in, float2* o
     return cf::FFT_GPU_OK;
 }
 
-// RAII: run on the device the plan's tables live on, whatever device the calling thread has current
-struct DeviceGuard
-{
-    int prev = -1;
-    bool switched = false;
-    explicit DeviceGuard (int want)
-    {
-        if (hipGetDevice (&prev) == hipSuccess && prev != want)
-            switched = hipSetDevice (want) == hipSuccess;
-    }
-    ~DeviceGuard()
-    {
-        if (switched)
-            (void) hipSetDevice (prev);
-    }
-};
-
 // in_stride / out_stride: floats between consecutive frames (0 = packed); validated by the caller
 int run_transform (Setup* s, const float* in, float* out, size_t batch, cf::fft_direction_t dir, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0)
 {
@@ -596,6 +579,12 @@ int fft_gpu_setup_is_real (void* setup)
 {
     Setup* s = as_setup (setup);
     return s != nullptr ? (s->transform == FFT_REAL ? 1 : 0) : FFT_GPU_EINVAL;
+}
+
+int fft_gpu_setup_device (void* setup)
+{
+    Setup* s = as_setup (setup);
+    return s != nullptr ? s->device : -1;
 }
 
 size_t fft_gpu_workspace_bytes (void* setup, size_t batch)

@@ -70,4 +70,20 @@ inline Setup* as_setup (void* p)
 }
 
 const DeviceTables* acquire_tables (int device, int N, int transform);
+// RAII: run on the device the plan's tables live on, whatever device the calling thread has current
+struct DeviceGuard
+{
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard (int want)
+    {
+        if (hipGetDevice (&prev) == hipSuccess && prev != want)
+            switched = hipSetDevice (want) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        if (switched)
+            (void) hipSetDevice (prev);
+    }
+};
 } // namespace cfft::host

@@ -66,6 +66,7 @@ int fft_gpu_size_supported (int N, fft_transform_t transform);
 int fft_gpu_plan_describe (int N, fft_transform_t transform, int desc[8]);
 int fft_gpu_setup_size (void* setup);              /* N, or negative error */
 int fft_gpu_setup_is_real (void* setup);           /* 1 REAL, 0 COMPLEX */
+int fft_gpu_setup_device (void* setup);            /* HIP device ordinal the plan's tables live on; -1 for a bad handle */
 /* scratch the plan needs per launch for N > 4096 (multi-pass through HBM), bytes for `batch` frames;
    0 for LDS-resident sizes.  The library allocates and caches it internally per (device, stream). */
 size_t fft_gpu_workspace_bytes (void* setup, size_t batch);
@@ -112,6 +113,20 @@ int fft_convolve_frames_batch (void* setup, const float* x, const float* dft_fil
    run on stream i%2, so that the PCIe transfers of one chunk overlap the other chunk's.  Synchronous: the result
    is in `output` on return.  input == output is allowed.  PCIe-bound by construction. */
 int fft_transform_host_batch (void* setup, const float* input, float* output, size_t batch, fft_direction_t direction);
+
+/* ---- JUCE FFT-engine layouts on the device (second half of row f3) ------------------------------------------
+   Batched counterparts of the three methods of the reference's JUCE adapter
+   (chowdsp_fft_juce/chowdsp_fft_juce.cpp:32-86): same buffer shapes, layout and scaling, `batch` device buffers
+   per call instead of one host buffer.
+   perform: complex transform, output != or == input, the inverse scaled by 1/N (:32-45). */
+int fft_juce_perform_batch (void* setup_complex, const float* input, float* output, size_t batch, int inverse, void* stream);
+/* performRealOnlyForwardTransform (:47-67): `batch` buffers of 2N floats with the N samples at the start of each;
+   on return each holds N/2+1 interleaved complex bins (Im of DC and Nyquist = 0) and, unless
+   ignore_negative_freqs, the conjugate bins N/2+1 .. N-1. */
+int fft_juce_real_forward_batch (void* setup_real, float* inout, size_t batch, int ignore_negative_freqs, void* stream);
+/* performRealOnlyInverseTransform (:69-86): N/2+1 interleaved bins at the start of each 2N-float buffer in, the N
+   real samples scaled by 1/N at the start of each buffer out. */
+int fft_juce_real_inverse_batch (void* setup_real, float* inout, size_t batch, void* stream);
 
 /* ---- streaming partitioned convolution engine -----------------------------------
    The caller-side structure that fft_convolve_unordered's "ab += a*b*scaling" and fft_accumulate exist for
