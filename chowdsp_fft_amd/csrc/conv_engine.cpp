@@ -1,12 +1,14 @@
 // Streaming uniformly-partitioned overlap-save convolution engine, host side.
-// Built only from the library's own public batched operations plus three small kernels (delay-line
-// multiply-accumulate, frame assembly, output extraction); see include/chowdsp_fft_gpu.h for the algorithm.
+// Blocks of 128 samples and more run as two fused kernels per block (conv_kernels.hpp: ols_r2c_kernel,
+// ols_mac_c2r_kernel); shorter blocks are built from the library's public batched operations plus three small
+// kernels (frame assembly, delay-line multiply-accumulate, output extraction).  See include/chowdsp_fft_gpu.h.
 #include "../../include/chowdsp_fft_gpu.h"
 
 #include "host_common.hpp"
 #include "launch.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -26,6 +28,10 @@ struct Engine
     unsigned head = 0; // delay-line slot that receives the next spectrum
     void* setup = nullptr;
     float *prev = nullptr, *frame = nullptr, *fdl = nullptr, *H = nullptr, *Y = nullptr;
+    // fused path (block >= 128 and LDS-resident): two kernels per block, the previous input block double-buffered
+    bool fused = false;
+    float* prev2 = nullptr;
+    unsigned cur_prev = 0; // which of prev / prev2 holds the previous block
 };
 
 Engine* as_engine (void* p)
@@ -38,7 +44,7 @@ void release (Engine* e)
 {
     if (e == nullptr)
         return;
-    for (float* p : { e->prev, e->frame, e->fdl, e->H, e->Y })
+    for (float* p : { e->prev, e->prev2, e->frame, e->fdl, e->H, e->Y })
         if (p != nullptr)
             (void) hipFree (p);
     if (e->setup != nullptr)
@@ -76,8 +82,15 @@ void* fft_conv_engine_create (int block, int channels, const float* ir, int ir_l
     e->shared = ir_is_shared != 0;
     e->setup = fft_new_setup (N, FFT_REAL, true);
     const size_t C = (size_t) channels, P = (size_t) e->partitions, Hc = e->shared ? 1 : C;
-    if (e->setup == nullptr || ! dev_alloc (e->prev, C * block) || ! dev_alloc (e->frame, C * N) || ! dev_alloc (e->fdl, P * C * N)
-        || ! dev_alloc (e->H, P * Hc * N) || ! dev_alloc (e->Y, C * N))
+    // CHOWDSP_FFT_ENGINE_FUSED=0 forces the five-kernel path (A/B measurements, tests of both paths)
+    const char* fenv = std::getenv ("CHOWDSP_FFT_ENGINE_FUSED");
+    e->fused = ols_fused_supported (block) && ! (fenv != nullptr && fenv[0] == '0');
+    bool ok_alloc = e->setup != nullptr && dev_alloc (e->prev, C * block) && dev_alloc (e->fdl, P * C * N) && dev_alloc (e->H, P * Hc * N);
+    if (e->fused)
+        ok_alloc = ok_alloc && dev_alloc (e->prev2, C * block);
+    else
+        ok_alloc = ok_alloc && dev_alloc (e->frame, C * N) && dev_alloc (e->Y, C * N);
+    if (! ok_alloc)
     {
         set_last_error ("fft_conv_engine_create: setup or device allocation failed");
         release (e);
@@ -118,6 +131,9 @@ int fft_conv_engine_reset (void* engine, void* stream_)
     const hipStream_t stream = (hipStream_t) stream_;
     const size_t C = (size_t) e->channels, N = 2 * (size_t) e->block;
     CFFT_HIP_TRY (hipMemsetAsync (e->prev, 0, C * e->block * sizeof (float), stream), FFT_GPU_ELAUNCH);
+    if (e->prev2 != nullptr)
+        CFFT_HIP_TRY (hipMemsetAsync (e->prev2, 0, C * e->block * sizeof (float), stream), FFT_GPU_ELAUNCH);
+    e->cur_prev = 0;
     CFFT_HIP_TRY (hipMemsetAsync (e->fdl, 0, (size_t) e->partitions * C * N * sizeof (float), stream), FFT_GPU_ELAUNCH);
     e->head = 0;
     return FFT_GPU_OK;
@@ -130,6 +146,27 @@ int fft_conv_engine_process (void* engine, const float* in, float* out, void* st
         return FFT_GPU_EINVAL;
     const hipStream_t stream = (hipStream_t) stream_;
     const size_t C = (size_t) e->channels, N = 2 * (size_t) e->block;
+    if (e->fused)
+    {
+        const Setup* su = as_setup (e->setup);
+        const DeviceGuard guard (su->device);
+        const DeviceTables* t = su->tables;
+        float* slot_f = e->fdl + (size_t) e->head * C * N;
+        float* pv = e->cur_prev == 0 ? e->prev : e->prev2;
+        float* keep = e->cur_prev == 0 ? e->prev2 : e->prev;
+        hipError_t hf = launch_ols_r2c (e->block, pv, in, keep, slot_f, t->stage_twiddles, t->real_twiddles, (unsigned) C, stream);
+        if (hf == hipSuccess)
+            hf = launch_ols_mac_c2r (e->block, e->fdl, e->H, out, t->stage_twiddles, t->real_twiddles, 1.0f / (float) N, (unsigned) C,
+                                     (unsigned) e->partitions, e->head, e->shared, stream);
+        if (hf != hipSuccess)
+        {
+            set_last_error ("engine: fused block kernels", hf);
+            return FFT_GPU_ELAUNCH;
+        }
+        e->cur_prev ^= 1u;
+        e->head = (e->head + 1) % (unsigned) e->partitions;
+        return FFT_GPU_OK;
+    }
     hipError_t he = launch_ols_assemble (in, e->prev, e->frame, (size_t) e->block, (unsigned) C, stream);
     if (he != hipSuccess)
     {

@@ -70,6 +70,27 @@ __global__ __launch_bounds__ (256) void accumulate_kernel (const float* __restri
 // ---- streaming partitioned convolution engine: frequency-domain delay line kernels -------------
 // Y[c][k] = sum_{p<P} FDL[(head - p) mod P][c][k] * H[p][c or 0][k] * scale, accumulated in partition order
 // (= P successive fft_convolve_unordered calls into a zeroed ab; reference sse.cpp:1621-1644 for one of them).
+__device__ __forceinline__ void fdl_mac_term (float4& acc, const float4 a, const float4 b, float scale, bool k0)
+{
+    float r0 = a.x * b.x - a.y * b.y;
+    float i0 = a.x * b.y + a.y * b.x;
+    const float r1 = a.z * b.z - a.w * b.w;
+    const float i1 = a.z * b.w + a.w * b.z;
+    if (k0)
+    {
+        r0 = a.x * b.x; // packed DC and Nyquist bins are purely real
+        i0 = a.y * b.y;
+    }
+    acc.x += r0 * scale;
+    acc.y += i0 * scale;
+    acc.z += r1 * scale;
+    acc.w += i1 * scale;
+}
+
+// The delay line is streamed once per block (nontemporal), the filter partitions stay in L2.  The partition loop
+// is unrolled by UNROLL with all loads of a group issued before the arithmetic: P is a run-time value, and without
+// this each 16-byte load waits for the previous term's multiply-adds.
+template <int UNROLL>
 __global__ __launch_bounds__ (256) void fdl_mac_kernel (const float4* __restrict__ fdl,
                                                        const float4* __restrict__ H,
                                                        float4* __restrict__ Y,
@@ -82,29 +103,38 @@ __global__ __launch_bounds__ (256) void fdl_mac_kernel (const float4* __restrict
 {
     const size_t total = (size_t) channels * pairs_per_frame;
     const size_t stride = (size_t) gridDim.x * blockDim.x;
+    const size_t slot_quads = (size_t) channels * pairs_per_frame;
+    const size_t h_part_quads = (size_t) (h_shared ? 1u : channels) * pairs_per_frame;
     for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride)
     {
         const unsigned c = (unsigned) (i / pairs_per_frame);
         const unsigned k = (unsigned) (i % pairs_per_frame);
+        const float4* __restrict__ hk = H + (h_shared ? (size_t) k : i); // + p * h_part_quads
+        const bool k0 = (k == 0);
+        (void) c;
         float4 acc = make_float4 (0.f, 0.f, 0.f, 0.f);
-        for (unsigned p = 0; p < P; ++p)
+        unsigned p = 0;
+        unsigned slot = head; // (head - p) mod P
+        for (; p + UNROLL <= P; p += UNROLL)
         {
-            const unsigned slot = (head + P - p) % P;
-            const float4 a = fdl[((size_t) slot * channels + c) * pairs_per_frame + k];
-            const float4 b = H[((size_t) p * (h_shared ? 1u : channels) + (h_shared ? 0u : c)) * pairs_per_frame + k];
-            float r0 = a.x * b.x - a.y * b.y;
-            float i0 = a.x * b.y + a.y * b.x;
-            const float r1 = a.z * b.z - a.w * b.w;
-            const float i1 = a.z * b.w + a.w * b.z;
-            if (k == 0)
+            float4 a[UNROLL], b[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
             {
-                r0 = a.x * b.x; // packed DC and Nyquist bins are purely real
-                i0 = a.y * b.y;
+                a[u] = gload4 (&fdl[(size_t) slot * slot_quads + i]);
+                b[u] = hk[(size_t) (p + u) * h_part_quads];
+                slot = (slot == 0 ? P : slot) - 1;
             }
-            acc.x += r0 * scale;
-            acc.y += i0 * scale;
-            acc.z += r1 * scale;
-            acc.w += i1 * scale;
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+                fdl_mac_term (acc, a[u], b[u], scale, k0);
+        }
+        for (; p < P; ++p)
+        {
+            const float4 a = gload4 (&fdl[(size_t) slot * slot_quads + i]);
+            const float4 b = hk[(size_t) p * h_part_quads];
+            slot = (slot == 0 ? P : slot) - 1;
+            fdl_mac_term (acc, a, b, scale, k0);
         }
         gstore4 (&Y[i], acc);
     }
@@ -514,6 +544,186 @@ __global__ __launch_bounds__ (P::T* FPB) void conv_frames_real_kernel_pf (const 
         for (int s = 0; s < P::R; ++s)
             v[s] = active ? gload (&src[team_base + (unsigned) input_index<P> (t, s)]) : make_float2 (0.f, 0.f);
         conv_real_finish<P, true, HREGS> (v, tw, pw, h, lds, out + (size_t) nfull * (FPB * M), team_base, t, scaling, active);
+    }
+}
+
+// ---- streaming partitioned convolution engine, fused per-block kernels ----------------------------
+// One block of the engine is two kernels instead of five (assemble, r2c, delay-line MAC, c2r, extract):
+//   ols_r2c_kernel      frame = [previous block | new block] read from the two half-frame buffers directly (no
+//                       assembled copy), the new block also stored for the next call, spectrum written into the
+//                       delay-line slot;
+//   ols_mac_c2r_kernel  Y = sum_p FDL[(head - p) mod P] * H[p] * scale accumulated in registers in partition order
+//                       while streaming the delay line (the sum never goes to memory), inverse transform, and only
+//                       the valid second half of the result is written.
+// HBM traffic per channel and block (N = 2L floats per frame): (P + 3) N instead of (P + 8.5) N.
+// For plans with register-direct teams (T >= 16, i.e. block >= 128); P is the M = N/2 = L point plan.
+template <class P, int FPB>
+__global__ __launch_bounds__ (P::T* FPB) void ols_r2c_kernel (const float2* __restrict__ prev, // [C][M/2] previous block
+                                                             const float2* __restrict__ cur,  // [C][M/2] new block
+                                                             float2* __restrict__ keep,       // [C][M/2] <- cur
+                                                             float2* __restrict__ slot,       // [C][M] packed spectrum
+                                                             const float2* __restrict__ twtab,
+                                                             const float2* __restrict__ wtab,
+                                                             unsigned channels)
+{
+    static_assert (P::R == P::radix (0), "input_index (t, s) == t + s * T is assumed below");
+    extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
+    constexpr int M = P::N, HALF = M / 2;
+    const int tid = threadIdx.x;
+    const int team = tid / P::T;
+    const int t = tid % P::T;
+    float2* lds = smem + team * LdsFrame<M>::floats2;
+    TwiddleRegs<P> tw;
+    load_twiddles<P> (tw, twtab, t);
+    PairTwiddles<P> pw;
+    load_pair_twiddles<P> (pw, wtab, t);
+
+    const unsigned ngroups = (channels + FPB - 1) / FPB;
+    for (unsigned g = blockIdx.x; g < ngroups; g += gridDim.x)
+    {
+        const unsigned c = g * FPB + team;
+        const bool active = c < channels;
+        const float2* __restrict__ lo = prev + (size_t) g * (FPB * HALF);
+        const float2* __restrict__ hi = cur + (size_t) g * (FPB * HALF);
+        float2* __restrict__ kp = keep + (size_t) g * (FPB * HALF);
+        const unsigned hbase = (unsigned) team * HALF + (unsigned) t;
+        float2 v[P::R];
+#pragma unroll
+        for (int s = 0; s < P::R / 2; ++s)
+            v[s] = active ? gload (&lo[hbase + (unsigned) (s * P::T)]) : make_float2 (0.f, 0.f);
+#pragma unroll
+        for (int s = P::R / 2; s < P::R; ++s)
+            v[s] = active ? gload (&hi[hbase + (unsigned) (s * P::T - HALF)]) : make_float2 (0.f, 0.f);
+        // keep the new block for the next call; after ALL loads were issued, so that no store sits between two loads
+        // in the in-order memory queue (a store needs its load's data, i.e. a wait for everything before it)
+        if (active)
+        {
+#pragma unroll
+            for (int s = P::R / 2; s < P::R; ++s)
+                gstore (&kp[hbase + (unsigned) (s * P::T - HALF)], v[s]);
+        }
+        r2c_finish<P, true> (v, tw, pw, lds, slot + (size_t) g * (FPB * M), (unsigned) team * M, t, active);
+    }
+}
+
+template <class P, int FPB>
+__global__ __launch_bounds__ (P::T* FPB) void ols_mac_c2r_kernel (const float2* __restrict__ fdl, // [Pn][C][M]
+                                                                 const float2* __restrict__ H,   // [Pn][C or 1][M]
+                                                                 float2* __restrict__ out,       // [C][M/2]
+                                                                 const float2* __restrict__ twtab,
+                                                                 const float2* __restrict__ wtab,
+                                                                 float scale,
+                                                                 unsigned channels,
+                                                                 unsigned Pn,
+                                                                 unsigned head,
+                                                                 int h_shared)
+{
+    extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
+    constexpr int M = P::N, HALF = M / 2;
+    const int tid = threadIdx.x;
+    const int team = tid / P::T;
+    const int t = tid % P::T;
+    float2* lds = smem + team * LdsFrame<M>::floats2;
+
+    const size_t slot_elems = (size_t) channels * M;
+    const size_t hpart_elems = (size_t) (h_shared ? 1u : channels) * M;
+    const unsigned ngroups = (channels + FPB - 1) / FPB;
+    for (unsigned g = blockIdx.x; g < ngroups; g += gridDim.x)
+    {
+        const unsigned c = g * FPB + team;
+        const bool active = c < channels;
+        // delay-line multiply-accumulate, partition order (= P successive fft_convolve_unordered calls into a zeroed
+        // ab; reference sse.cpp:1621-1644 for one of them)
+        float2 yk[P::R / 2], yp[P::R / 2];
+#pragma unroll
+        for (int q = 0; q < P::R / 2; ++q)
+            yk[q] = yp[q] = make_float2 (0.f, 0.f);
+        if (active)
+        {
+            // workgroup-uniform bases (SGPR pairs) + 32-bit per-work-item offsets: no 64-bit address VGPRs per load
+            const float2* __restrict__ fg = fdl + (size_t) g * (FPB * M);
+            const float2* __restrict__ hg = H + (h_shared ? (size_t) 0 : (size_t) g * (FPB * M));
+            const unsigned fo = (unsigned) team * M, ho = h_shared ? 0u : (unsigned) team * M;
+            unsigned sl = head;
+#pragma unroll 1
+            for (unsigned p = 0; p < Pn; ++p)
+            {
+                const float2* __restrict__ fs = fg + (size_t) sl * slot_elems;
+                const float2* __restrict__ hs = hg + (size_t) p * hpart_elems;
+                float2 ak[P::R / 2], ap[P::R / 2], bk[P::R / 2], bp[P::R / 2];
+#pragma unroll
+                for (int q = 0; q < P::R / 2; ++q)
+                {
+                    const int k = t + P::T * q;
+                    const int kq = (k == 0 ? M / 2 : M - k);
+                    ak[q] = gload (&fs[fo + (unsigned) k]);
+                    ap[q] = gload (&fs[fo + (unsigned) kq]);
+                    bk[q] = hs[ho + (unsigned) k];
+                    bp[q] = hs[ho + (unsigned) kq];
+                }
+#pragma unroll
+                for (int q = 0; q < P::R / 2; ++q)
+                {
+                    const int k = t + P::T * q;
+                    float2 mk = cmul (ak[q], bk[q]);
+                    if (k == 0)
+                        mk = make_float2 (ak[q].x * bk[q].x, ak[q].y * bk[q].y); // packed DC / Nyquist: real products
+                    const float2 mp = cmul (ap[q], bp[q]);
+                    yk[q] = make_float2 (yk[q].x + mk.x * scale, yk[q].y + mk.y * scale);
+                    yp[q] = make_float2 (yp[q].x + mp.x * scale, yp[q].y + mp.y * scale);
+                }
+                sl = (sl == 0 ? Pn : sl) - 1;
+            }
+        }
+        // from here on: c2r_kernel with the pair inputs already in registers.
+        // The twiddles are (re)loaded from L2 HERE, per frame, not kept across the loop as in the other kernels: during
+        // the accumulation above the registers hold 2 x R accumulators and 4 x R loads in flight, and the 2 x ~40
+        // twiddle registers on top would halve the occupancy.  (The pointer laundering keeps the compiler from
+        // hoisting the loads back out of the loop.)  ~40 L2 loads per frame next to 32 x P streamed ones.
+        const float2* twp = twtab;
+        const float2* wp = wtab;
+        asm volatile ("" : "+s"(twp), "+s"(wp));
+        TwiddleRegs<P> tw;
+        load_twiddles<P> (tw, twp, t);
+        PairTwiddles<P> pw;
+        load_pair_twiddles<P> (pw, wp, t);
+        float2 zk[P::R / 2], zp[P::R / 2];
+#pragma unroll
+        for (int q = 0; q < P::R / 2; ++q)
+        {
+            const int k = t + P::T * q;
+            real_merge_pair (yk[q], yp[q], pw.w[q], zk[q], zp[q]);
+            if (k == 0)
+            {
+                zk[q] = make_float2 (yk[q].x + yk[q].y, yk[q].x - yk[q].y);
+                zp[q] = make_float2 (2.f * yp[q].x, -2.f * yp[q].y);
+            }
+        }
+        team_sync<P::T>(); // previous frame's LDS reads are finished
+#pragma unroll
+        for (int q = 0; q < P::R / 2; ++q)
+        {
+            const int k = t + P::T * q;
+            lds[lds_phys (k)] = make_float2 (zk[q].y, zk[q].x);
+            lds[lds_phys (k == 0 ? M / 2 : M - k)] = make_float2 (zp[q].y, zp[q].x);
+        }
+        team_sync<P::T>();
+        float2 v[P::R];
+        lds_load_input_order<P> (v, lds, t);
+        team_sync<P::T>();
+        fft_core<P> (v, tw, lds, t);
+        if (active)
+        {
+            // overlap-save: the first half of the circular convolution is aliased, only the second half leaves the chip
+            float2* __restrict__ dst = out + (size_t) c * HALF;
+#pragma unroll
+            for (int s = 0; s < P::R; ++s)
+            {
+                const int o = output_index<P> (t, s);
+                if (o >= HALF)
+                    gstore (&dst[o - HALF], make_float2 (v[s].y, v[s].x));
+            }
+        }
     }
 }
 } // namespace cfft

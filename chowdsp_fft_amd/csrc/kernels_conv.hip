@@ -118,8 +118,68 @@ hipError_t launch_fdl_mac (const float* fdl, const float* H, float* Y, float sca
     const unsigned grid = stream_grid ((size_t) channels * ppf);
     if (grid == 0)
         return hipErrorNoDevice;
-    hipLaunchKernelGGL (fdl_mac_kernel, dim3 (grid), dim3 (256), 0, stream, (const float4*) fdl, (const float4*) H, (float4*) Y, scale, ppf, channels, P, head, h_shared ? 1 : 0);
+#ifndef CFFT_FDL_UNROLL
+#define CFFT_FDL_UNROLL 4
+#endif
+    hipLaunchKernelGGL (fdl_mac_kernel<CFFT_FDL_UNROLL>, dim3 (grid), dim3 (256), 0, stream, (const float4*) fdl, (const float4*) H, (float4*) Y, scale, ppf, channels, P, head, h_shared ? 1 : 0);
     return hipGetLastError();
+}
+
+namespace
+{
+template <int M>
+hipError_t launch_ols_r2c_m (const float2* prev, const float2* cur, float2* keep, float2* slot, const float2* tw, const float2* rtw, unsigned channels, hipStream_t stream)
+{
+    using P = typename CorePlan<M>::type;
+    using G = Geometry<P>;
+    if constexpr (G::staged)
+        return hipErrorNotSupported; // narrow teams go through the LDS staging area: the engine uses the unfused path
+    else
+    {
+        auto kernel = ols_r2c_kernel<P, G::FPB>;
+        const unsigned grid = persistent_grid (kernel, G::threads, G::lds_bytes, (channels + G::FPB - 1) / G::FPB);
+        if (grid == 0)
+            return hipErrorNoDevice;
+        hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (G::threads), G::lds_bytes, stream, prev, cur, keep, slot, tw, rtw, channels);
+        return hipGetLastError();
+    }
+}
+
+template <int M>
+hipError_t launch_ols_mac_c2r_m (const float2* fdl, const float2* H, float2* out, const float2* tw, const float2* rtw, float scale, unsigned channels, unsigned P_, unsigned head, bool h_shared, hipStream_t stream)
+{
+    using P = typename CorePlan<M>::type;
+    using G = Geometry<P>;
+    if constexpr (G::staged)
+        return hipErrorNotSupported;
+    else
+    {
+        auto kernel = ols_mac_c2r_kernel<P, G::FPB>;
+        const unsigned grid = persistent_grid (kernel, G::threads, G::lds_bytes, (channels + G::FPB - 1) / G::FPB);
+        if (grid == 0)
+            return hipErrorNoDevice;
+        hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (G::threads), G::lds_bytes, stream, fdl, H, out, tw, rtw, scale, channels, P_, head, h_shared ? 1 : 0);
+        return hipGetLastError();
+    }
+}
+} // namespace
+
+bool ols_fused_supported (int m)
+{
+    PlanDesc d;
+    return core_plan_desc (m, d) && d.T >= 16;
+}
+
+hipError_t launch_ols_r2c (int m, const float* prev, const float* cur, float* keep, float* slot, const float2* stage_tw, const float2* real_tw, unsigned channels, hipStream_t stream)
+{
+    CFFT_DISPATCH_N (m, return (launch_ols_r2c_m<N_> ((const float2*) prev, (const float2*) cur, (float2*) keep, (float2*) slot, stage_tw, real_tw, channels, stream)));
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_ols_mac_c2r (int m, const float* fdl, const float* H, float* out, const float2* stage_tw, const float2* real_tw, float scale, unsigned channels, unsigned P, unsigned head, bool h_shared, hipStream_t stream)
+{
+    CFFT_DISPATCH_N (m, return (launch_ols_mac_c2r_m<N_> ((const float2*) fdl, (const float2*) H, (float2*) out, stage_tw, real_tw, scale, channels, P, head, h_shared, stream)));
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_ols_assemble (const float* in, float* prev, float* frame, size_t block, unsigned channels, hipStream_t stream)

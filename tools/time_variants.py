@@ -45,6 +45,7 @@ WORK = {
     "r64": (64, 0, 8388608, False),
     "r256": (256, 0, 2097152, False),
     "r2048": (2048, 0, 262144, False),
+    "ols": (4096, 0, 8192, False),
     "c9216": (9216, 1, 16384, False),
     "c3072": (3072, 1, 65536, False),
     "c768": (768, 1, 262144, False),
@@ -73,8 +74,23 @@ def main():
         z = torch.empty_like(x)
         H = torch.rand((1, ff), device=dev)
         setups = [(name, L, L.fft_new_setup(n, tr, True)) for name, L in handles]
+        engines = {}
+        if wname.startswith("ols"):
+            # partitioned overlap-save engine: `frames` channels, block n/2, 16 partitions, shared impulse response
+            block, parts = n // 2, 16
+            ir = torch.rand((block * parts,), device=dev) * 2 - 1
+            xb = torch.rand((frames, block), device=dev) * 2 - 1
+            yb = torch.empty_like(xb)
+            for name, L in handles:
+                engines[name] = L.fft_conv_engine_create(block, frames, ir.data_ptr(), block * parts, 1, stream)
+                assert engines[name], L.fft_gpu_last_error()
 
         def step(L, s):
+            if engines:
+                name = [nm for nm, LL, _ in setups if LL is L][0]
+                rc = L.fft_conv_engine_process(engines[name], xb.data_ptr(), yb.data_ptr(), stream)
+                assert rc == 0, L.fft_gpu_last_error()
+                return
             if fused:
                 rc = L.fft_convolve_frames_batch(s, x.data_ptr(), H.data_ptr(), y.data_ptr(), 1.0 / n, frames, stream)
             else:
@@ -95,14 +111,18 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 times[name].append(e0.elapsed_time(e1) / args.iters)
-        launches = 1 if fused else 2
+        launches = 1 if (fused or engines) else 2
         alg = 2 * 4 * ff * frames  # bytes per launch
+        if engines:
+            alg = 4 * (2 * (n // 2) + (16 + 1) * n) * frames  # in + out blocks, delay line read, one spectrum write
         print(f"--- {wname}: N={n} {'complex' if tr else 'real'} frames={frames} {'fused conv' if fused else 'fwd+bwd'}")
         for name, ts in times.items():
             med, best = statistics.median(ts), min(ts)
             print(f"{name:28s} median {med:8.4f} ms/step  min {best:8.4f}  -> {alg * launches / med * 1e-6:7.0f} GB/s  "
                   f"{2 * frames / med * 1e-6:8.4f} GFFT/s")
         for name, L, s in setups:
+            if engines:
+                L.fft_conv_engine_destroy(engines[name])
             L.fft_destroy_setup(s)
         del x, y, z
         torch.cuda.empty_cache()
