@@ -93,6 +93,9 @@ def main() -> int:
     ap.add_argument("--frames-per-gpu", type=int, default=0, help="override the workload's batch (debugging only)")
     ap.add_argument("--cpu-seconds", type=float, default=4.0, help="seconds per CPU-baseline regime (3 regimes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prewarm-seconds", type=float, default=0.3,
+                    help="untimed: run the step for this long BEFORE the W warm-up steps so that the GPU has left its idle "
+                         "clocks (measured: the first ~3 ms after idle run 10-25 %% slower); the timed region is still exactly K steps")
     ap.add_argument("--gather", action="store_true", help="also time the final all-gather of results over xGMI (reported separately)")
     args = ap.parse_args()
 
@@ -171,6 +174,12 @@ def main() -> int:
     launches_per_step = 1 if (fused or engine is not None) else 2
     transforms_per_frame_step = 2  # forward + backward (fused: both inside one kernel)
 
+    if args.prewarm_seconds > 0:
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < args.prewarm_seconds:
+            for _ in range(8):
+                step()
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()

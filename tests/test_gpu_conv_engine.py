@@ -41,9 +41,15 @@ def _oracle_engine(oracle, block, x, ir):
     return y
 
 
-@pytest.mark.parametrize("block,ir_len,channels,nblocks", [(16, 40, 3, 7), (64, 64, 2, 5), (256, 1000, 4, 6), (2048, 5000, 2, 4), (8192, 20000, 1, 3)])
-def test_engine_vs_oracle_and_direct(gpu, oracle, block, ir_len, channels, nblocks):
+# fused: blocks >= 128 run as two fused kernels per block; CHOWDSP_FFT_ENGINE_FUSED=0 (read at engine creation) forces
+# the five-kernel path built from the public batched operations, which shorter / two-pass blocks always take
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("block,ir_len,channels,nblocks", [(16, 40, 3, 7), (64, 64, 2, 5), (128, 300, 37, 5), (256, 1000, 4, 6),
+                                                           (1024, 1500, 5, 4), (2048, 5000, 3, 4), (4096, 4096, 2, 3),
+                                                           (8192, 20000, 1, 3)])
+def test_engine_vs_oracle_and_direct(gpu, oracle, monkeypatch, fused, block, ir_len, channels, nblocks):
     api, torch, dev = gpu
+    monkeypatch.setenv("CHOWDSP_FFT_ENGINE_FUSED", "1" if fused else "0")
     rng = np.random.RandomState(block + ir_len)
     ir = (rng.uniform(-1, 1, ir_len) * np.exp(-np.arange(ir_len) / (ir_len / 4.0))).astype(np.float32)
     x = rng.uniform(-1, 1, (channels, nblocks * block)).astype(np.float32)

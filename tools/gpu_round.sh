@@ -37,7 +37,7 @@ echo "== rocprofv3 kernel stats (same command as the bench line)"
 cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_stats" -- python3 "$REPO/bench.py" --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/prof_stats.log" 2>&1
 cd "$REPO"
-find "$OUT/prof_stats" -name "*kernel_stats.csv" | head -1 | xargs -r head -8
+find "$OUT/prof_stats" -name "*kernel_stats.csv" | head -1 | xargs -r head -4 | cut -c1-220
 
 echo "== rocprofv3 HBM counters (separate passes; FETCH_SIZE and WRITE_SIZE do not fit one pass)"
 cd /tmp

@@ -73,6 +73,8 @@ def main():
         y = torch.empty_like(x)
         z = torch.empty_like(x)
         H = torch.rand((1, ff), device=dev)
+        if os.environ.get("TV_SPECTRUM_H"):  # a real filter spectrum (random signs, |H| ~ sqrt(N)) instead of uniform [0,1)
+            H = (torch.randn((1, ff), device=dev) * (n / 3.0) ** 0.5).contiguous()
         setups = [(name, L, L.fft_new_setup(n, tr, True)) for name, L in handles]
         engines = {}
         if wname.startswith("ols"):
