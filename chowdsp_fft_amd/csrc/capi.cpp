@@ -9,6 +9,7 @@
 
 #include "host_common.hpp"
 #include "launch.hpp"
+#include "plans.hpp"
 #include "tables.hpp"
 
 #include <cstdlib>
@@ -672,7 +673,7 @@ int fft_convolve_frames_batch (void* setup, const float* x, const float* dft_fil
         return FFT_GPU_EINVAL;
     const DeviceTables* t = s->tables;
     const int nc = complex_len (s);
-    if (t->core_n != nc)
+    if (t->core_n != nc || nc > cfft::kMaxFusedN)
     {
         set_last_error ("fft_convolve_frames_batch: frame too long for the fused kernel");
         return FFT_GPU_ENOTSUP;

@@ -44,11 +44,11 @@ hipError_t launch_c2c (int n, bool inverse, const float2* in, float2* out, const
         return hipErrorInvalidValue;
     if (inverse)
     {
-        CFFT_DISPATCH_N (n, return (launch_c2c_n<N_, true> (in, out, stage_tw, batch, stream, (unsigned) in_stride, (unsigned) out_stride)));
+        CFFT_DISPATCH_CORE_N (n, return (launch_c2c_n<N_, true> (in, out, stage_tw, batch, stream, (unsigned) in_stride, (unsigned) out_stride)));
     }
     else
     {
-        CFFT_DISPATCH_N (n, return (launch_c2c_n<N_, false> (in, out, stage_tw, batch, stream, (unsigned) in_stride, (unsigned) out_stride)));
+        CFFT_DISPATCH_CORE_N (n, return (launch_c2c_n<N_, false> (in, out, stage_tw, batch, stream, (unsigned) in_stride, (unsigned) out_stride)));
     }
     return hipErrorInvalidValue;
 }

@@ -167,7 +167,7 @@ hipError_t launch_ols_mac_c2r_m (const float2* fdl, const float2* H, float2* out
 bool ols_fused_supported (int m)
 {
     PlanDesc d;
-    return core_plan_desc (m, d) && d.T >= 16;
+    return m <= kMaxFusedN && core_plan_desc (m, d) && d.T >= 16;
 }
 
 hipError_t launch_ols_r2c (int m, const float* prev, const float* cur, float* keep, float* slot, const float2* stage_tw, const float2* real_tw, unsigned channels, hipStream_t stream)

@@ -52,7 +52,7 @@ hipError_t launch_r2c (int m, const float2* in, float2* out, const float2* stage
         return hipSuccess;
     if (batch > 0x7FFFFFFFull || in_stride > kMaxFrameStride || out_stride > kMaxFrameStride)
         return hipErrorInvalidValue;
-    CFFT_DISPATCH_N (m, return (launch_real_m<N_, true> (in, out, stage_tw, real_tw, batch, stream, (unsigned) in_stride, (unsigned) out_stride)));
+    CFFT_DISPATCH_CORE_N (m, return (launch_real_m<N_, true> (in, out, stage_tw, real_tw, batch, stream, (unsigned) in_stride, (unsigned) out_stride)));
     return hipErrorInvalidValue;
 }
 
@@ -62,7 +62,7 @@ hipError_t launch_c2r (int m, const float2* in, float2* out, const float2* stage
         return hipSuccess;
     if (batch > 0x7FFFFFFFull || in_stride > kMaxFrameStride || out_stride > kMaxFrameStride)
         return hipErrorInvalidValue;
-    CFFT_DISPATCH_N (m, return (launch_real_m<N_, false> (in, out, stage_tw, real_tw, batch, stream, (unsigned) in_stride, (unsigned) out_stride)));
+    CFFT_DISPATCH_CORE_N (m, return (launch_real_m<N_, false> (in, out, stage_tw, real_tw, batch, stream, (unsigned) in_stride, (unsigned) out_stride)));
     return hipErrorInvalidValue;
 }
 } // namespace cfft::host

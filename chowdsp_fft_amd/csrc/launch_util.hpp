@@ -37,4 +37,14 @@ inline unsigned persistent_grid (K kernel, int threads, size_t lds_bytes, size_t
         case 4096: { constexpr int N_ = 4096; CALL; } break; \
         default: return hipErrorInvalidValue;     \
     }
+
+// the plain transforms also have the 8192-point single-pass plan (kMaxCoreN); the fused kernels stop at kMaxFusedN
+#define CFFT_DISPATCH_CORE_N(n, CALL)                        \
+    if ((n) == 8192)                                         \
+    {                                                        \
+        constexpr int N_ = 8192;                             \
+        CALL;                                                \
+    }                                                        \
+    else                                                     \
+        CFFT_DISPATCH_N (n, CALL)
 } // namespace cfft::host

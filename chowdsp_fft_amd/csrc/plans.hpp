@@ -42,12 +42,16 @@ template <> struct CorePlan<4096> { using type = Plan<4096, 512, 8, 8, 8, 8>;   
 #else
 template <> struct CorePlan<4096> { using type = Plan<4096, 256, 16, 16, 16>;    };
 #endif
+// 8192 points = 64 KiB: the frame still fits the CU's 160 KiB LDS (one 512-thread workgroup per CU, 68 KiB image), so it
+// stays a single pass over HBM instead of the two-pass four-step (2x the traffic)
+template <> struct CorePlan<8192> { using type = Plan<8192, 512, 16, 16, 16, 2>; };
 // clang-format on
 
 // the 65536 = 256 x 256 fast path (multipass_kernels.hpp) is written for this plan, independent of CorePlan<256>
 using Plan256 = Plan<256, 16, 16, 16>;
 
-static constexpr int kMaxCoreN = 4096;
+static constexpr int kMaxCoreN = 8192;
+static constexpr int kMaxFusedN = 4096; // longest core the fused convolution / engine kernels are instantiated for
 static constexpr int kMinCoreN = 16;
 static constexpr int kBlockThreads = 256;
 
@@ -113,6 +117,7 @@ inline bool core_plan_desc (int n, PlanDesc& d)
         case 1024: d = describe<CorePlan<1024>::type>(); return true;
         case 2048: d = describe<CorePlan<2048>::type>(); return true;
         case 4096: d = describe<CorePlan<4096>::type>(); return true;
+        case 8192: d = describe<CorePlan<8192>::type>(); return true;
         default: return false;
     }
 }

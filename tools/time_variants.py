@@ -46,6 +46,11 @@ WORK = {
     "r256": (256, 0, 2097152, False),
     "r2048": (2048, 0, 262144, False),
     "ols": (4096, 0, 8192, False),
+    "c8192": (8192, 1, 32768, False),
+    "r16384": (16384, 0, 32768, False),
+    "c16384": (16384, 1, 16384, False),
+    "c32768": (32768, 1, 8192, False),
+    "r32768": (32768, 0, 16384, False),
     "c9216": (9216, 1, 16384, False),
     "c3072": (3072, 1, 65536, False),
     "c768": (768, 1, 262144, False),
