@@ -24,7 +24,7 @@ struct GenericPlan
     int ns;                           // number of stages
     int frames;                       // frames per workgroup pass (F)
     unsigned in_stride, out_stride;   // float2 between consecutive frames in global memory (n for packed batches)
-    int radix[kGenericMaxStages];     // each in {2, 3, 4, 5, 8}
+    int radix[kGenericMaxStages];     // each in {2, 3, 4, 5, 8, 16}
     int tw_offset[kGenericMaxStages]; // float2 offset of the stage's table: (radix-1) * p entries, [a-1][k]
 };
 
@@ -60,24 +60,35 @@ __device__ __forceinline__ void fft_reg<5> (float2 (&u)[5])
     u[3] = make_float2 (m2.x - q2.y, m2.y + q2.x);
 }
 
-// one Stockham stage of radix R over `nframes` frames of n points: src -> dst (frame f at offset f*n)
-template <int R, int BLOCK>
+// One Stockham stage of radix R over `nframes` frames of n points: src -> dst.
+// IO 0: LDS image -> LDS image (frame f at f*n).  IO 1: global memory (frame stride gs, optional re<->im swap) -> LDS:
+// the first stage of a complex transform reads its operands where they are, x[i + a*m] is lane-contiguous.
+// IO 2: LDS -> global memory: the last stage stores y[j + b*p] straight to the result (lane-contiguous in k).
+// IO 3: global -> global (single-stage plans).
+template <int R, int BLOCK, int IO, bool SWAP>
 __device__ __forceinline__ void generic_stage (const float2* __restrict__ src, float2* __restrict__ dst,
-                                               const float2* __restrict__ tw, int n, int p, int nframes, int tid)
+                                               const float2* __restrict__ tw, int n, int p, int nframes, int tid,
+                                               unsigned gs_in, unsigned gs_out)
 {
     const int m = n / R;
+    const bool p_pow2 = (p & (p - 1)) == 0;
+    const unsigned fs_in = (IO & 1) ? gs_in : (unsigned) n, fs_out = (IO & 2) ? gs_out : (unsigned) n;
     for (int idx = tid; idx < nframes * m; idx += BLOCK)
     {
-        const int f = idx / m;
+        // one frame per workgroup pass (n > 512) and power-of-two p are the common cases: no integer division there
+        const int f = (nframes == 1) ? 0 : idx / m;
         const int i = idx - f * m;
-        const int k = i % p;
+        const int k = p_pow2 ? (i & (p - 1)) : (i % p);
         const int j = (i - k) * R + k;
-        const float2* s = src + f * n;
-        float2* d = dst + f * n;
+        const float2* s = src + (size_t) f * fs_in;
+        float2* d = dst + (size_t) f * fs_out;
         float2 u[R];
 #pragma unroll
         for (int a = 0; a < R; ++a)
-            u[a] = s[i + a * m];
+        {
+            const float2 x = (IO & 1) ? gload (&s[i + a * m]) : s[i + a * m];
+            u[a] = ((IO & 1) && SWAP) ? make_float2 (x.y, x.x) : x;
+        }
         if (p > 1)
         {
 #pragma unroll
@@ -87,13 +98,37 @@ __device__ __forceinline__ void generic_stage (const float2* __restrict__ src, f
         fft_reg<R> (u);
 #pragma unroll
         for (int b = 0; b < R; ++b)
-            d[j + b * p] = u[b];
+        {
+            if (IO & 2)
+                gstore (&d[j + b * p], SWAP ? make_float2 (u[b].y, u[b].x) : u[b]);
+            else
+                d[j + b * p] = u[b];
+        }
     }
 }
 
-// all stages; the frames start in `a`, returns the image that holds the result
-template <int BLOCK>
-__device__ __forceinline__ float2* generic_core (const GenericPlan& plan, const float2* __restrict__ twtab, float2* a, float2* b, int nframes, int tid)
+template <int BLOCK, int IO, bool SWAP>
+__device__ __forceinline__ void generic_stage_dispatch (int r, const float2* __restrict__ src, float2* __restrict__ dst,
+                                                        const float2* __restrict__ tw, int n, int p, int nframes, int tid,
+                                                        unsigned gs_in, unsigned gs_out)
+{
+    switch (r)
+    {
+        case 2: generic_stage<2, BLOCK, IO, SWAP> (src, dst, tw, n, p, nframes, tid, gs_in, gs_out); break;
+        case 3: generic_stage<3, BLOCK, IO, SWAP> (src, dst, tw, n, p, nframes, tid, gs_in, gs_out); break;
+        case 4: generic_stage<4, BLOCK, IO, SWAP> (src, dst, tw, n, p, nframes, tid, gs_in, gs_out); break;
+        case 5: generic_stage<5, BLOCK, IO, SWAP> (src, dst, tw, n, p, nframes, tid, gs_in, gs_out); break;
+        case 8: generic_stage<8, BLOCK, IO, SWAP> (src, dst, tw, n, p, nframes, tid, gs_in, gs_out); break;
+        default: generic_stage<16, BLOCK, IO, SWAP> (src, dst, tw, n, p, nframes, tid, gs_in, gs_out); break;
+    }
+}
+
+// All stages.  IN_GLOBAL: stage 0 reads the frames from `gin` (frame stride plan.in_stride) instead of image `a`.
+// OUT_GLOBAL: the last stage writes to `gout`; otherwise the image holding the result is returned.
+// SWAP: re<->im swap on the global side(s) (inverse transform).
+template <int BLOCK, bool IN_GLOBAL, bool OUT_GLOBAL, bool SWAP>
+__device__ __forceinline__ float2* generic_core (const GenericPlan& plan, const float2* __restrict__ twtab, float2* a, float2* b,
+                                                  const float2* __restrict__ gin, float2* __restrict__ gout, int nframes, int tid)
 {
     float2 *src = a, *dst = b;
     int p = 1;
@@ -101,15 +136,17 @@ __device__ __forceinline__ float2* generic_core (const GenericPlan& plan, const 
     {
         const int r = plan.radix[s];
         const float2* tw = twtab + plan.tw_offset[s];
-        switch (r)
-        {
-            case 2: generic_stage<2, BLOCK> (src, dst, tw, plan.n, p, nframes, tid); break;
-            case 3: generic_stage<3, BLOCK> (src, dst, tw, plan.n, p, nframes, tid); break;
-            case 4: generic_stage<4, BLOCK> (src, dst, tw, plan.n, p, nframes, tid); break;
-            case 5: generic_stage<5, BLOCK> (src, dst, tw, plan.n, p, nframes, tid); break;
-            default: generic_stage<8, BLOCK> (src, dst, tw, plan.n, p, nframes, tid); break;
-        }
-        __syncthreads();
+        const bool first = IN_GLOBAL && s == 0, last = OUT_GLOBAL && s == plan.ns - 1;
+        if (first && last)
+            generic_stage_dispatch<BLOCK, 3, SWAP> (r, gin, gout, tw, plan.n, p, nframes, tid, plan.in_stride, plan.out_stride);
+        else if (first)
+            generic_stage_dispatch<BLOCK, 1, SWAP> (r, gin, dst, tw, plan.n, p, nframes, tid, plan.in_stride, plan.out_stride);
+        else if (last)
+            generic_stage_dispatch<BLOCK, 2, SWAP> (r, src, gout, tw, plan.n, p, nframes, tid, plan.in_stride, plan.out_stride);
+        else
+            generic_stage_dispatch<BLOCK, 0, false> (r, src, dst, tw, plan.n, p, nframes, tid, plan.in_stride, plan.out_stride);
+        if (! last)
+            __syncthreads();
         float2* t = src;
         src = dst;
         dst = t;
@@ -170,17 +207,11 @@ __global__ __launch_bounds__ (BLOCK) void generic_kernel (const float2* __restri
                     bufA[f * n + kp] = make_float2 (zp.y, zp.x);
             }
         }
-        else
-        {
-            for (int e = tid; e < nframes * n; e += BLOCK)
-            {
-                const unsigned ge = (is == (unsigned) n) ? (unsigned) e : (unsigned) (e / n) * is + (unsigned) (e % n);
-                const float2 x = gload (&src[ge]);
-                bufA[e] = (MODE == 0 && INV) ? make_float2 (x.y, x.x) : x;
-            }
-        }
-        __syncthreads();
-        const float2* res = generic_core<BLOCK> (plan, twtab, bufA, bufB, nframes, tid);
+        // MODE 0 / 1: stage 0 reads the frames straight from global memory
+        if (MODE == 2)
+            __syncthreads();
+        constexpr bool IN_GLOBAL = (MODE != 2), OUT_GLOBAL = (MODE != 1);
+        const float2* res = generic_core<BLOCK, IN_GLOBAL, OUT_GLOBAL, (MODE == 2) || INV> (plan, twtab, bufA, bufB, src, dst, nframes, tid);
         if (MODE == 1)
         {
             for (int idx = tid; idx < nframes * half; idx += BLOCK)
@@ -205,15 +236,6 @@ __global__ __launch_bounds__ (BLOCK) void generic_kernel (const float2* __restri
                 gstore (&dst[f * os + k], Xk);
                 if (kp != k)
                     gstore (&dst[f * os + kp], Xp);
-            }
-        }
-        else
-        {
-            for (int e = tid; e < nframes * n; e += BLOCK)
-            {
-                const float2 y = res[e];
-                const unsigned ge = (os == (unsigned) n) ? (unsigned) e : (unsigned) (e / n) * os + (unsigned) (e % n);
-                gstore (&dst[ge], (MODE == 2 || INV) ? make_float2 (y.y, y.x) : y);
             }
         }
     }

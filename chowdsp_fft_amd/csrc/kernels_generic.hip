@@ -1,6 +1,7 @@
 // Instantiation + launch of the generic mixed-radix kernel (frames that are not powers of two).
 #include "generic_kernels.hpp"
 #include "launch_util.hpp"
+#include "tables.hpp"
 
 namespace cfft::host
 {
@@ -28,14 +29,10 @@ hipError_t launch_generic_mb (const GenericPlan& plan, const DeviceTables& t, co
 template <int MODE, bool INV>
 hipError_t launch_generic_m (GenericPlan& plan, const DeviceTables& t, const float2* in, float2* out, size_t batch, hipStream_t stream)
 {
-    // Short frames: several per workgroup so that each of the 256 work-items has butterflies (about 2048 points in
-    // flight).  Long frames: the two LDS images allow one workgroup per CU, so it gets 1024 work-items.
-    if (2 * (size_t) plan.n * sizeof (float2) > 64 * 1024)
-    {
-        plan.frames = 1;
+    int block = 256;
+    generic_geometry (plan.n, plan.frames, block); // tables.hpp: the stage radices were chosen for this geometry
+    if (block == 1024)
         return launch_generic_mb<MODE, INV, 1024> (plan, t, in, out, batch, stream);
-    }
-    plan.frames = plan.n <= 512 ? std::max (1, 2048 / plan.n) : 1; // measured: N=480 +4 % with 4 frames, N=768 -13 % with 2
     return launch_generic_mb<MODE, INV, 256> (plan, t, in, out, batch, stream);
 }
 } // namespace

@@ -86,17 +86,30 @@ bool size_supported (int N, int transform)
     return is_235_smooth (N) && (real ? N / 2 : N) <= kGenericMaxComplexLen;
 }
 
-// stage radices of the generic kernel for a 2^a 3^b 5^c length: fives, threes, then the power of two as 8s/4s/2
+// stage radices of the generic kernel for a 2^a 3^b 5^c length: fives, threes, then the power of two in as few
+// stages as the radix cap allows, the bits spread evenly (2^10 -> 16, 8, 8; 2^5 -> 8, 4).  The cap keeps at least a quarter
+// of the workgroup's work-items busy with a butterfly each: fewer, larger butterflies mean fewer LDS round trips
+// (N=9216: 7 -> 5 stages, +33 %), but 48 radix-16 butterflies on 256 work-items (N=768) lost 16 %.
 static void generic_radices (int n, std::vector<int>& radix)
 {
+    int frames = 1, block = 256;
+    generic_geometry (n, frames, block);
+    int cap_bits = 4;
+    while (cap_bits > 2 && (frames * n) >> cap_bits < block / 4)
+        --cap_bits;
     radix.clear();
     while (n % 5 == 0) { radix.push_back (5); n /= 5; }
     while (n % 3 == 0) { radix.push_back (3); n /= 3; }
     int e = 0;
     while (n % 2 == 0) { ++e; n /= 2; }
-    if (e % 2 == 1 && e >= 3) { radix.push_back (8); e -= 3; }
-    while (e >= 2) { radix.push_back (4); e -= 2; }
-    if (e == 1) radix.push_back (2);
+    int stages = (e + cap_bits - 1) / cap_bits;
+    while (e > 0)
+    {
+        const int bits = (e + stages - 1) / stages;
+        radix.push_back (1 << bits);
+        e -= bits;
+        --stages;
+    }
 }
 
 bool build_host_tables (int N, int transform, HostTables& out)

@@ -28,6 +28,23 @@ bool build_host_tables (int N, int transform, HostTables& out);
 bool size_supported (int N, int transform);
 // stage radices of the LDS-resident core of length n (0-padded); false if n has no core plan
 bool core_radices (int n, int radix[4]);
+// launch geometry of the generic mixed-radix kernel for complex length n: frames per workgroup pass and work-items
+// per workgroup (shared by the radix choice in tables.cpp and the launcher in kernels_generic.hip)
+inline void generic_geometry (int n, int& frames, int& block)
+{
+    // Long frames: the two LDS images (16 bytes per point) allow one workgroup per CU, so it gets 1024 work-items.
+    // Short frames: several per workgroup so that each of the 256 work-items has butterflies (~2048 points in flight;
+    // measured: N=480 +4 % with 4 frames, N=768 -13 % with 2).
+    block = (2 * (size_t) n * 8 > 64 * 1024) ? 1024 : 256;
+#ifndef CFFT_GENERIC_MULTI_MAX
+#define CFFT_GENERIC_MULTI_MAX 1024
+#endif
+#ifndef CFFT_GENERIC_POINTS
+#define CFFT_GENERIC_POINTS 2048
+#endif
+    frames = (block == 256 && n <= CFFT_GENERIC_MULTI_MAX) ? (CFFT_GENERIC_POINTS / n > 1 ? CFFT_GENERIC_POINTS / n : 1) : 1;
+}
+
 // stage radices of the generic mixed-radix kernel for a complex length that is not a power of two
 void generic_plan_radices (int n_complex, std::vector<int>& radix);
 // For multi-pass sizes: N = n1 * n2 with both factors LDS-resident; (0,0) if N is LDS-resident itself.

@@ -55,6 +55,12 @@ WORK = {
     "c3072": (3072, 1, 65536, False),
     "c768": (768, 1, 262144, False),
     "c480": (480, 1, 524288, False),
+    "c384": (384, 1, 524288, False),
+    "c640": (640, 1, 262144, False),
+    "c1536": (1536, 1, 131072, False),
+    "c2000": (2000, 1, 131072, False),
+    "c6400": (6400, 1, 32768, False),
+    "r960": (960, 0, 524288, False),
     "r9216": (9216, 0, 32768, False),
 }
 
