@@ -374,4 +374,107 @@ __global__ __launch_bounds__ (P::T* FPB) void c2r_kernel (const float2* __restri
         }
     }
 }
+
+// Software-pipelined c2r for one-frame-per-workgroup plans (M >= 4096): the next frame's pair loads are issued
+// before this frame's merge stage, core and stores (same reasoning as c2c_kernel_pf).  Packed batches only.
+template <class P>
+__device__ __forceinline__ void c2r_finish (const float2 (&a)[P::R / 2], const float2 (&xp)[P::R / 2], const TwiddleRegs<P>& tw,
+                                            const PairTwiddles<P>& pw, float2* __restrict__ lds, float2* __restrict__ dst, int t)
+{
+    constexpr int M = P::N;
+    float2 zk[P::R / 2], zp[P::R / 2];
+#pragma unroll
+    for (int q = 0; q < P::R / 2; ++q)
+    {
+        const int k = t + P::T * q;
+        real_merge_pair (a[q], xp[q], pw.w[q], zk[q], zp[q]);
+        if (k == 0)
+        {
+            zk[q] = make_float2 (a[q].x + a[q].y, a[q].x - a[q].y);
+            zp[q] = make_float2 (2.f * xp[q].x, -2.f * xp[q].y);
+        }
+    }
+    team_sync<P::T>(); // previous frame's LDS reads are finished
+#pragma unroll
+    for (int q = 0; q < P::R / 2; ++q)
+    {
+        const int k = t + P::T * q;
+        lds[lds_phys (k)] = make_float2 (zk[q].y, zk[q].x);
+        lds[lds_phys (k == 0 ? M / 2 : M - k)] = make_float2 (zp[q].y, zp[q].x);
+    }
+    team_sync<P::T>();
+    float2 v[P::R];
+    lds_load_input_order<P> (v, lds, t);
+    team_sync<P::T>();
+    fft_core<P> (v, tw, lds, t);
+#pragma unroll
+    for (int s = 0; s < P::R; ++s)
+        gstore (&dst[(unsigned) output_index<P> (t, s)], make_float2 (v[s].y, v[s].x));
+}
+
+template <class P>
+__global__ __launch_bounds__ (P::T) void c2r_kernel_pf (const float2* __restrict__ in,
+                                                      float2* __restrict__ out,
+                                                      const float2* __restrict__ twtab,
+                                                      const float2* __restrict__ wtab,
+                                                      unsigned batch)
+{
+    extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
+    constexpr int M = P::N;
+    const int t = threadIdx.x;
+    float2* lds = smem;
+    TwiddleRegs<P> tw;
+    load_twiddles<P> (tw, twtab, t);
+    PairTwiddles<P> pw;
+    load_pair_twiddles<P> (pw, wtab, t);
+
+    unsigned g = blockIdx.x;
+    if (g >= batch)
+        return;
+    float nax[P::R / 2], nay[P::R / 2], npx[P::R / 2], npy[P::R / 2]; // prefetch registers
+#define CFFT_C2R_LOAD(G, AX, AY, PX, PY)                                              \
+    {                                                                                 \
+        const float2* __restrict__ src_ = in + (size_t) (G) * M;                      \
+        _Pragma ("unroll") for (int q = 0; q < P::R / 2; ++q)                         \
+        {                                                                             \
+            const int k_ = t + P::T * q;                                              \
+            const float2 a_ = gload (&src_[(unsigned) k_]);                           \
+            const float2 p_ = gload (&src_[(unsigned) (k_ == 0 ? M / 2 : M - k_)]);   \
+            AX[q] = a_.x;                                                             \
+            AY[q] = a_.y;                                                             \
+            PX[q] = p_.x;                                                             \
+            PY[q] = p_.y;                                                             \
+        }                                                                             \
+    }
+    {
+        float ax[P::R / 2], ay[P::R / 2], px[P::R / 2], py[P::R / 2];
+        CFFT_C2R_LOAD (g, ax, ay, px, py)
+        float2 a[P::R / 2], xp[P::R / 2];
+#pragma unroll
+        for (int q = 0; q < P::R / 2; ++q)
+        {
+            a[q] = make_float2 (ax[q], ay[q]);
+            xp[q] = make_float2 (px[q], py[q]);
+        }
+        const unsigned gn = g + gridDim.x;
+        if (gn < batch)
+            CFFT_C2R_LOAD (gn, nax, nay, npx, npy)
+        c2r_finish<P> (a, xp, tw, pw, lds, out + (size_t) g * M, t);
+    }
+    for (g += gridDim.x; g < batch; g += gridDim.x)
+    {
+        float2 a[P::R / 2], xp[P::R / 2];
+#pragma unroll
+        for (int q = 0; q < P::R / 2; ++q)
+        {
+            a[q] = make_float2 (nax[q], nay[q]);
+            xp[q] = make_float2 (npx[q], npy[q]);
+        }
+        const unsigned gn = g + gridDim.x;
+        if (gn < batch)
+            CFFT_C2R_LOAD (gn, nax, nay, npx, npy)
+        c2r_finish<P> (a, xp, tw, pw, lds, out + (size_t) g * M, t);
+    }
+#undef CFFT_C2R_LOAD
+}
 } // namespace cfft
