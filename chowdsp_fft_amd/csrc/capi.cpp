@@ -675,8 +675,19 @@ int fft_convolve_frames_batch (void* setup, const float* x, const float* dft_fil
     const int nc = complex_len (s);
     if (t->core_n != nc || nc > cfft::kMaxFusedN)
     {
-        set_last_error ("fft_convolve_frames_batch: frame too long for the fused kernel");
-        return FFT_GPU_ENOTSUP;
+        // No fused kernel for this size (two-pass, 8192-point and mixed-radix plans): the same three steps as separate
+        // launches, with `y` holding the spectra in between -- forward x -> y, y = y * H * scaling, backward in place.
+        int rc = run_transform (s, x, y, batch, FFT_FORWARD, (hipStream_t) stream);
+        if (rc != FFT_GPU_OK)
+            return rc;
+        const DeviceGuard guard (s->device);
+        const hipError_t em = launch_conv_mac (s->transform == FFT_REAL, y, dft_filter, y, scaling, (size_t) nc, batch, true, (hipStream_t) stream, false);
+        if (em != hipSuccess)
+        {
+            set_last_error ("fft_convolve_frames_batch: multiply kernel launch", em);
+            return FFT_GPU_ELAUNCH;
+        }
+        return run_transform (s, y, y, batch, FFT_BACKWARD, (hipStream_t) stream);
     }
     const hipError_t e = (s->transform == FFT_COMPLEX)
                              ? launch_conv_frames_c2c (nc, (const float2*) x, (const float2*) dft_filter, (float2*) y, t->stage_twiddles, scaling, batch, (hipStream_t) stream)

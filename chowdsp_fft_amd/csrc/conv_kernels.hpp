@@ -12,9 +12,10 @@
 namespace cfft
 {
 // ab[f][k] += a[f][k] * b[f or 0][k] * scaling ; frame = `cplx_per_frame` float2 values.
+// ACCUMULATE == false: ab = a * b * scaling (a may alias ab) -- the middle step of the unfused convolution sequence.
 // REAL: element 0 of every frame packs two purely real bins (DC, Nyquist) and is multiplied per
 // component (reference :1614-1619, :1640-1644).
-template <bool REAL>
+template <bool REAL, bool ACCUMULATE>
 __global__ __launch_bounds__ (256) void conv_mac_kernel (const float4* __restrict__ a,
                                                         const float4* __restrict__ b,
                                                         float4* __restrict__ ab,
@@ -29,7 +30,7 @@ __global__ __launch_bounds__ (256) void conv_mac_kernel (const float4* __restric
         const unsigned in_frame = (unsigned) (i % pairs_per_frame);
         const float4 va = gload4 (&a[i]);
         const float4 vb = b_is_shared ? b[in_frame] : gload4 (&b[i]);
-        float4 acc = gload4 (&ab[i]);
+        float4 acc = ACCUMULATE ? gload4 (&ab[i]) : make_float4 (0.f, 0.f, 0.f, 0.f);
         float r0 = va.x * vb.x - va.y * vb.y;
         float i0 = va.x * vb.y + va.y * vb.x;
         const float r1 = va.z * vb.z - va.w * vb.w;

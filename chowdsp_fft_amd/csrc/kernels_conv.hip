@@ -86,7 +86,7 @@ hipError_t launch_cf_real_m (const float2* in, const float2* H, float2* out, con
 }
 } // namespace
 
-hipError_t launch_conv_mac (bool real_packed, const float* a, const float* b, float* ab, float scaling, size_t cplx_per_frame, size_t batch, bool b_is_shared, hipStream_t stream)
+hipError_t launch_conv_mac (bool real_packed, const float* a, const float* b, float* ab, float scaling, size_t cplx_per_frame, size_t batch, bool b_is_shared, hipStream_t stream, bool accumulate)
 {
     const size_t total_pairs = batch * cplx_per_frame / 2;
     if (total_pairs == 0)
@@ -94,10 +94,9 @@ hipError_t launch_conv_mac (bool real_packed, const float* a, const float* b, fl
     const unsigned grid = stream_grid (total_pairs);
     if (grid == 0)
         return hipErrorNoDevice;
-    if (real_packed)
-        hipLaunchKernelGGL (conv_mac_kernel<true>, dim3 (grid), dim3 (256), 0, stream, (const float4*) a, (const float4*) b, (float4*) ab, scaling, (unsigned) (cplx_per_frame / 2), total_pairs, b_is_shared ? 1 : 0);
-    else
-        hipLaunchKernelGGL (conv_mac_kernel<false>, dim3 (grid), dim3 (256), 0, stream, (const float4*) a, (const float4*) b, (float4*) ab, scaling, (unsigned) (cplx_per_frame / 2), total_pairs, b_is_shared ? 1 : 0);
+    auto kernel = real_packed ? (accumulate ? conv_mac_kernel<true, true> : conv_mac_kernel<true, false>)
+                              : (accumulate ? conv_mac_kernel<false, true> : conv_mac_kernel<false, false>);
+    hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (256), 0, stream, (const float4*) a, (const float4*) b, (float4*) ab, scaling, (unsigned) (cplx_per_frame / 2), total_pairs, b_is_shared ? 1 : 0);
     return hipGetLastError();
 }
 

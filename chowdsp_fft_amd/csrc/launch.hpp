@@ -21,7 +21,7 @@ hipError_t launch_r2c (int m, const float2* in, float2* out, const float2* stage
 hipError_t launch_c2r (int m, const float2* in, float2* out, const float2* stage_tw, const float2* real_tw, size_t batch, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
 
 // ab += a*b*scaling on `batch` frames of `cplx_per_frame` complex values; real_packed: bin 0 is (DC, Nyquist)
-hipError_t launch_conv_mac (bool real_packed, const float* a, const float* b, float* ab, float scaling, size_t cplx_per_frame, size_t batch, bool b_is_shared, hipStream_t stream);
+hipError_t launch_conv_mac (bool real_packed, const float* a, const float* b, float* ab, float scaling, size_t cplx_per_frame, size_t batch, bool b_is_shared, hipStream_t stream, bool accumulate = true);
 hipError_t launch_accumulate (const float* a, const float* b, float* ab, size_t count, hipStream_t stream);
 
 // streaming partitioned convolution engine (conv_engine.cpp)

@@ -101,8 +101,9 @@ int fft_accumulate_batch (void* setup, const float* a, const float* b, float* ab
    i.e. the reference call sequence of test/test.cpp:161-166 / :212-215       unordered layout)
        fft_transform_unordered(x, FORWARD) -> fft_convolve_unordered(X, H, 0-initialised, scaling)
        -> fft_transform_unordered(BACKWARD)
-   in ONE kernel: the spectrum never leaves the CU, HBM traffic is one read + one write per frame.
-   Available for LDS-resident sizes (N <= 4096 complex, N <= 8192 real); FFT_GPU_ENOTSUP otherwise. */
+   in ONE kernel for N <= 4096 complex / N <= 8192 real powers of two: the spectrum never leaves the CU, HBM
+   traffic is one read + one write per frame.  Every other supported size runs the same three steps as separate
+   launches with `y` holding the spectra in between (x == y allowed either way). */
 int fft_convolve_frames_batch (void* setup, const float* x, const float* dft_filter, float* y, float scaling, size_t batch, void* stream);
 
 /* ---- host-memory streaming mode ------------------------------------------------

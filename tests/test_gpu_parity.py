@@ -253,7 +253,11 @@ def test_convolution_golden(gpu, golden, n, tag):
     api.fft_destroy_setup(s)
 
 
-@pytest.mark.parametrize("n,tr", [(16, COMPLEX), (1024, COMPLEX), (4096, COMPLEX), (32, REAL), (1024, REAL), (4096, REAL), (8192, REAL)])
+# sizes with a fused convolution kernel (incl. the 128-thread-workgroup 2048-point plan and the pipelined variants), and
+# sizes where fft_convolve_frames_batch runs the three steps as separate launches (8192-point plan, two-pass, mixed radix)
+@pytest.mark.parametrize("n,tr", [(16, COMPLEX), (1024, COMPLEX), (2048, COMPLEX), (4096, COMPLEX), (32, REAL), (1024, REAL),
+                                  (2048, REAL), (4096, REAL), (8192, REAL),
+                                  (8192, COMPLEX), (65536, COMPLEX), (16384, REAL), (32768, REAL), (480, COMPLEX), (960, REAL)])
 def test_batched_convolution_ops_vs_oracle(gpu, oracle, n, tr):
     """fft_convolve_unordered_batch (per-frame and shared filter), accumulate into a non-zero ab, fused kernel"""
     api, torch, dev = gpu
@@ -297,6 +301,10 @@ def test_batched_convolution_ops_vs_oracle(gpu, oracle, n, tr):
         want[f] = oracle.transform(so, oracle.convolve(so, a, b0, np.zeros(nf, np.float32), 1.0 / n), BACKWARD, False)
     assert_frames_close(y.cpu().numpy(), want, what="shared-filter convolution")
     assert_frames_close(fused.cpu().numpy(), want, what="fused convolution")
+    inplace = xd.clone()
+    api.fft_convolve_frames_batch(s, inplace, H[:1].contiguous(), inplace, 1.0 / n)  # x == y
+    torch.cuda.synchronize()
+    assert_frames_close(inplace.cpu().numpy(), want, what="fused convolution in place")
     # accumulate
     out = torch.empty_like(xd)
     api.fft_accumulate_batch(s, xd, hd, out)
