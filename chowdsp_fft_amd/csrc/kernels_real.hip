@@ -29,10 +29,10 @@ hipError_t launch_real_m (const float2* in, float2* out, const float2* tw, const
         }();
         if (strided) // frames embedded in larger buffers: run-time strides, plain kernel
             kernel = &r2c_kernel<P, G::FPB, true>;
-        const unsigned grid = persistent_grid (kernel, G::threads, G::lds_bytes, ngroups);
+        const unsigned grid = persistent_grid (kernel, G::threads, G::lds_bytes_real, ngroups);
         if (grid == 0)
             return hipErrorNoDevice;
-        hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (G::threads), G::lds_bytes, stream, in, out, tw, rtw, (unsigned) batch, in_stride ? in_stride : (unsigned) M, out_stride ? out_stride : (unsigned) M);
+        hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (G::threads), G::lds_bytes_real, stream, in, out, tw, rtw, (unsigned) batch, in_stride ? in_stride : (unsigned) M, out_stride ? out_stride : (unsigned) M);
     }
     else
     {
@@ -47,10 +47,10 @@ hipError_t launch_real_m (const float2* in, float2* out, const float2* tw, const
             if (! strided)
             {
                 auto kpf = c2r_kernel_pf<P>;
-                const unsigned gpf = persistent_grid (kpf, G::threads, G::lds_bytes, ngroups);
+                const unsigned gpf = persistent_grid (kpf, G::threads, G::lds_bytes_real, ngroups);
                 if (gpf == 0)
                     return hipErrorNoDevice;
-                hipLaunchKernelGGL (kpf, dim3 (gpf), dim3 (G::threads), G::lds_bytes, stream, in, out, tw, rtw, (unsigned) batch);
+                hipLaunchKernelGGL (kpf, dim3 (gpf), dim3 (G::threads), G::lds_bytes_real, stream, in, out, tw, rtw, (unsigned) batch);
                 return hipGetLastError();
             }
         }
@@ -60,10 +60,10 @@ hipError_t launch_real_m (const float2* in, float2* out, const float2* tw, const
             if (! strided)
                 kernel = &c2r_kernel<P, G::FPB, false>;
         }
-        const unsigned grid = persistent_grid (kernel, G::threads, G::lds_bytes, ngroups);
+        const unsigned grid = persistent_grid (kernel, G::threads, G::lds_bytes_real, ngroups);
         if (grid == 0)
             return hipErrorNoDevice;
-        hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (G::threads), G::lds_bytes, stream, in, out, tw, rtw, (unsigned) batch, in_stride ? in_stride : (unsigned) M, out_stride ? out_stride : (unsigned) M);
+        hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (G::threads), G::lds_bytes_real, stream, in, out, tw, rtw, (unsigned) batch, in_stride ? in_stride : (unsigned) M, out_stride ? out_stride : (unsigned) M);
     }
     return hipGetLastError();
 }

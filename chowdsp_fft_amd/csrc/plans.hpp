@@ -71,6 +71,10 @@ struct Geometry
     static constexpr bool staged = (P::T < 16);
     static constexpr size_t image_floats2 = (size_t) FPB * LdsFrame<P::N>::floats2;
     static constexpr size_t lds_bytes = (image_floats2 + (staged ? (size_t) FPB * P::N : 0)) * sizeof (float2);
+    // The real kernels also touch the mirrored bins M-k, whose 16-lane runs start one element off a 128-byte line:
+    // 16-lane teams (M = 128, real N = 256) are staged as well there (CFFT_REAL_STAGED_MAX_T, stockham.hpp).
+    static constexpr bool staged_real = (P::T <= CFFT_REAL_STAGED_MAX_T);
+    static constexpr size_t lds_bytes_real = (image_floats2 + (staged_real ? (size_t) FPB * P::N : 0)) * sizeof (float2);
 };
 
 // Width (adjacent columns / rows) of the tiles the two-pass kernels work on, for a core of length n:

@@ -101,7 +101,7 @@ __global__ __launch_bounds__ (P::T* FPB) void r2c_kernel (const float2* __restri
     const unsigned ngroups = (batch + FPB - 1) / FPB;
     const unsigned team_base = (unsigned) team * M; // inside the LDS staging area
     const unsigned team_in = (unsigned) team * in_stride, team_out = (unsigned) team * out_stride; // in global memory
-    constexpr bool STAGED = (P::T < 16); // narrow teams: whole-workgroup coalesced copies through LDS (plans.hpp)
+    constexpr bool STAGED = (P::T <= CFFT_REAL_STAGED_MAX_T); // narrow teams: whole-workgroup coalesced copies through LDS (plans.hpp)
     float2* stage = smem + FPB * LdsFrame<M>::floats2;
     for (unsigned g = blockIdx.x; g < ngroups; g += gridDim.x)
     {
@@ -311,7 +311,7 @@ __global__ __launch_bounds__ (P::T* FPB) void c2r_kernel (const float2* __restri
     const unsigned ngroups = (batch + FPB - 1) / FPB;
     const unsigned team_base = (unsigned) team * M; // inside the LDS staging area
     const unsigned team_in = (unsigned) team * in_stride, team_out = (unsigned) team * out_stride; // in global memory
-    constexpr bool STAGED = (P::T < 16); // narrow teams: whole-workgroup coalesced copies through LDS (plans.hpp)
+    constexpr bool STAGED = (P::T <= CFFT_REAL_STAGED_MAX_T); // narrow teams: whole-workgroup coalesced copies through LDS (plans.hpp)
     float2* stage = smem + FPB * LdsFrame<M>::floats2;
     for (unsigned g = blockIdx.x; g < ngroups; g += gridDim.x)
     {

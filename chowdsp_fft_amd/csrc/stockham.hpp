@@ -192,6 +192,13 @@ __device__ __forceinline__ constexpr int output_index (int t, int slot)
     return (t + P::T * (slot / r)) + (slot % r) * (P::N / r);
 }
 
+// widest team whose REAL kernels (r2c / c2r) go through the staging area: see Geometry::staged_real (plans.hpp).
+// Measured on MI355X (fwd+inv): real N=256 (16 lanes) 4.63 -> 5.32 TB/s, N=512 (32 lanes) +2..5 %, 64 lanes: N=1024 -2 %,
+// N=2048 -26 % (the staging area costs occupancy there).
+#ifndef CFFT_REAL_STAGED_MAX_T
+#define CFFT_REAL_STAGED_MAX_T 32
+#endif
+
 // ---- staged global I/O for narrow teams (T < 16): the workgroup's FPB contiguous frames <-> LDS, 16 B per lane ----
 template <int THREADS, int ELEMS>
 __device__ __forceinline__ void stage_in (const float2* __restrict__ src, float2* __restrict__ stage, unsigned valid, int tid)

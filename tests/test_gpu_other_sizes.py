@@ -110,7 +110,7 @@ def test_reference_other_sizes_sequence_host_pointers(gpu, oracle, n, tr, preall
 
 
 def test_other_size_convolution_ops(gpu, oracle):
-    """multiply-accumulate / accumulate work on any supported size; the fused kernel is power-of-two only"""
+    """multiply-accumulate / accumulate / the one-call convolution work on any supported size"""
     api, torch, dev = gpu
     n, tr = 480, REAL
     s, so = api.fft_new_setup(n, tr), oracle.new_setup(n, tr)
@@ -127,7 +127,10 @@ def test_other_size_convolution_ops(gpu, oracle):
     hb = oracle.transform(so, h[0], FORWARD, False)
     want = np.stack([oracle.transform(so, oracle.convolve(so, oracle.transform(so, x[i], FORWARD, False), hb, np.zeros(n, np.float32), 1.0 / n), BACKWARD, False) for i in range(3)])
     assert_frames_close(y.cpu().numpy(), want, what="N=480 convolution pipeline")
-    with pytest.raises(api.FFTError):
-        api.fft_convolve_frames_batch(s, xd, H, y, 1.0 / n)
+    # no fused kernel for mixed-radix sizes: the one-call convolution runs the same three steps through y
+    y2 = torch.empty_like(xd)
+    api.fft_convolve_frames_batch(s, xd, H, y2, 1.0 / n)
+    torch.cuda.synchronize()
+    assert_frames_close(y2.cpu().numpy(), want, what="N=480 one-call convolution")
     api.fft_destroy_setup(s)
     oracle.destroy_setup(so)

@@ -78,6 +78,10 @@ def main():
     dev = torch.device("cuda:0")
     stream = int(torch.cuda.current_stream().cuda_stream)
     for wname in args.workloads.split(","):
+        if wname not in WORK and wname[0] in "cr" and wname[1:].isdigit():
+            # any size: c<N> / r<N>, ~512 MiB of frames
+            nn, trr = int(wname[1:]), (1 if wname[0] == "c" else 0)
+            WORK[wname] = (nn, trr, max(1, (512 << 20) // (4 * (2 * nn if trr else nn))), False)
         n, tr, frames, fused = WORK[wname]
         ff = 2 * n if tr == 1 else n
         x = torch.rand((frames, ff), device=dev) * 2 - 1
