@@ -119,6 +119,17 @@ def main() -> int:
     import torch
     import torch.distributed as dist
 
+    if not os.path.exists(os.path.join(ROOT, "chowdsp_fft_amd", "libchowdsp_fft_hip.so")):
+        # source-only checkout: compile the library first (rank 0 builds, the others wait for the file)
+        if local_rank == 0:
+            import __graft_entry__
+
+            __graft_entry__.build()
+        else:
+            t_wait = time.time()
+            while not os.path.exists(os.path.join(ROOT, "chowdsp_fft_amd", "libchowdsp_fft_hip.so")) and time.time() - t_wait < 1800:
+                time.sleep(2.0)
+            time.sleep(5.0)
     from chowdsp_fft_amd import api, sharding
     if world != args.gpus:
         if rank == 0:
