@@ -103,6 +103,18 @@ def main() -> int:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
+    if not os.path.exists(os.path.join(ROOT, "chowdsp_fft_amd", "libchowdsp_fft_hip.so")):
+        # source-only checkout: compile the library first (rank 0 builds, the others wait for the file)
+        if local_rank == 0:
+            import __graft_entry__
+
+            __graft_entry__.build()
+        else:
+            t_wait = time.time()
+            while not os.path.exists(os.path.join(ROOT, "chowdsp_fft_amd", "libchowdsp_fft_hip.so")) and time.time() - t_wait < 1800:
+                time.sleep(2.0)
+            time.sleep(5.0)
+
     # The CPU baseline runs a child process (oracle/_ref/ref_bench): do it BEFORE anything touches the GPU
     # (a process that has initialised HIP must not fork+exec on this pool).
     cb = None
@@ -119,17 +131,6 @@ def main() -> int:
     import torch
     import torch.distributed as dist
 
-    if not os.path.exists(os.path.join(ROOT, "chowdsp_fft_amd", "libchowdsp_fft_hip.so")):
-        # source-only checkout: compile the library first (rank 0 builds, the others wait for the file)
-        if local_rank == 0:
-            import __graft_entry__
-
-            __graft_entry__.build()
-        else:
-            t_wait = time.time()
-            while not os.path.exists(os.path.join(ROOT, "chowdsp_fft_amd", "libchowdsp_fft_hip.so")) and time.time() - t_wait < 1800:
-                time.sleep(2.0)
-            time.sleep(5.0)
     from chowdsp_fft_amd import api, sharding
     if world != args.gpus:
         if rank == 0:
