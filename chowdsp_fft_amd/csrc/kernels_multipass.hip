@@ -141,8 +141,10 @@ hipError_t launch_real_pair (bool forward, const float2* in, float2* out, const 
     DeviceInfo dev;
     if (! current_device_info (dev))
         return hipErrorNoDevice;
+    if ((m / 2) % 256 != 0)
+        return hipErrorInvalidValue; // only used for M > kMaxCoreN
     const size_t total = batch * (m / 2);
-    const unsigned grid = (unsigned) std::max<size_t> (1, std::min<size_t> ((total + 255) / 256, (size_t) dev.num_cus * 8));
+    const unsigned grid = (unsigned) std::max<size_t> (1, std::min<size_t> (total / 256, (size_t) dev.num_cus * 16));
     if (forward)
         hipLaunchKernelGGL (real_pair_kernel<true>, dim3 (grid), dim3 (256), 0, stream, in, out, real_tw, m, (unsigned) batch, in_stride, out_stride);
     else

@@ -174,22 +174,24 @@ __global__ __launch_bounds__ (256) void real_pair_kernel (const float2* __restri
                                                          size_t in_stride,
                                                          size_t out_stride)
 {
-    const unsigned half = M / 2; // pairs per frame, k = 0 .. M/2-1
-    const size_t total = (size_t) batch * half;
-    const size_t stride = (size_t) gridDim.x * blockDim.x;
-    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride)
+    // work item = (frame, chunk of 256 pairs): the frame / chunk split is workgroup-uniform (scalar) arithmetic, every
+    // work-item then handles pair k = chunk * 256 + tid: ascending k and descending M - k, both lane-contiguous
+    const unsigned half = M / 2; // pairs per frame, k = 0 .. M/2-1 (M >= 8192 here: a multiple of 256)
+    const unsigned chunks = half / 256;
+    const size_t nwork = (size_t) batch * chunks;
+    for (size_t w = blockIdx.x; w < nwork; w += gridDim.x)
     {
-        const unsigned f = (unsigned) (i / half);
-        const unsigned k = (unsigned) (i % half);
+        const unsigned f = (unsigned) (w / chunks);
+        const unsigned k = (unsigned) (w % chunks) * 256u + threadIdx.x;
         const unsigned kp = (k == 0 ? half : M - k);
         const float2* __restrict__ src = in + (size_t) f * in_stride;
         float2* __restrict__ dst = out + (size_t) f * out_stride;
         const float2 A = gload (&src[k]), Bp = gload (&src[kp]);
-        const float2 w = wtab[k];
+        const float2 w2 = wtab[k];
         float2 rk, rp;
         if (FORWARD)
         {
-            real_split_pair (A, Bp, w, rk, rp);
+            real_split_pair (A, Bp, w2, rk, rp);
             if (k == 0)
             {
                 rk = make_float2 (A.x + A.y, A.x - A.y);
@@ -198,7 +200,7 @@ __global__ __launch_bounds__ (256) void real_pair_kernel (const float2* __restri
         }
         else
         {
-            real_merge_pair (A, Bp, w, rk, rp);
+            real_merge_pair (A, Bp, w2, rk, rp);
             if (k == 0)
             {
                 rk = make_float2 (A.x + A.y, A.x - A.y);
