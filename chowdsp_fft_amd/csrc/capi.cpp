@@ -98,6 +98,20 @@ struct Lanes
 std::mutex g_ws_mutex;
 std::map<std::pair<int, hipStream_t>, Lanes> g_lanes;
 
+// CHOWDSP_FFT_PAIR_CHUNK_DIV: how much smaller the chunks of long REAL transforms are than those of complex ones.
+// Measured on MI355X, real N = 32768 / 131072 / 1048576 fwd+inv: pair stage after the whole batch 1.68 / 1.63 / 1.25 TB/s;
+// per chunk inside the two-lane pipeline, divisor 1: 1.83 / 1.67 / 1.25, 2: 1.83 / 1.68 / 1.36, 4: 1.70 / 1.55 / 1.36,
+// 8: 1.53 / 1.34 / 0.91 (launches get too short).
+size_t pair_chunk_divisor()
+{
+    static const size_t n = [] {
+        const char* e = std::getenv ("CHOWDSP_FFT_PAIR_CHUNK_DIV");
+        const long v = e != nullptr ? std::atol (e) : 2;
+        return (size_t) (v >= 1 && v <= 64 ? v : 2);
+    }();
+    return n;
+}
+
 int lane_count()
 {
     static const int n = [] {
@@ -155,7 +169,11 @@ Lanes* get_lanes (int device, hipStream_t stream, size_t bytes_each)
 // complex length the plan's core transforms
 int complex_len (const Setup* s) { return s->transform == cf::FFT_COMPLEX ? s->N : s->N / 2; }
 
-int big_c2c_chunked (Setup* s, int nc, bool inverse, const float2* in, float2* out, size_t batch, hipStream_t stream, size_t is2, size_t os2)
+// pair: 0 = complex transform; +1 = REAL FORWARD: the pair (split) stage runs on each chunk's output right after its
+// pass B, in place; -1 = REAL BACKWARD: the pair (merge) stage in -> out runs on each chunk right before its pass A,
+// which then works in place on `out`.  Doing it per chunk (and with smaller chunks) lets the stage find its operands in
+// the Infinity Cache instead of re-reading the whole batch from HBM afterwards.
+int big_c2c_chunked (Setup* s, int nc, bool inverse, const float2* in, float2* out, size_t batch, hipStream_t stream, size_t is2, size_t os2, int pair = 0)
 {
     int n1 = 0, n2 = 0;
     split_large (nc, n1, n2);
@@ -163,6 +181,8 @@ int big_c2c_chunked (Setup* s, int nc, bool inverse, const float2* in, float2* o
     const int want_lanes = lane_count();
     // the cap covers BOTH workspaces, so that they fit the Infinity Cache together
     size_t chunk = workspace_cap() / (size_t) want_lanes / frame_bytes;
+    if (pair != 0)
+        chunk /= pair_chunk_divisor(); // the chunk's output has to stay cached next to the two workspaces
     if (chunk < 1)
         chunk = 1;
     if (chunk > batch)
@@ -188,8 +208,19 @@ int big_c2c_chunked (Setup* s, int nc, bool inverse, const float2* in, float2* o
         const size_t nb = (batch - f0 < chunk) ? batch - f0 : chunk;
         const int k = (lanes == 2) ? (int) (i & 1) : 0;
         const hipStream_t st = (lanes == 2) ? L->lane[k] : stream;
-        const hipError_t e = launch_big_c2c (n1, n2, inverse, in + f0 * is2, L->ws[k], out + f0 * os2, s->tables->stage_twiddles,
-                                             s->tables->big_twiddles, nb, lanes, st, is2, os2);
+        hipError_t e = hipSuccess;
+        const float2* cin = in + f0 * is2;
+        size_t cis = is2;
+        if (pair < 0)
+        {
+            e = launch_real_pair (false, cin, out + f0 * os2, s->tables->real_twiddles, (unsigned) nc, nb, st, is2, os2);
+            cin = out + f0 * os2;
+            cis = os2;
+        }
+        if (e == hipSuccess)
+            e = launch_big_c2c (n1, n2, inverse, cin, L->ws[k], out + f0 * os2, s->tables->stage_twiddles, s->tables->big_twiddles, nb, lanes, st, cis, os2);
+        if (e == hipSuccess && pair > 0)
+            e = launch_real_pair (true, out + f0 * os2, out + f0 * os2, s->tables->real_twiddles, (unsigned) nc, nb, st, os2, os2);
         if (e != hipSuccess)
         {
             set_last_error ("two-pass kernel launch", e);
@@ -242,16 +273,12 @@ int run_transform (Setup* s, const float* in, float* out, size_t batch, cf::fft_
     else if (! inverse)
     {
         // long real frames: complex two-pass transform of z[n] = x[2n] + i x[2n+1], then the pair stage in place
-        const int rc = big_c2c_chunked (s, nc, false, cin, cout, batch, stream, is2, os2);
-        if (rc != cf::FFT_GPU_OK)
-            return rc;
-        e = launch_real_pair (true, cout, cout, t->real_twiddles, (unsigned) nc, batch, stream, os2, os2);
+        return big_c2c_chunked (s, nc, false, cin, cout, batch, stream, is2, os2, +1);
     }
     else
     {
-        e = launch_real_pair (false, cin, cout, t->real_twiddles, (unsigned) nc, batch, stream, is2, os2);
-        if (e == hipSuccess)
-            return big_c2c_chunked (s, nc, true, cout, cout, batch, stream, os2, os2);
+        // packed spectrum -> Z (pair stage) -> complex two-pass backward, chunk by chunk
+        return big_c2c_chunked (s, nc, true, cin, cout, batch, stream, is2, os2, -1);
     }
     if (e != hipSuccess)
     {
