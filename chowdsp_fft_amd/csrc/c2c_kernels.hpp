@@ -179,4 +179,37 @@ __global__ __launch_bounds__ (P::T* FPB) void c2c_kernel_pf (const float2* __res
     }
 #undef CFFT_PF_BODY
 }
+
+// One frame per 1024-thread workgroup with streamed twiddles (fft_core_streamed): the N = 16384 plan, whose 128 KiB frame
+// still fits the CU's 160 KiB LDS, so it stays a single pass over HBM.  Run-time frame strides (packed or strided).
+template <class P, bool INV>
+__global__ __launch_bounds__ (P::T) void c2c_kernel_streamed (const float2* __restrict__ in,
+                                                            float2* __restrict__ out,
+                                                            const float2* __restrict__ twtab,
+                                                            unsigned batch,
+                                                            unsigned in_stride,
+                                                            unsigned out_stride)
+{
+    extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
+    const int t0 = threadIdx.x;
+    for (unsigned g = blockIdx.x; g < batch; g += gridDim.x)
+    {
+        int t = t0;
+        CFFT_LAUNDER_INDEX (t);
+        const float2* __restrict__ src = in + (size_t) g * in_stride;
+        float2* __restrict__ dst = out + (size_t) g * out_stride;
+        float2 v[P::R];
+#pragma unroll
+        for (int s = 0; s < P::R; ++s)
+        {
+            const float2 x = gload (&src[(unsigned) input_index<P> (t, s)]);
+            v[s] = INV ? make_float2 (x.y, x.x) : x;
+        }
+        team_sync<P::T>(); // the previous frame's last-stage LDS reads are finished
+        fft_core_streamed<P> (v, twtab, smem, t);
+#pragma unroll
+        for (int s = 0; s < P::R; ++s)
+            gstore (&dst[(unsigned) output_index<P> (t, s)], INV ? make_float2 (v[s].y, v[s].x) : v[s]);
+    }
+}
 } // namespace cfft

@@ -11,6 +11,18 @@ hipError_t launch_c2c_n (const float2* in, float2* out, const float2* tw, size_t
 {
     using P = typename CorePlan<N>::type;
     using G = Geometry<P>;
+    if constexpr (N >= kStreamedCoreN)
+    {
+        // 1024 work-items, 128 VGPRs: twiddles streamed from L2 (c2c_kernel_streamed), one frame per workgroup
+        auto kernel = c2c_kernel_streamed<P, INV>;
+        const unsigned grid = persistent_grid (kernel, G::threads, G::lds_bytes, batch);
+        if (grid == 0)
+            return hipErrorNoDevice;
+        hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (G::threads), G::lds_bytes, stream, in, out, tw, (unsigned) batch, in_stride ? in_stride : (unsigned) N, out_stride ? out_stride : (unsigned) N);
+        return hipGetLastError();
+    }
+    else
+    {
     // CFFT_C2C_PREFETCH: 0 = never, 1 = every size, default (2) = only one-frame-per-workgroup plans, where the
     // software-pipelined kernel keeps a compile-time store count and measured +6.8 % (N=4096: 5.35 -> 5.71 TB/s);
     // multi-frame workgroups (N <= 2048) measured -2 % .. +1 % and keep the simple kernel.
@@ -33,6 +45,7 @@ hipError_t launch_c2c_n (const float2* in, float2* out, const float2* tw, size_t
         return hipErrorNoDevice;
     hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (G::threads), G::lds_bytes, stream, in, out, tw, (unsigned) batch, in_stride ? in_stride : (unsigned) N, out_stride ? out_stride : (unsigned) N);
     return hipGetLastError();
+    }
 }
 } // namespace
 

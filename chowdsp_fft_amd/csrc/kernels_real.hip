@@ -11,6 +11,18 @@ hipError_t launch_real_m (const float2* in, float2* out, const float2* tw, const
 {
     using P = typename CorePlan<M>::type;
     using G = Geometry<P>;
+    if constexpr (M >= kStreamedCoreN)
+    {
+        // 1024 work-items, 128 VGPRs: twiddles streamed from L2, one frame per workgroup
+        auto kernel = FWD ? r2c_kernel_streamed<P> : c2r_kernel_streamed<P>;
+        const unsigned grid = persistent_grid (kernel, G::threads, G::lds_bytes, batch);
+        if (grid == 0)
+            return hipErrorNoDevice;
+        hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (G::threads), G::lds_bytes, stream, in, out, tw, rtw, (unsigned) batch, in_stride ? in_stride : (unsigned) M, out_stride ? out_stride : (unsigned) M);
+        return hipGetLastError();
+    }
+    else
+    {
     const size_t ngroups = (batch + G::FPB - 1) / G::FPB;
     const bool strided = (in_stride != 0 && in_stride != (unsigned) M) || (out_stride != 0 && out_stride != (unsigned) M);
     if constexpr (FWD)
@@ -66,6 +78,7 @@ hipError_t launch_real_m (const float2* in, float2* out, const float2* tw, const
         hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (G::threads), G::lds_bytes_real, stream, in, out, tw, rtw, (unsigned) batch, in_stride ? in_stride : (unsigned) M, out_stride ? out_stride : (unsigned) M);
     }
     return hipGetLastError();
+    }
 }
 } // namespace
 

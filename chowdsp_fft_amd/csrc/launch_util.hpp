@@ -45,6 +45,11 @@ inline unsigned persistent_grid (K kernel, int threads, size_t lds_bytes, size_t
         constexpr int N_ = 8192;                             \
         CALL;                                                \
     }                                                        \
+    else if ((n) == 16384)                                   \
+    {                                                        \
+        constexpr int N_ = 16384;                            \
+        CALL;                                                \
+    }                                                        \
     else                                                     \
         CFFT_DISPATCH_N (n, CALL)
 } // namespace cfft::host

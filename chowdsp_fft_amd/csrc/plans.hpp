@@ -45,12 +45,19 @@ template <> struct CorePlan<4096> { using type = Plan<4096, 256, 16, 16, 16>;   
 // 8192 points = 64 KiB: the frame still fits the CU's 160 KiB LDS (one 512-thread workgroup per CU, 68 KiB image), so it
 // stays a single pass over HBM instead of the two-pass four-step (2x the traffic)
 template <> struct CorePlan<8192> { using type = Plan<8192, 512, 16, 16, 16, 2>; };
+// 16384 points = 128 KiB: one 1024-thread workgroup per CU (136 KiB image); 128 VGPRs per work-item, so the twiddles
+// are streamed from L2 one stage ahead instead of living in registers (fft_core_streamed, stockham.hpp)
+template <> struct CorePlan<16384> { using type = Plan<16384, 1024, 16, 16, 16, 4>; };
+static constexpr int kStreamedCoreN = 16384; // plans from this length on use the *_streamed kernels
 // clang-format on
 
 // the 65536 = 256 x 256 fast path (multipass_kernels.hpp) is written for this plan, independent of CorePlan<256>
 using Plan256 = Plan<256, 16, 16, 16>;
 
-static constexpr int kMaxCoreN = 8192;
+#ifndef CFFT_MAX_CORE_N
+#define CFFT_MAX_CORE_N 16384
+#endif
+static constexpr int kMaxCoreN = CFFT_MAX_CORE_N;
 static constexpr int kMaxFusedN = 4096; // longest core the fused convolution / engine kernels are instantiated for
 static constexpr int kMinCoreN = 16;
 static constexpr int kBlockThreads = 256;
@@ -122,6 +129,7 @@ inline bool core_plan_desc (int n, PlanDesc& d)
         case 2048: d = describe<CorePlan<2048>::type>(); return true;
         case 4096: d = describe<CorePlan<4096>::type>(); return true;
         case 8192: d = describe<CorePlan<8192>::type>(); return true;
+        case 16384: d = describe<CorePlan<16384>::type>(); return true;
         default: return false;
     }
 }

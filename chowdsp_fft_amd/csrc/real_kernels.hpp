@@ -477,4 +477,111 @@ __global__ __launch_bounds__ (P::T) void c2r_kernel_pf (const float2* __restrict
     }
 #undef CFFT_C2R_LOAD
 }
+
+// ---- streamed-twiddle variants for the N/2 = 16384 plan (see c2c_kernel_streamed) ---------------------------------
+template <class P>
+__global__ __launch_bounds__ (P::T) void r2c_kernel_streamed (const float2* __restrict__ in,
+                                                            float2* __restrict__ out,
+                                                            const float2* __restrict__ twtab,
+                                                            const float2* __restrict__ wtab,
+                                                            unsigned batch,
+                                                            unsigned in_stride,
+                                                            unsigned out_stride)
+{
+    extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
+    constexpr int M = P::N;
+    const int t0 = threadIdx.x;
+    float2* lds = smem;
+    for (unsigned g = blockIdx.x; g < batch; g += gridDim.x)
+    {
+        int t = t0;
+        CFFT_LAUNDER_INDEX (t);
+        const float2* __restrict__ src = in + (size_t) g * in_stride;
+        float2* __restrict__ dst = out + (size_t) g * out_stride;
+        float2 v[P::R];
+#pragma unroll
+        for (int s = 0; s < P::R; ++s)
+            v[s] = gload (&src[(unsigned) input_index<P> (t, s)]);
+        team_sync<P::T>();
+        fft_core_streamed<P> (v, twtab, lds, t);
+        team_sync<P::T>(); // last-stage reads done before the image is overwritten
+        CFFT_PHASE_FENCE();
+        lds_store_output_order<P> (v, lds, t);
+        CFFT_PHASE_FENCE();
+        float2 pw[P::R / 2];
+#pragma unroll
+        for (int q = 0; q < P::R / 2; ++q)
+            pw[q] = wtab[t + P::T * q];
+        team_sync<P::T>();
+#pragma unroll
+        for (int q = 0; q < P::R / 2; ++q)
+        {
+            const int k = t + P::T * q;
+            const float2 A = lds[lds_phys (k)];
+            const float2 Zp = lds[lds_phys (k == 0 ? M / 2 : M - k)];
+            float2 Xk, Xp;
+            real_split_pair (A, Zp, pw[q], Xk, Xp);
+            if (k == 0)
+            {
+                Xk = make_float2 (A.x + A.y, A.x - A.y);
+                Xp = make_float2 (Zp.x, -Zp.y);
+            }
+            gstore (&dst[(unsigned) k], Xk);
+            gstore (&dst[(unsigned) (k == 0 ? M / 2 : M - k)], Xp);
+        }
+    }
+}
+
+template <class P>
+__global__ __launch_bounds__ (P::T) void c2r_kernel_streamed (const float2* __restrict__ in,
+                                                            float2* __restrict__ out,
+                                                            const float2* __restrict__ twtab,
+                                                            const float2* __restrict__ wtab,
+                                                            unsigned batch,
+                                                            unsigned in_stride,
+                                                            unsigned out_stride)
+{
+    extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
+    constexpr int M = P::N;
+    const int t0 = threadIdx.x;
+    float2* lds = smem;
+    for (unsigned g = blockIdx.x; g < batch; g += gridDim.x)
+    {
+        int t = t0;
+        CFFT_LAUNDER_INDEX (t);
+        const float2* __restrict__ src = in + (size_t) g * in_stride;
+        float2* __restrict__ dst = out + (size_t) g * out_stride;
+        float2 zk[P::R / 2], zp[P::R / 2];
+#pragma unroll
+        for (int q = 0; q < P::R / 2; ++q)
+        {
+            const int k = t + P::T * q;
+            const float2 A = gload (&src[(unsigned) k]);
+            const float2 Xp = gload (&src[(unsigned) (k == 0 ? M / 2 : M - k)]);
+            real_merge_pair (A, Xp, wtab[k], zk[q], zp[q]);
+            if (k == 0)
+            {
+                zk[q] = make_float2 (A.x + A.y, A.x - A.y);
+                zp[q] = make_float2 (2.f * Xp.x, -2.f * Xp.y);
+            }
+        }
+        team_sync<P::T>(); // previous frame's LDS reads are finished
+#pragma unroll
+        for (int q = 0; q < P::R / 2; ++q)
+        {
+            const int k = t + P::T * q;
+            lds[lds_phys (k)] = make_float2 (zk[q].y, zk[q].x);
+            lds[lds_phys (k == 0 ? M / 2 : M - k)] = make_float2 (zp[q].y, zp[q].x);
+        }
+        team_sync<P::T>();
+        CFFT_PHASE_FENCE();
+        float2 v[P::R];
+        lds_load_input_order<P> (v, lds, t);
+        team_sync<P::T>();
+        fft_core_streamed<P> (v, twtab, lds, t);
+#pragma unroll
+        for (int s = 0; s < P::R; ++s)
+            gstore (&dst[(unsigned) output_index<P> (t, s)], make_float2 (v[s].y, v[s].x));
+    }
+}
 } // namespace cfft

@@ -116,8 +116,9 @@ __device__ __forceinline__ void load_twiddles (TwiddleRegs<P>& tw, const float2*
 
 // ---- one stage ---------------------------------------------------------------------------------
 // compute part: twiddle (S>0) + DFT_r on every butterfly slot of this work-item
+// w: this stage's twiddles of this work-item, [q * (r-1) + (a-1)] (unused for S == 0)
 template <class P, int S>
-__device__ __forceinline__ void stage_compute (float2 (&v)[P::R], const TwiddleRegs<P>& tw)
+__device__ __forceinline__ void stage_compute_row (float2 (&v)[P::R], const float2 (&w)[P::R])
 {
     constexpr int r = P::radix (S);
     constexpr int Q = P::R / r;
@@ -132,13 +133,19 @@ __device__ __forceinline__ void stage_compute (float2 (&v)[P::R], const TwiddleR
         {
 #pragma unroll
             for (int a = 1; a < r; ++a)
-                u[a] = cmul (u[a], tw.w[S - 1][q * (r - 1) + (a - 1)]);
+                u[a] = cmul (u[a], w[q * (r - 1) + (a - 1)]);
         }
         fft_reg<r> (u);
 #pragma unroll
         for (int a = 0; a < r; ++a)
             v[q * r + a] = u[a];
     }
+}
+
+template <class P, int S>
+__device__ __forceinline__ void stage_compute (float2 (&v)[P::R], const TwiddleRegs<P>& tw)
+{
+    stage_compute_row<P, S> (v, tw.w[S > 0 ? S - 1 : 0]);
 }
 
 // scatter the outputs of stage S into the LDS image (Y[j + b*p])
@@ -288,6 +295,67 @@ __device__ __forceinline__ void fft_core (float2 (&v)[P::R], const TwiddleRegs<P
         team_sync<P::T>();
         stage_read_lds<P, 3> (v, lds, t);
         stage_compute<P, 3> (v, tw);
+    }
+}
+
+// ---- the same core with STREAMED twiddles ------------------------------------------------------------------------
+// For the N = 16384 plan: 1024 work-items x 16 points leave 128 VGPRs per work-item, not enough to keep every stage's
+// twiddles resident.  One stage's twiddles at a time are fetched from the (L2-resident) table while the previous
+// stage's outputs travel through LDS.  Two things keep the register count at 120 (tools/kres.py), both needed:
+//  * the caller launders the work-item index once per frame (CFFT_LAUNDER_INDEX): otherwise the ~100 loop-invariant
+//    LDS / table offsets of the four stages are hoisted out of the persistent loop and held (then spilled) for good;
+//  * scheduling fences between the phases, so that the next phase's loads are not hoisted over this phase's registers.
+#define CFFT_LAUNDER_INDEX(var) asm volatile ("" : "+v"(var))
+#define CFFT_PHASE_FENCE() __builtin_amdgcn_sched_barrier (0)
+
+template <class P, int S>
+__device__ __forceinline__ void fetch_stage_twiddles (float2 (&w)[P::R], const float2* __restrict__ table, int t)
+{
+    constexpr int r = P::radix (S);
+    constexpr int p = P::prod (S);
+    constexpr int Q = P::R / r;
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+    {
+        const int k = (t + P::T * q) & (p - 1);
+#pragma unroll
+        for (int a = 1; a < r; ++a)
+            w[q * (r - 1) + (a - 1)] = table[P::tw_offset (S) + (a - 1) * p + k];
+    }
+}
+
+template <class P, int S>
+__device__ __forceinline__ void streamed_stage (float2 (&v)[P::R], float2 (&w)[P::R], const float2* __restrict__ table,
+                                                float2* __restrict__ lds, int t)
+{
+    // v holds stage S-1's outputs: exchange them through LDS while stage S's twiddles arrive, then stage S
+    CFFT_PHASE_FENCE();
+    stage_write_lds<P, S - 1> (v, lds, t);
+    CFFT_PHASE_FENCE();
+    fetch_stage_twiddles<P, S> (w, table, t);
+    team_sync<P::T>();
+    stage_read_lds<P, S> (v, lds, t);
+    CFFT_PHASE_FENCE();
+    stage_compute_row<P, S> (v, w);
+    CFFT_PHASE_FENCE();
+}
+
+template <class P>
+__device__ __forceinline__ void fft_core_streamed (float2 (&v)[P::R], const float2* __restrict__ table, float2* __restrict__ lds, int t)
+{
+    float2 w[P::R];
+    stage_compute_row<P, 0> (v, w);
+    if constexpr (P::NS > 1)
+        streamed_stage<P, 1> (v, w, table, lds, t);
+    if constexpr (P::NS > 2)
+    {
+        team_sync<P::T>();
+        streamed_stage<P, 2> (v, w, table, lds, t);
+    }
+    if constexpr (P::NS > 3)
+    {
+        team_sync<P::T>();
+        streamed_stage<P, 3> (v, w, table, lds, t);
     }
 }
 } // namespace cfft
