@@ -11,7 +11,12 @@ hipError_t launch_c2c_n (const float2* in, float2* out, const float2* tw, size_t
 {
     using P = typename CorePlan<N>::type;
     using G = Geometry<P>;
-    if constexpr (N >= kStreamedCoreN)
+    // CFFT_C2C_STREAM_MIN_N (experiment): the streamed-twiddle kernel at 4 waves per SIMD for shorter plans measured
+    // slower than resident twiddles + prefetch at 2 (N=4096 5.26 vs 5.74 TB/s, N=8192 4.83 vs 5.65)
+#ifndef CFFT_C2C_STREAM_MIN_N
+#define CFFT_C2C_STREAM_MIN_N kStreamedCoreN
+#endif
+    if constexpr (N >= CFFT_C2C_STREAM_MIN_N)
     {
         // 1024 work-items, 128 VGPRs: twiddles streamed from L2 (c2c_kernel_streamed), one frame per workgroup
         auto kernel = c2c_kernel_streamed<P, INV>;
