@@ -13,6 +13,7 @@
 #include "tables.hpp"
 
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <new>
@@ -69,6 +70,48 @@ struct Staging
     }
 };
 thread_local Staging g_staging;
+
+// Per-thread PINNED host buffer for short frames on the legacy host-pointer path: the kernel reads its input from and
+// writes its result to host memory directly over PCIe (zero-copy), which replaces two DMA submissions and their
+// completions by two host memcpys -- the per-call cost is all latency at these sizes.  Longer frames keep the DMA copies.
+struct PinnedStaging
+{
+    float* host = nullptr;
+    size_t floats = 0;
+    ~PinnedStaging()
+    {
+        if (host != nullptr)
+            (void) hipHostFree (host);
+    }
+    float* get (size_t need)
+    {
+        if (need <= floats)
+            return host;
+        if (host != nullptr)
+            (void) hipHostFree (host);
+        host = nullptr;
+        floats = 0;
+        if (hipHostMalloc ((void**) &host, need * sizeof (float), hipHostMallocDefault) != hipSuccess)
+        {
+            (void) hipGetLastError();
+            host = nullptr;
+            return nullptr;
+        }
+        floats = need;
+        return host;
+    }
+};
+thread_local PinnedStaging g_pinned;
+
+// CHOWDSP_FFT_ZEROCOPY_MAX_BYTES: longest frame (bytes) that takes the zero-copy legacy path; 0 disables it
+size_t zerocopy_max_bytes()
+{
+    static const size_t n = [] {
+        const char* e = std::getenv ("CHOWDSP_FFT_ZEROCOPY_MAX_BYTES");
+        return e != nullptr ? (size_t) std::atoll (e) : (size_t) 262144;
+    }();
+    return n;
+}
 
 // grow-only scratch for the two-pass sizes, one per (device, stream); bounded by workspace_cap() so that the
 // intermediate of one chunk of frames stays inside the 256 MiB Infinity Cache between pass A and pass B.
@@ -314,6 +357,19 @@ void legacy_transform (void* setup, const float* input, float* output, cf::fft_d
             (void) hipStreamSynchronize (nullptr);
         return;
     }
+    if (! in_dev && ! out_dev && nf * sizeof (float) <= zerocopy_max_bytes())
+    {
+        float* pin = g_pinned.get (2 * nf);
+        if (pin != nullptr)
+        {
+            std::memcpy (pin, input, nf * sizeof (float));
+            if (run_transform (s, pin, pin + nf, 1, direction, nullptr) != cf::FFT_GPU_OK)
+                return;
+            if (hipStreamSynchronize (nullptr) == hipSuccess)
+                std::memcpy (output, pin + nf, nf * sizeof (float));
+            return;
+        }
+    }
     float* stage = g_staging.get (2 * nf, s->device);
     if (stage == nullptr)
     {
@@ -343,6 +399,24 @@ template <class Op>
 void legacy_elementwise (Setup* s, const float* a, const float* b, float* ab, size_t nf, Op&& op, bool ab_is_input)
 {
     const bool a_dev = is_device_pointer (a), b_dev = is_device_pointer (b), ab_dev = is_device_pointer (ab);
+    if (! a_dev && ! b_dev && ! ab_dev && nf * sizeof (float) <= zerocopy_max_bytes())
+    {
+        // all operands in host memory, short frame: the kernel works on a pinned copy directly (see PinnedStaging)
+        float* pin = g_pinned.get (3 * nf);
+        if (pin != nullptr)
+        {
+            float *pa = pin, *pb = pin + nf, *pab = pin + 2 * nf;
+            std::memcpy (pa, a, nf * sizeof (float));
+            std::memcpy (pb, b, nf * sizeof (float));
+            if (ab_is_input)
+                std::memcpy (pab, ab, nf * sizeof (float));
+            if (op (pa, pb, pab) != cf::FFT_GPU_OK)
+                return;
+            if (hipStreamSynchronize (nullptr) == hipSuccess)
+                std::memcpy (ab, pab, nf * sizeof (float));
+            return;
+        }
+    }
     float* stage = nullptr;
     if (! (a_dev && b_dev && ab_dev))
     {
