@@ -27,11 +27,15 @@ for n, tr, name in ((4096, api.FFT_COMPLEX, "complex"), (1024, api.FFT_REAL, "re
     # the streaming mode: the same frames in ONE call, pinned in place, two-stream pipeline
     nb = max(64, (512 << 20) // (4 * nf))
     X = np.random.default_rng(1).uniform(-1, 1, (nb, nf)).astype(np.float32)
-    Y = np.empty_like(X)
+    Y = np.zeros_like(X)  # touched: the first call would otherwise also pay the page faults of a fresh output buffer
     api.fft_transform_host_batch(s, X[:64], Y[:64], api.FFT_FORWARD)
     t0 = time.perf_counter()
     api.fft_transform_host_batch(s, X, Y, api.FFT_FORWARD)
+    dt_first = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    api.fft_transform_host_batch(s, X, Y, api.FFT_FORWARD)
     dt = time.perf_counter() - t0
+    print(f"   (first call on these buffers: {X.nbytes / dt_first / 1e9:.1f} GB/s each way; steady state below)")
     print(f"fft_transform_host_batch,        N={n} {name}: {dt / nb * 1e6:8.2f} us/frame {nb / dt:10.0f} FFT/s  "
           f"({X.nbytes / dt / 1e9:.1f} GB/s each way over PCIe, {nb} frames, pin + copy + transform + copy)")
     api.fft_destroy_setup(s)
