@@ -91,7 +91,7 @@ struct PinnedStaging
             (void) hipHostFree (host);
         host = nullptr;
         floats = 0;
-        if (hipHostMalloc ((void**) &host, need * sizeof (float), hipHostMallocDefault) != hipSuccess)
+        if (hipHostMalloc ((void**) &host, need * sizeof (float), hipHostMallocPortable) != hipSuccess)
         {
             (void) hipGetLastError();
             host = nullptr;
