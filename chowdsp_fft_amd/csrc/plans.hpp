@@ -90,7 +90,12 @@ struct Geometry
 constexpr int tile_width (int n, int team_threads)
 {
     const int fpb = 256 / team_threads;
-    return n >= 1024 ? 8 : (fpb > 16 ? fpb : 16);
+    // CFFT_TILE1024_WIDTH (experiment): 16 columns of a 1024-point core are a 139 KiB image, one workgroup per CU --
+    // measured slower than 8 columns x two workgroups (N = 2^20: 1.47 vs 1.67 TB/s)
+#ifndef CFFT_TILE1024_WIDTH
+#define CFFT_TILE1024_WIDTH 8
+#endif
+    return n >= 1024 ? CFFT_TILE1024_WIDTH : (fpb > 16 ? fpb : 16);
 }
 inline int tile_width_for (int n); // run-time version, defined after core_plan_desc
 
