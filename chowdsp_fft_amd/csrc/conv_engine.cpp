@@ -31,7 +31,7 @@ struct Engine
     // fused path (block >= 128 and LDS-resident): two kernels per block, the previous input block double-buffered
     bool fused = false;
     float* prev2 = nullptr;
-    unsigned cur_prev = 0; // which of prev / prev2 holds the previous block
+    void* state = nullptr; // device-resident position (OlsState): a captured process() call can be replayed block after block
 };
 
 Engine* as_engine (void* p)
@@ -47,6 +47,8 @@ void release (Engine* e)
     for (float* p : { e->prev, e->prev2, e->frame, e->fdl, e->H, e->Y })
         if (p != nullptr)
             (void) hipFree (p);
+    if (e->state != nullptr)
+        (void) hipFree (e->state);
     if (e->setup != nullptr)
         cf::fft_destroy_setup (e->setup);
     e->magic = 0;
@@ -87,7 +89,7 @@ void* fft_conv_engine_create (int block, int channels, const float* ir, int ir_l
     e->fused = ols_fused_supported (block) && ! (fenv != nullptr && fenv[0] == '0');
     bool ok_alloc = e->setup != nullptr && dev_alloc (e->prev, C * block) && dev_alloc (e->fdl, P * C * N) && dev_alloc (e->H, P * Hc * N);
     if (e->fused)
-        ok_alloc = ok_alloc && dev_alloc (e->prev2, C * block);
+        ok_alloc = ok_alloc && dev_alloc (e->prev2, C * block) && hipMalloc (&e->state, ols_state_bytes()) == hipSuccess;
     else
         ok_alloc = ok_alloc && dev_alloc (e->frame, C * N) && dev_alloc (e->Y, C * N);
     if (! ok_alloc)
@@ -133,7 +135,8 @@ int fft_conv_engine_reset (void* engine, void* stream_)
     CFFT_HIP_TRY (hipMemsetAsync (e->prev, 0, C * e->block * sizeof (float), stream), FFT_GPU_ELAUNCH);
     if (e->prev2 != nullptr)
         CFFT_HIP_TRY (hipMemsetAsync (e->prev2, 0, C * e->block * sizeof (float), stream), FFT_GPU_ELAUNCH);
-    e->cur_prev = 0;
+    if (e->state != nullptr)
+        CFFT_HIP_TRY (hipMemsetAsync (e->state, 0, ols_state_bytes(), stream), FFT_GPU_ELAUNCH);
     CFFT_HIP_TRY (hipMemsetAsync (e->fdl, 0, (size_t) e->partitions * C * N * sizeof (float), stream), FFT_GPU_ELAUNCH);
     e->head = 0;
     return FFT_GPU_OK;
@@ -151,20 +154,15 @@ int fft_conv_engine_process (void* engine, const float* in, float* out, void* st
         const Setup* su = as_setup (e->setup);
         const DeviceGuard guard (su->device);
         const DeviceTables* t = su->tables;
-        float* slot_f = e->fdl + (size_t) e->head * C * N;
-        float* pv = e->cur_prev == 0 ? e->prev : e->prev2;
-        float* keep = e->cur_prev == 0 ? e->prev2 : e->prev;
-        hipError_t hf = launch_ols_r2c (e->block, pv, in, keep, slot_f, t->stage_twiddles, t->real_twiddles, (unsigned) C, stream);
+        hipError_t hf = launch_ols_r2c (e->block, e->prev, e->prev2, in, e->fdl, t->stage_twiddles, t->real_twiddles, (unsigned) C, e->state, stream);
         if (hf == hipSuccess)
             hf = launch_ols_mac_c2r (e->block, e->fdl, e->H, out, t->stage_twiddles, t->real_twiddles, 1.0f / (float) N, (unsigned) C,
-                                     (unsigned) e->partitions, e->head, e->shared, stream);
+                                     (unsigned) e->partitions, e->state, e->shared, stream);
         if (hf != hipSuccess)
         {
             set_last_error ("engine: fused block kernels", hf);
             return FFT_GPU_ELAUNCH;
         }
-        e->cur_prev ^= 1u;
-        e->head = (e->head + 1) % (unsigned) e->partitions;
         return FFT_GPU_OK;
     }
     hipError_t he = launch_ols_assemble (in, e->prev, e->frame, (size_t) e->block, (unsigned) C, stream);

@@ -558,15 +558,40 @@ __global__ __launch_bounds__ (P::T* FPB) void conv_frames_real_kernel_pf (const 
 //                       the valid second half of the result is written.
 // HBM traffic per channel and block (N = 2L floats per frame): (P + 3) N instead of (P + 8.5) N.
 // For plans with register-direct teams (T >= 16, i.e. block >= 128); P is the M = N/2 = L point plan.
+// Engine position, kept in DEVICE memory so that one captured process() call (a hipGraph) can be replayed for
+// successive blocks: head = delay-line slot that receives this block's spectrum, cur = which of the two half-frame
+// buffers holds the previous block.  The last workgroup of ols_mac_c2r_kernel to finish moves both on (every workgroup
+// has read them by then, so no extra launch is needed); ols_advance_kernel does the same for other callers.
+struct OlsState
+{
+    unsigned head;
+    unsigned cur;
+    unsigned done; // workgroups of the block's last kernel that have finished (the last one moves head / cur on)
+};
+
+__global__ void ols_advance_kernel (OlsState* state, unsigned partitions)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+    {
+        state->head = (state->head + 1) % partitions;
+        state->cur ^= 1u;
+    }
+}
+
 template <class P, int FPB>
-__global__ __launch_bounds__ (P::T* FPB) void ols_r2c_kernel (const float2* __restrict__ prev, // [C][M/2] previous block
+__global__ __launch_bounds__ (P::T* FPB) void ols_r2c_kernel (float2* buf0,                    // [C][M/2] the two half-frame buffers:
+                                                             float2* buf1,                    //   state->cur says which holds the previous block
                                                              const float2* __restrict__ cur,  // [C][M/2] new block
-                                                             float2* __restrict__ keep,       // [C][M/2] <- cur
-                                                             float2* __restrict__ slot,       // [C][M] packed spectrum
+                                                             float2* __restrict__ fdl,        // [Pn][C][M] delay line
                                                              const float2* __restrict__ twtab,
                                                              const float2* __restrict__ wtab,
-                                                             unsigned channels)
+                                                             unsigned channels,
+                                                             const OlsState* __restrict__ state)
 {
+    const unsigned st_cur = state->cur, st_head = state->head; // workgroup-uniform (scalar loads)
+    const float2* __restrict__ prev = st_cur == 0 ? buf0 : buf1;
+    float2* __restrict__ keep = st_cur == 0 ? buf1 : buf0;
+    float2* __restrict__ slot = fdl + (size_t) st_head * channels * P::N;
     static_assert (P::R == P::radix (0), "input_index (t, s) == t + s * T is assumed below");
     extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
     constexpr int M = P::N, HALF = M / 2;
@@ -616,11 +641,12 @@ __global__ __launch_bounds__ (P::T* FPB) void ols_mac_c2r_kernel (const float2* 
                                                                  float scale,
                                                                  unsigned channels,
                                                                  unsigned Pn,
-                                                                 unsigned head,
+                                                                 OlsState* state,
                                                                  int h_shared)
 {
     extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
     constexpr int M = P::N, HALF = M / 2;
+    const unsigned head = state->head;
     const int tid = threadIdx.x;
     const int team = tid / P::T;
     const int t = tid % P::T;
@@ -724,6 +750,18 @@ __global__ __launch_bounds__ (P::T* FPB) void ols_mac_c2r_kernel (const float2* 
                 if (o >= HALF)
                     gstore (&dst[o - HALF], make_float2 (v[s].y, v[s].x));
             }
+        }
+    }
+    // end of the block: the last workgroup to get here moves the engine position on.  Every workgroup has read
+    // head (above) before it arrives, so nobody can see the new value within this launch.
+    if (threadIdx.x == 0)
+    {
+        const unsigned arrived = atomicAdd (&state->done, 1u);
+        if (arrived == gridDim.x - 1)
+        {
+            state->done = 0;
+            state->head = (head + 1) % Pn;
+            state->cur ^= 1u;
         }
     }
 }

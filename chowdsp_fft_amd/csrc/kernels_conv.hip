@@ -127,7 +127,7 @@ hipError_t launch_fdl_mac (const float* fdl, const float* H, float* Y, float sca
 namespace
 {
 template <int M>
-hipError_t launch_ols_r2c_m (const float2* prev, const float2* cur, float2* keep, float2* slot, const float2* tw, const float2* rtw, unsigned channels, hipStream_t stream)
+hipError_t launch_ols_r2c_m (float2* buf0, float2* buf1, const float2* cur, float2* fdl, const float2* tw, const float2* rtw, unsigned channels, const OlsState* state, hipStream_t stream)
 {
     using P = typename CorePlan<M>::type;
     using G = Geometry<P>;
@@ -139,13 +139,13 @@ hipError_t launch_ols_r2c_m (const float2* prev, const float2* cur, float2* keep
         const unsigned grid = persistent_grid (kernel, G::threads, G::lds_bytes, (channels + G::FPB - 1) / G::FPB);
         if (grid == 0)
             return hipErrorNoDevice;
-        hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (G::threads), G::lds_bytes, stream, prev, cur, keep, slot, tw, rtw, channels);
+        hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (G::threads), G::lds_bytes, stream, buf0, buf1, cur, fdl, tw, rtw, channels, state);
         return hipGetLastError();
     }
 }
 
 template <int M>
-hipError_t launch_ols_mac_c2r_m (const float2* fdl, const float2* H, float2* out, const float2* tw, const float2* rtw, float scale, unsigned channels, unsigned P_, unsigned head, bool h_shared, hipStream_t stream)
+hipError_t launch_ols_mac_c2r_m (const float2* fdl, const float2* H, float2* out, const float2* tw, const float2* rtw, float scale, unsigned channels, unsigned P_, OlsState* state, bool h_shared, hipStream_t stream)
 {
     using P = typename CorePlan<M>::type;
     using G = Geometry<P>;
@@ -157,7 +157,7 @@ hipError_t launch_ols_mac_c2r_m (const float2* fdl, const float2* H, float2* out
         const unsigned grid = persistent_grid (kernel, G::threads, G::lds_bytes, (channels + G::FPB - 1) / G::FPB);
         if (grid == 0)
             return hipErrorNoDevice;
-        hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (G::threads), G::lds_bytes, stream, fdl, H, out, tw, rtw, scale, channels, P_, head, h_shared ? 1 : 0);
+        hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (G::threads), G::lds_bytes, stream, fdl, H, out, tw, rtw, scale, channels, P_, state, h_shared ? 1 : 0);
         return hipGetLastError();
     }
 }
@@ -169,17 +169,25 @@ bool ols_fused_supported (int m)
     return m <= kMaxFusedN && core_plan_desc (m, d) && d.T >= 16;
 }
 
-hipError_t launch_ols_r2c (int m, const float* prev, const float* cur, float* keep, float* slot, const float2* stage_tw, const float2* real_tw, unsigned channels, hipStream_t stream)
+hipError_t launch_ols_r2c (int m, float* buf0, float* buf1, const float* cur, float* fdl, const float2* stage_tw, const float2* real_tw, unsigned channels, const void* state, hipStream_t stream)
 {
-    CFFT_DISPATCH_N (m, return (launch_ols_r2c_m<N_> ((const float2*) prev, (const float2*) cur, (float2*) keep, (float2*) slot, stage_tw, real_tw, channels, stream)));
+    CFFT_DISPATCH_N (m, return (launch_ols_r2c_m<N_> ((float2*) buf0, (float2*) buf1, (const float2*) cur, (float2*) fdl, stage_tw, real_tw, channels, (const OlsState*) state, stream)));
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_ols_mac_c2r (int m, const float* fdl, const float* H, float* out, const float2* stage_tw, const float2* real_tw, float scale, unsigned channels, unsigned P, unsigned head, bool h_shared, hipStream_t stream)
+hipError_t launch_ols_mac_c2r (int m, const float* fdl, const float* H, float* out, const float2* stage_tw, const float2* real_tw, float scale, unsigned channels, unsigned P, void* state, bool h_shared, hipStream_t stream)
 {
-    CFFT_DISPATCH_N (m, return (launch_ols_mac_c2r_m<N_> ((const float2*) fdl, (const float2*) H, (float2*) out, stage_tw, real_tw, scale, channels, P, head, h_shared, stream)));
+    CFFT_DISPATCH_N (m, return (launch_ols_mac_c2r_m<N_> ((const float2*) fdl, (const float2*) H, (float2*) out, stage_tw, real_tw, scale, channels, P, (OlsState*) state, h_shared, stream)));
     return hipErrorInvalidValue;
 }
+
+hipError_t launch_ols_advance (void* state, unsigned partitions, hipStream_t stream)
+{
+    hipLaunchKernelGGL (ols_advance_kernel, dim3 (1), dim3 (64), 0, stream, (OlsState*) state, partitions);
+    return hipGetLastError();
+}
+
+size_t ols_state_bytes() { return sizeof (OlsState); }
 
 hipError_t launch_ols_assemble (const float* in, float* prev, float* frame, size_t block, unsigned channels, hipStream_t stream)
 {

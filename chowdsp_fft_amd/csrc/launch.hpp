@@ -31,8 +31,10 @@ hipError_t launch_ols_extract (const float* y, float* out, size_t block, unsigne
 
 // fused per-block kernels of the engine (block = m >= 128 and LDS-resident): see conv_kernels.hpp
 bool ols_fused_supported (int m);
-hipError_t launch_ols_r2c (int m, const float* prev, const float* cur, float* keep, float* slot, const float2* stage_tw, const float2* real_tw, unsigned channels, hipStream_t stream);
-hipError_t launch_ols_mac_c2r (int m, const float* fdl, const float* H, float* out, const float2* stage_tw, const float2* real_tw, float scale, unsigned channels, unsigned P, unsigned head, bool h_shared, hipStream_t stream);
+hipError_t launch_ols_r2c (int m, float* buf0, float* buf1, const float* cur, float* fdl, const float2* stage_tw, const float2* real_tw, unsigned channels, const void* state, hipStream_t stream);
+hipError_t launch_ols_mac_c2r (int m, const float* fdl, const float* H, float* out, const float2* stage_tw, const float2* real_tw, float scale, unsigned channels, unsigned P, void* state, bool h_shared, hipStream_t stream); // also moves the position on
+hipError_t launch_ols_advance (void* state, unsigned partitions, hipStream_t stream); // the same step on its own
+size_t ols_state_bytes();                                                             // device-resident engine position
 
 // fused forward -> *H*scaling -> backward
 hipError_t launch_conv_frames_c2c (int n, const float2* in, const float2* H, float2* out, const float2* stage_tw, float scaling, size_t batch, hipStream_t stream);
