@@ -56,8 +56,9 @@ const char* fft_gpu_last_error (void);
 
 /* ---- plan introspection -------------------------------------------------------------------------- */
 /* 1 if fft_new_setup would accept (N, transform) on a machine with a usable device, else 0.  Pure host
-   logic (no GPU needed); the rule is the reference's SSE size rule restricted to powers of two
-   (reference simd/chowdsp_fft_impl_common.hpp:168-177, 216-225). */
+   logic (no GPU needed); the rule is the reference's SSE size rule (N % 16 complex / N % 32 real, N = 2^a 3^b 5^c;
+   reference simd/chowdsp_fft_impl_common.hpp:168-177, 216-225) with powers of two up to 2^20 and mixed-radix
+   sizes up to a complex length of 9216. */
 int fft_gpu_size_supported (int N, fft_transform_t transform);
 /* How (N, transform) is executed.  Fills desc[0..7] = { complex length transformed, number of passes
    through device memory (1 = LDS-resident, 2 = two-pass), n1, n2 (two-pass split, else 0), then up to
@@ -67,7 +68,7 @@ int fft_gpu_plan_describe (int N, fft_transform_t transform, int desc[8]);
 int fft_gpu_setup_size (void* setup);              /* N, or negative error */
 int fft_gpu_setup_is_real (void* setup);           /* 1 REAL, 0 COMPLEX */
 int fft_gpu_setup_device (void* setup);            /* HIP device ordinal the plan's tables live on; -1 for a bad handle */
-/* scratch the plan needs per launch for N > 4096 (multi-pass through HBM), bytes for `batch` frames;
+/* scratch the plan needs per launch for two-pass sizes (complex length > 16384), bytes for `batch` frames;
    0 for LDS-resident sizes.  The library allocates and caches it internally per (device, stream). */
 size_t fft_gpu_workspace_bytes (void* setup, size_t batch);
 
