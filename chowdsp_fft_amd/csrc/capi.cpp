@@ -218,8 +218,10 @@ int complex_len (const Setup* s) { return s->transform == cf::FFT_COMPLEX ? s->N
 // the Infinity Cache instead of re-reading the whole batch from HBM afterwards.
 int big_c2c_chunked (Setup* s, int nc, bool inverse, const float2* in, float2* out, size_t batch, hipStream_t stream, size_t is2, size_t os2, int pair = 0)
 {
+    const bool mixed = s->tables->mixed_n2 > 0; // long mixed-radix frame: generic column pass + power-of-two row pass
     int n1 = 0, n2 = 0;
-    split_large (nc, n1, n2);
+    if (! mixed)
+        split_large (nc, n1, n2);
     const size_t frame_bytes = (size_t) nc * sizeof (float2);
     const int want_lanes = lane_count();
     // the cap covers BOTH workspaces, so that they fit the Infinity Cache together
@@ -261,7 +263,8 @@ int big_c2c_chunked (Setup* s, int nc, bool inverse, const float2* in, float2* o
             cis = os2;
         }
         if (e == hipSuccess)
-            e = launch_big_c2c (n1, n2, inverse, cin, L->ws[k], out + f0 * os2, s->tables->stage_twiddles, s->tables->big_twiddles, nb, lanes, st, cis, os2);
+            e = mixed ? launch_mixed_big_c2c (*s->tables, inverse, cin, L->ws[k], out + f0 * os2, nb, lanes, st, cis, os2)
+                      : launch_big_c2c (n1, n2, inverse, cin, L->ws[k], out + f0 * os2, s->tables->stage_twiddles, s->tables->big_twiddles, nb, lanes, st, cis, os2);
         if (e == hipSuccess && pair > 0)
             e = launch_real_pair (true, out + f0 * os2, out + f0 * os2, s->tables->real_twiddles, (unsigned) nc, nb, st, os2, os2);
         if (e != hipSuccess)
@@ -296,6 +299,13 @@ int run_transform (Setup* s, const float* in, float* out, size_t batch, cf::fft_
     // strides in float2, always explicit from here on
     const size_t is2 = in_stride ? in_stride / 2 : (size_t) nc, os2 = out_stride ? out_stride / 2 : (size_t) nc;
     hipError_t e = hipSuccess;
+    if (t->mixed_n2 > 0)
+    {
+        // long mixed-radix frame (complex length > 9216): two passes; real frames add the pair stage per chunk
+        if (s->transform == cf::FFT_COMPLEX)
+            return big_c2c_chunked (s, nc, inverse, cin, cout, batch, stream, is2, os2);
+        return big_c2c_chunked (s, nc, inverse, cin, cout, batch, stream, is2, os2, inverse ? -1 : +1);
+    }
     if (t->gen_ns > 0)
     {
         // N = 2^a 3^b 5^c, not a power of two: generic mixed-radix kernel
@@ -645,6 +655,21 @@ int fft_gpu_plan_describe (int N, fft_transform_t transform, int desc[8])
     const int nc = (transform == FFT_COMPLEX) ? N : N / 2;
     if ((nc & (nc - 1)) != 0)
     {
+        int m1 = 0, m2 = 0;
+        if (nc > 9216 && split_mixed (nc, m1, m2))
+        {
+            // long mixed-radix frame: two passes, generic n2-point columns then power-of-two n1-point rows (radices of n1)
+            int radix1[4] = { 0, 0, 0, 0 };
+            if (! core_radices (m1, radix1))
+                return FFT_GPU_EINVAL;
+            desc[0] = nc;
+            desc[1] = 2;
+            desc[2] = m1;
+            desc[3] = m2;
+            for (int i = 0; i < 4; ++i)
+                desc[4 + i] = radix1[i];
+            return FFT_GPU_OK;
+        }
         // mixed-radix plan of the generic kernel: one pass, first four stage radices reported
         std::vector<int> r;
         generic_plan_radices (nc, r);
@@ -692,7 +717,7 @@ int fft_gpu_setup_device (void* setup)
 size_t fft_gpu_workspace_bytes (void* setup, size_t batch)
 {
     Setup* s = as_setup (setup);
-    if (s == nullptr || s->tables->core_n == complex_len (s) || s->tables->gen_ns > 0)
+    if (s == nullptr || s->tables->core_n == complex_len (s) || (s->tables->gen_ns > 0 && s->tables->mixed_n2 == 0))
         return 0;
     const size_t frame_bytes = (size_t) complex_len (s) * sizeof (float2);
     size_t chunk = workspace_cap() / (size_t) lane_count() / frame_bytes;

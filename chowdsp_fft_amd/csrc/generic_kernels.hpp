@@ -68,11 +68,12 @@ __device__ __forceinline__ void fft_reg<5> (float2 (&u)[5])
 template <int R, int BLOCK, int IO, bool SWAP>
 __device__ __forceinline__ void generic_stage (const float2* __restrict__ src, float2* __restrict__ dst,
                                                const float2* __restrict__ tw, int n, int p, int nframes, int tid,
-                                               unsigned gs_in, unsigned gs_out)
+                                               unsigned gs_in, unsigned gs_out, unsigned lfs)
 {
+    // lfs: distance between consecutive frames inside an LDS image (n, or n + 1 where lanes walk across frames)
     const int m = n / R;
     const bool p_pow2 = (p & (p - 1)) == 0;
-    const unsigned fs_in = (IO & 1) ? gs_in : (unsigned) n, fs_out = (IO & 2) ? gs_out : (unsigned) n;
+    const unsigned fs_in = (IO & 1) ? gs_in : lfs, fs_out = (IO & 2) ? gs_out : lfs;
     for (int idx = tid; idx < nframes * m; idx += BLOCK)
     {
         // one frame per workgroup pass (n > 512) and power-of-two p are the common cases: no integer division there
@@ -110,16 +111,16 @@ __device__ __forceinline__ void generic_stage (const float2* __restrict__ src, f
 template <int BLOCK, int IO, bool SWAP>
 __device__ __forceinline__ void generic_stage_dispatch (int r, const float2* __restrict__ src, float2* __restrict__ dst,
                                                         const float2* __restrict__ tw, int n, int p, int nframes, int tid,
-                                                        unsigned gs_in, unsigned gs_out)
+                                                        unsigned gs_in, unsigned gs_out, unsigned lfs)
 {
     switch (r)
     {
-        case 2: generic_stage<2, BLOCK, IO, SWAP> (src, dst, tw, n, p, nframes, tid, gs_in, gs_out); break;
-        case 3: generic_stage<3, BLOCK, IO, SWAP> (src, dst, tw, n, p, nframes, tid, gs_in, gs_out); break;
-        case 4: generic_stage<4, BLOCK, IO, SWAP> (src, dst, tw, n, p, nframes, tid, gs_in, gs_out); break;
-        case 5: generic_stage<5, BLOCK, IO, SWAP> (src, dst, tw, n, p, nframes, tid, gs_in, gs_out); break;
-        case 8: generic_stage<8, BLOCK, IO, SWAP> (src, dst, tw, n, p, nframes, tid, gs_in, gs_out); break;
-        default: generic_stage<16, BLOCK, IO, SWAP> (src, dst, tw, n, p, nframes, tid, gs_in, gs_out); break;
+        case 2: generic_stage<2, BLOCK, IO, SWAP> (src, dst, tw, n, p, nframes, tid, gs_in, gs_out, lfs); break;
+        case 3: generic_stage<3, BLOCK, IO, SWAP> (src, dst, tw, n, p, nframes, tid, gs_in, gs_out, lfs); break;
+        case 4: generic_stage<4, BLOCK, IO, SWAP> (src, dst, tw, n, p, nframes, tid, gs_in, gs_out, lfs); break;
+        case 5: generic_stage<5, BLOCK, IO, SWAP> (src, dst, tw, n, p, nframes, tid, gs_in, gs_out, lfs); break;
+        case 8: generic_stage<8, BLOCK, IO, SWAP> (src, dst, tw, n, p, nframes, tid, gs_in, gs_out, lfs); break;
+        default: generic_stage<16, BLOCK, IO, SWAP> (src, dst, tw, n, p, nframes, tid, gs_in, gs_out, lfs); break;
     }
 }
 
@@ -128,7 +129,8 @@ __device__ __forceinline__ void generic_stage_dispatch (int r, const float2* __r
 // SWAP: re<->im swap on the global side(s) (inverse transform).
 template <int BLOCK, bool IN_GLOBAL, bool OUT_GLOBAL, bool SWAP>
 __device__ __forceinline__ float2* generic_core (const GenericPlan& plan, const float2* __restrict__ twtab, float2* a, float2* b,
-                                                  const float2* __restrict__ gin, float2* __restrict__ gout, int nframes, int tid)
+                                                  const float2* __restrict__ gin, float2* __restrict__ gout, int nframes, int tid,
+                                                  unsigned lfs)
 {
     float2 *src = a, *dst = b;
     int p = 1;
@@ -138,13 +140,13 @@ __device__ __forceinline__ float2* generic_core (const GenericPlan& plan, const 
         const float2* tw = twtab + plan.tw_offset[s];
         const bool first = IN_GLOBAL && s == 0, last = OUT_GLOBAL && s == plan.ns - 1;
         if (first && last)
-            generic_stage_dispatch<BLOCK, 3, SWAP> (r, gin, gout, tw, plan.n, p, nframes, tid, plan.in_stride, plan.out_stride);
+            generic_stage_dispatch<BLOCK, 3, SWAP> (r, gin, gout, tw, plan.n, p, nframes, tid, plan.in_stride, plan.out_stride, lfs);
         else if (first)
-            generic_stage_dispatch<BLOCK, 1, SWAP> (r, gin, dst, tw, plan.n, p, nframes, tid, plan.in_stride, plan.out_stride);
+            generic_stage_dispatch<BLOCK, 1, SWAP> (r, gin, dst, tw, plan.n, p, nframes, tid, plan.in_stride, plan.out_stride, lfs);
         else if (last)
-            generic_stage_dispatch<BLOCK, 2, SWAP> (r, src, gout, tw, plan.n, p, nframes, tid, plan.in_stride, plan.out_stride);
+            generic_stage_dispatch<BLOCK, 2, SWAP> (r, src, gout, tw, plan.n, p, nframes, tid, plan.in_stride, plan.out_stride, lfs);
         else
-            generic_stage_dispatch<BLOCK, 0, false> (r, src, dst, tw, plan.n, p, nframes, tid, plan.in_stride, plan.out_stride);
+            generic_stage_dispatch<BLOCK, 0, false> (r, src, dst, tw, plan.n, p, nframes, tid, plan.in_stride, plan.out_stride, lfs);
         if (! last)
             __syncthreads();
         float2* t = src;
@@ -211,7 +213,7 @@ __global__ __launch_bounds__ (BLOCK) void generic_kernel (const float2* __restri
         if (MODE == 2)
             __syncthreads();
         constexpr bool IN_GLOBAL = (MODE != 2), OUT_GLOBAL = (MODE != 1);
-        const float2* res = generic_core<BLOCK, IN_GLOBAL, OUT_GLOBAL, (MODE == 2) || INV> (plan, twtab, bufA, bufB, src, dst, nframes, tid);
+        const float2* res = generic_core<BLOCK, IN_GLOBAL, OUT_GLOBAL, (MODE == 2) || INV> (plan, twtab, bufA, bufB, src, dst, nframes, tid, (unsigned) n);
         if (MODE == 1)
         {
             for (int idx = tid; idx < nframes * half; idx += BLOCK)
@@ -237,6 +239,56 @@ __global__ __launch_bounds__ (BLOCK) void generic_kernel (const float2* __restri
                 if (kp != k)
                     gstore (&dst[f * os + kp], Xp);
             }
+        }
+    }
+}
+
+// ---- long mixed-radix frames (complex length > 9216): pass A of the two-pass plan -----------------------------------
+// N = n1 * n2 as in multipass_kernels.hpp, with n2 = (odd part) * 2^j a mixed-radix length and n1 a power of two:
+// this kernel does the n2-point COLUMN FFTs of a tile of 16 adjacent columns with the run-time stage list above and
+// writes them, times W_N^{a kb}, in the same tile-major workspace layout as pass_a_kernel; pass B is then the ordinary
+// power-of-two pass_b_kernel.  LDS: two images of 16 frames of n2 + 1 points (the + 1 keeps the 16 lanes that walk
+// across frames while the tile is loaded / stored off each other's banks).
+template <bool SWAP_IN>
+__global__ __launch_bounds__ (256) void pass_a_generic_kernel (const float2* __restrict__ in,
+                                                              float2* __restrict__ work,
+                                                              const float2* __restrict__ twtab,
+                                                              const float2* __restrict__ big_tw,
+                                                              GenericPlan plan, // n = n2, frames = 16
+                                                              unsigned n1,
+                                                              unsigned batch,
+                                                              size_t in_stride)
+{
+    extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
+    constexpr int CA = 16;
+    const int tid = threadIdx.x;
+    const int n2 = plan.n;
+    const unsigned lfs = (unsigned) n2 + 1u;
+    float2* bufA = smem;
+    float2* bufB = smem + (size_t) CA * lfs;
+    const unsigned tiles = n1 / CA;
+    const size_t frame_len = (size_t) n1 * n2;
+    const size_t nwork = (size_t) batch * tiles;
+    for (size_t w = blockIdx.x; w < nwork; w += gridDim.x)
+    {
+        const unsigned f = (unsigned) (w / tiles);
+        const unsigned tile = (unsigned) (w % tiles);
+        const float2* __restrict__ src = in + (size_t) f * in_stride + (size_t) tile * CA;
+        float2* __restrict__ dst = work + (size_t) f * frame_len + (size_t) tile * ((size_t) n2 * CA);
+        const float2* __restrict__ twp = big_tw + (size_t) tile * ((size_t) n2 * CA);
+        __syncthreads(); // previous tile fully stored
+        for (int e = tid; e < CA * n2; e += 256)
+        {
+            const int c = e % CA, j = e / CA;
+            const float2 x = gload (&src[(size_t) j * n1 + c]);
+            bufA[c * lfs + j] = SWAP_IN ? make_float2 (x.y, x.x) : x;
+        }
+        __syncthreads();
+        const float2* res = generic_core<256, false, false, false> (plan, twtab, bufA, bufB, nullptr, nullptr, CA, tid, lfs);
+        for (int e = tid; e < CA * n2; e += 256)
+        {
+            const int c = e % CA, k = e / CA;
+            dst[e] = cmul (res[c * lfs + k], twp[e]); // plain store: the workspace should stay cached
         }
     }
 }

@@ -114,6 +114,9 @@ const DeviceTables* acquire_tables (int device, int N, int transform)
         t->gen_radix[i] = h.generic_radix[(size_t) i];
         t->gen_tw_offset[i] = h.generic_tw_offset[(size_t) i];
     }
+    t->mixed_n1 = h.mixed_n1;
+    t->mixed_n2 = h.mixed_n2;
+    t->mixed_tw1_offset = h.mixed_tw1_offset;
     t->stage_twiddles = upload (h.stage_twiddles);
     t->real_twiddles = upload (h.real_twiddles);
     t->big_twiddles = upload (h.big_twiddles);

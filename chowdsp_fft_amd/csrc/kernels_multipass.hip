@@ -1,6 +1,8 @@
 // Instantiation + launch of the two-pass (N > 4096) kernels and the stand-alone real pair stage.
 #include "launch_util.hpp"
 #include "multipass_kernels.hpp"
+#include "generic_kernels.hpp"
+#include "tables.hpp"
 
 namespace cfft::host
 {
@@ -42,7 +44,7 @@ hipError_t pass_a (int n1, const float2* in, float2* work, const float2* tw2, co
 
 // pass B: n1-point row FFTs, transposed store, work -> out
 template <int N1, bool INV>
-hipError_t pass_b (int n2, const float2* work, float2* out, const float2* tw1, size_t batch, int div, hipStream_t stream, size_t out_stride)
+hipError_t pass_b (int n2, const float2* work, float2* out, const float2* tw1, size_t batch, int div, hipStream_t stream, size_t out_stride, int ca = 0)
 {
     using TG = TileGeom<N1>;
     auto kernel = pass_b_kernel<typename TG::P, TG::C, INV>;
@@ -54,8 +56,10 @@ hipError_t pass_b (int n2, const float2* work, float2* out, const float2* tw1, s
     if (grid == 0)
         return hipErrorNoDevice;
     grid = std::max (1u, grid / (unsigned) div);
+    // pass A's tile width: that of the n2 core, or given explicitly (mixed-radix column pass: 16)
+    const int ca_width = ca > 0 ? ca : tile_width_for (n2);
     unsigned ca_log2 = 0;
-    while ((1 << ca_log2) < tile_width_for (n2))
+    while ((1 << ca_log2) < ca_width)
         ++ca_log2;
     hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (256), TG::lds_bytes, stream, work, out, tw1, (unsigned) n2, ca_log2, (unsigned) batch, out_stride);
     return hipGetLastError();
@@ -128,6 +132,50 @@ hipError_t launch_big_c2c (int n1, int n2, bool inverse, const float2* in, float
         if (e != hipSuccess)
             return e;
         CFFT_DISPATCH_BIG (n1, e = (pass_b<N_, false> (n2, work, out, tw1, batch, grid_divisor, stream, out_stride)));
+    }
+    return e;
+}
+
+// long mixed-radix frames: generic n2-point column pass (generic_kernels.hpp), then the ordinary n1-point row pass
+hipError_t launch_mixed_big_c2c (const DeviceTables& t, bool inverse, const float2* in, float2* work, float2* out, size_t batch, int grid_divisor, hipStream_t stream, size_t in_stride, size_t out_stride)
+{
+    if (batch == 0)
+        return hipSuccess;
+    const int n1 = t.mixed_n1, n2 = t.mixed_n2;
+    if (batch > 0x7FFFFFFFull || n1 < 64 || n2 < 16 || t.gen_ns < 1 || t.gen_ns > kGenericMaxStages)
+        return hipErrorInvalidValue;
+    const size_t frame_len = (size_t) n1 * (size_t) n2;
+    in_stride = in_stride ? in_stride : frame_len;
+    out_stride = out_stride ? out_stride : frame_len;
+    GenericPlan plan {};
+    plan.n = n2;
+    plan.ns = t.gen_ns;
+    plan.frames = kMixedTileWidth;
+    plan.in_stride = plan.out_stride = (unsigned) n2;
+    for (int i = 0; i < t.gen_ns; ++i)
+    {
+        plan.radix[i] = t.gen_radix[i];
+        plan.tw_offset[i] = t.gen_tw_offset[i];
+    }
+    const size_t lds = (size_t) 2 * kMixedTileWidth * ((size_t) n2 + 1) * sizeof (float2);
+    auto ka = inverse ? pass_a_generic_kernel<true> : pass_a_generic_kernel<false>;
+    unsigned grid = persistent_grid (ka, 256, lds, batch * (size_t) (n1 / kMixedTileWidth));
+    if (grid == 0)
+        return hipErrorNoDevice;
+    grid = std::max (1u, grid / (unsigned) grid_divisor);
+    hipLaunchKernelGGL (ka, dim3 (grid), dim3 (256), lds, stream, in, work, (const float2*) t.stage_twiddles, (const float2*) t.big_twiddles, plan, (unsigned) n1, (unsigned) batch, in_stride);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return e;
+    const float2* tw1 = t.stage_twiddles + t.mixed_tw1_offset;
+    e = hipErrorInvalidValue;
+    if (inverse)
+    {
+        CFFT_DISPATCH_BIG (n1, e = (pass_b<N_, true> (n2, work, out, tw1, batch, grid_divisor, stream, out_stride, kMixedTileWidth)));
+    }
+    else
+    {
+        CFFT_DISPATCH_BIG (n1, e = (pass_b<N_, false> (n2, work, out, tw1, batch, grid_divisor, stream, out_stride, kMixedTileWidth)));
     }
     return e;
 }

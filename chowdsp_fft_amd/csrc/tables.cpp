@@ -6,7 +6,7 @@
 
 namespace cfft::host
 {
-static void generic_radices (int n, std::vector<int>& radix);
+static void generic_radices (int n, std::vector<int>& radix, int frames_override);
 namespace
 {
 constexpr int kMaxLog2 = 20;
@@ -35,7 +35,7 @@ void append_stage_twiddles (const PlanDesc& d, std::vector<float2>& out)
 }
 } // namespace
 
-void generic_plan_radices (int n_complex, std::vector<int>& radix) { generic_radices (n_complex, radix); }
+void generic_plan_radices (int n_complex, std::vector<int>& radix) { generic_radices (n_complex, radix, 0); }
 
 bool core_radices (int n, int radix[4])
 {
@@ -58,6 +58,30 @@ void split_large (int n_complex, int& n1, int& n2)
     const int l2 = lg / 2; // pass A (column) length 2^l2, pass B (row) length 2^(lg-l2)
     n2 = 1 << l2;
     n1 = 1 << (lg - l2);
+}
+
+bool split_mixed (int n_complex, int& n1, int& n2)
+{
+    n1 = n2 = 0;
+    if (n_complex <= 0 || is_pow2 (n_complex))
+        return false;
+    int odd = n_complex, e = 0;
+    while (odd % 2 == 0) { odd /= 2; ++e; }
+    for (int j = 4; j <= e; ++j)
+    {
+        const long long c2 = (long long) odd << j;
+        if (c2 > kMixedMaxN2)
+            break;
+        const int r1 = 1 << (e - j);
+        // pass B works on tiles of tile_width_for (n1) adjacent rows (32 for n1 = 64): n2 must be a whole number of them
+        if (r1 >= 64 && r1 <= 1024 && c2 % tile_width_for (r1) == 0)
+        {
+            n1 = r1;
+            n2 = (int) c2;
+            return true;
+        }
+    }
+    return false;
 }
 
 // 2^a 3^b 5^c ?  (the reference's accepted prime factors, simd/chowdsp_fft_impl_common.hpp:51-82)
@@ -83,17 +107,29 @@ bool size_supported (int N, int transform)
     if (is_pow2 (N))
         return N <= (1 << kMaxLog2);
     // mixed-radix sizes run LDS-resident in the generic kernel: bounded by what two frame images need
-    return is_235_smooth (N) && (real ? N / 2 : N) <= kGenericMaxComplexLen;
+    if (! is_235_smooth (N))
+        return false;
+    const int nc = real ? N / 2 : N;
+    if (nc <= kGenericMaxComplexLen)
+        return true;
+    // longer frames: two passes (generic columns x power-of-two rows) where such a split exists
+    int n1 = 0, n2 = 0;
+    return split_mixed (nc, n1, n2);
 }
 
 // stage radices of the generic kernel for a 2^a 3^b 5^c length: fives, threes, then the power of two in as few
 // stages as the radix cap allows, the bits spread evenly (2^10 -> 16, 8, 8; 2^5 -> 8, 4).  The cap keeps at least a quarter
 // of the workgroup's work-items busy with a butterfly each: fewer, larger butterflies mean fewer LDS round trips
 // (N=9216: 7 -> 5 stages, +33 %), but 48 radix-16 butterflies on 256 work-items (N=768) lost 16 %.
-static void generic_radices (int n, std::vector<int>& radix)
+static void generic_radices (int n, std::vector<int>& radix, int frames_override)
 {
     int frames = 1, block = 256;
     generic_geometry (n, frames, block);
+    if (frames_override > 0) // column FFTs of a two-pass tile: that many frames per 256-thread workgroup
+    {
+        frames = frames_override;
+        block = 256;
+    }
     int cap_bits = 4;
     while (cap_bits > 2 && (frames * n) >> cap_bits < block / 4)
         --cap_bits;
@@ -127,11 +163,45 @@ bool build_host_tables (int N, int transform, HostTables& out)
             out.real_twiddles.push_back (unit_root (k, N));
     }
 
+    if (! is_pow2 (nc) && nc > kGenericMaxComplexLen)
+    {
+        // long mixed-radix frame: nc = n1 * n2, generic n2-point column FFTs then power-of-two n1-point row FFTs
+        int n1 = 0, n2 = 0;
+        if (! split_mixed (nc, n1, n2))
+            return false;
+        out.core_n = 0;
+        out.mixed_n1 = n1;
+        out.mixed_n2 = n2;
+        generic_radices (n2, out.generic_radix, kMixedTileWidth);
+        int p = 1;
+        for (int r : out.generic_radix)
+        {
+            out.generic_tw_offset.push_back ((int) out.stage_twiddles.size());
+            for (int a = 1; a < r; ++a)
+                for (int k = 0; k < p; ++k)
+                    out.stage_twiddles.push_back (unit_root ((long long) a * k, (long long) p * r));
+            p *= r;
+        }
+        if (p != n2 || out.generic_radix.size() > 10)
+            return false;
+        PlanDesc d1;
+        if (! core_plan_desc (n1, d1))
+            return false;
+        out.mixed_tw1_offset = (int) out.stage_twiddles.size();
+        append_stage_twiddles (d1, out.stage_twiddles);
+        // W_nc^{a*k2} in the workspace's tile-major order: [tile tA][k2][c], a = tA*16 + c (multipass_kernels.hpp)
+        out.big_twiddles.reserve ((size_t) nc);
+        for (int ta = 0; ta < n1 / kMixedTileWidth; ++ta)
+            for (int k2 = 0; k2 < n2; ++k2)
+                for (int c = 0; c < kMixedTileWidth; ++c)
+                    out.big_twiddles.push_back (unit_root ((long long) (ta * kMixedTileWidth + c) * k2, nc));
+        return true;
+    }
     if (! is_pow2 (nc))
     {
         // generic mixed-radix plan: per stage (r-1)*p entries [a-1][k] = W_{p*r}^{a*k}
         out.core_n = 0;
-        generic_radices (nc, out.generic_radix);
+        generic_radices (nc, out.generic_radix, 0);
         int p = 1;
         for (int r : out.generic_radix)
         {

@@ -19,6 +19,9 @@ struct HostTables
     std::vector<float2> big_twiddles;   // multi-pass plans, see multipass.hpp
     std::vector<int> generic_radix;     // non-power-of-two plans: stage radices of the generic kernel
     std::vector<int> generic_tw_offset; // ... and the offset of each stage's table inside stage_twiddles
+    // long mixed-radix plans (complex length > 9216): two passes, n2-point generic column FFTs (the radices above)
+    // then n1-point power-of-two row FFTs whose stage table starts at mixed_tw1_offset inside stage_twiddles
+    int mixed_n1 = 0, mixed_n2 = 0, mixed_tw1_offset = 0;
 };
 
 // Validates (N, transform) and fills the tables.  false = unsupported size.
@@ -49,4 +52,10 @@ inline void generic_geometry (int n, int& frames, int& block)
 void generic_plan_radices (int n_complex, std::vector<int>& radix);
 // For multi-pass sizes: N = n1 * n2 with both factors LDS-resident; (0,0) if N is LDS-resident itself.
 void split_large (int n_complex, int& n1, int& n2);
+// Long mixed-radix lengths (2^a 3^b 5^c, not a power of two, > kGenericMaxComplexLen): n = n1 * n2 with n2 = (odd part)
+// * 2^j the generic column length (a multiple of 16, at most kMixedMaxN2) and n1 a power of two in [64, 1024].
+// false if no such split exists (then the size is not supported).
+bool split_mixed (int n_complex, int& n1, int& n2);
+static constexpr int kMixedTileWidth = 16;  // columns per pass-A tile of the mixed two-pass plans
+static constexpr int kMixedMaxN2 = 640;     // two LDS images of 16 columns: 256 * n2 bytes <= 160 KiB
 } // namespace cfft::host

@@ -90,7 +90,12 @@ def test_size_rule_host_logic():
     for n in (96, 192, 384, 480, 640, 768, 9216):
         assert api.size_supported(n, api.FFT_COMPLEX) and api.size_supported(n, api.FFT_REAL)
     assert api.size_supported(1 << 20, api.FFT_REAL)
-    assert not api.size_supported(9216 + 1024, api.FFT_COMPLEX)  # 10240 = 2^11 * 5: too long for the LDS-resident generic kernel
+    # longer mixed-radix frames run in two passes when N = (odd part * 2^j <= 640) * (power of two in 64..1024) exists
+    assert api.size_supported(10240, api.FFT_COMPLEX) and api.size_supported(12288, api.FFT_COMPLEX)
+    assert api.size_supported(2 * 245760, api.FFT_REAL)
+    assert api.plan_describe(12288, api.FFT_COMPLEX) == {"complex_len": 12288, "passes": 2, "n1": 256, "n2": 48, "radices": [8, 8, 4]}
+    for n in (10368, 15360, 46080):  # 81 * 128, 15 * 1024 (240 x 64 does not tile), 45 * 1024: no such split -> NULL
+        assert not api.size_supported(n, api.FFT_COMPLEX), n
     assert api.size_supported(2 * 9216, api.FFT_REAL)
 
 

@@ -11,7 +11,7 @@ from oracle_lib import COMPLEX, REAL
 pytestmark = pytest.mark.gpu
 
 POW2 = [1 << k for k in range(4, 18)]
-MIXED = [48, 96, 160, 192, 240, 384, 480, 640, 768, 960, 1536, 2000, 3072, 5120, 9216]
+MIXED = [48, 96, 160, 192, 240, 384, 480, 640, 768, 960, 1536, 2000, 3072, 5120, 9216, 12288, 20480, 24576]
 
 
 def _exact_forward(x, n, tr):
