@@ -1,6 +1,6 @@
 // Streaming uniformly-partitioned overlap-save convolution engine, host side.
-// Blocks of 128 samples and more run as two fused kernels per block (conv_kernels.hpp: ols_r2c_kernel,
-// ols_mac_c2r_kernel); shorter blocks are built from the library's public batched operations plus three small
+// Blocks up to 4096 samples run as two fused kernels per block (conv_kernels.hpp: ols_r2c_kernel,
+// ols_mac_c2r_kernel); longer blocks are built from the library's public batched operations plus three small
 // kernels (frame assembly, delay-line multiply-accumulate, output extraction).  See include/chowdsp_fft_gpu.h.
 #include "../../include/chowdsp_fft_gpu.h"
 
@@ -28,7 +28,7 @@ struct Engine
     unsigned head = 0; // delay-line slot that receives the next spectrum
     void* setup = nullptr;
     float *prev = nullptr, *frame = nullptr, *fdl = nullptr, *H = nullptr, *Y = nullptr;
-    // fused path (block >= 128 and LDS-resident): two kernels per block, the previous input block double-buffered
+    // fused path (block <= 4096): two kernels per block, the previous input block double-buffered
     bool fused = false;
     float* prev2 = nullptr;
     void* state = nullptr; // device-resident position (OlsState): a captured process() call can be replayed block after block

@@ -557,7 +557,7 @@ __global__ __launch_bounds__ (P::T* FPB) void conv_frames_real_kernel_pf (const 
 //                       while streaming the delay line (the sum never goes to memory), inverse transform, and only
 //                       the valid second half of the result is written.
 // HBM traffic per channel and block (N = 2L floats per frame): (P + 3) N instead of (P + 8.5) N.
-// For plans with register-direct teams (T >= 16, i.e. block >= 128); P is the M = N/2 = L point plan.
+// P is the M = N/2 = L point plan (any LDS-resident length up to kMaxFusedN; narrow teams load directly as well).
 // Engine position, kept in DEVICE memory so that one captured process() call (a hipGraph) can be replayed for
 // successive blocks: head = delay-line slot that receives this block's spectrum, cur = which of the two half-frame
 // buffers holds the previous block.  The last workgroup of ols_mac_c2r_kernel to finish moves both on (every workgroup

@@ -131,10 +131,9 @@ hipError_t launch_ols_r2c_m (float2* buf0, float2* buf1, const float2* cur, floa
 {
     using P = typename CorePlan<M>::type;
     using G = Geometry<P>;
-    if constexpr (G::staged)
-        return hipErrorNotSupported; // narrow teams go through the LDS staging area: the engine uses the unfused path
-    else
     {
+        // narrow teams (block < 128) load and store directly too: they touch 32- or 64-byte pieces of a line per
+        // instruction, but a block is two launches instead of five, which is what counts at these sizes
         auto kernel = ols_r2c_kernel<P, G::FPB>;
         const unsigned grid = persistent_grid (kernel, G::threads, G::lds_bytes, (channels + G::FPB - 1) / G::FPB);
         if (grid == 0)
@@ -149,9 +148,6 @@ hipError_t launch_ols_mac_c2r_m (const float2* fdl, const float2* H, float2* out
 {
     using P = typename CorePlan<M>::type;
     using G = Geometry<P>;
-    if constexpr (G::staged)
-        return hipErrorNotSupported;
-    else
     {
         auto kernel = ols_mac_c2r_kernel<P, G::FPB>;
         const unsigned grid = persistent_grid (kernel, G::threads, G::lds_bytes, (channels + G::FPB - 1) / G::FPB);
@@ -166,7 +162,7 @@ hipError_t launch_ols_mac_c2r_m (const float2* fdl, const float2* H, float2* out
 bool ols_fused_supported (int m)
 {
     PlanDesc d;
-    return m <= kMaxFusedN && core_plan_desc (m, d) && d.T >= 16;
+    return m <= kMaxFusedN && core_plan_desc (m, d);
 }
 
 hipError_t launch_ols_r2c (int m, float* buf0, float* buf1, const float* cur, float* fdl, const float2* stage_tw, const float2* real_tw, unsigned channels, const void* state, hipStream_t stream)

@@ -41,8 +41,8 @@ def _oracle_engine(oracle, block, x, ir):
     return y
 
 
-# fused: blocks >= 128 run as two fused kernels per block; CHOWDSP_FFT_ENGINE_FUSED=0 (read at engine creation) forces
-# the five-kernel path built from the public batched operations, which shorter / two-pass blocks always take
+# fused: blocks <= 4096 run as two fused kernels per block; CHOWDSP_FFT_ENGINE_FUSED=0 (read at engine creation) forces
+# the five-kernel path built from the public batched operations, which longer blocks always take
 @pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("block,ir_len,channels,nblocks", [(16, 40, 3, 7), (64, 64, 2, 5), (128, 300, 37, 5), (256, 1000, 4, 6),
                                                            (1024, 1500, 5, 4), (2048, 5000, 3, 4), (4096, 4096, 2, 3),
