@@ -154,10 +154,22 @@ int fft_conv_engine_process (void* engine, const float* in, float* out, void* st
         const Setup* su = as_setup (e->setup);
         const DeviceGuard guard (su->device);
         const DeviceTables* t = su->tables;
-        hipError_t hf = launch_ols_r2c (e->block, e->prev, e->prev2, in, e->fdl, t->stage_twiddles, t->real_twiddles, (unsigned) C, e->state, stream);
-        if (hf == hipSuccess)
-            hf = launch_ols_mac_c2r (e->block, e->fdl, e->H, out, t->stage_twiddles, t->real_twiddles, 1.0f / (float) N, (unsigned) C,
-                                     (unsigned) e->partitions, e->state, e->shared, stream);
+        // CHOWDSP_FFT_ENGINE_SINGLE=0: two kernels per block (ols_r2c_kernel, ols_mac_c2r_kernel) instead of one
+        static const bool single = [] {
+            const char* v = std::getenv ("CHOWDSP_FFT_ENGINE_SINGLE");
+            return ! (v != nullptr && v[0] == '0');
+        }();
+        hipError_t hf = hipSuccess;
+        if (single)
+            hf = launch_ols_block (e->block, e->prev, e->prev2, in, e->fdl, e->H, out, t->stage_twiddles, t->real_twiddles, 1.0f / (float) N,
+                                   (unsigned) C, (unsigned) e->partitions, e->state, e->shared, stream);
+        else
+        {
+            hf = launch_ols_r2c (e->block, e->prev, e->prev2, in, e->fdl, t->stage_twiddles, t->real_twiddles, (unsigned) C, e->state, stream);
+            if (hf == hipSuccess)
+                hf = launch_ols_mac_c2r (e->block, e->fdl, e->H, out, t->stage_twiddles, t->real_twiddles, 1.0f / (float) N, (unsigned) C,
+                                         (unsigned) e->partitions, e->state, e->shared, stream);
+        }
         if (hf != hipSuccess)
         {
             set_last_error ("engine: fused block kernels", hf);

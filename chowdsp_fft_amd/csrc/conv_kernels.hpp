@@ -765,4 +765,196 @@ __global__ __launch_bounds__ (P::T* FPB) void ols_mac_c2r_kernel (const float2* 
         }
     }
 }
+
+// ---- the whole block in ONE kernel ------------------------------------------------------------------------------
+// Channels are independent, so the team that transforms a channel's new frame can go straight on to that channel's
+// delay-line sum and inverse transform: ols_r2c_kernel + ols_mac_c2r_kernel back to back per channel, with the new
+// spectrum used from registers for partition 0 (it is still written to its delay-line slot for the following blocks).
+// One launch per block instead of two (what counts for a handful of channels), (P + 2) N of traffic instead of (P + 3) N.
+template <class P, int FPB>
+__global__ __launch_bounds__ (P::T* FPB) void ols_block_kernel (float2* buf0, // [C][M/2] the two half-frame buffers
+                                                               float2* buf1,
+                                                               const float2* __restrict__ cur,  // [C][M/2] new block
+                                                               float2* fdl,                     // [Pn][C][M] delay line
+                                                               const float2* __restrict__ H,    // [Pn][C or 1][M]
+                                                               float2* __restrict__ out,        // [C][M/2]
+                                                               const float2* __restrict__ twtab,
+                                                               const float2* __restrict__ wtab,
+                                                               float scale,
+                                                               unsigned channels,
+                                                               unsigned Pn,
+                                                               OlsState* state,
+                                                               int h_shared)
+{
+    static_assert (P::R == P::radix (0), "input_index (t, s) == t + s * T is assumed below");
+    extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
+    constexpr int M = P::N, HALF = M / 2;
+    const unsigned st_cur = state->cur, head = state->head; // workgroup-uniform (scalar loads)
+    const float2* __restrict__ prev = st_cur == 0 ? buf0 : buf1;
+    float2* __restrict__ keep = st_cur == 0 ? buf1 : buf0;
+    const int tid = threadIdx.x;
+    const int team = tid / P::T;
+    const int t = tid % P::T;
+    float2* lds = smem + team * LdsFrame<M>::floats2;
+    const size_t slot_elems = (size_t) channels * M;
+    const size_t hpart_elems = (size_t) (h_shared ? 1u : channels) * M;
+    const unsigned ngroups = (channels + FPB - 1) / FPB;
+    for (unsigned g = blockIdx.x; g < ngroups; g += gridDim.x)
+    {
+        const unsigned c = g * FPB + team;
+        const bool active = c < channels;
+        // twiddles are (re)loaded per frame and per half: between the two transforms the registers hold the accumulators
+        // and the loads in flight (see ols_mac_c2r_kernel); the laundering keeps the compiler from hoisting them
+        const float2* twp = twtab;
+        const float2* wp = wtab;
+        asm volatile ("" : "+s"(twp), "+s"(wp));
+        PairTwiddles<P> pw;
+        load_pair_twiddles<P> (pw, wp, t);
+        float2 xk[P::R / 2], xp[P::R / 2]; // this block's spectrum, pairs (k, M - k)
+        {
+            TwiddleRegs<P> tw;
+            load_twiddles<P> (tw, twp, t);
+            const float2* __restrict__ lo = prev + (size_t) g * (FPB * HALF);
+            const float2* __restrict__ hi = cur + (size_t) g * (FPB * HALF);
+            float2* __restrict__ kp = keep + (size_t) g * (FPB * HALF);
+            const unsigned hbase = (unsigned) team * HALF + (unsigned) t;
+            float2 v[P::R];
+#pragma unroll
+            for (int s = 0; s < P::R / 2; ++s)
+                v[s] = active ? gload (&lo[hbase + (unsigned) (s * P::T)]) : make_float2 (0.f, 0.f);
+#pragma unroll
+            for (int s = P::R / 2; s < P::R; ++s)
+                v[s] = active ? gload (&hi[hbase + (unsigned) (s * P::T - HALF)]) : make_float2 (0.f, 0.f);
+            if (active)
+            {
+#pragma unroll
+                for (int s = P::R / 2; s < P::R; ++s)
+                    gstore (&kp[hbase + (unsigned) (s * P::T - HALF)], v[s]);
+            }
+            team_sync<P::T>();
+            fft_core<P> (v, tw, lds, t);
+            if constexpr (P::NS > 1)
+                team_sync<P::T>();
+            lds_store_output_order<P> (v, lds, t);
+            team_sync<P::T>();
+        }
+        float2* __restrict__ slot = fdl + (size_t) head * slot_elems + (size_t) g * (FPB * M);
+        const unsigned fo = (unsigned) team * M, ho = h_shared ? 0u : (unsigned) team * M;
+        const float2* __restrict__ hg = H + (h_shared ? (size_t) 0 : (size_t) g * (FPB * M));
+        float2 yk[P::R / 2], yp[P::R / 2];
+#pragma unroll
+        for (int q = 0; q < P::R / 2; ++q)
+        {
+            const int k = t + P::T * q;
+            const int kq = (k == 0 ? M / 2 : M - k);
+            const float2 A = lds[lds_phys (k)];
+            const float2 Zp = lds[lds_phys (kq)];
+            real_split_pair (A, Zp, pw.w[q], xk[q], xp[q]);
+            if (k == 0)
+            {
+                xk[q] = make_float2 (A.x + A.y, A.x - A.y);
+                xp[q] = make_float2 (Zp.x, -Zp.y);
+            }
+            if (active)
+            {
+                gstore (&slot[fo + (unsigned) k], xk[q]);
+                gstore (&slot[fo + (unsigned) kq], xp[q]);
+            }
+            // partition 0 straight from the registers
+            const float2 bk = hg[ho + (unsigned) k], bp = hg[ho + (unsigned) kq];
+            float2 mk = cmul (xk[q], bk);
+            if (k == 0)
+                mk = make_float2 (xk[q].x * bk.x, xk[q].y * bk.y); // packed DC / Nyquist: real products
+            const float2 mp = cmul (xp[q], bp);
+            yk[q] = make_float2 (mk.x * scale, mk.y * scale);
+            yp[q] = make_float2 (mp.x * scale, mp.y * scale);
+        }
+        if (active)
+        {
+            const float2* __restrict__ fg = fdl + (size_t) g * (FPB * M);
+            unsigned sl = (head == 0 ? Pn : head) - 1;
+#pragma unroll 1
+            for (unsigned p = 1; p < Pn; ++p)
+            {
+                const float2* __restrict__ fs = fg + (size_t) sl * slot_elems;
+                const float2* __restrict__ hs = hg + (size_t) p * hpart_elems;
+                float2 ak[P::R / 2], ap[P::R / 2], bk[P::R / 2], bp[P::R / 2];
+#pragma unroll
+                for (int q = 0; q < P::R / 2; ++q)
+                {
+                    const int k = t + P::T * q;
+                    const int kq = (k == 0 ? M / 2 : M - k);
+                    ak[q] = gload (&fs[fo + (unsigned) k]);
+                    ap[q] = gload (&fs[fo + (unsigned) kq]);
+                    bk[q] = hs[ho + (unsigned) k];
+                    bp[q] = hs[ho + (unsigned) kq];
+                }
+#pragma unroll
+                for (int q = 0; q < P::R / 2; ++q)
+                {
+                    const int k = t + P::T * q;
+                    float2 mk = cmul (ak[q], bk[q]);
+                    if (k == 0)
+                        mk = make_float2 (ak[q].x * bk[q].x, ak[q].y * bk[q].y);
+                    const float2 mp = cmul (ap[q], bp[q]);
+                    yk[q] = make_float2 (yk[q].x + mk.x * scale, yk[q].y + mk.y * scale);
+                    yp[q] = make_float2 (yp[q].x + mp.x * scale, yp[q].y + mp.y * scale);
+                }
+                sl = (sl == 0 ? Pn : sl) - 1;
+            }
+        }
+        // inverse half: as ols_mac_c2r_kernel
+        const float2* twp2 = twtab;
+        asm volatile ("" : "+s"(twp2));
+        TwiddleRegs<P> tw2;
+        load_twiddles<P> (tw2, twp2, t);
+        float2 zk[P::R / 2], zp[P::R / 2];
+#pragma unroll
+        for (int q = 0; q < P::R / 2; ++q)
+        {
+            const int k = t + P::T * q;
+            real_merge_pair (yk[q], yp[q], pw.w[q], zk[q], zp[q]);
+            if (k == 0)
+            {
+                zk[q] = make_float2 (yk[q].x + yk[q].y, yk[q].x - yk[q].y);
+                zp[q] = make_float2 (2.f * yp[q].x, -2.f * yp[q].y);
+            }
+        }
+        team_sync<P::T>(); // every pair of the forward spectrum has been read from the image
+#pragma unroll
+        for (int q = 0; q < P::R / 2; ++q)
+        {
+            const int k = t + P::T * q;
+            lds[lds_phys (k)] = make_float2 (zk[q].y, zk[q].x);
+            lds[lds_phys (k == 0 ? M / 2 : M - k)] = make_float2 (zp[q].y, zp[q].x);
+        }
+        team_sync<P::T>();
+        float2 u[P::R];
+        lds_load_input_order<P> (u, lds, t);
+        team_sync<P::T>();
+        fft_core<P> (u, tw2, lds, t);
+        if (active)
+        {
+            float2* __restrict__ dst = out + (size_t) c * HALF;
+#pragma unroll
+            for (int s = 0; s < P::R; ++s)
+            {
+                const int o = output_index<P> (t, s);
+                if (o >= HALF)
+                    gstore (&dst[o - HALF], make_float2 (u[s].y, u[s].x));
+            }
+        }
+        team_sync<P::T>(); // the image is free for the next channel's forward transform
+    }
+    if (threadIdx.x == 0)
+    {
+        const unsigned arrived = atomicAdd (&state->done, 1u);
+        if (arrived == gridDim.x - 1)
+        {
+            state->done = 0;
+            state->head = (head + 1) % Pn;
+            state->cur ^= 1u;
+        }
+    }
+}
 } // namespace cfft

@@ -159,6 +159,28 @@ hipError_t launch_ols_mac_c2r_m (const float2* fdl, const float2* H, float2* out
 }
 } // namespace
 
+namespace
+{
+template <int M>
+hipError_t launch_ols_block_m (float2* buf0, float2* buf1, const float2* cur, float2* fdl, const float2* H, float2* out, const float2* tw, const float2* rtw, float scale, unsigned channels, unsigned P_, OlsState* state, bool h_shared, hipStream_t stream)
+{
+    using P = typename CorePlan<M>::type;
+    using G = Geometry<P>;
+    auto kernel = ols_block_kernel<P, G::FPB>;
+    const unsigned grid = persistent_grid (kernel, G::threads, G::lds_bytes, (channels + G::FPB - 1) / G::FPB);
+    if (grid == 0)
+        return hipErrorNoDevice;
+    hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (G::threads), G::lds_bytes, stream, buf0, buf1, cur, fdl, H, out, tw, rtw, scale, channels, P_, state, h_shared ? 1 : 0);
+    return hipGetLastError();
+}
+} // namespace
+
+hipError_t launch_ols_block (int m, float* buf0, float* buf1, const float* cur, float* fdl, const float* H, float* out, const float2* stage_tw, const float2* real_tw, float scale, unsigned channels, unsigned P, void* state, bool h_shared, hipStream_t stream)
+{
+    CFFT_DISPATCH_N (m, return (launch_ols_block_m<N_> ((float2*) buf0, (float2*) buf1, (const float2*) cur, (float2*) fdl, (const float2*) H, (float2*) out, stage_tw, real_tw, scale, channels, P, (OlsState*) state, h_shared, stream)));
+    return hipErrorInvalidValue;
+}
+
 bool ols_fused_supported (int m)
 {
     PlanDesc d;

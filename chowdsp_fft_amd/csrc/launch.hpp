@@ -33,6 +33,8 @@ hipError_t launch_ols_extract (const float* y, float* out, size_t block, unsigne
 bool ols_fused_supported (int m);
 hipError_t launch_ols_r2c (int m, float* buf0, float* buf1, const float* cur, float* fdl, const float2* stage_tw, const float2* real_tw, unsigned channels, const void* state, hipStream_t stream);
 hipError_t launch_ols_mac_c2r (int m, const float* fdl, const float* H, float* out, const float2* stage_tw, const float2* real_tw, float scale, unsigned channels, unsigned P, void* state, bool h_shared, hipStream_t stream); // also moves the position on
+// the whole block in one launch (ols_block_kernel): forward transform, delay-line sum, inverse transform per channel
+hipError_t launch_ols_block (int m, float* buf0, float* buf1, const float* cur, float* fdl, const float* H, float* out, const float2* stage_tw, const float2* real_tw, float scale, unsigned channels, unsigned P, void* state, bool h_shared, hipStream_t stream);
 hipError_t launch_ols_advance (void* state, unsigned partitions, hipStream_t stream); // the same step on its own
 size_t ols_state_bytes();                                                             // device-resident engine position
 
