@@ -145,7 +145,7 @@ int fft_juce_real_inverse_batch (void* setup_real, float* inout, size_t batch, v
    All state (delay line, filter spectra, previous block) lives on the device.  `block` must be a power of two,
    16 <= block <= 2^19.  ir: host or device pointer, [ir_len] if ir_is_shared else [channels][ir_len].
    in / out: device pointers, [channels][block] floats each.  Returns NULL / negative codes on failure.
-   For block <= 4096 a block is two kernel launches and the engine's position is device-resident too, so one
+   For block <= 4096 a block is one kernel launch and the engine's position is device-resident too, so one
    fft_conv_engine_process() call captured into a hipGraph can be replayed for every following block (refresh `in`,
    launch the graph); other block sizes advance their position on the host and must be called, not replayed. */
 void* fft_conv_engine_create (int block, int channels, const float* ir, int ir_len, int ir_is_shared, void* stream);
