@@ -95,7 +95,9 @@ constexpr int tile_width (int n, int team_threads)
 #ifndef CFFT_TILE1024_WIDTH
 #define CFFT_TILE1024_WIDTH 8
 #endif
-    return n >= 1024 ? CFFT_TILE1024_WIDTH : (fpb > 16 ? fpb : 16);
+    // n = 64 (32 teams per workgroup) also takes 16: only the long mixed-radix plans still use a 64-point row pass, and
+    // their column length (odd part * 16) is a multiple of 16, not of 32; half of the teams idle there
+    return n >= 1024 ? CFFT_TILE1024_WIDTH : (fpb > 16 && n != 64 ? fpb : 16);
 }
 inline int tile_width_for (int n); // run-time version, defined after core_plan_desc
 

@@ -94,7 +94,8 @@ def test_size_rule_host_logic():
     assert api.size_supported(10240, api.FFT_COMPLEX) and api.size_supported(12288, api.FFT_COMPLEX)
     assert api.size_supported(2 * 245760, api.FFT_REAL)
     assert api.plan_describe(12288, api.FFT_COMPLEX) == {"complex_len": 12288, "passes": 2, "n1": 256, "n2": 48, "radices": [8, 8, 4]}
-    for n in (10368, 15360, 46080):  # 81 * 128, 15 * 1024 (240 x 64 does not tile), 45 * 1024: no such split -> NULL
+    assert api.size_supported(15360, api.FFT_COMPLEX)  # 240 x 64
+    for n in (10368, 46080):  # 81 * 128, 45 * 1024: no such split -> NULL
         assert not api.size_supported(n, api.FFT_COMPLEX), n
     assert api.size_supported(2 * 9216, api.FFT_REAL)
 
