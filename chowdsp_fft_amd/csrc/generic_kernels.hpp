@@ -245,22 +245,21 @@ __global__ __launch_bounds__ (BLOCK) void generic_kernel (const float2* __restri
 
 // ---- long mixed-radix frames (complex length > 9216): pass A of the two-pass plan -----------------------------------
 // N = n1 * n2 as in multipass_kernels.hpp, with n2 = (odd part) * 2^j a mixed-radix length and n1 a power of two:
-// this kernel does the n2-point COLUMN FFTs of a tile of 16 adjacent columns with the run-time stage list above and
+// this kernel does the n2-point COLUMN FFTs of a tile of CA (16, or 8 for n2 > 640) adjacent columns with the run-time stage list above and
 // writes them, times W_N^{a kb}, in the same tile-major workspace layout as pass_a_kernel; pass B is then the ordinary
 // power-of-two pass_b_kernel.  LDS: two images of 16 frames of n2 + 1 points (the + 1 keeps the 16 lanes that walk
 // across frames while the tile is loaded / stored off each other's banks).
-template <bool SWAP_IN>
+template <bool SWAP_IN, int CA>
 __global__ __launch_bounds__ (256) void pass_a_generic_kernel (const float2* __restrict__ in,
                                                               float2* __restrict__ work,
                                                               const float2* __restrict__ twtab,
                                                               const float2* __restrict__ big_tw,
-                                                              GenericPlan plan, // n = n2, frames = 16
+                                                              GenericPlan plan, // n = n2, frames = CA
                                                               unsigned n1,
                                                               unsigned batch,
                                                               size_t in_stride)
 {
     extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
-    constexpr int CA = 16;
     const int tid = threadIdx.x;
     const int n2 = plan.n;
     const unsigned lfs = (unsigned) n2 + 1u;

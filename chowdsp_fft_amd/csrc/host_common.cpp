@@ -117,6 +117,7 @@ const DeviceTables* acquire_tables (int device, int N, int transform)
     t->mixed_n1 = h.mixed_n1;
     t->mixed_n2 = h.mixed_n2;
     t->mixed_tw1_offset = h.mixed_tw1_offset;
+    t->mixed_ca = h.mixed_ca;
     t->stage_twiddles = upload (h.stage_twiddles);
     t->real_twiddles = upload (h.real_twiddles);
     t->big_twiddles = upload (h.big_twiddles);

@@ -49,7 +49,7 @@ struct DeviceTables
     int gen_tw_offset[10] = { 0 };
     // long mixed-radix plans: two passes, gen_* describe the n2-point column FFT, the n1-point row core's table starts at
     // stage_twiddles + mixed_tw1_offset; both 0 otherwise
-    int mixed_n1 = 0, mixed_n2 = 0, mixed_tw1_offset = 0;
+    int mixed_n1 = 0, mixed_n2 = 0, mixed_tw1_offset = 0, mixed_ca = 0;
 };
 
 // The plan header.  Lives either in a block we allocated (fft_new_setup) or in caller memory

@@ -150,16 +150,20 @@ hipError_t launch_mixed_big_c2c (const DeviceTables& t, bool inverse, const floa
     GenericPlan plan {};
     plan.n = n2;
     plan.ns = t.gen_ns;
-    plan.frames = kMixedTileWidth;
+    const int ca = t.mixed_ca;
+    if (ca != 16 && ca != 8)
+        return hipErrorInvalidValue;
+    plan.frames = ca;
     plan.in_stride = plan.out_stride = (unsigned) n2;
     for (int i = 0; i < t.gen_ns; ++i)
     {
         plan.radix[i] = t.gen_radix[i];
         plan.tw_offset[i] = t.gen_tw_offset[i];
     }
-    const size_t lds = (size_t) 2 * kMixedTileWidth * ((size_t) n2 + 1) * sizeof (float2);
-    auto ka = inverse ? pass_a_generic_kernel<true> : pass_a_generic_kernel<false>;
-    unsigned grid = persistent_grid (ka, 256, lds, batch * (size_t) (n1 / kMixedTileWidth));
+    const size_t lds = (size_t) 2 * ca * ((size_t) n2 + 1) * sizeof (float2);
+    auto ka = ca == 16 ? (inverse ? pass_a_generic_kernel<true, 16> : pass_a_generic_kernel<false, 16>)
+                       : (inverse ? pass_a_generic_kernel<true, 8> : pass_a_generic_kernel<false, 8>);
+    unsigned grid = persistent_grid (ka, 256, lds, batch * (size_t) (n1 / ca));
     if (grid == 0)
         return hipErrorNoDevice;
     grid = std::max (1u, grid / (unsigned) grid_divisor);
@@ -171,11 +175,11 @@ hipError_t launch_mixed_big_c2c (const DeviceTables& t, bool inverse, const floa
     e = hipErrorInvalidValue;
     if (inverse)
     {
-        CFFT_DISPATCH_BIG (n1, e = (pass_b<N_, true> (n2, work, out, tw1, batch, grid_divisor, stream, out_stride, kMixedTileWidth)));
+        CFFT_DISPATCH_BIG (n1, e = (pass_b<N_, true> (n2, work, out, tw1, batch, grid_divisor, stream, out_stride, ca)));
     }
     else
     {
-        CFFT_DISPATCH_BIG (n1, e = (pass_b<N_, false> (n2, work, out, tw1, batch, grid_divisor, stream, out_stride, kMixedTileWidth)));
+        CFFT_DISPATCH_BIG (n1, e = (pass_b<N_, false> (n2, work, out, tw1, batch, grid_divisor, stream, out_stride, ca)));
     }
     return e;
 }

@@ -172,7 +172,9 @@ bool build_host_tables (int N, int transform, HostTables& out)
         out.core_n = 0;
         out.mixed_n1 = n1;
         out.mixed_n2 = n2;
-        generic_radices (n2, out.generic_radix, kMixedTileWidth);
+        const int ca = mixed_tile_width (n2);
+        out.mixed_ca = ca;
+        generic_radices (n2, out.generic_radix, ca);
         int p = 1;
         for (int r : out.generic_radix)
         {
@@ -189,12 +191,12 @@ bool build_host_tables (int N, int transform, HostTables& out)
             return false;
         out.mixed_tw1_offset = (int) out.stage_twiddles.size();
         append_stage_twiddles (d1, out.stage_twiddles);
-        // W_nc^{a*k2} in the workspace's tile-major order: [tile tA][k2][c], a = tA*16 + c (multipass_kernels.hpp)
+        // W_nc^{a*k2} in the workspace's tile-major order: [tile tA][k2][c], a = tA*ca + c (multipass_kernels.hpp)
         out.big_twiddles.reserve ((size_t) nc);
-        for (int ta = 0; ta < n1 / kMixedTileWidth; ++ta)
+        for (int ta = 0; ta < n1 / ca; ++ta)
             for (int k2 = 0; k2 < n2; ++k2)
-                for (int c = 0; c < kMixedTileWidth; ++c)
-                    out.big_twiddles.push_back (unit_root ((long long) (ta * kMixedTileWidth + c) * k2, nc));
+                for (int c = 0; c < ca; ++c)
+                    out.big_twiddles.push_back (unit_root ((long long) (ta * ca + c) * k2, nc));
         return true;
     }
     if (! is_pow2 (nc))

@@ -21,7 +21,7 @@ struct HostTables
     std::vector<int> generic_tw_offset; // ... and the offset of each stage's table inside stage_twiddles
     // long mixed-radix plans (complex length > 9216): two passes, n2-point generic column FFTs (the radices above)
     // then n1-point power-of-two row FFTs whose stage table starts at mixed_tw1_offset inside stage_twiddles
-    int mixed_n1 = 0, mixed_n2 = 0, mixed_tw1_offset = 0;
+    int mixed_n1 = 0, mixed_n2 = 0, mixed_tw1_offset = 0, mixed_ca = 0; // mixed_ca: columns per pass-A tile (16 or 8)
 };
 
 // Validates (N, transform) and fills the tables.  false = unsupported size.
@@ -56,6 +56,9 @@ void split_large (int n_complex, int& n1, int& n2);
 // * 2^j the generic column length (a multiple of 16, at most kMixedMaxN2) and n1 a power of two in [64, 1024].
 // false if no such split exists (then the size is not supported).
 bool split_mixed (int n_complex, int& n1, int& n2);
-static constexpr int kMixedTileWidth = 16;  // columns per pass-A tile of the mixed two-pass plans
-static constexpr int kMixedMaxN2 = 640;     // two LDS images of 16 columns: 256 * n2 bytes <= 160 KiB
+// columns per pass-A tile of the mixed two-pass plans: 16 (128-byte rows) while two LDS images of 16 columns fit the CU's
+// 160 KiB (n2 <= 640), else 8 (n2 <= 1280)
+static constexpr int kMixedMaxN2Wide = 640;
+static constexpr int kMixedMaxN2 = 1280;
+inline int mixed_tile_width (int n2) { return n2 <= kMixedMaxN2Wide ? 16 : 8; }
 } // namespace cfft::host

@@ -95,7 +95,8 @@ def test_size_rule_host_logic():
     assert api.size_supported(2 * 245760, api.FFT_REAL)
     assert api.plan_describe(12288, api.FFT_COMPLEX) == {"complex_len": 12288, "passes": 2, "n1": 256, "n2": 48, "radices": [8, 8, 4]}
     assert api.size_supported(15360, api.FFT_COMPLEX)  # 240 x 64
-    for n in (10368, 46080):  # 81 * 128, 45 * 1024: no such split -> NULL
+    assert api.size_supported(46080, api.FFT_COMPLEX)  # 720 x 64, 8-wide column tiles
+    for n in (10368, 20736):  # 81 * 128, 81 * 256: odd part > 80, no such split -> NULL
         assert not api.size_supported(n, api.FFT_COMPLEX), n
     assert api.size_supported(2 * 9216, api.FFT_REAL)
 
