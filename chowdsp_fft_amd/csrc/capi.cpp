@@ -656,7 +656,7 @@ int fft_gpu_plan_describe (int N, fft_transform_t transform, int desc[8])
     if ((nc & (nc - 1)) != 0)
     {
         int m1 = 0, m2 = 0;
-        if (nc > 9216 && split_mixed (nc, m1, m2))
+        if (nc > 20000 && split_mixed (nc, m1, m2))
         {
             // long mixed-radix frame: two passes, generic n2-point columns then power-of-two n1-point rows (radices of n1)
             int radix1[4] = { 0, 0, 0, 0 };

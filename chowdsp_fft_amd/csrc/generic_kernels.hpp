@@ -16,7 +16,7 @@
 namespace cfft
 {
 static constexpr int kGenericMaxStages = 10;
-static constexpr int kGenericMaxN = 9216; // two LDS images of 8*N bytes must fit the CU's 160 KiB
+static constexpr int kGenericMaxN = 20000; // one LDS image of 8*N bytes (in-place stages, see below) within the CU's 160 KiB
 
 struct GenericPlan
 {
@@ -238,6 +238,228 @@ __global__ __launch_bounds__ (BLOCK) void generic_kernel (const float2* __restri
                 gstore (&dst[f * os + k], Xk);
                 if (kp != k)
                     gstore (&dst[f * os + kp], Xp);
+            }
+        }
+    }
+}
+
+// ---- long single frames (n > 2048): ONE LDS image, stages in place ------------------------------------------------------
+// A Stockham stage cannot overwrite its input while other work-items still read it, which is why generic_kernel ping-pongs
+// between two images.  With one frame per workgroup every work-item can afford to hold ALL of its butterflies of a stage
+// in registers (at most 20 points per work-item: the workgroup size grows with n), so a stage becomes: read everything,
+// barrier, twiddle + butterfly + write everything, barrier -- on a single image.  Half the LDS means two workgroups per
+// CU up to n = 10240 (their load / compute / store phases overlap), and frames of up to 20000 points fit at all.
+static constexpr int kInplaceMaxPoints = 20; // points per work-item and stage
+
+template <int R, int BLOCK, int IO, bool SWAP>
+__device__ __forceinline__ void inplace_stage (const float2* __restrict__ gin, float2* __restrict__ gout, float2* __restrict__ buf,
+                                               const float2* __restrict__ tw, int n, int p, int tid)
+{
+    constexpr int J = (kInplaceMaxPoints + R - 1) / R; // butterflies per work-item
+    const int m = n / R;
+    if constexpr ((IO & 1) != 0)
+    {
+        // the stage that reads global memory is always the first one (p == 1: no twiddles, output index i * R + b) and
+        // overwrites nothing it reads: U butterflies at a time, all their loads issued before the first butterfly
+        constexpr int U = R <= 4 ? 4 : (R <= 8 ? 2 : 1);
+#pragma unroll 1
+        for (int i0 = tid; i0 < m; i0 += U * BLOCK)
+        {
+            float2 u[U][R];
+#pragma unroll
+            for (int q = 0; q < U; ++q)
+            {
+                const int i = i0 + q * BLOCK;
+                if (i < m)
+                {
+#pragma unroll
+                    for (int a = 0; a < R; ++a)
+                    {
+                        const float2 x = gload (&gin[(unsigned) (i + a * m)]); // 32-bit offset from a uniform base
+                        u[q][a] = SWAP ? make_float2 (x.y, x.x) : x;
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < U; ++q)
+            {
+                const int i = i0 + q * BLOCK;
+                if (i < m)
+                {
+                    fft_reg<R> (u[q]);
+#pragma unroll
+                    for (int b = 0; b < R; ++b)
+                    {
+                        if (IO & 2)
+                            gstore (&gout[(unsigned) (i * R + b)], SWAP ? make_float2 (u[q][b].y, u[q][b].x) : u[q][b]);
+                        else
+                            buf[i * R + b] = u[q][b];
+                    }
+                }
+            }
+        }
+        if (! (IO & 2))
+            __syncthreads();
+        return;
+    }
+    else
+    {
+        const bool p_pow2 = (p & (p - 1)) == 0;
+        float2 u[J][R];
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+        {
+            const int i = tid + j * BLOCK;
+            if (i < m)
+            {
+#pragma unroll
+                for (int a = 0; a < R; ++a)
+                    u[j][a] = buf[i + a * m];
+            }
+        }
+        __syncthreads(); // every operand of this stage has left the image
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+        {
+            const int i = tid + j * BLOCK;
+            if (i < m)
+            {
+                const int k = p_pow2 ? (i & (p - 1)) : (i % p);
+                const int jj = (i - k) * R + k;
+                if (p > 1)
+                {
+#pragma unroll
+                    for (int a = 1; a < R; ++a)
+                        u[j][a] = cmul (u[j][a], tw[(a - 1) * p + k]);
+                }
+                fft_reg<R> (u[j]);
+#pragma unroll
+                for (int b = 0; b < R; ++b)
+                {
+                    if (IO & 2)
+                        gstore (&gout[(unsigned) (jj + b * p)], SWAP ? make_float2 (u[j][b].y, u[j][b].x) : u[j][b]);
+                    else
+                        buf[jj + b * p] = u[j][b];
+                }
+            }
+        }
+        if (! (IO & 2))
+            __syncthreads(); // the image holds this stage's result
+    }
+}
+
+template <int BLOCK, int IO, bool SWAP>
+__device__ __forceinline__ void inplace_stage_dispatch (int r, const float2* __restrict__ gin, float2* __restrict__ gout, float2* __restrict__ buf,
+                                                        const float2* __restrict__ tw, int n, int p, int tid)
+{
+    switch (r)
+    {
+        case 2: inplace_stage<2, BLOCK, IO, SWAP> (gin, gout, buf, tw, n, p, tid); break;
+        case 3: inplace_stage<3, BLOCK, IO, SWAP> (gin, gout, buf, tw, n, p, tid); break;
+        case 4: inplace_stage<4, BLOCK, IO, SWAP> (gin, gout, buf, tw, n, p, tid); break;
+        case 5: inplace_stage<5, BLOCK, IO, SWAP> (gin, gout, buf, tw, n, p, tid); break;
+        case 8: inplace_stage<8, BLOCK, IO, SWAP> (gin, gout, buf, tw, n, p, tid); break;
+        default:
+            // 1024-thread workgroups (n > 10240) have 128 VGPRs: two radix-16 butterflies in flight do not fit, and the
+            // plans for those lengths are built with radices up to 8 (tables.cpp)
+            if constexpr (BLOCK < 1024)
+                inplace_stage<16, BLOCK, IO, SWAP> (gin, gout, buf, tw, n, p, tid);
+            break;
+    }
+}
+
+template <int BLOCK, bool IN_GLOBAL, bool OUT_GLOBAL, bool SWAP>
+__device__ __forceinline__ void inplace_core (const GenericPlan& plan, const float2* __restrict__ twtab, float2* buf,
+                                              const float2* __restrict__ gin, float2* __restrict__ gout, int tid)
+{
+    int p = 1;
+    for (int s = 0; s < plan.ns; ++s)
+    {
+        const int r = plan.radix[s];
+        const float2* tw = twtab + plan.tw_offset[s];
+        const bool first = IN_GLOBAL && s == 0, last = OUT_GLOBAL && s == plan.ns - 1;
+        if (first && last)
+            inplace_stage_dispatch<BLOCK, 3, SWAP> (r, gin, gout, buf, tw, plan.n, p, tid);
+        else if (first)
+            inplace_stage_dispatch<BLOCK, 1, SWAP> (r, gin, gout, buf, tw, plan.n, p, tid);
+        else if (last)
+            inplace_stage_dispatch<BLOCK, 2, SWAP> (r, gin, gout, buf, tw, plan.n, p, tid);
+        else
+            inplace_stage_dispatch<BLOCK, 0, false> (r, gin, gout, buf, tw, plan.n, p, tid);
+        p *= r;
+    }
+}
+
+// same MODEs as generic_kernel; one frame per workgroup pass
+template <int MODE, bool INV, int BLOCK>
+__global__ __launch_bounds__ (BLOCK) void generic_inplace_kernel (const float2* __restrict__ in,
+                                                                 float2* __restrict__ out,
+                                                                 const float2* __restrict__ twtab,
+                                                                 const float2* __restrict__ wtab,
+                                                                 GenericPlan plan,
+                                                                 unsigned batch)
+{
+    extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
+    const int tid = threadIdx.x;
+    const int n = plan.n;
+    const int half = n / 2 + 1;
+    float2* buf = smem;
+    for (unsigned g = blockIdx.x; g < batch; g += gridDim.x)
+    {
+        const float2* __restrict__ src = in + (size_t) g * plan.in_stride;
+        float2* __restrict__ dst = out + (size_t) g * plan.out_stride;
+        __syncthreads(); // previous frame's reads of the image are finished
+        if (MODE == 2)
+        {
+            for (int k = tid; k < half; k += BLOCK)
+            {
+                const int kp = (k == 0) ? 0 : n - k;
+                const float2 A = gload (&src[k]);
+                const float2 Xp = gload (&src[kp]);
+                float2 zk, zp;
+                if (k == 0)
+                {
+                    zk = make_float2 (A.x + A.y, A.x - A.y);
+                    zp = zk;
+                }
+                else if (2 * k == n)
+                {
+                    zk = make_float2 (2.f * A.x, -2.f * A.y);
+                    zp = zk;
+                }
+                else
+                    real_merge_pair (A, Xp, wtab[k], zk, zp);
+                buf[k] = make_float2 (zk.y, zk.x);
+                if (kp != k)
+                    buf[kp] = make_float2 (zp.y, zp.x);
+            }
+            __syncthreads();
+        }
+        constexpr bool IN_GLOBAL = (MODE != 2), OUT_GLOBAL = (MODE != 1);
+        inplace_core<BLOCK, IN_GLOBAL, OUT_GLOBAL, (MODE == 2) || INV> (plan, twtab, buf, src, dst, tid);
+        if (MODE == 1)
+        {
+            for (int k = tid; k < half; k += BLOCK)
+            {
+                const int kp = (k == 0) ? 0 : n - k;
+                const float2 A = buf[k];
+                const float2 Zp = buf[kp];
+                float2 Xk, Xp;
+                if (k == 0)
+                {
+                    Xk = make_float2 (A.x + A.y, A.x - A.y);
+                    Xp = Xk;
+                }
+                else if (2 * k == n)
+                {
+                    Xk = make_float2 (A.x, -A.y);
+                    Xp = Xk;
+                }
+                else
+                    real_split_pair (A, Zp, wtab[k], Xk, Xp);
+                gstore (&dst[k], Xk);
+                if (kp != k)
+                    gstore (&dst[kp], Xp);
             }
         }
     }

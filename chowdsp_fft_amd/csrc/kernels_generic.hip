@@ -3,6 +3,8 @@
 #include "launch_util.hpp"
 #include "tables.hpp"
 
+#include <cstdlib>
+
 namespace cfft::host
 {
 namespace
@@ -26,13 +28,56 @@ hipError_t launch_generic_mb (const GenericPlan& plan, const DeviceTables& t, co
     return hipGetLastError();
 }
 
+template <int MODE, bool INV, int BLOCK>
+hipError_t launch_generic_inplace (const GenericPlan& plan, const DeviceTables& t, const float2* in, float2* out, size_t batch, hipStream_t stream)
+{
+    auto kernel = generic_inplace_kernel<MODE, INV, BLOCK>;
+    const size_t lds = (size_t) plan.n * sizeof (float2);
+    const unsigned grid = persistent_grid (kernel, BLOCK, lds, batch); // raises the dynamic-LDS cap when lds > 64 KiB
+    if (grid == 0)
+        return hipErrorNoDevice;
+    hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (BLOCK), lds, stream, in, out, (const float2*) t.stage_twiddles, (const float2*) t.real_twiddles, plan, (unsigned) batch);
+    return hipGetLastError();
+}
+
 template <int MODE, bool INV>
 hipError_t launch_generic_m (GenericPlan& plan, const DeviceTables& t, const float2* in, float2* out, size_t batch, hipStream_t stream)
 {
     int block = 256;
     generic_geometry (plan.n, plan.frames, block); // tables.hpp: the stage radices were chosen for this geometry
-    if (block == 1024)
-        return launch_generic_mb<MODE, INV, 1024> (plan, t, in, out, batch, stream);
+    // CHOWDSP_FFT_GENERIC_INPLACE (experiment): 0 = two-image kernel wherever it fits (n <= 9216), 1 = in-place kernel for
+    // every n > 2048; default: see use_inplace below
+    static const int force = [] {
+        const char* e = std::getenv ("CHOWDSP_FFT_GENERIC_INPLACE");
+        return e != nullptr ? std::atoi (e) : -1;
+    }();
+    // measured on MI355X (fwd+inv, in-place vs two images): complex n = 2304 / 3072 / 4608 / 5120: 3.07 / 3.62 / 3.40 / 3.96 vs
+    // 2.65 / 2.92 / 2.39 / 2.51 TB/s; real N = 6144 / 9216 / 18432: 3.27 / 3.16 / 3.15 vs 2.31 / 2.15 / 2.49; but complex
+    // n = 6400 / 7680 / 9216 (512-thread in-place workgroups): 2.40 / 2.58 / 2.62 vs 2.46 / 2.82 / 2.83
+    bool use_inplace = generic_uses_inplace (plan.n) && ! (MODE == 0 && plan.n > 5120 && plan.n <= 9216);
+    if (force == 0 && plan.n <= 9216)
+        use_inplace = false;
+    if (force == 1 && plan.n > 2048)
+        use_inplace = true;
+    if (! use_inplace && plan.n > 2048)
+    {
+        // the two-image kernel for a long frame: one frame per workgroup, 1024 work-items when the images exceed 64 KiB
+        plan.frames = 1;
+        if (2 * (size_t) plan.n * sizeof (float2) > 64 * 1024)
+            return launch_generic_mb<MODE, INV, 1024> (plan, t, in, out, batch, stream);
+        return launch_generic_mb<MODE, INV, 256> (plan, t, in, out, batch, stream);
+    }
+    if (use_inplace)
+    {
+        if ((plan.n + block - 1) / block > kInplaceMaxPoints)
+            return hipErrorInvalidValue;
+        switch (block)
+        {
+            case 256: return launch_generic_inplace<MODE, INV, 256> (plan, t, in, out, batch, stream);
+            case 512: return launch_generic_inplace<MODE, INV, 512> (plan, t, in, out, batch, stream);
+            default: return launch_generic_inplace<MODE, INV, 1024> (plan, t, in, out, batch, stream);
+        }
+    }
     return launch_generic_mb<MODE, INV, 256> (plan, t, in, out, batch, stream);
 }
 } // namespace

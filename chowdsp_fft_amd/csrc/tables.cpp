@@ -95,7 +95,7 @@ static bool is_235_smooth (int n)
     return n == 1;
 }
 
-static constexpr int kGenericMaxComplexLen = 9216; // = cfft::kGenericMaxN (two LDS images per workgroup)
+static constexpr int kGenericMaxComplexLen = 20000; // = cfft::kGenericMaxN (one LDS image per workgroup, in-place stages)
 
 bool size_supported (int N, int transform)
 {
@@ -130,7 +130,7 @@ static void generic_radices (int n, std::vector<int>& radix, int frames_override
         frames = frames_override;
         block = 256;
     }
-    int cap_bits = 4;
+    int cap_bits = (frames_override == 0 && block == 1024) ? 3 : 4; // 1024-thread in-place kernel: radices up to 8
     while (cap_bits > 2 && (frames * n) >> cap_bits < block / 4)
         --cap_bits;
     radix.clear();

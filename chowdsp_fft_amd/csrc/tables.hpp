@@ -35,18 +35,26 @@ bool core_radices (int n, int radix[4]);
 // per workgroup (shared by the radix choice in tables.cpp and the launcher in kernels_generic.hip)
 inline void generic_geometry (int n, int& frames, int& block)
 {
-    // Long frames: the two LDS images (16 bytes per point) allow one workgroup per CU, so it gets 1024 work-items.
-    // Short frames: several per workgroup so that each of the 256 work-items has butterflies (~2048 points in flight;
-    // measured: N=480 +4 % with 4 frames, N=768 -13 % with 2).
-    block = (2 * (size_t) n * 8 > 64 * 1024) ? 1024 : 256;
+    // Long frames (n > 2048): one frame per workgroup in ONE LDS image with in-place stages (generic_inplace_kernel); the
+    // workgroup grows with n so that a work-item never holds more than 20 points of a stage.
+    // Short frames: two images, several frames per workgroup so that each of the 256 work-items has butterflies (~2048
+    // points in flight; measured: N=480 +4 % with 4 frames, N=640 +86 % with 3).
+    if (n > 2048)
+    {
+        block = n <= 5120 ? 256 : (n <= 10240 ? 512 : 1024);
+        frames = 1;
+        return;
+    }
+    block = 256;
 #ifndef CFFT_GENERIC_MULTI_MAX
 #define CFFT_GENERIC_MULTI_MAX 1024
 #endif
 #ifndef CFFT_GENERIC_POINTS
 #define CFFT_GENERIC_POINTS 2048
 #endif
-    frames = (block == 256 && n <= CFFT_GENERIC_MULTI_MAX) ? (CFFT_GENERIC_POINTS / n > 1 ? CFFT_GENERIC_POINTS / n : 1) : 1;
+    frames = (n <= CFFT_GENERIC_MULTI_MAX) ? (CFFT_GENERIC_POINTS / n > 1 ? CFFT_GENERIC_POINTS / n : 1) : 1;
 }
+inline bool generic_uses_inplace (int n) { return n > 2048; }
 
 // stage radices of the generic mixed-radix kernel for a complex length that is not a power of two
 void generic_plan_radices (int n_complex, std::vector<int>& radix);

@@ -90,13 +90,15 @@ def test_size_rule_host_logic():
     for n in (96, 192, 384, 480, 640, 768, 9216):
         assert api.size_supported(n, api.FFT_COMPLEX) and api.size_supported(n, api.FFT_REAL)
     assert api.size_supported(1 << 20, api.FFT_REAL)
-    # longer mixed-radix frames run in two passes when N = (odd part * 2^j <= 640) * (power of two in 64..1024) exists
-    assert api.size_supported(10240, api.FFT_COMPLEX) and api.size_supported(12288, api.FFT_COMPLEX)
+    # mixed-radix frames: one pass (in-place stages in one LDS image) up to a complex length of 20000, longer ones in two
+    # passes when N = (odd part * 2^j <= 1280, j >= 4) * (power of two in 64..1024) exists
+    for n in (10240, 10368, 11520, 12288, 13824, 19200):
+        assert api.size_supported(n, api.FFT_COMPLEX), n
+        assert api.plan_describe(n, api.FFT_COMPLEX)["passes"] == 1
     assert api.size_supported(2 * 245760, api.FFT_REAL)
-    assert api.plan_describe(12288, api.FFT_COMPLEX) == {"complex_len": 12288, "passes": 2, "n1": 256, "n2": 48, "radices": [8, 8, 4]}
-    assert api.size_supported(15360, api.FFT_COMPLEX)  # 240 x 64
+    assert api.plan_describe(24576, api.FFT_COMPLEX) == {"complex_len": 24576, "passes": 2, "n1": 512, "n2": 48, "radices": [8, 8, 8]}
     assert api.size_supported(46080, api.FFT_COMPLEX)  # 720 x 64, 8-wide column tiles
-    for n in (10368, 20736):  # 81 * 128, 81 * 256: odd part > 80, no such split -> NULL
+    for n in (20736, 41472):  # 81 * 256, 81 * 512: odd part > 80, no such split -> NULL
         assert not api.size_supported(n, api.FFT_COMPLEX), n
     assert api.size_supported(2 * 9216, api.FFT_REAL)
 

@@ -13,10 +13,10 @@ from oracle_lib import BACKWARD, COMPLEX, FORWARD, REAL
 pytestmark = pytest.mark.gpu
 
 REFERENCE_OTHER_SIZES = [96, 192, 384, 480, 640, 768, 9216]
-MORE_SIZES = [48, 80, 160, 240, 320, 720, 1440, 2000, 3072, 5120, 6400, 7680, 8640]
-# complex length > 9216: two passes (generic n2-point column FFTs x power-of-two n1-point row FFTs) where such a split
+MORE_SIZES = [48, 80, 160, 240, 320, 720, 1440, 2000, 2304, 3072, 5120, 6400, 7680, 8640, 10240, 10368, 11520, 13824, 17280, 19200]
+# complex length > 20000 (and some below, as real frames of twice the length): two passes (generic n2-point column FFTs x power-of-two n1-point row FFTs) where such a split
 # exists; sizes without one (test_long_mixed_sizes_without_a_split) come back NULL although the reference accepts them
-LONG_MIXED_SIZES = [10240, 12288, 15360, 18432, 20480, 24576, 25600, 46080, 61440, 76800, 98304, 245760]
+LONG_MIXED_SIZES = [12288, 15360, 18432, 20480, 24576, 25600, 46080, 61440, 76800, 98304, 245760]
 
 
 def _gpu(gpu, s, x, direction):
@@ -118,7 +118,7 @@ def test_long_mixed_sizes_without_a_split(gpu, oracle):
     """documented gap: the reference plans any 2^a 3^b 5^c length; this backend returns NULL where the complex length is
     > 9216 and has no (odd part * 2^j <= 1280) x (power of two in 64..1024) factorisation"""
     api = gpu[0]
-    for n in (10368, 20736):
+    for n in (20736, 41472):
         so = oracle.new_setup(n, COMPLEX)
         assert so is not None
         oracle.destroy_setup(so)
