@@ -58,8 +58,8 @@ const char* fft_gpu_last_error (void);
 /* 1 if fft_new_setup would accept (N, transform) on a machine with a usable device, else 0.  Pure host
    logic (no GPU needed); the rule is the reference's SSE size rule (N % 16 complex / N % 32 real, N = 2^a 3^b 5^c;
    reference simd/chowdsp_fft_impl_common.hpp:168-177, 216-225) with powers of two up to 2^20, mixed-radix
-   sizes up to a complex length of 9216, and longer mixed-radix sizes that factor as (odd part * 2^j <= 1280,
-   j >= 4) x (power of two in 64..1024), e.g. 12288 = 48 x 256, 46080 = 720 x 64. */
+   sizes up to a complex length of 20000, and longer mixed-radix sizes that factor as (odd part * 2^j <= 1280,
+   j >= 4) x (power of two in 64..1024), e.g. 24576 = 48 x 512, 46080 = 720 x 64. */
 int fft_gpu_size_supported (int N, fft_transform_t transform);
 /* How (N, transform) is executed.  Fills desc[0..7] = { complex length transformed, number of passes
    through device memory (1 = LDS-resident, 2 = two-pass), n1, n2 (two-pass split, else 0), then up to
