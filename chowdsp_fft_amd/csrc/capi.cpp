@@ -301,7 +301,7 @@ int run_transform (Setup* s, const float* in, float* out, size_t batch, cf::fft_
     hipError_t e = hipSuccess;
     if (t->mixed_n2 > 0)
     {
-        // long mixed-radix frame (complex length > 9216): two passes; real frames add the pair stage per chunk
+        // long mixed-radix frame (complex length > 20000): two passes; real frames add the pair stage per chunk
         if (s->transform == cf::FFT_COMPLEX)
             return big_c2c_chunked (s, nc, inverse, cin, cout, batch, stream, is2, os2);
         return big_c2c_chunked (s, nc, inverse, cin, cout, batch, stream, is2, os2, inverse ? -1 : +1);

@@ -465,7 +465,7 @@ __global__ __launch_bounds__ (BLOCK) void generic_inplace_kernel (const float2* 
     }
 }
 
-// ---- long mixed-radix frames (complex length > 9216): pass A of the two-pass plan -----------------------------------
+// ---- long mixed-radix frames (complex length > 20000): pass A of the two-pass plan -----------------------------------
 // N = n1 * n2 as in multipass_kernels.hpp, with n2 = (odd part) * 2^j a mixed-radix length and n1 a power of two:
 // this kernel does the n2-point COLUMN FFTs of a tile of CA (16, or 8 for n2 > 640) adjacent columns with the run-time stage list above and
 // writes them, times W_N^{a kb}, in the same tile-major workspace layout as pass_a_kernel; pass B is then the ordinary

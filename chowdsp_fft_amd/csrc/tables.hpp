@@ -19,7 +19,7 @@ struct HostTables
     std::vector<float2> big_twiddles;   // multi-pass plans, see multipass.hpp
     std::vector<int> generic_radix;     // non-power-of-two plans: stage radices of the generic kernel
     std::vector<int> generic_tw_offset; // ... and the offset of each stage's table inside stage_twiddles
-    // long mixed-radix plans (complex length > 9216): two passes, n2-point generic column FFTs (the radices above)
+    // long mixed-radix plans (complex length > 20000): two passes, n2-point generic column FFTs (the radices above)
     // then n1-point power-of-two row FFTs whose stage table starts at mixed_tw1_offset inside stage_twiddles
     int mixed_n1 = 0, mixed_n2 = 0, mixed_tw1_offset = 0, mixed_ca = 0; // mixed_ca: columns per pass-A tile (16 or 8)
 };

@@ -73,7 +73,7 @@ def test_bytes_required_is_never_below_the_reference_figure():
 
 def test_size_rule_host_logic():
     """the reference's rule (common.hpp:168-177, 216-225): N % 16 (complex) / N % 32 (real) and no prime
-    factor other than 2, 3, 5; powers of two up to 2^20, mixed-radix sizes while the complex length <= 9216"""
+    factor other than 2, 3, 5; powers of two up to 2^20, mixed-radix sizes in one pass up to a complex length of 20000, longer ones where a two-pass split exists"""
 
     def smooth(n):
         for f in (2, 3, 5):
