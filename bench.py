@@ -243,7 +243,7 @@ def main() -> int:
             alg_bytes_per_launch = 4 * frames * (2 * (n // 2) + 16 * n + n)
             transforms_per_frame_step = 2
         achieved = alg_bytes_per_launch / avg_launch_s / 1e9
-        kernel = {"complex": "cfft::c2c_kernel<Plan<4096,256,16,16,16>> (forward and backward instantiations)"}.get(
+        kernel = {"complex": "cfft::c2c_kernel_pf<Plan<4096,256,16,16,16>, 1, INV, false> (forward and backward instantiations)"}.get(
             transform if n == 4096 and not fused else "", f"{args.workload} kernels")
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
