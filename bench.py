@@ -243,8 +243,14 @@ def main() -> int:
             alg_bytes_per_launch = 4 * frames * (2 * (n // 2) + 16 * n + n)
             transforms_per_frame_step = 2
         achieved = alg_bytes_per_launch / avg_launch_s / 1e9
-        kernel = {"complex": "cfft::c2c_kernel_pf<Plan<4096,256,16,16,16>, 1, INV, false> (forward and backward instantiations)"}.get(
-            transform if n == 4096 and not fused else "", f"{args.workload} kernels")
+        kernel = {
+            "c2c_n4096_b65536_fwd_inv": "cfft::c2c_kernel_pf<Plan<4096,256,16,16,16>, 1, INV, false> (forward and backward instantiations)",
+            "real_n1024_b262144_fwd_inv": "cfft::r2c_kernel<Plan<512,64,8,8,8>, 4, false> and cfft::c2r_kernel<Plan<512,64,8,8,8>, 4, false>",
+            "conv_real_n4096_b131072": "cfft::conv_frames_real_kernel_pf<Plan<2048,128,16,16,8>, 1, false>",
+            "c2c_n65536_b8192_fwd_inv": "cfft::pass_a256_kernel<INV> + cfft::pass_b256_kernel<INV> per 256-frame chunk (two passes over the frame)",
+            "c2c_n9216_b16384_fwd_inv": "cfft::generic_kernel<0, INV, 1024>",
+            "ols_engine_b2048_p16_c8192": "cfft::ols_block_kernel<Plan<2048,128,16,16,8>, 2>",
+        }.get(args.workload, f"{args.workload} kernels")
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
