@@ -14,6 +14,9 @@ struct TileGeom
     using P = typename CorePlan<N>::type;
     static constexpr int C = tile_width (N, P::T);
     static constexpr size_t lds_bytes = (size_t) C * TileFrame<N>::stride * sizeof (float2);
+    // work-items per workgroup: enough teams for every frame of the tile at once where that needs more than 256
+    // (CFFT_TILE_BLOCK_MIN_N, plans.hpp): one round of per-frame FFTs instead of C * T / 256 rounds with barriers between
+    static constexpr int BLOCK = (N >= CFFT_TILE_BLOCK_MIN_N && C * P::T > 256) ? (C * P::T > 1024 ? 1024 : C * P::T) : 256;
 };
 
 template <class K>
@@ -29,16 +32,16 @@ template <int N2, bool INV>
 hipError_t pass_a (int n1, const float2* in, float2* work, const float2* tw2, const float2* big_tw, size_t batch, int div, hipStream_t stream, size_t in_stride)
 {
     using TG = TileGeom<N2>;
-    auto kernel = pass_a_kernel<typename TG::P, TG::C, INV>;
+    auto kernel = pass_a_kernel<typename TG::P, TG::C, INV, TG::BLOCK>;
     hipError_t e = ensure_lds (kernel, TG::lds_bytes);
     if (e != hipSuccess)
         return e;
     const size_t tiles = (size_t) (n1 / TG::C);
-    unsigned grid = persistent_grid (kernel, 256, TG::lds_bytes, batch * tiles);
+    unsigned grid = persistent_grid (kernel, TG::BLOCK, TG::lds_bytes, batch * tiles);
     if (grid == 0)
         return hipErrorNoDevice;
     grid = std::max (1u, grid / (unsigned) div);
-    hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (256), TG::lds_bytes, stream, in, work, tw2, big_tw, (unsigned) n1, (unsigned) batch, in_stride);
+    hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (TG::BLOCK), TG::lds_bytes, stream, in, work, tw2, big_tw, (unsigned) n1, (unsigned) batch, in_stride);
     return hipGetLastError();
 }
 
@@ -47,12 +50,12 @@ template <int N1, bool INV>
 hipError_t pass_b (int n2, const float2* work, float2* out, const float2* tw1, size_t batch, int div, hipStream_t stream, size_t out_stride, int ca = 0)
 {
     using TG = TileGeom<N1>;
-    auto kernel = pass_b_kernel<typename TG::P, TG::C, INV>;
+    auto kernel = pass_b_kernel<typename TG::P, TG::C, INV, TG::BLOCK>;
     hipError_t e = ensure_lds (kernel, TG::lds_bytes);
     if (e != hipSuccess)
         return e;
     const size_t tiles = (size_t) (n2 / TG::C);
-    unsigned grid = persistent_grid (kernel, 256, TG::lds_bytes, batch * tiles);
+    unsigned grid = persistent_grid (kernel, TG::BLOCK, TG::lds_bytes, batch * tiles);
     if (grid == 0)
         return hipErrorNoDevice;
     grid = std::max (1u, grid / (unsigned) div);
@@ -61,7 +64,7 @@ hipError_t pass_b (int n2, const float2* work, float2* out, const float2* tw1, s
     unsigned ca_log2 = 0;
     while ((1 << ca_log2) < ca_width)
         ++ca_log2;
-    hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (256), TG::lds_bytes, stream, work, out, tw1, (unsigned) n2, ca_log2, (unsigned) batch, out_stride);
+    hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (TG::BLOCK), TG::lds_bytes, stream, work, out, tw1, (unsigned) n2, ca_log2, (unsigned) batch, out_stride);
     return hipGetLastError();
 }
 

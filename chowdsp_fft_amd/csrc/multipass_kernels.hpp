@@ -28,11 +28,11 @@ struct TileFrame
 };
 
 // phase 2 of both passes: LDS-resident FFT of each of the C frames of the tile image (FS floats2 apart)
-template <class P, int C>
+template <class P, int C, int BLOCK>
 __device__ __forceinline__ void tile_fft_frames (float2* __restrict__ smem, const TwiddleRegs<P>& tw, int team, int t)
 {
     constexpr int FS = TileFrame<P::N>::stride;
-    constexpr int FPB = 256 / P::T;
+    constexpr int FPB = BLOCK / P::T;
     static_assert (C % FPB == 0 || FPB % C == 0, "tile width vs teams per workgroup");
     constexpr int ROUNDS = (C + FPB - 1) / FPB;
 #pragma unroll 1
@@ -59,8 +59,8 @@ __device__ __forceinline__ void tile_fft_frames (float2* __restrict__ smem, cons
 // The inter-pass twiddle table uses the same order, so its reads are contiguous as well.
 
 // ---- pass A: n2-point column FFTs of CA adjacent columns, times W_N^{a*kb} ----------------------------
-template <class P, int CA, bool SWAP_IN>
-__global__ __launch_bounds__ (256) void pass_a_kernel (const float2* __restrict__ in,
+template <class P, int CA, bool SWAP_IN, int BLOCK>
+__global__ __launch_bounds__ (BLOCK) void pass_a_kernel (const float2* __restrict__ in,
                                                       float2* __restrict__ work,
                                                       const float2* __restrict__ stage_tw,
                                                       const float2* __restrict__ big_tw,
@@ -90,17 +90,17 @@ __global__ __launch_bounds__ (256) void pass_a_kernel (const float2* __restrict_
 
         __syncthreads(); // previous tile fully stored
 #pragma unroll 4
-        for (int e = tid; e < CA * n2; e += 256)
+        for (int e = tid; e < CA * n2; e += BLOCK)
         {
             const int c = e % CA, j = e / CA;
             const float2 x = gload (&src[(size_t) j * n1 + c]); // caller's input: streamed once
             smem[c * FS + lds_phys (j)] = SWAP_IN ? make_float2 (x.y, x.x) : x;
         }
         __syncthreads();
-        tile_fft_frames<P, CA> (smem, tw, team, t);
+        tile_fft_frames<P, CA, BLOCK> (smem, tw, team, t);
         __syncthreads();
 #pragma unroll 4
-        for (int e = tid; e < CA * n2; e += 256)
+        for (int e = tid; e < CA * n2; e += BLOCK)
         {
             const int c = e % CA, k = e / CA;
             dst[e] = cmul (smem[c * FS + lds_phys (k)], twp[e]); // plain store: the workspace should stay cached
@@ -109,8 +109,8 @@ __global__ __launch_bounds__ (256) void pass_a_kernel (const float2* __restrict_
 }
 
 // ---- pass B: n1-point row FFTs of CB adjacent rows, transposed store X[n2*ka + kb] -------------------
-template <class P, int CB, bool SWAP_OUT>
-__global__ __launch_bounds__ (256) void pass_b_kernel (const float2* __restrict__ work,
+template <class P, int CB, bool SWAP_OUT, int BLOCK>
+__global__ __launch_bounds__ (BLOCK) void pass_b_kernel (const float2* __restrict__ work,
                                                       float2* __restrict__ out,
                                                       const float2* __restrict__ stage_tw,
                                                       unsigned n2,
@@ -141,7 +141,7 @@ __global__ __launch_bounds__ (256) void pass_b_kernel (const float2* __restrict_
 
         __syncthreads();
 #pragma unroll 4
-        for (int e = tid; e < CB * n1; e += 256)
+        for (int e = tid; e < CB * n1; e += BLOCK)
         {
             // c fastest (ca), then the tile's row kbl (CB), then pass A's tile index tA
             const unsigned c = (unsigned) e & (ca - 1);
@@ -151,10 +151,10 @@ __global__ __launch_bounds__ (256) void pass_b_kernel (const float2* __restrict_
             smem[kbl * FS + lds_phys ((int) (tA * ca + c))] = x;
         }
         __syncthreads();
-        tile_fft_frames<P, CB> (smem, tw, team, t);
+        tile_fft_frames<P, CB, BLOCK> (smem, tw, team, t);
         __syncthreads();
 #pragma unroll 4
-        for (int e = tid; e < CB * n1; e += 256)
+        for (int e = tid; e < CB * n1; e += BLOCK)
         {
             const int c = e % CB, k = e / CB;
             const float2 y = smem[c * FS + lds_phys (k)];

@@ -95,6 +95,12 @@ constexpr int tile_width (int n, int team_threads)
 #ifndef CFFT_TILE1024_WIDTH
 #define CFFT_TILE1024_WIDTH 8
 #endif
+    // CFFT_TILE_BLOCK_MIN_N: cores from this length on run their tile kernels with one team per tile frame (up to 1024
+    // work-items per workgroup) instead of 256 work-items doing the frames in rounds.  Measured on MI355X: N = 2^18
+    // (512 x 512) 1.98 -> 2.07 TB/s, 2^19 (1024 x 512) 1.78 -> 1.93, 2^20 unchanged; from 256 on: 2^15 -3 %.
+#ifndef CFFT_TILE_BLOCK_MIN_N
+#define CFFT_TILE_BLOCK_MIN_N 512
+#endif
     // n = 64 (32 teams per workgroup) also takes 16: only the long mixed-radix plans still use a 64-point row pass, and
     // their column length (odd part * 16) is a multiple of 16, not of 32; half of the teams idle there
     return n >= 1024 ? CFFT_TILE1024_WIDTH : (fpb > 16 && n != 64 ? fpb : 16);
