@@ -28,8 +28,15 @@ struct TileFrame
 };
 
 // phase 2 of both passes: LDS-resident FFT of each of the C frames of the tile image (FS floats2 apart)
+// 1024-thread workgroups have 128 VGPRs per work-item: the radix-16 plans then stream their twiddles (stockham.hpp)
+template <class P, int BLOCK>
+struct TileStreamsTwiddles
+{
+    static constexpr bool value = (BLOCK == 1024 && P::R >= 16);
+};
+
 template <class P, int C, int BLOCK>
-__device__ __forceinline__ void tile_fft_frames (float2* __restrict__ smem, const TwiddleRegs<P>& tw, int team, int t)
+__device__ __forceinline__ void tile_fft_frames (float2* __restrict__ smem, const TwiddleRegs<P>& tw, const float2* __restrict__ stage_tw, int team, int t)
 {
     constexpr int FS = TileFrame<P::N>::stride;
     constexpr int FPB = BLOCK / P::T;
@@ -46,7 +53,17 @@ __device__ __forceinline__ void tile_fft_frames (float2* __restrict__ smem, cons
             lds_load_input_order<P> (v, lds, t);
         __syncthreads();
         if (have)
-            fft_core<P> (v, tw, lds, t); // T > 64: its workgroup barriers are reached by every team (have is uniform)
+        {
+            // T > 64: fft_core's workgroup barriers are reached by every team (have is uniform)
+            if constexpr (TileStreamsTwiddles<P, BLOCK>::value)
+            {
+                int tt = t;
+                CFFT_LAUNDER_INDEX (tt);
+                fft_core_streamed<P> (v, stage_tw, lds, tt);
+            }
+            else
+                fft_core<P> (v, tw, lds, t);
+        }
         __syncthreads();
         if (have)
             lds_store_output_order<P> (v, lds, t);
@@ -75,7 +92,8 @@ __global__ __launch_bounds__ (BLOCK) void pass_a_kernel (const float2* __restric
     const int team = tid / P::T;
     const int t = tid % P::T;
     TwiddleRegs<P> tw;
-    load_twiddles<P> (tw, stage_tw, t);
+    if constexpr (! TileStreamsTwiddles<P, BLOCK>::value)
+        load_twiddles<P> (tw, stage_tw, t);
 
     const unsigned tiles = n1 / CA;
     const size_t frame_len = (size_t) n1 * n2;
@@ -97,7 +115,7 @@ __global__ __launch_bounds__ (BLOCK) void pass_a_kernel (const float2* __restric
             smem[c * FS + lds_phys (j)] = SWAP_IN ? make_float2 (x.y, x.x) : x;
         }
         __syncthreads();
-        tile_fft_frames<P, CA, BLOCK> (smem, tw, team, t);
+        tile_fft_frames<P, CA, BLOCK> (smem, tw, stage_tw, team, t);
         __syncthreads();
 #pragma unroll 4
         for (int e = tid; e < CA * n2; e += BLOCK)
@@ -125,7 +143,8 @@ __global__ __launch_bounds__ (BLOCK) void pass_b_kernel (const float2* __restric
     const int team = tid / P::T;
     const int t = tid % P::T;
     TwiddleRegs<P> tw;
-    load_twiddles<P> (tw, stage_tw, t);
+    if constexpr (! TileStreamsTwiddles<P, BLOCK>::value)
+        load_twiddles<P> (tw, stage_tw, t);
 
     const unsigned tiles = n2 / CB;
     const size_t frame_len = (size_t) n1 * n2;
@@ -151,7 +170,7 @@ __global__ __launch_bounds__ (BLOCK) void pass_b_kernel (const float2* __restric
             smem[kbl * FS + lds_phys ((int) (tA * ca + c))] = x;
         }
         __syncthreads();
-        tile_fft_frames<P, CB, BLOCK> (smem, tw, team, t);
+        tile_fft_frames<P, CB, BLOCK> (smem, tw, stage_tw, team, t);
         __syncthreads();
 #pragma unroll 4
         for (int e = tid; e < CB * n1; e += BLOCK)

@@ -90,10 +90,11 @@ struct Geometry
 constexpr int tile_width (int n, int team_threads)
 {
     const int fpb = 256 / team_threads;
-    // CFFT_TILE1024_WIDTH (experiment): 16 columns of a 1024-point core are a 139 KiB image, one workgroup per CU --
-    // measured slower than 8 columns x two workgroups (N = 2^20: 1.47 vs 1.67 TB/s)
+    // CFFT_TILE1024_WIDTH: 16 columns of a 1024-point core are a 139 KiB image, i.e. one workgroup per CU.  With 256
+    // work-items doing the 16 frames in rounds that measured slower than 8 columns x two workgroups (N = 2^20: 1.47 vs
+    // 1.67 TB/s); with one 64-lane team per frame (1024 work-items, streamed twiddles) it is faster: 1.61 -> 1.87 TB/s.
 #ifndef CFFT_TILE1024_WIDTH
-#define CFFT_TILE1024_WIDTH 8
+#define CFFT_TILE1024_WIDTH 16
 #endif
     // CFFT_TILE_BLOCK_MIN_N: cores from this length on run their tile kernels with one team per tile frame (up to 1024
     // work-items per workgroup) instead of 256 work-items doing the frames in rounds.  Measured on MI355X: N = 2^18
