@@ -45,14 +45,20 @@ WORKLOADS = {
 }
 
 
+DEFAULT_WORKLOAD = "c2c_n4096_b65536_fwd_inv"
+# the other BASELINE.json configurations, reported under "secondary" of the default run's ONE JSON line
+SECONDARY_WORKLOADS = ("real_n1024_b262144_fwd_inv", "conv_real_n4096_b131072", "c2c_n65536_b8192_fwd_inv")
+
+
 def cpu_baseline(n: int, transform: str, seconds: float) -> dict:
     """Time the reference on the host CPU (bounded: 3 regimes x `seconds`)."""
     ref_so = os.path.join(ROOT, "oracle", "_ref", "libchowdsp_fft_ref.so")
     ref_bench = os.path.join(ROOT, "oracle", "_ref", "ref_bench")
-    ncpu = os.cpu_count() or 1
     if os.path.exists(ref_so) and os.path.exists(ref_bench):
         try:
-            out = subprocess.run([ref_bench, ref_so, str(n), transform, "1", f"{seconds:.2f}", str(ncpu), "512"],
+            # threads = 0: ref_bench sizes its all-core pool to the CPUs this process can really use (affinity mask, cgroup
+            # quota, and a measured parallel-speedup probe for containers throttled by a layer neither of those shows)
+            out = subprocess.run([ref_bench, ref_so, str(n), transform, "1", f"{seconds:.2f}", "0", "512"],
                                  capture_output=True, text=True, timeout=120 + 6 * seconds, check=True).stdout
             d = json.loads(out.strip().splitlines()[-1])
             return {
@@ -61,6 +67,10 @@ def cpu_baseline(n: int, transform: str, seconds: float) -> dict:
                           f"FORWARD+BACKWARD with work buffer, one cache-hot frame repeated for {seconds:.1f} s on one thread",
                 "stream_1t_GFFT_s": d["stream_1t_transforms_per_s"] / 1e9,
                 "allcore_GFFT_s": d["allcore_transforms_per_s"] / 1e9, "allcore_threads": d["allcore_threads"],
+                "cores_effective": d.get("cores_effective"), "affinity_cpus": d.get("affinity_cpus"),
+                "cgroup_cpu_quota": d.get("cgroup_cpu_quota"), "parallel_speedup_probe": d.get("parallel_speedup_probe"),
+                "host_hardware_threads": d.get("host_hardware_threads"),
+                "allcore_over_1t": (d["allcore_transforms_per_s"] / d["stream_1t_transforms_per_s"]) if d["stream_1t_transforms_per_s"] > 0 else None,
                 "stream_sample": f"{d['stream_mib']} MiB of distinct frames, out of place, {seconds:.1f} s per regime",
             }
         except Exception as e:  # fall through to the port
@@ -84,70 +94,16 @@ def cpu_baseline(n: int, transform: str, seconds: float) -> dict:
             "sample": f"plain-C oracle (scalar restatement of the SSE path), N={n} {transform}, 64 frames fwd+bwd repeated for {seconds:.1f} s"}
 
 
-def main() -> int:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2c_n4096_b65536_fwd_inv", choices=sorted(WORKLOADS))
-    ap.add_argument("--frames-per-gpu", type=int, default=0, help="override the workload's batch (debugging only)")
-    ap.add_argument("--cpu-seconds", type=float, default=4.0, help="seconds per CPU-baseline regime (3 regimes)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--prewarm-seconds", type=float, default=0.3,
-                    help="untimed: run the step for this long BEFORE the W warm-up steps so that the GPU has left its idle "
-                         "clocks (measured: the first ~3 ms after idle run 10-25 %% slower); the timed region is still exactly K steps")
-    ap.add_argument("--gather", action="store_true", help="also time the final all-gather of results over xGMI (reported separately)")
-    args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-
-    if not os.path.exists(os.path.join(ROOT, "chowdsp_fft_amd", "libchowdsp_fft_hip.so")):
-        # source-only checkout: compile the library first (rank 0 builds, the others wait for the file)
-        if local_rank == 0:
-            import __graft_entry__
-
-            __graft_entry__.build()
-        else:
-            t_wait = time.time()
-            while not os.path.exists(os.path.join(ROOT, "chowdsp_fft_amd", "libchowdsp_fft_hip.so")) and time.time() - t_wait < 1800:
-                time.sleep(2.0)
-            time.sleep(5.0)
-
-    # The CPU baseline runs a child process (oracle/_ref/ref_bench): do it BEFORE anything touches the GPU
-    # (a process that has initialised HIP must not fork+exec on this pool).
-    cb = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        n0, transform0 = WORKLOADS[args.workload][0], WORKLOADS[args.workload][1]
-        cb = cpu_baseline(n0, transform0, args.cpu_seconds)
-        try:
-            with open("/proc/cpuinfo") as f:
-                cb["host_cpu"] = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "unknown")
-        except OSError:
-            pass
-        cb["host_threads"] = os.cpu_count()
-
+def run_workload(workload, args, world, rank, dev, frames_override=0, gather=False):
+    """One workload, the full protocol; returns the JSON line (dict) on rank 0, None on the other ranks, an int exit code on failure."""
     import torch
     import torch.distributed as dist
 
     from chowdsp_fft_amd import api, sharding
-    if world != args.gpus:
-        if rank == 0:
-            sys.stderr.write(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1\n")
-        if world == 1 and args.gpus > 1:
-            return 2
-    if not torch.cuda.is_available():
-        sys.stderr.write("[bench] no GPU visible: the HIP path cannot run (there is no CPU fallback)\n")
-        return 3
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    n, transform, frames, desc = WORKLOADS[args.workload]
-    if args.frames_per_gpu > 0:
-        frames = args.frames_per_gpu
+    n, transform, frames, desc = WORKLOADS[workload]
+    if frames_override > 0:
+        frames = frames_override
     tr = api.FFT_COMPLEX if transform == "complex" else api.FFT_REAL
     frame_floats = 2 * n if transform == "complex" else n
     setup = api.fft_new_setup(n, tr)
@@ -161,9 +117,9 @@ def main() -> int:
     x = torch.rand((frames, frame_floats), device=dev, generator=g) * 2 - 1
     y = torch.empty_like(x)
     z = torch.empty_like(x)
-    fused = args.workload.startswith("conv_")
+    fused = workload.startswith("conv_")
     engine = None
-    if args.workload.startswith("ols_engine"):
+    if workload.startswith("ols_engine"):
         block, parts = n // 2, 16
         ir = torch.rand((block * parts,), device=dev, generator=g) * 2 - 1
         engine = api.ConvEngine(block, frames, ir, shared=True)
@@ -220,7 +176,7 @@ def main() -> int:
             return 5
 
     gather_info = None
-    if args.gather and world > 1:
+    if gather and world > 1:
         torch.cuda.synchronize()
         dist.barrier()
         tg = time.perf_counter()
@@ -232,6 +188,7 @@ def main() -> int:
                        "GB_s_per_gpu": full.numel() * 4 * (world - 1) / world / tg / 1e9}
         del full
 
+    line = None
     if rank == 0:
         total_transforms = transforms_per_frame_step * frames * world * args.steps
         value = total_transforms / elapsed / 1e9
@@ -250,37 +207,130 @@ def main() -> int:
             "c2c_n65536_b8192_fwd_inv": "cfft::pass_a256_kernel<INV> + cfft::pass_b256_kernel<INV> per 256-frame chunk (two passes over the frame)",
             "c2c_n9216_b16384_fwd_inv": "cfft::generic_kernel<0, INV, 1024>",
             "ols_engine_b2048_p16_c8192": "cfft::ols_block_kernel<Plan<2048,128,16,16,8>, 2>",
-        }.get(args.workload, f"{args.workload} kernels")
-        traffic = None
+        }.get(workload, f"{workload} kernels")
+        # HBM bytes per launch from the PMC counters: NOT measured by this run (rocprofv3 --pmc needs its own passes);
+        # read from the committed summary of the last profiling session and labelled with where it was taken
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(args.workload)
+                tj = json.load(open(tpath))
+                traffic = tj.get(workload)
+                traffic_source = tj.get("_taken_at")
             except Exception:
                 traffic = None
         line = {
-            "metric": "GFFT/s (batched fp32 complex, N=4096) + achieved HBM GB/s vs roofline" if args.workload == "c2c_n4096_b65536_fwd_inv"
-                      else f"GFFT/s ({args.workload})",
+            "metric": "GFFT/s (batched fp32 complex, N=4096) + achieved HBM GB/s vs roofline" if workload == "c2c_n4096_b65536_fwd_inv"
+                      else f"GFFT/s ({workload})",
             "value": value, "unit": "GFFT/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic uniform(-1,1), seed 1234",
-            "config": {"workload": args.workload, "description": desc, "N": n, "transform": transform,
+            "config": {"workload": workload, "description": desc, "N": n, "transform": transform,
                        "frames_per_gpu": frames, "global_frames": frames * world,
                        "transforms_per_frame_per_step": transforms_per_frame_step,
                        "sharding": f"contiguous batch blocks over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kernel,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel,
                          "algorithmic_bytes_per_launch": alg_bytes_per_launch, "avg_launch_ms": avg_launch_s * 1e3,
                          "launches_timed": launches, "timer": "HIP events on the launch stream"},
         }
         if gather_info:
             line["gather_xgmi"] = gather_info
+    api.fft_destroy_setup(setup)
+    del x, y, z, engine
+    torch.cuda.empty_cache()
+    return line
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
+    ap.add_argument("--frames-per-gpu", type=int, default=0, help="override the workload's batch (debugging only)")
+    ap.add_argument("--cpu-seconds", type=float, default=4.0, help="seconds per CPU-baseline regime (3 regimes)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="default workload only: skip the secondary BASELINE configurations")
+    ap.add_argument("--prewarm-seconds", type=float, default=0.3,
+                    help="untimed: run the step for this long BEFORE the W warm-up steps so that the GPU has left its idle "
+                         "clocks (measured: the first ~3 ms after idle run 10-25 %% slower); the timed region is still exactly K steps")
+    ap.add_argument("--gather", action="store_true", help="also time the final all-gather of results over xGMI (reported separately)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    if not os.path.exists(os.path.join(ROOT, "chowdsp_fft_amd", "libchowdsp_fft_hip.so")):
+        # source-only checkout: compile the library first (rank 0 builds, the others wait for the file)
+        if local_rank == 0:
+            import __graft_entry__
+
+            __graft_entry__.build()
+        else:
+            t_wait = time.time()
+            while not os.path.exists(os.path.join(ROOT, "chowdsp_fft_amd", "libchowdsp_fft_hip.so")) and time.time() - t_wait < 1800:
+                time.sleep(2.0)
+            time.sleep(5.0)
+
+    # The CPU baseline runs a child process (oracle/_ref/ref_bench): do it BEFORE anything touches the GPU
+    # (a process that has initialised HIP must not fork+exec on this pool).
+    cb = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        n0, transform0 = WORKLOADS[args.workload][0], WORKLOADS[args.workload][1]
+        cb = cpu_baseline(n0, transform0, args.cpu_seconds)
+        try:
+            with open("/proc/cpuinfo") as f:
+                cb["host_cpu"] = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "unknown")
+        except OSError:
+            pass
+        cb.setdefault("host_hardware_threads", os.cpu_count())
+        if cb.get("cores_effective") is None:
+            try:
+                cb["cores_effective"] = len(os.sched_getaffinity(0))
+            except (AttributeError, OSError):
+                cb["cores_effective"] = os.cpu_count()
+
+    import torch
+    import torch.distributed as dist
+
+    from chowdsp_fft_amd import api, sharding
+    if world != args.gpus:
+        if rank == 0:
+            sys.stderr.write(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1\n")
+        if world == 1 and args.gpus > 1:
+            return 2
+    if not torch.cuda.is_available():
+        sys.stderr.write("[bench] no GPU visible: the HIP path cannot run (there is no CPU fallback)\n")
+        return 3
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    line = run_workload(args.workload, args, world, rank, dev, frames_override=args.frames_per_gpu, gather=args.gather)
+    if isinstance(line, int):
+        return line
+    # BASELINE.json's other configurations, driver-timed in the same run (each is a few ms of GPU time per step): same
+    # protocol (prewarm, W warm-up steps, exactly K timed steps between barriers + synchronize, MAX over ranks)
+    secondary = []
+    if args.workload == DEFAULT_WORKLOAD and not args.no_secondary:
+        for name in SECONDARY_WORKLOADS:
+            sec = run_workload(name, args, world, rank, dev)
+            if isinstance(sec, int):
+                return sec
+            if rank == 0:
+                secondary.append({"workload": name, "description": sec["config"]["description"], "value": sec["value"], "unit": sec["unit"],
+                                  "ms_per_step": sec["ms_per_step"], "steps": sec["steps"], "warmup": sec["warmup"],
+                                  "frames_per_gpu": sec["config"]["frames_per_gpu"], "roofline": sec["roofline"]})
+    if rank == 0:
+        if secondary:
+            line["secondary"] = secondary
         if cb is not None:
-            cb["gpu_over_cpu"] = value / cb["value"] if cb["value"] > 0 else None
+            cb["gpu_over_cpu"] = line["value"] / cb["value"] if cb["value"] > 0 else None
             line["cpu_baseline"] = cb
         print(json.dumps(line), flush=True)
-
-    api.fft_destroy_setup(setup)
     if world > 1:
         dist.destroy_process_group()
     return 0

@@ -343,6 +343,7 @@ int run_transform (Setup* s, const float* in, float* out, size_t batch, cf::fft_
 
 int run_convolve (Setup* s, const float* a, const float* b, float* ab, float scaling, size_t batch, bool b_is_shared, hipStream_t stream)
 {
+    const DeviceGuard guard (s->device);
     const bool real = (s->transform == cf::FFT_REAL);
     const hipError_t e = launch_conv_mac (real, a, b, ab, scaling, (size_t) complex_len (s), batch, b_is_shared, stream);
     if (e != hipSuccess)
@@ -354,17 +355,26 @@ int run_convolve (Setup* s, const float* a, const float* b, float* ab, float sca
 }
 
 // legacy single-frame entry: host pointers are staged, device pointers used in place; synchronous.
+// The reference's entry points return void (chowdsp_fft.h:138-160): a failure cannot be reported through the return
+// value, so every early return records its reason for fft_gpu_last_error().
 void legacy_transform (void* setup, const float* input, float* output, cf::fft_direction_t direction)
 {
     Setup* s = as_setup (setup);
     if (s == nullptr || input == nullptr || output == nullptr)
+    {
+        set_last_error ("fft_transform: bad setup handle or NULL buffer");
         return;
+    }
+    // ONE guard for the whole body: the staging allocation, the copies, the launch and the final synchronisation all
+    // have to address the plan's device, whatever device the calling thread has current (a new host thread starts on
+    // device 0); the null stream that is synchronised below is a per-device object.
+    const DeviceGuard guard (s->device);
     const size_t nf = frame_floats (s);
     const bool in_dev = is_device_pointer (input), out_dev = is_device_pointer (output);
     if (in_dev && out_dev)
     {
         if (run_transform (s, input, output, 1, direction, nullptr) == cf::FFT_GPU_OK)
-            (void) hipStreamSynchronize (nullptr);
+            CFFT_HIP_TRY (hipStreamSynchronize (nullptr), (void) 0);
         return;
     }
     if (! in_dev && ! out_dev && nf * sizeof (float) <= zerocopy_max_bytes())
@@ -374,9 +384,9 @@ void legacy_transform (void* setup, const float* input, float* output, cf::fft_d
         {
             std::memcpy (pin, input, nf * sizeof (float));
             if (run_transform (s, pin, pin + nf, 1, direction, nullptr) != cf::FFT_GPU_OK)
-                return;
-            if (hipStreamSynchronize (nullptr) == hipSuccess)
-                std::memcpy (output, pin + nf, nf * sizeof (float));
+                return; // run_transform recorded the error
+            CFFT_HIP_TRY (hipStreamSynchronize (nullptr), (void) 0);
+            std::memcpy (output, pin + nf, nf * sizeof (float));
             return;
         }
     }
@@ -390,8 +400,7 @@ void legacy_transform (void* setup, const float* input, float* output, cf::fft_d
     float* dout = output;
     if (! in_dev)
     {
-        if (hipMemcpyAsync (stage, input, nf * sizeof (float), hipMemcpyHostToDevice, nullptr) != hipSuccess)
-            return;
+        CFFT_HIP_TRY (hipMemcpyAsync (stage, input, nf * sizeof (float), hipMemcpyHostToDevice, nullptr), (void) 0);
         din = stage;
     }
     if (! out_dev)
@@ -399,8 +408,8 @@ void legacy_transform (void* setup, const float* input, float* output, cf::fft_d
     if (run_transform (s, din, dout, 1, direction, nullptr) != cf::FFT_GPU_OK)
         return;
     if (! out_dev)
-        (void) hipMemcpyAsync (output, dout, nf * sizeof (float), hipMemcpyDeviceToHost, nullptr);
-    (void) hipStreamSynchronize (nullptr);
+        CFFT_HIP_TRY (hipMemcpyAsync (output, dout, nf * sizeof (float), hipMemcpyDeviceToHost, nullptr), (void) 0);
+    CFFT_HIP_TRY (hipStreamSynchronize (nullptr), (void) 0);
 }
 
 // legacy three-operand entry (convolve / accumulate): stage whichever operands live in host memory.
@@ -408,6 +417,7 @@ void legacy_transform (void* setup, const float* input, float* output, cf::fft_d
 template <class Op>
 void legacy_elementwise (Setup* s, const float* a, const float* b, float* ab, size_t nf, Op&& op, bool ab_is_input)
 {
+    const DeviceGuard guard (s->device); // whole body: see legacy_transform
     const bool a_dev = is_device_pointer (a), b_dev = is_device_pointer (b), ab_dev = is_device_pointer (ab);
     if (! a_dev && ! b_dev && ! ab_dev && nf * sizeof (float) <= zerocopy_max_bytes())
     {
@@ -421,9 +431,9 @@ void legacy_elementwise (Setup* s, const float* a, const float* b, float* ab, si
             if (ab_is_input)
                 std::memcpy (pab, ab, nf * sizeof (float));
             if (op (pa, pb, pab) != cf::FFT_GPU_OK)
-                return;
-            if (hipStreamSynchronize (nullptr) == hipSuccess)
-                std::memcpy (ab, pab, nf * sizeof (float));
+                return; // op recorded the error
+            CFFT_HIP_TRY (hipStreamSynchronize (nullptr), (void) 0);
+            std::memcpy (ab, pab, nf * sizeof (float));
             return;
         }
     }
@@ -443,26 +453,24 @@ void legacy_elementwise (Setup* s, const float* a, const float* b, float* ab, si
     if (! ab_dev)
     {
         dab = stage + 2 * nf;
-        if (ab_is_input && hipMemcpyAsync (dab, ab, nf * sizeof (float), hipMemcpyHostToDevice, nullptr) != hipSuccess)
-            return;
+        if (ab_is_input)
+            CFFT_HIP_TRY (hipMemcpyAsync (dab, ab, nf * sizeof (float), hipMemcpyHostToDevice, nullptr), (void) 0);
     }
     if (! a_dev)
     {
-        if (hipMemcpyAsync (stage, a, nf * sizeof (float), hipMemcpyHostToDevice, nullptr) != hipSuccess)
-            return;
+        CFFT_HIP_TRY (hipMemcpyAsync (stage, a, nf * sizeof (float), hipMemcpyHostToDevice, nullptr), (void) 0);
         da = stage;
     }
     if (! b_dev)
     {
-        if (hipMemcpyAsync (stage + nf, b, nf * sizeof (float), hipMemcpyHostToDevice, nullptr) != hipSuccess)
-            return;
+        CFFT_HIP_TRY (hipMemcpyAsync (stage + nf, b, nf * sizeof (float), hipMemcpyHostToDevice, nullptr), (void) 0);
         db = stage + nf;
     }
     if (op (da, db, dab) != cf::FFT_GPU_OK)
         return;
     if (! ab_dev)
-        (void) hipMemcpyAsync (ab, dab, nf * sizeof (float), hipMemcpyDeviceToHost, nullptr);
-    (void) hipStreamSynchronize (nullptr);
+        CFFT_HIP_TRY (hipMemcpyAsync (ab, dab, nf * sizeof (float), hipMemcpyDeviceToHost, nullptr), (void) 0);
+    CFFT_HIP_TRY (hipStreamSynchronize (nullptr), (void) 0);
 }
 } // namespace
 
@@ -567,7 +575,10 @@ void fft_convolve_unordered (void* setup, const float* a, const float* b, float*
 {
     Setup* s = as_setup (setup);
     if (s == nullptr || a == nullptr || b == nullptr || ab == nullptr)
+    {
+        set_last_error ("fft_convolve_unordered: bad setup handle or NULL buffer");
         return;
+    }
     const size_t nf = frame_floats (s);
     legacy_elementwise (s, a, b, ab, nf, [&] (const float* da, const float* db, float* dab) {
         return run_convolve (s, da, db, dab, scaling, 1, false, nullptr);
@@ -578,7 +589,10 @@ void fft_accumulate (void* setup, const float* a, const float* b, float* ab, int
 {
     Setup* s = as_setup (setup);
     if (s == nullptr || a == nullptr || b == nullptr || ab == nullptr || N <= 0)
+    {
+        set_last_error ("fft_accumulate: bad setup handle, NULL buffer or N <= 0");
         return;
+    }
     legacy_elementwise (s, a, b, ab, (size_t) N, [&] (const float* da, const float* db, float* dab) {
         const hipError_t e = launch_accumulate (da, db, dab, (size_t) N, nullptr);
         if (e != hipSuccess)
@@ -781,8 +795,10 @@ int fft_convolve_unordered_batch (void* setup, const float* dft_a, const float* 
 
 int fft_accumulate_batch (void* setup, const float* a, const float* b, float* ab, size_t count, void* stream)
 {
-    if (as_setup (setup) == nullptr || a == nullptr || b == nullptr || ab == nullptr)
+    Setup* s = as_setup (setup);
+    if (s == nullptr || a == nullptr || b == nullptr || ab == nullptr)
         return FFT_GPU_EINVAL;
+    const DeviceGuard guard (s->device);
     const hipError_t e = launch_accumulate (a, b, ab, count, (hipStream_t) stream);
     if (e != hipSuccess)
     {
@@ -797,6 +813,7 @@ int fft_convolve_frames_batch (void* setup, const float* x, const float* dft_fil
     Setup* s = as_setup (setup);
     if (s == nullptr || x == nullptr || dft_filter == nullptr || y == nullptr)
         return FFT_GPU_EINVAL;
+    const DeviceGuard guard (s->device);
     const DeviceTables* t = s->tables;
     const int nc = complex_len (s);
     if (t->core_n != nc || nc > cfft::kMaxFusedN)
@@ -806,7 +823,6 @@ int fft_convolve_frames_batch (void* setup, const float* x, const float* dft_fil
         int rc = run_transform (s, x, y, batch, FFT_FORWARD, (hipStream_t) stream);
         if (rc != FFT_GPU_OK)
             return rc;
-        const DeviceGuard guard (s->device);
         const hipError_t em = launch_conv_mac (s->transform == FFT_REAL, y, dft_filter, y, scaling, (size_t) nc, batch, true, (hipStream_t) stream, false);
         if (em != hipSuccess)
         {

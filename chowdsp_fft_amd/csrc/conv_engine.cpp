@@ -128,8 +128,9 @@ void* fft_conv_engine_create (int block, int channels, const float* ir, int ir_l
 int fft_conv_engine_reset (void* engine, void* stream_)
 {
     Engine* e = as_engine (engine);
-    if (e == nullptr)
+    if (e == nullptr || as_setup (e->setup) == nullptr)
         return FFT_GPU_EINVAL;
+    const DeviceGuard guard (as_setup (e->setup)->device);
     const hipStream_t stream = (hipStream_t) stream_;
     const size_t C = (size_t) e->channels, N = 2 * (size_t) e->block;
     CFFT_HIP_TRY (hipMemsetAsync (e->prev, 0, C * e->block * sizeof (float), stream), FFT_GPU_ELAUNCH);
@@ -145,14 +146,14 @@ int fft_conv_engine_reset (void* engine, void* stream_)
 int fft_conv_engine_process (void* engine, const float* in, float* out, void* stream_)
 {
     Engine* e = as_engine (engine);
-    if (e == nullptr || in == nullptr || out == nullptr)
+    if (e == nullptr || in == nullptr || out == nullptr || as_setup (e->setup) == nullptr)
         return FFT_GPU_EINVAL;
+    const DeviceGuard guard (as_setup (e->setup)->device); // whole call: the unfused path launches helper kernels itself
     const hipStream_t stream = (hipStream_t) stream_;
     const size_t C = (size_t) e->channels, N = 2 * (size_t) e->block;
     if (e->fused)
     {
         const Setup* su = as_setup (e->setup);
-        const DeviceGuard guard (su->device);
         const DeviceTables* t = su->tables;
         // CHOWDSP_FFT_ENGINE_SINGLE=0: two kernels per block (ols_r2c_kernel, ols_mac_c2r_kernel) instead of one
         static const bool single = [] {

@@ -839,7 +839,9 @@ __global__ __launch_bounds__ (P::T* FPB) void ols_block_kernel (float2* buf0, //
             team_sync<P::T>();
         }
         float2* __restrict__ slot = fdl + (size_t) head * slot_elems + (size_t) g * (FPB * M);
-        const unsigned fo = (unsigned) team * M, ho = h_shared ? 0u : (unsigned) team * M;
+        // idle teams of the last group (channels % FPB != 0) read the group's first channel's filter bins instead of
+        // running past the end of a per-channel H (Pn == 1: there is no next partition behind it)
+        const unsigned fo = (unsigned) team * M, ho = (h_shared || ! active) ? 0u : (unsigned) team * M;
         const float2* __restrict__ hg = H + (h_shared ? (size_t) 0 : (size_t) g * (FPB * M));
         float2 yk[P::R / 2], yp[P::R / 2];
 #pragma unroll

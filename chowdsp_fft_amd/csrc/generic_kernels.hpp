@@ -479,12 +479,12 @@ __global__ __launch_bounds__ (256) void pass_a_generic_kernel (const float2* __r
                                                               GenericPlan plan, // n = n2, frames = CA
                                                               unsigned n1,
                                                               unsigned batch,
-                                                              size_t in_stride)
+                                                              size_t in_stride,
+                                                              unsigned lfs) // frame stride inside an image: n2 + 1, or n2 where the padded images would not fit the CU's LDS
 {
     extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
     const int tid = threadIdx.x;
     const int n2 = plan.n;
-    const unsigned lfs = (unsigned) n2 + 1u;
     float2* bufA = smem;
     float2* bufB = smem + (size_t) CA * lfs;
     const unsigned tiles = n1 / CA;

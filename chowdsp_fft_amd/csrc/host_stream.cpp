@@ -5,6 +5,7 @@
 #include "host_common.hpp"
 
 #include <algorithm>
+#include <map>
 #include <mutex>
 
 using namespace cfft::host;
@@ -22,11 +23,11 @@ struct Pipe
     bool ok = false;
 };
 std::mutex g_pipe_mutex; // one streaming call at a time per process (it saturates PCIe anyway)
-Pipe g_pipe;
+std::map<int, Pipe> g_pipes; // streams and device buffers belong to ONE device: keyed by the plan's device ordinal
 
-bool ensure_pipe (size_t floats)
+// caller holds g_pipe_mutex and has the plan's device current
+bool grow_pipe (Pipe& p, size_t floats)
 {
-    Pipe& p = g_pipe;
     if (! p.ok)
     {
         for (int k = 0; k < 2; ++k)
@@ -50,6 +51,12 @@ bool ensure_pipe (size_t floats)
             return false;
     p.floats = floats;
     return true;
+}
+
+Pipe* ensure_pipe (int device, size_t floats)
+{
+    Pipe& p = g_pipes[device];
+    return grow_pipe (p, floats) ? &p : nullptr;
 }
 
 // pin a caller buffer in place; returns true if WE registered it (and must unregister)
@@ -77,13 +84,26 @@ int fft_transform_host_batch (void* setup, const float* input, float* output, si
         return FFT_GPU_OK;
     const size_t frame = (s->transform == FFT_COMPLEX) ? 2 * (size_t) s->N : (size_t) s->N;
     const size_t chunk_frames = std::max<size_t> (1, std::min (batch, kChunkBytes / (frame * sizeof (float))));
+    const size_t total_bytes = batch * frame * sizeof (float);
+    // in place (input == output) is fine; any other overlap would let one chunk's result overwrite another chunk's input
+    if (input != output)
+    {
+        const char *ib = (const char*) input, *ob = (const char*) output;
+        if (ib < ob + total_bytes && ob < ib + total_bytes)
+        {
+            set_last_error ("fft_transform_host_batch: input and output overlap without being the same buffer");
+            return FFT_GPU_EINVAL;
+        }
+    }
+    const DeviceGuard guard (s->device); // the pipe's streams / buffers and the copies below belong to the plan's device
     std::lock_guard<std::mutex> lock (g_pipe_mutex);
-    if (! ensure_pipe (chunk_frames * frame))
+    Pipe* pipe = ensure_pipe (s->device, chunk_frames * frame);
+    if (pipe == nullptr)
     {
         set_last_error ("fft_transform_host_batch: stream / device buffer creation failed");
         return FFT_GPU_ENOMEM;
     }
-    const size_t total_bytes = batch * frame * sizeof (float);
+    Pipe& g_pipe = *pipe;
     const bool pinned_in = pin (input, total_bytes);
     const bool pinned_out = (output != input) ? pin (output, total_bytes) : false;
     int rc = FFT_GPU_OK;

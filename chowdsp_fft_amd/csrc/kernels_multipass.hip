@@ -163,14 +163,24 @@ hipError_t launch_mixed_big_c2c (const DeviceTables& t, bool inverse, const floa
         plan.radix[i] = t.gen_radix[i];
         plan.tw_offset[i] = t.gen_tw_offset[i];
     }
-    const size_t lds = (size_t) 2 * ca * ((size_t) n2 + 1) * sizeof (float2);
+    // two images of ca frames; a frame is padded by one point (bank spread while the tile is loaded / stored) unless that
+    // pushes the images past the CU's LDS (n2 = 1280 with 8 columns: 163968 B > 160 KiB)
+    DeviceInfo dev;
+    if (! current_device_info (dev))
+        return hipErrorNoDevice;
+    unsigned lfs = (unsigned) n2 + 1u;
+    if ((size_t) 2 * ca * lfs * sizeof (float2) > dev.lds_per_cu)
+        lfs = (unsigned) n2;
+    const size_t lds = (size_t) 2 * ca * lfs * sizeof (float2);
+    if (lds > dev.lds_per_cu)
+        return hipErrorInvalidValue;
     auto ka = ca == 16 ? (inverse ? pass_a_generic_kernel<true, 16> : pass_a_generic_kernel<false, 16>)
                        : (inverse ? pass_a_generic_kernel<true, 8> : pass_a_generic_kernel<false, 8>);
     unsigned grid = persistent_grid (ka, 256, lds, batch * (size_t) (n1 / ca));
     if (grid == 0)
         return hipErrorNoDevice;
     grid = std::max (1u, grid / (unsigned) grid_divisor);
-    hipLaunchKernelGGL (ka, dim3 (grid), dim3 (256), lds, stream, in, work, (const float2*) t.stage_twiddles, (const float2*) t.big_twiddles, plan, (unsigned) n1, (unsigned) batch, in_stride);
+    hipLaunchKernelGGL (ka, dim3 (grid), dim3 (256), lds, stream, in, work, (const float2*) t.stage_twiddles, (const float2*) t.big_twiddles, plan, (unsigned) n1, (unsigned) batch, in_stride, lfs);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return e;

@@ -64,9 +64,9 @@ void split_large (int n_complex, int& n1, int& n2);
 // * 2^j the generic column length (a multiple of 16, at most kMixedMaxN2) and n1 a power of two in [64, 1024].
 // false if no such split exists (then the size is not supported).
 bool split_mixed (int n_complex, int& n1, int& n2);
-// columns per pass-A tile of the mixed two-pass plans: 16 (128-byte rows) while two LDS images of 16 columns fit the CU's
-// 160 KiB (n2 <= 640), else 8 (n2 <= 1280)
-static constexpr int kMixedMaxN2Wide = 640;
+// columns per pass-A tile of the mixed two-pass plans: 16 (128-byte rows) while two LDS images of 16 padded columns,
+// 2 * 16 * (n2 + 1) * 8 bytes, fit the CU's 160 KiB (n2 <= 639), else 8 (n2 <= 1280; n2 = 1280 runs unpadded)
+static constexpr int kMixedMaxN2Wide = 639;
 static constexpr int kMixedMaxN2 = 1280;
 inline int mixed_tile_width (int n2) { return n2 <= kMixedMaxN2Wide ? 16 : 8; }
 } // namespace cfft::host

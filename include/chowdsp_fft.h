@@ -19,9 +19,15 @@
       fft_simd_width_bytes() always reports 16, the value the reference reports on its SSE/NEON path.
     * the "unordered" frequency-domain layout is implementation defined in the reference (its SSE and
       AVX paths already differ); here it is the canonical ordered layout.
-    * accepted sizes: powers of two, 16 <= N (complex) / 32 <= N (real), N <= 2^20.  Other sizes
-      return NULL from setup creation, exactly like an unsupported size does in the reference
-      (simd/chowdsp_fft_impl_common.hpp:168-177, 216-225).
+    * accepted sizes: the reference's rule -- N % 16 == 0 (complex) / N % 32 == 0 (real), N = 2^a 3^b 5^c
+      (simd/chowdsp_fft_impl_common.hpp:168-177, 216-225).  fft_gpu_size_supported() (chowdsp_fft_gpu.h) is the
+      authoritative, GPU-free test; sizes it rejects return NULL from setup creation, exactly like an
+      unsupported size does in the reference (which returns the tagged pointer 0x1 there,
+      chowdsp_fft.cpp:271-273 -- a defect this backend does not imitate).
+    * one deliberate numerical deviation: for REAL sizes divisible by 25 the reference's FORWARD transform is
+      wrong (radf5_ps with ido > 1, simd/chowdsp_fft_impl_sse.cpp:747-782; SSE and AVX alike: N = 800 is
+      O(1) away from the DFT and does not round-trip).  This backend returns the exact DFT for those sizes;
+      everywhere else results match the reference's SSE path within 1e-6 relative per frame.
 
   Throughput work should use the batched device-pointer extension in chowdsp_fft_gpu.h.
 */

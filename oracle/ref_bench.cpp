@@ -13,6 +13,7 @@
 //
 // usage: ref_bench <lib.so> <N> <real|complex> <avx 0|1> <seconds per regime> <threads> <stream MiB>
 #include <dlfcn.h>
+#include <sched.h>
 
 #include <atomic>
 #include <chrono>
@@ -43,6 +44,75 @@ static bool sym (void* h, const char* name, F& out)
     return out != nullptr;
 }
 
+// CPUs this process may actually use: the affinity mask, cut down by a cgroup CPU quota where one is set (v2
+// cpu.max = "<quota> <period>" or "max ..."; v1 cpu.cfs_quota_us / cpu.cfs_period_us).  hardware_concurrency()
+// reports the machine, not the container: a 256-thread host with a 16-CPU quota runs 16 threads' worth of work.
+static int affinity_cpus()
+{
+    cpu_set_t set;
+    CPU_ZERO (&set);
+    if (sched_getaffinity (0, sizeof (set), &set) == 0)
+        return CPU_COUNT (&set);
+    return (int) std::thread::hardware_concurrency();
+}
+static double cgroup_cpu_quota() // CPUs, or 0 when unlimited / unknown
+{
+    if (FILE* f = fopen ("/sys/fs/cgroup/cpu.max", "r"))
+    {
+        char q[64] = { 0 };
+        long long period = 0;
+        const int n = fscanf (f, "%63s %lld", q, &period);
+        fclose (f);
+        if (n == 2 && strcmp (q, "max") != 0 && period > 0)
+            return (double) atoll (q) / (double) period;
+        return 0;
+    }
+    long long quota = -1, period = 0;
+    if (FILE* f = fopen ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r"))
+    {
+        if (fscanf (f, "%lld", &quota) != 1)
+            quota = -1;
+        fclose (f);
+    }
+    if (FILE* f = fopen ("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r"))
+    {
+        if (fscanf (f, "%lld", &period) != 1)
+            period = 0;
+        fclose (f);
+    }
+    return (quota > 0 && period > 0) ? (double) quota / (double) period : 0;
+}
+
+// Measured parallelism: some containers show every host CPU in the affinity mask and no cgroup quota, yet are
+// throttled to a few CPUs' worth of time by a layer the process cannot read.  Spin a register-only loop on 1 thread and on
+// `nthreads` threads for `secs` each and return (aggregate rate with nthreads) / (rate with one).
+static double parallel_speedup_probe (int nthreads, double secs)
+{
+    auto run = [secs] (int nt) {
+        std::atomic<unsigned long long> total { 0 };
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nt; ++t)
+            pool.emplace_back ([&total, secs] {
+                const auto t0 = clk::now();
+                unsigned long long n = 0;
+                unsigned x = 12345u;
+                do
+                {
+                    for (int i = 0; i < 20000; ++i)
+                        x = x * 1664525u + 1013904223u;
+                    n += 20000;
+                } while (std::chrono::duration<double> (clk::now() - t0).count() < secs);
+                total += n + (x & 1u);
+            });
+        for (auto& th : pool)
+            th.join();
+        return (double) total.load();
+    };
+    const double one = run (1);
+    const double many = run (nthreads);
+    return one > 0 ? many / one : 1.0;
+}
+
 static double seconds_since (clk::time_point t0) { return std::chrono::duration<double> (clk::now() - t0).count(); }
 
 int main (int argc, char** argv)
@@ -59,8 +129,17 @@ int main (int argc, char** argv)
     const double secs = atof (argv[5]);
     int threads = atoi (argv[6]);
     const size_t stream_mib = (size_t) atol (argv[7]);
+    const int aff = affinity_cpus();
+    const double quota = cgroup_cpu_quota();
+    int effective = aff;
+    if (quota > 0 && quota < (double) effective)
+        effective = (int) (quota + 0.5) > 0 ? (int) (quota + 0.5) : 1;
+    const int probe_threads = effective < 64 ? effective : 64;
+    const double probe = probe_threads > 1 ? parallel_speedup_probe (probe_threads, 0.25) : 1.0;
+    if (probe_threads > 1 && probe < 0.75 * (double) probe_threads) // throttled below what the masks promise
+        effective = (int) (probe + 0.5) > 0 ? (int) (probe + 0.5) : 1;
     if (threads <= 0)
-        threads = (int) std::thread::hardware_concurrency();
+        threads = effective; // the all-core regime runs one thread per CPU this process can really use
 
     void* h = dlopen (libpath, RTLD_NOW | RTLD_LOCAL);
     if (! h)
@@ -170,8 +249,10 @@ int main (int argc, char** argv)
 
     printf ("{\"N\": %d, \"transform\": \"%s\", \"simd_width_bytes\": %d, \"seconds_per_regime\": %.2f, "
             "\"hot_1t_transforms_per_s\": %.1f, \"stream_1t_transforms_per_s\": %.1f, "
-            "\"allcore_transforms_per_s\": %.1f, \"allcore_threads\": %d, \"stream_mib\": %zu}\n",
-            N, is_real ? "real" : "complex", width, secs, hot_tps, stream_tps, all_tps, threads, stream_mib);
+            "\"allcore_transforms_per_s\": %.1f, \"allcore_threads\": %d, \"stream_mib\": %zu, "
+            "\"host_hardware_threads\": %u, \"affinity_cpus\": %d, \"cgroup_cpu_quota\": %.2f, \"parallel_speedup_probe\": %.2f, \"probe_threads\": %d, \"cores_effective\": %d}\n",
+            N, is_real ? "real" : "complex", width, secs, hot_tps, stream_tps, all_tps, threads, stream_mib,
+            std::thread::hardware_concurrency(), aff, quota, probe, probe_threads, effective);
     api.destroy_setup (setup);
     dlclose (h);
     return 0;

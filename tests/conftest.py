@@ -20,12 +20,14 @@ import oracle_lib  # noqa: E402
 # parity bound of the north star: results match the reference SSE path within 1e-6 relative fp32,
 # normalised per frame: relative L2 error <= 1e-6.
 PARITY_TOL = 1.0e-6
-# Secondary, element-wise check: max-abs error over the frame's max-abs value.  The reference algorithm is
-# itself up to 8e-7 away from the exact (float64) result in this metric on single-tone spectra (its
-# twiddle angles are formed in float: oracle vs float64, N=262144 tone, BACKWARD: 8.2e-7; N=4096: 5.6e-7),
-# so two correct fp32 implementations can differ by more than 1e-6 element-wise while both are within
-# 1e-6 of the truth.  Bound: 2e-6 (1e-6 for each side).
-MAXABS_TOL = 2.0e-6
+# Secondary, element-wise check: max-abs error over the frame's max-abs value, same bound (1e-6) by default.
+# Named exception, passed explicitly (maxabs_tol=TONE_MAXABS_TOL) by the tests it applies to: on SINGLE-TONE inputs
+# the reference algorithm is itself up to 8e-7 away from the exact (float64) result in this metric (its twiddle
+# angles are formed in float: oracle vs float64, N=262144 tone, BACKWARD: 8.2e-7; N=4096: 5.6e-7), so two correct
+# fp32 implementations can differ by more than 1e-6 element-wise while each is within 1e-6 of the truth.  Those tests
+# use 2e-6 (1e-6 for each side); their relative-L2 bound stays 1e-6.
+MAXABS_TOL = PARITY_TOL
+TONE_MAXABS_TOL = 2.0e-6
 
 
 def pytest_configure(config):
@@ -72,8 +74,10 @@ def gpu():
     return api, torch, torch.device("cuda:0")
 
 
-def assert_frames_close(got, want, tol=PARITY_TOL, what=""):
-    """per-frame relative L2 and max-abs/frame-max, both <= tol"""
+def assert_frames_close(got, want, tol=PARITY_TOL, what="", maxabs_tol=None):
+    """per-frame relative L2 <= tol and max-abs/frame-max <= maxabs_tol (default: tol; see TONE_MAXABS_TOL)"""
+    if maxabs_tol is None:
+        maxabs_tol = tol
     got = np.asarray(got, dtype=np.float64)
     want = np.asarray(want, dtype=np.float64)
     assert got.shape == want.shape, f"{what}: shape {got.shape} vs {want.shape}"
@@ -84,5 +88,5 @@ def assert_frames_close(got, want, tol=PARITY_TOL, what=""):
     l2 = float((num / den).max())
     mx = float((np.abs(g2 - w2).max(axis=1) / np.maximum(np.abs(w2).max(axis=1), 1e-300)).max())
     assert l2 <= tol, f"{what}: relative L2 {l2:.3e} > {tol:.1e}"
-    assert mx <= 2 * tol, f"{what}: max-abs/frame-max {mx:.3e} > {2 * tol:.1e}"
+    assert mx <= maxabs_tol, f"{what}: max-abs/frame-max {mx:.3e} > {maxabs_tol:.1e}"
     return l2, mx

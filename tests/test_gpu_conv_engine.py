@@ -95,6 +95,29 @@ def test_engine_per_channel_filters(gpu):
     eng.close()
 
 
+@pytest.mark.parametrize("block,channels", [(128, 5), (2048, 3), (512, 7)])
+def test_engine_per_channel_single_partition_ragged_group(gpu, block, channels):
+    """per-channel filters, ONE partition, channels not a multiple of the teams per workgroup: the idle teams of the last
+    group must not read filter bins past the end of H (there is no next partition behind it)"""
+    api, torch, dev = gpu
+    ir_len, nblocks = block, 3
+    rng = np.random.RandomState(block + channels)
+    ir = rng.uniform(-1, 1, (channels, ir_len)).astype(np.float32)
+    x = rng.uniform(-1, 1, (channels, nblocks * block)).astype(np.float32)
+    eng = api.ConvEngine(block, channels, torch.from_numpy(ir).to(dev), shared=False)
+    assert eng.partitions == 1
+    out = torch.empty((channels, block), device=dev)
+    y = np.empty_like(x)
+    for t in range(nblocks):
+        eng.process(torch.from_numpy(np.ascontiguousarray(x[:, t * block:(t + 1) * block])).to(dev), out)
+        torch.cuda.synchronize()
+        y[:, t * block:(t + 1) * block] = out.cpu().numpy()
+    for c in range(channels):
+        d = np.convolve(x[c].astype(np.float64), ir[c].astype(np.float64))[: x.shape[1]]
+        assert np.abs(y[c] - d).max() <= 5e-6 * np.abs(d).max()
+    eng.close()
+
+
 def test_engine_rejects_bad_arguments(gpu):
     api, torch, dev = gpu
     for block in (0, 8, 24, 100):

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as ol
-from conftest import assert_frames_close
+from conftest import TONE_MAXABS_TOL, assert_frames_close
 from oracle_lib import BACKWARD, COMPLEX, FORWARD, REAL
 
 pytestmark = pytest.mark.gpu
@@ -16,7 +16,9 @@ REFERENCE_OTHER_SIZES = [96, 192, 384, 480, 640, 768, 9216]
 MORE_SIZES = [48, 80, 160, 240, 320, 720, 1440, 2000, 2304, 3072, 5120, 6400, 7680, 8640, 10240, 10368, 11520, 13824, 17280, 19200]
 # complex length > 20000 (and some below, as real frames of twice the length): two passes (generic n2-point column FFTs x power-of-two n1-point row FFTs) where such a split
 # exists; sizes without one (test_long_mixed_sizes_without_a_split) come back NULL although the reference accepts them
-LONG_MIXED_SIZES = [12288, 15360, 18432, 20480, 24576, 25600, 46080, 61440, 76800, 98304, 245760]
+# 655360 = 640 x 1024 and 1310720 = 1280 x 1024: the column lengths at the edge of the CU's 160 KiB LDS (two padded
+# 16-column images of 640 points are 164096 B; two padded 8-column images of 1280 points 163968 B)
+LONG_MIXED_SIZES = [12288, 15360, 18432, 20480, 24576, 25600, 46080, 61440, 76800, 98304, 245760, 655360, 1310720]
 
 
 def _gpu(gpu, s, x, direction):
@@ -40,7 +42,7 @@ def test_other_sizes_batch_vs_oracle(gpu, oracle, n, tr):
     if s is None:
         return
     nf = 2 * n if tr == COMPLEX else n
-    batch = 11
+    batch = 11 if n < 500000 else 3
     x = ol.uniform(batch * nf, 7 + n).reshape(batch, nf)
     want_f = oracle.transform_batch(so, x, FORWARD)
     got_f = _gpu(gpu, s, x, api.FFT_FORWARD)
@@ -100,11 +102,11 @@ def test_reference_other_sizes_sequence_host_pointers(gpu, oracle, n, tr, preall
         exact[0], exact[1] = t[0].real, t[n // 2].real
         exact[2::2], exact[3::2] = t[1:n // 2].real, t[1:n // 2].imag
     assert np.abs(data - exact).max() <= 2.0e-7 * nf
-    assert_frames_close(data, want_f, what="other size fwd")
+    assert_frames_close(data, want_f, what="other size fwd", maxabs_tol=TONE_MAXABS_TOL)  # tone input
     api.fft_transform(s, data, data, work, api.FFT_BACKWARD)
     assert np.abs(data / n - x0).max() <= 2.0e-7 * nf  # BACKWARD(FORWARD(x)) = N x
     want_b = oracle.transform(so, oracle.transform(so, x0, FORWARD), BACKWARD)
-    assert_frames_close(data, want_b, what="other size round trip")
+    assert_frames_close(data, want_b, what="other size round trip", maxabs_tol=TONE_MAXABS_TOL)
     if preallocate:
         api.aligned_free(prealloc)
     else:

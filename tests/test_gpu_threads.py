@@ -80,3 +80,44 @@ def test_batched_calls_from_threads_on_their_own_streams(gpu, oracle):
     assert not errors, errors[0]
     api.fft_destroy_setup(s)
     oracle.destroy_setup(so)
+
+
+def test_legacy_call_from_a_fresh_thread_on_another_device(oracle):
+    """A setup created on device 1, called through the legacy host-pointer symbols from a thread that has never selected
+    a device (its current device is 0): the staging memory, the copies, the launch and the final synchronisation all have to
+    address the PLAN's device.  Needs two devices (skipped on a one-GPU lease)."""
+    from chowdsp_fft_amd import _lib, api
+
+    lib = _lib.lib()
+    if lib.fft_gpu_device_count() < 2:
+        pytest.skip("needs two HIP devices")
+    n, tr = 4096, COMPLEX
+    assert lib.fft_gpu_set_device(1) == 0
+    s = api.fft_new_setup(n, tr)
+    assert s is not None and lib.fft_gpu_setup_device(s) == 1
+    assert lib.fft_gpu_set_device(0) == 0
+    so = oracle.new_setup(n, tr)
+    x = ol.uniform(2 * n, 5)
+    want = oracle.transform(so, x, FORWARD)
+    errors = []
+
+    def worker():
+        try:
+            xb, xp = api.aligned_array(2 * n)
+            yb, yp = api.aligned_array(2 * n)
+            xb[:] = x
+            for _ in range(20):
+                yb[:] = 0
+                api.fft_transform(s, xb, yb, None, api.FFT_FORWARD)
+                assert_frames_close(yb, want, what="device-1 plan from a fresh thread")
+            api.aligned_free(xp)
+            api.aligned_free(yp)
+        except Exception as e:
+            errors.append(e)
+
+    th = threading.Thread(target=worker)
+    th.start()
+    th.join()
+    assert not errors, errors[0]
+    api.fft_destroy_setup(s)
+    oracle.destroy_setup(so)
