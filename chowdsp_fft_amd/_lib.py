@@ -42,6 +42,7 @@ PROTOTYPES = {
     "fft_gpu_memcpy": (_i, [_vp, _vp, _sz, _i, _vp]),
     "fft_gpu_stream_synchronize": (_i, [_vp]),
     "fft_gpu_last_error": (C.c_char_p, []),
+    "fft_gpu_set_option": (_i, [C.c_char_p, C.c_long]),
     "fft_gpu_size_supported": (_i, [_i, _i]),
     "fft_gpu_plan_describe": (_i, [_i, _i, C.POINTER(C.c_int)]),
     "fft_gpu_setup_size": (_i, [_vp]),

@@ -257,6 +257,11 @@ class ConvEngine:
             pass
 
 
+def set_option(name: str, value: int) -> None:
+    """fft_gpu_set_option: run-time knobs of the library (chowdsp_fft_gpu.h)"""
+    _check(_lib.lib().fft_gpu_set_option(name.encode(), int(value)), f"fft_gpu_set_option({name})")
+
+
 def size_supported(N: int, transform: int) -> bool:
     return bool(_lib.lib().fft_gpu_size_supported(N, transform))
 

@@ -12,6 +12,8 @@
 #include "plans.hpp"
 #include "tables.hpp"
 
+#include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -137,6 +139,11 @@ struct Lanes
     float2* ws[2] = { nullptr, nullptr };
     size_t bytes = 0; // per workspace
     bool ok = false;
+    // fused (one-launch) two-pass plans: queue state + the per-XCD slot ring of intermediates
+    void* fused_state = nullptr;
+    float2* fused_ws = nullptr;
+    size_t fused_ws_bytes = 0;
+    unsigned* fused_err_host = nullptr; // pinned: the state's error word, copied back after every launch, looked at by the next call
 };
 std::mutex g_ws_mutex;
 std::map<std::pair<int, hipStream_t>, Lanes> g_lanes;
@@ -209,6 +216,85 @@ Lanes* get_lanes (int device, hipStream_t stream, size_t bytes_each)
     return &L;
 }
 
+// Run-time options of the one-launch two-pass form (fft_gpu_set_option; initial values from the environment):
+//   fused_two_pass   CHOWDSP_FFT_FUSED            0 = always two launches per chunk (A/B timing), 1 = one launch where it exists
+//   fused_min_batch  CHOWDSP_FFT_FUSED_MIN_BATCH  smallest batch that takes it.  Its queue needs `lag` steps to fill and drain,
+//                                                 so short batches are faster as two launches (MI355X, N = 65536: batch 1:
+//                                                 13 vs 67 us, 64: 32 vs 54, 256: 98 vs 124, 1024: 417 vs 434, 8192: equal)
+//   fused_lag        CHOWDSP_FFT_FUSED_LAG        steps between a frame's pass A and its pass B
+//   fused_slots      CHOWDSP_FFT_FUSED_SLOTS      workspace slots (frames) per XCD queue, > lag (default lag + 2)
+// Measured (N = 65536 x 8192, profiles/r02_fused_two_pass.txt): lag 3 / 5 slots keeps every intermediate in L2 (fabric
+// traffic 1.50 x algorithmic) at 3.10 ms per transform; lag 4 / 6 slots 1.58 x at 2.90 ms (= the two-launch form's time,
+// whose traffic is 2.0 x); lag 5 / 7 slots no longer fits L2 (1.9 x).
+struct FusedOptions
+{
+    std::atomic<long> enabled, min_batch, lag, slots;
+    FusedOptions()
+    {
+        const auto env = [] (const char* name, long dflt) {
+            const char* e = std::getenv (name);
+            return e != nullptr ? std::atol (e) : dflt;
+        };
+        enabled = env ("CHOWDSP_FFT_FUSED", 1);
+        min_batch = std::max (1l, env ("CHOWDSP_FFT_FUSED_MIN_BATCH", 2048));
+        long l = env ("CHOWDSP_FFT_FUSED_LAG", 4);
+        l = (l >= 1 && l <= 6) ? l : 4;
+        long sl = env ("CHOWDSP_FFT_FUSED_SLOTS", l + 2);
+        sl = (sl > l && sl <= 8) ? sl : l + 2;
+        lag = l;
+        slots = sl;
+    }
+};
+FusedOptions& fused_options()
+{
+    static FusedOptions o;
+    return o;
+}
+bool fused_enabled() { return fused_options().enabled.load() != 0; }
+size_t fused_min_batch() { return (size_t) fused_options().min_batch.load(); }
+int fused_lag() { return (int) fused_options().lag.load(); }
+int fused_slots() { return (int) fused_options().slots.load(); }
+
+// caller holds g_ws_mutex
+Lanes* get_fused (int device, hipStream_t stream, size_t ws_bytes)
+{
+    Lanes& L = g_lanes[std::make_pair (device, stream)];
+    if (L.fused_state == nullptr && hipMalloc (&L.fused_state, fused_state_bytes()) != hipSuccess)
+    {
+        L.fused_state = nullptr;
+        set_last_error ("fused two-pass state allocation failed");
+        return nullptr;
+    }
+    if (L.fused_err_host == nullptr)
+    {
+        if (hipHostMalloc ((void**) &L.fused_err_host, sizeof (unsigned), hipHostMallocDefault) != hipSuccess)
+        {
+            L.fused_err_host = nullptr;
+            set_last_error ("fused two-pass status word allocation failed");
+            return nullptr;
+        }
+        *L.fused_err_host = 0;
+    }
+    if (L.fused_ws_bytes < ws_bytes)
+    {
+        if (L.fused_ws != nullptr)
+        {
+            (void) hipStreamSynchronize (stream);
+            (void) hipFree (L.fused_ws);
+            L.fused_ws = nullptr;
+            L.fused_ws_bytes = 0;
+        }
+        if (hipMalloc ((void**) &L.fused_ws, ws_bytes) != hipSuccess)
+        {
+            L.fused_ws = nullptr;
+            set_last_error ("fused two-pass workspace allocation failed");
+            return nullptr;
+        }
+        L.fused_ws_bytes = ws_bytes;
+    }
+    return &L;
+}
+
 // complex length the plan's core transforms
 int complex_len (const Setup* s) { return s->transform == cf::FFT_COMPLEX ? s->N : s->N / 2; }
 
@@ -222,6 +308,31 @@ int big_c2c_chunked (Setup* s, int nc, bool inverse, const float2* in, float2* o
     int n1 = 0, n2 = 0;
     if (! mixed)
         split_large (nc, n1, n2);
+    if (! mixed && pair == 0 && fused_enabled() && fused_supported (n1, n2) && batch >= fused_min_batch())
+    {
+        // both passes in one launch, hand-off inside an XCD's L2: no chunking, no lanes, 1.5 x instead of 2 x the traffic
+        std::lock_guard<std::mutex> lock (g_ws_mutex);
+        const int lag = fused_lag(), slots = fused_slots();
+        Lanes* L = get_fused (s->device, stream, fused_workspace_bytes (nc, slots));
+        if (L == nullptr)
+            return cf::FFT_GPU_ENOMEM;
+        if (*L->fused_err_host != 0)
+        {
+            // a bounded wait inside an EARLIER launch on this stream ran out (its output is not valid): say so now
+            *L->fused_err_host = 0;
+            set_last_error ("an earlier one-launch two-pass transform on this stream did not complete its hand-offs");
+            return cf::FFT_GPU_ELAUNCH;
+        }
+        hipError_t e = launch_fused_c2c (n1, n2, inverse, in, L->fused_ws, out, s->tables->stage_twiddles, s->tables->big_twiddles, L->fused_state, batch, lag, slots, stream, is2, os2);
+        if (e == hipSuccess) // the state's error word (offset 4) travels back behind the kernel
+            e = hipMemcpyAsync (L->fused_err_host, (const char*) L->fused_state + sizeof (unsigned), sizeof (unsigned), hipMemcpyDeviceToHost, stream);
+        if (e != hipSuccess)
+        {
+            set_last_error ("fused two-pass kernel launch", e);
+            return cf::FFT_GPU_ELAUNCH;
+        }
+        return cf::FFT_GPU_OK;
+    }
     const size_t frame_bytes = (size_t) nc * sizeof (float2);
     const int want_lanes = lane_count();
     // the cap covers BOTH workspaces, so that they fit the Infinity Cache together
@@ -707,6 +818,31 @@ int fft_gpu_plan_describe (int N, fft_transform_t transform, int desc[8])
     desc[3] = n2;
     for (int i = 0; i < 4; ++i)
         desc[4 + i] = radix[i];
+    return FFT_GPU_OK;
+}
+
+int fft_gpu_set_option (const char* name, long value)
+{
+    if (name == nullptr)
+        return FFT_GPU_EINVAL;
+    FusedOptions& o = fused_options();
+    if (std::strcmp (name, "fused_two_pass") == 0)
+        o.enabled = value != 0;
+    else if (std::strcmp (name, "fused_min_batch") == 0 && value >= 1)
+        o.min_batch = value;
+    else if (std::strcmp (name, "fused_lag") == 0 && value >= 1 && value <= 6)
+    {
+        o.lag = value;
+        if (o.slots.load() <= value || o.slots.load() > 8)
+            o.slots = value + 2;
+    }
+    else if (std::strcmp (name, "fused_slots") == 0 && value > o.lag.load() && value <= 8)
+        o.slots = value;
+    else
+    {
+        set_last_error ("fft_gpu_set_option: unknown option or value out of range");
+        return FFT_GPU_EINVAL;
+    }
     return FFT_GPU_OK;
 }
 

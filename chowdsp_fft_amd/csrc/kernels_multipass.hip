@@ -1,8 +1,12 @@
 // Instantiation + launch of the two-pass (N > 4096) kernels and the stand-alone real pair stage.
 #include "launch_util.hpp"
 #include "multipass_kernels.hpp"
+#include "fused_twopass_kernels.hpp"
 #include "generic_kernels.hpp"
 #include "tables.hpp"
+
+#include <cstdio>
+#include <cstdlib>
 
 namespace cfft::host
 {
@@ -135,6 +139,66 @@ hipError_t launch_big_c2c (int n1, int n2, bool inverse, const float2* in, float
         if (e != hipSuccess)
             return e;
         CFFT_DISPATCH_BIG (n1, e = (pass_b<N_, false> (n2, work, out, tw1, batch, grid_divisor, stream, out_stride)));
+    }
+    return e;
+}
+
+// ---- both passes in one launch, hand-off inside an XCD's L2 (fused_twopass_kernels.hpp) -------------------------------
+size_t fused_state_bytes() { return sizeof (FusedState); }
+size_t fused_workspace_bytes (int nc, int slots) { return (size_t) kFusedMaxXcc * (size_t) slots * (size_t) nc * sizeof (float2); }
+bool fused_supported (int n1, int n2) { return n1 == 256 && n2 == 256; }
+
+hipError_t launch_fused_c2c (int n1, int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, void* state, size_t batch, int lag, int slots, hipStream_t stream, size_t in_stride, size_t out_stride)
+{
+    if (batch == 0)
+        return hipSuccess;
+    if (! fused_supported (n1, n2) || batch >= 0x7FFFFFFFull || lag < 1 || slots <= lag || slots > kFusedMaxSlots)
+        return hipErrorInvalidValue;
+    const size_t frame_len = (size_t) n1 * (size_t) n2;
+    in_stride = in_stride ? in_stride : frame_len;
+    out_stride = out_stride ? out_stride : frame_len;
+    // queue state: tickets, claims and counters start from zero in every launch
+    hipError_t e = hipMemsetAsync (state, 0, sizeof (FusedState), stream);
+    if (e != hipSuccess)
+        return e;
+    constexpr size_t lds = (size_t) 16 * TileFrame<256>::stride * sizeof (float2);
+    auto k = inverse ? fused256_kernel<true> : fused256_kernel<false>;
+    // every tile of both passes is a work item; the grid never exceeds what is resident, so every ticket holder runs
+    unsigned grid = persistent_grid (k, 256, lds, batch * 32);
+    if (grid == 0)
+        return hipErrorNoDevice;
+    // two workgroups per CU: more of them lengthen the queue (tickets in flight) and with it the time an intermediate has
+    // to survive in L2, for no gain in rate (measured; CHOWDSP_FFT_FUSED_WG_PER_CU overrides)
+    static const int grid_cap = [] {
+        const char* v = std::getenv ("CHOWDSP_FFT_FUSED_WG_PER_CU");
+        return v != nullptr ? std::atoi (v) : 2;
+    }();
+    static const int dbg_mode = [] {
+        const char* v = std::getenv ("CHOWDSP_FFT_FUSED_EXPERIMENT");
+        return v != nullptr ? std::atoi (v) : 0;
+    }();
+    if (grid_cap > 0)
+    {
+        DeviceInfo dev;
+        if (current_device_info (dev))
+            grid = std::min (grid, (unsigned) (dev.num_cus * grid_cap));
+    }
+    hipLaunchKernelGGL (k, dim3 (grid), dim3 (256), lds, stream, in, work, out, stage_tw, big_tw, (FusedState*) state, (unsigned) batch, in_stride, out_stride, (unsigned) lag, (unsigned) slots, (unsigned) dbg_mode);
+    e = hipGetLastError();
+    static const bool debug = std::getenv ("CHOWDSP_FFT_FUSED_DEBUG") != nullptr;
+    if (debug && e == hipSuccess)
+    {
+        // developer aid: wait for the launch and show how the work spread over the XCD queues
+        FusedState h;
+        if (hipStreamSynchronize (stream) == hipSuccess && hipMemcpy (&h, state, sizeof (h), hipMemcpyDeviceToHost) == hipSuccess)
+        {
+            fprintf (stderr, "[fused] grid %u batch %zu lag %d slots %d error %u claimed %u stats B-prefetched %u B-late %u unresolved %u polls %u A-slot-checks %u tickets:",
+                     grid, batch, lag, slots, h.error, h.next_frame, h.stat[0], h.stat[1], h.stat[2], h.stat[3], h.stat[4]);
+            for (int x = 0; x < kFusedMaxXcc; ++x)
+                if (h.q[x].ticket != 0)
+                    fprintf (stderr, " xcc%d=%u", x, h.q[x].ticket);
+            fprintf (stderr, "\n");
+        }
     }
     return e;
 }

@@ -46,6 +46,12 @@ hipError_t launch_conv_frames_real (int m, const float2* in, const float2* H, fl
 // stage_tw holds the n2-core table followed by the n1-core table.  grid_divisor: 2 when two launches are meant
 // to share the GPU (two-lane pipeline), else 1.
 hipError_t launch_big_c2c (int n1, int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, size_t batch, int grid_divisor, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
+// the same two passes in ONE launch with the intermediate handed over inside an XCD's L2 (fused_twopass_kernels.hpp):
+// `state` = fused_state_bytes() of device memory (zeroed by the launcher on `stream`), `work` = fused_workspace_bytes()
+bool fused_supported (int n1, int n2);
+size_t fused_state_bytes();
+size_t fused_workspace_bytes (int nc, int slots);
+hipError_t launch_fused_c2c (int n1, int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, void* state, size_t batch, int lag, int slots, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
 // long mixed-radix frames (t.mixed_n2 > 0): generic column pass + power-of-two row pass, in -> work -> out
 hipError_t launch_mixed_big_c2c (const DeviceTables& t, bool inverse, const float2* in, float2* work, float2* out, size_t batch, int grid_divisor, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
 hipError_t launch_real_pair (bool forward, const float2* in, float2* out, const float2* real_tw, unsigned m, size_t batch, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);

@@ -54,6 +54,15 @@ int fft_gpu_stream_synchronize (void* stream);
 /* Last HIP error string seen by this thread inside the library ("" if none). */
 const char* fft_gpu_last_error (void);
 
+/* Run-time options (process-wide; initial values come from the environment variables named in INTEGRATION.md):
+     "fused_two_pass"   1 / 0: run two-pass sizes that have a one-launch form (N = 65536 complex) in one launch with the
+                        inter-pass hand-off inside an XCD's L2, or always as two launches per chunk
+     "fused_min_batch"  smallest batch that takes the one-launch form (default 2048)
+     "fused_lag", "fused_slots"   queue depth of the one-launch form (steps between a frame's two passes; workspace
+                        frames per XCD, > lag)
+   Returns 0, or FFT_GPU_EINVAL for an unknown name / a value out of range. */
+int fft_gpu_set_option (const char* name, long value);
+
 /* ---- plan introspection -------------------------------------------------------------------------- */
 /* 1 if fft_new_setup would accept (N, transform) on a machine with a usable device, else 0.  Pure host
    logic (no GPU needed); the rule is the reference's SSE size rule (N % 16 complex / N % 32 real, N = 2^a 3^b 5^c;

@@ -26,8 +26,13 @@ PARITY_TOL = 1.0e-6
 # angles are formed in float: oracle vs float64, N=262144 tone, BACKWARD: 8.2e-7; N=4096: 5.6e-7), so two correct
 # fp32 implementations can differ by more than 1e-6 element-wise while each is within 1e-6 of the truth.  Those tests
 # use 2e-6 (1e-6 for each side); their relative-L2 bound stays 1e-6.
+# Second named exception (maxabs_tol=MIXED_RADIX_MAXABS_TOL, tests/test_gpu_other_sizes.py): sizes with radix-3 / radix-5
+# passes.  The reference evaluates those passes' twiddle angles in float too, and its element-wise distance from the
+# exact transform grows with the length (N = 9216 complex: 1.4e-6).  The tests that use this bound also require the HIP
+# result to be within 1e-6 (relative L2 AND element-wise) of the float64 transform of the same input.
 MAXABS_TOL = PARITY_TOL
 TONE_MAXABS_TOL = 2.0e-6
+MIXED_RADIX_MAXABS_TOL = 2.0e-6
 
 
 def pytest_configure(config):

@@ -1,0 +1,106 @@
+"""The one-launch two-pass form (csrc/fused_twopass_kernels.hpp): both passes of N = 65536 complex in ONE kernel, the
+inter-pass hand-off inside an XCD's L2, work handed out by per-XCD ticket queues.  Forced on for every batch size here
+(by default only batches >= 2048 take it): parity with the oracle, and agreement with the two-launch form, for
+batches that fill the queue's pipeline only partly, exactly, and many times over; both directions; in place; strided.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from conftest import assert_frames_close
+from oracle_lib import BACKWARD, COMPLEX, FORWARD
+
+pytestmark = pytest.mark.gpu
+
+N = 65536
+
+
+@pytest.fixture()
+def fused_on(gpu):
+    api = gpu[0]
+    api.set_option("fused_two_pass", 1)
+    api.set_option("fused_min_batch", 1)
+    yield api
+    api.set_option("fused_min_batch", 2048)
+    api.set_option("fused_lag", 4)
+    api.set_option("fused_two_pass", 1)
+
+
+def _run(gpu, s, x, direction, fused):
+    api, torch, dev = gpu
+    api.set_option("fused_two_pass", 1 if fused else 0)
+    xd = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    yd = torch.empty_like(xd)
+    api.fft_transform_batch(s, xd, yd, direction)
+    torch.cuda.synchronize()
+    api.set_option("fused_two_pass", 1)
+    return yd.cpu().numpy()
+
+
+@pytest.mark.parametrize("batch", [1, 2, 7, 8, 9, 31, 64, 100])
+@pytest.mark.parametrize("lag", [1, 3, 4])
+def test_fused_vs_oracle_and_two_launch(gpu, oracle, fused_on, batch, lag):
+    api = fused_on
+    api.set_option("fused_lag", lag)
+    s, so = api.fft_new_setup(N, api.FFT_COMPLEX), oracle.new_setup(N, COMPLEX)
+    x = ol.uniform(batch * 2 * N, 900 + batch).reshape(batch, 2 * N)
+    nref = min(batch, 3)
+    for direction, odir in ((api.FFT_FORWARD, FORWARD), (api.FFT_BACKWARD, BACKWARD)):
+        got = _run(gpu, s, x, direction, True)
+        two = _run(gpu, s, x, direction, False)
+        # same algorithm and tables; the compiler contracts the two kernels' multiply-adds differently
+        assert_frames_close(got, two, tol=2e-7, maxabs_tol=6e-7, what="one-launch vs two-launch form")
+        want = oracle.transform_batch(so, x[:nref], odir)
+        assert_frames_close(got[:nref], want, what=f"fused N={N} batch={batch} lag={lag} dir={direction}")
+        last = oracle.transform_batch(so, x[-1:], odir)
+        assert_frames_close(got[-1:], last, what="last frame of the batch (queue drain)")
+    api.fft_destroy_setup(s)
+    oracle.destroy_setup(so)
+
+
+def test_fused_in_place_and_strided(gpu, oracle, fused_on):
+    api, torch, dev = gpu
+    batch, pad = 37, 64
+    s, so = api.fft_new_setup(N, api.FFT_COMPLEX), oracle.new_setup(N, COMPLEX)
+    x = ol.uniform(batch * 2 * N, 77).reshape(batch, 2 * N)
+    want = oracle.transform_batch(so, x[[0, 17, 36]], FORWARD)
+    xd = torch.from_numpy(x).to(dev)
+    api.fft_transform_batch(s, xd, xd, api.FFT_FORWARD)  # in place: pass A of a frame has read all of it before pass B writes
+    torch.cuda.synchronize()
+    assert_frames_close(xd.cpu().numpy()[[0, 17, 36]], want, what="fused in place")
+    stride = 2 * N + pad
+    buf = torch.full((batch, stride), 123.0, device=dev)
+    buf[:, :2 * N] = torch.from_numpy(x).to(dev)
+    out = torch.full((batch, stride), -7.0, device=dev)
+    api.fft_transform_batch_strided(s, buf, stride, out, stride, batch, api.FFT_FORWARD)
+    torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    assert_frames_close(o[[0, 17, 36], :2 * N], want, what="fused strided")
+    assert np.all(o[:, 2 * N:] == -7.0), "padding between output frames untouched"
+    api.fft_destroy_setup(s)
+    oracle.destroy_setup(so)
+
+
+def test_fused_many_launches_back_to_back(gpu, fused_on):
+    """state and workspace are re-used by consecutive launches on one stream (tickets, claims and flags start from zero)"""
+    api, torch, dev = gpu
+    s = api.fft_new_setup(N, api.FFT_COMPLEX)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    x = torch.rand((48, 2 * N), device=dev, generator=g) * 2 - 1
+    y = torch.empty_like(x)
+    z = torch.empty_like(x)
+    for _ in range(20):
+        api.fft_transform_batch(s, x, y, api.FFT_FORWARD)
+        api.fft_transform_batch(s, y, z, api.FFT_BACKWARD)
+    torch.cuda.synchronize()
+    assert float((z / N - x).abs().max()) < 3e-6
+    api.fft_destroy_setup(s)
+
+
+def test_set_option_rejects_nonsense(gpu):
+    api = gpu[0]
+    with pytest.raises(api.FFTError):
+        api.set_option("no_such_option", 1)
+    with pytest.raises(api.FFTError):
+        api.set_option("fused_lag", 99)

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as ol
-from conftest import TONE_MAXABS_TOL, assert_frames_close
+from conftest import MIXED_RADIX_MAXABS_TOL, TONE_MAXABS_TOL, assert_frames_close
 from oracle_lib import BACKWARD, COMPLEX, FORWARD, REAL
 
 pytestmark = pytest.mark.gpu
@@ -28,6 +28,27 @@ def _gpu(gpu, s, x, direction):
     api.fft_transform_batch(s, xd, yd, direction)
     torch.cuda.synchronize()
     return yd.cpu().numpy()
+
+
+def _exact(x, n, tr, direction):
+    """float64 transform of a batch in the library's layouts (interleaved complex / packed real spectrum), unscaled"""
+    x = np.asarray(x, dtype=np.float64)
+    if tr == COMPLEX:
+        z = x[:, 0::2] + 1j * x[:, 1::2]
+        t = np.fft.fft(z, axis=1) if direction == FORWARD else np.fft.ifft(z, axis=1) * n
+        out = np.empty_like(x)
+        out[:, 0::2], out[:, 1::2] = t.real, t.imag
+        return out
+    if direction == FORWARD:
+        t = np.fft.rfft(x, axis=1)
+        out = np.empty_like(x)
+        out[:, 0], out[:, 1] = t[:, 0].real, t[:, n // 2].real
+        out[:, 2::2], out[:, 3::2] = t[:, 1:n // 2].real, t[:, 1:n // 2].imag
+        return out
+    spec = np.zeros((x.shape[0], n // 2 + 1), dtype=np.complex128)
+    spec[:, 0], spec[:, n // 2] = x[:, 0], x[:, 1]
+    spec[:, 1:n // 2] = x[:, 2::2] + 1j * x[:, 3::2]
+    return np.fft.irfft(spec, n=n, axis=1) * n
 
 
 @pytest.mark.parametrize("n", REFERENCE_OTHER_SIZES + MORE_SIZES + LONG_MIXED_SIZES)
@@ -60,9 +81,12 @@ def test_other_sizes_batch_vs_oracle(gpu, oracle, n, tr):
         assert ol.rel_l2(want_f[0], exact[0]) > 0.1, "the reference defect seems to be gone: drop this special case"
         want_f = exact.astype(np.float32)  # the reference's BACKWARD path is correct: feed both the true spectrum
     else:
-        assert_frames_close(got_f, want_f, what=f"N={n} fwd")
+        assert_frames_close(got_f, want_f, what=f"N={n} fwd", maxabs_tol=MIXED_RADIX_MAXABS_TOL)
+        assert_frames_close(got_f, _exact(x, n, tr, FORWARD), what=f"N={n} fwd vs float64")
     want_b = oracle.transform_batch(so, want_f, BACKWARD)
-    assert_frames_close(_gpu(gpu, s, want_f, api.FFT_BACKWARD), want_b, what=f"N={n} bwd")
+    got_b = _gpu(gpu, s, want_f, api.FFT_BACKWARD)
+    assert_frames_close(got_b, want_b, what=f"N={n} bwd", maxabs_tol=MIXED_RADIX_MAXABS_TOL)
+    assert_frames_close(got_b, _exact(want_f, n, tr, BACKWARD), what=f"N={n} bwd vs float64")
     api.fft_destroy_setup(s)
     oracle.destroy_setup(so)
 

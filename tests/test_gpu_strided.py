@@ -61,7 +61,8 @@ def test_strided_equals_packed_and_oracle(gpu, oracle, n, tr, batch, direction):
     got = yout.cpu().numpy()
     # same algorithm; where the packed call takes the software-pipelined kernel variant the compiler may contract
     # multiply-adds differently, so allow last-bit differences (far inside the 1e-6 parity bound)
-    assert_frames_close(got[:, :nf], yp.cpu().numpy(), tol=2e-7, what=f"N={n} strided vs packed")
+    # the strided and the packed instantiation of one kernel: same algorithm, the compiler may contract differently
+    assert_frames_close(got[:, :nf], yp.cpu().numpy(), tol=2e-7, maxabs_tol=4e-7, what=f"N={n} strided vs packed")
     assert np.all(got[:, nf:] == SENTINEL), "floats between the output frames were written"
     assert np.all(xin.cpu().numpy()[:, nf:] == SENTINEL)
     idx = np.unique(np.concatenate([np.arange(0, batch, max(1, batch // 9)), [batch - 1]]))
