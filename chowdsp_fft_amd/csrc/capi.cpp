@@ -427,7 +427,12 @@ int run_transform (Setup* s, const float* in, float* out, size_t batch, cf::fft_
     {
         if (! lds_resident)
             return big_c2c_chunked (s, nc, inverse, cin, cout, batch, stream, is2, os2);
-        e = launch_c2c (nc, inverse, cin, cout, t->stage_twiddles, batch, stream, is2, os2);
+        e = (nc == cfft::kSplitCoreN) ? launch_c2c_split (inverse, cin, cout, t->stage_twiddles, batch, stream, is2, os2)
+                                      : launch_c2c (nc, inverse, cin, cout, t->stage_twiddles, batch, stream, is2, os2);
+    }
+    else if (lds_resident && nc == cfft::kSplitCoreN)
+    {
+        e = launch_real_split (! inverse, cin, cout, t->stage_twiddles, t->real_twiddles, batch, stream, is2, os2);
     }
     else if (lds_resident)
     {
@@ -810,6 +815,8 @@ int fft_gpu_plan_describe (int N, fft_transform_t transform, int desc[8])
     int radix[4] = { 0, 0, 0, 0 };
     if (n1 == 256 && n2 == 256)
         radix[0] = radix[1] = 16; // the 65536 fast path has its own radix-16 x 16 plan
+    else if (nc == cfft::kSplitCoreN)
+        radix[0] = radix[1] = radix[2] = 32; // split-plane single pass
     else if (! core_radices (n2 != 0 ? n2 : nc, radix))
         return FFT_GPU_EINVAL;
     desc[0] = nc;

@@ -58,6 +58,9 @@ using Plan256 = Plan<256, 16, 16, 16>;
 #define CFFT_MAX_CORE_N 16384
 #endif
 static constexpr int kMaxCoreN = CFFT_MAX_CORE_N;
+// 32768 points: still one pass over HBM, but through its own kernels (split_plane_kernels.hpp: three radix-32 stages in
+// registers, the exchanges one component at a time) and its own twiddle-table layout, not through a CorePlan
+static constexpr int kSplitCoreN = 32768;
 static constexpr int kMaxFusedN = 4096; // longest core the fused convolution / engine kernels are instantiated for
 static constexpr int kMinCoreN = 16;
 static constexpr int kBlockThreads = 256;

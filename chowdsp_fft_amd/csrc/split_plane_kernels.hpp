@@ -1,0 +1,395 @@
+// N = 32768 complex points (and real N = 65536 on top of it) in ONE pass over HBM.
+//
+// A 32768-point frame is 256 KiB: its interleaved LDS image does not fit the CU's 160 KiB, which is why round 1 ran it as
+// two passes through device memory (2 x the traffic, 2.9 TB/s).  Here one 1024-thread workgroup keeps the whole frame in
+// registers -- 32 complex points per work-item -- and the two Stockham exchanges go through LDS ONE COMPONENT AT A TIME:
+// the real parts of all 32768 points (128 KiB + padding), then the imaginary parts through the same 132 KiB plane.
+//     32768 = 32 x 32 x 32: three radix-32 stages in registers, two exchanges, eight workgroup barriers per frame.
+// Same autosort index algebra as stockham.hpp (stage s, p = product of the radices before it):
+//     butterfly i = t:   k = i mod p,  j = (i - k) * 32 + k;   inputs X[i + a * 1024], outputs Y[j + b * p]
+// so stage 0 reads global memory lane-contiguously, the last stage writes it lane-contiguously, and the result is in
+// natural order (the reference's finalize / zreorder steps, simd/chowdsp_fft_impl_sse.cpp:434-496, 1466-1515, have no
+// counterpart).
+//
+// Registers: 1024 work-items leave 128 VGPRs each, 64 of them hold the frame.  A radix-32 butterfly needs 31 twiddles
+// W^(a k), a = 1..31; instead of loading 31 (62 VGPRs) the input index is split a = a_lo + 8 a_hi, matching the 8 x 4
+// decomposition of the butterfly itself:  W^(a k) = W^(a_lo k) W^(8 a_hi k)  -- 7 + 3 table entries per butterfly,
+// the a_hi factor applied before the inner 4-point transforms, the a_lo factor (common to all a_hi) after them.
+// The tables (10 x 32 and 10 x 1024 entries) stay in L2; they are requested before the exchange they follow.
+#pragma once
+#include "real_kernels.hpp"
+
+namespace cfft
+{
+constexpr int kSplitN = 32768;   // complex points per frame
+constexpr int kSplitT = 1024;    // work-items per frame
+constexpr int kSplitR = 32;      // points per work-item = the radix of every stage
+constexpr int kSplitPlaneFloats = kSplitN + (kSplitN >> 5); // one float per point, one float of padding after every 32
+constexpr size_t kSplitLdsBytes = (size_t) kSplitPlaneFloats * sizeof (float);
+// twiddle table layout: stage 1 (p = 32) then stage 2 (p = 1024); per stage [j][k], j = 0..6: a = 1..7, j = 7..9: a = 8, 16, 24
+constexpr int kSplitTwStage1 = 0;
+constexpr int kSplitTwStage2 = 10 * 32;
+constexpr int kSplitTwTotal = 10 * 32 + 10 * 1024;
+
+__device__ __forceinline__ constexpr int sp_phys (int idx) { return idx + (idx >> 5); }
+
+// cos / sin of pi * m / 16
+__device__ __forceinline__ constexpr float cos16 (int m)
+{
+    constexpr float c[9] = { 1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f, 0.70710678118654752440f,
+                             0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f, 0.0f };
+    m &= 31;
+    if (m > 16)
+        m = 32 - m;
+    return m <= 8 ? c[m] : -c[16 - m];
+}
+__device__ __forceinline__ constexpr float sin16 (int m) { return cos16 (m - 8); }
+
+// u *= W32^M   (M a compile-time constant: multiples of 8 and 4 take the cheap forms)
+template <int M>
+__device__ __forceinline__ float2 mul_w32 (float2 u)
+{
+    constexpr int m = M & 31;
+    if constexpr (m == 0)
+        return u;
+    else if constexpr (m == 8)
+        return mul_mi (u);
+    else if constexpr (m == 16)
+        return make_float2 (-u.x, -u.y);
+    else if constexpr (m == 24)
+        return mul_pi (u);
+    else if constexpr (m == 4)
+        return mul_w8_1 (u);
+    else if constexpr (m == 12)
+        return mul_w8_3 (u);
+    else
+        return cmul (u, make_float2 (cos16 (m), -sin16 (m)));
+}
+
+// 32-point forward DFT in registers, natural order in and out, 32 = 8 (n1) x 4 (n2):
+//     X[4 k1 + k2] = sum_{n1<8} W8^{n1 k1} [ W32^{n1 k2} sum_{n2<4} x[n1 + 8 n2] W4^{n2 k2} ]
+// TW: the inputs are first multiplied by the stage twiddle W^(a k), a = n1 + 8 n2, given as wlo[n1 - 1] = W^(n1 k) and
+// whi[n2 - 1] = W^(8 n2 k): whi before the inner transforms, wlo (common to the four n2) after them.
+template <bool TW>
+__device__ __forceinline__ void fft_reg32 (float2 (&u)[32], const float2 (&w)[10])
+{
+    if constexpr (TW)
+    {
+#pragma unroll
+        for (int n2 = 1; n2 < 4; ++n2)
+#pragma unroll
+            for (int n1 = 0; n1 < 8; ++n1)
+                u[n1 + 8 * n2] = cmul (u[n1 + 8 * n2], w[7 + n2 - 1]);
+    }
+    // inner 4-point DFTs over n2: A[n1][k2] lands in u[n1 + 8 k2]
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1)
+        bfly4 (u[n1], u[n1 + 8], u[n1 + 16], u[n1 + 24]);
+    if constexpr (TW)
+    {
+#pragma unroll
+        for (int n1 = 1; n1 < 8; ++n1)
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2)
+                u[n1 + 8 * k2] = cmul (u[n1 + 8 * k2], w[n1 - 1]);
+    }
+    // W32^{n1 k2}
+#define CFFT_W32(N1, K2) u[N1 + 8 * K2] = mul_w32<N1 * K2> (u[N1 + 8 * K2]);
+#define CFFT_W32_ROW(K2) CFFT_W32 (1, K2) CFFT_W32 (2, K2) CFFT_W32 (3, K2) CFFT_W32 (4, K2) CFFT_W32 (5, K2) CFFT_W32 (6, K2) CFFT_W32 (7, K2)
+    CFFT_W32_ROW (1)
+    CFFT_W32_ROW (2)
+    CFFT_W32_ROW (3)
+#undef CFFT_W32_ROW
+#undef CFFT_W32
+    // outer 8-point DFTs over n1 for each k2: X[4 k1 + k2]
+    float2 o[32];
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2)
+    {
+        float2 a[8];
+#pragma unroll
+        for (int n1 = 0; n1 < 8; ++n1)
+            a[n1] = u[8 * k2 + n1];
+        fft_reg<8> (a);
+#pragma unroll
+        for (int k1 = 0; k1 < 8; ++k1)
+            o[4 * k1 + k2] = a[k1];
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i)
+        u[i] = o[i];
+}
+
+// the 10 twiddles of work-item t's butterfly in stage S (1 or 2)
+template <int S>
+__device__ __forceinline__ void sp_load_twiddles (float2 (&w)[10], const float2* __restrict__ tw, int t)
+{
+    constexpr int p = (S == 1) ? 32 : 1024;
+    constexpr int off = (S == 1) ? kSplitTwStage1 : kSplitTwStage2;
+    const int k = t & (p - 1);
+#pragma unroll
+    for (int j = 0; j < 10; ++j)
+        w[j] = tw[off + j * p + k];
+}
+
+// Stockham exchange after stage S - 1 (p = product of the radices so far: 32^S / 32 ... P_ = 1 after stage 0, 32 after
+// stage 1), one component at a time through the plane.  Bank check (ds_*_b32: 32 banks per 32-lane group): the writes go
+// to phys (j + b p) with bank (t + b) mod 32, the reads to phys (t + 1024 a) with bank (t + t / 32) mod 32 -- both
+// conflict-free over 32 consecutive t.
+template <int P_>
+__device__ __forceinline__ void sp_exchange (float2 (&v)[32], float* __restrict__ plane, int t)
+{
+    // Addresses written out as ONE base per side + compile-time offsets (so that they fold into the instructions'
+    // immediate fields instead of costing a VGPR each):
+    //   write  phys (j + b p):  p = 1:  j = 32 t          -> 33 t + b
+    //                           p = 32: j = 32 (t - k) + k -> 33 (t - k) + k + 33 b        (k = t mod 32)
+    //   read   phys (t + 1024 a) = t + t / 32 + 1056 a
+    const int k = t & (P_ - 1);
+    float* __restrict__ wp = plane + ((P_ == 1) ? 33 * t : 33 * (t - k) + k);
+    constexpr int ws = (P_ == 1) ? 1 : 33;
+    const float* __restrict__ rp0 = plane + (t + (t >> 5));
+    int r1 = t + (t >> 5) + 16 * 1056; // ds offsets are 16 bits: a second base for the upper half, kept from being folded
+    CFFT_LAUNDER_INDEX (r1);           // back into the first one (which costs one address VGPR per read instead)
+    const float* __restrict__ rp1 = plane + r1;
+    __syncthreads(); // whoever read the plane last (previous exchange, previous frame) is done
+#pragma unroll
+    for (int b = 0; b < 32; ++b)
+        wp[b * ws] = v[b].x;
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 16; ++a)
+    {
+        v[a].x = rp0[a * 1056];
+        v[a + 16].x = rp1[a * 1056];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 32; ++b)
+        wp[b * ws] = v[b].y;
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 16; ++a)
+    {
+        v[a].y = rp0[a * 1056];
+        v[a + 16].y = rp1[a * 1056];
+    }
+}
+
+// v (input order: v[a] = x[t + 1024 a]) -> v[b] = X[t + 1024 b]
+__device__ __forceinline__ void sp_core (float2 (&v)[32], const float2* __restrict__ tw, float* __restrict__ plane, int t)
+{
+    float2 w[10];
+    fft_reg32<false> (v, w);
+    CFFT_PHASE_FENCE();
+    sp_load_twiddles<1> (w, tw, t);
+    sp_exchange<1> (v, plane, t);
+    CFFT_PHASE_FENCE();
+    fft_reg32<true> (v, w);
+    CFFT_PHASE_FENCE();
+    CFFT_LAUNDER_INDEX (t);
+    sp_load_twiddles<2> (w, tw, t);
+    sp_exchange<32> (v, plane, t);
+    CFFT_PHASE_FENCE();
+    fft_reg32<true> (v, w);
+    CFFT_PHASE_FENCE();
+}
+
+// ---- complex ------------------------------------------------------------------------------------------------------
+template <bool INV>
+__global__ __launch_bounds__ (kSplitT) void c2c_split_kernel (const float2* __restrict__ in,
+                                                            float2* __restrict__ out,
+                                                            const float2* __restrict__ tw,
+                                                            unsigned batch,
+                                                            unsigned in_stride,
+                                                            unsigned out_stride)
+{
+    extern __shared__ __attribute__ ((aligned (16))) float sp_plane[];
+    const int t0 = threadIdx.x;
+    for (unsigned g = blockIdx.x; g < batch; g += gridDim.x)
+    {
+        int t = t0;
+        CFFT_LAUNDER_INDEX (t); // keep the ~200 loop-invariant LDS / table offsets from being hoisted and held (stockham.hpp)
+        const float2* __restrict__ src = in + (size_t) g * in_stride;
+        float2* __restrict__ dst = out + (size_t) g * out_stride;
+        float2 v[32];
+#pragma unroll
+        for (int a = 0; a < 32; ++a)
+        {
+            const float2 x = gload (&src[(unsigned) (t + 1024 * a)]);
+            v[a] = INV ? make_float2 (x.y, x.x) : x;
+        }
+        sp_core (v, tw, sp_plane, t);
+        int ts = t0;
+        CFFT_LAUNDER_INDEX (ts); // the store addresses are formed here, not at the top of the loop (where they would be spilled)
+#pragma unroll
+        for (int b = 0; b < 32; ++b)
+            gstore (&dst[(unsigned) (ts + 1024 * b)], INV ? make_float2 (v[b].y, v[b].x) : v[b]);
+    }
+}
+
+// ---- real, N = 65536 = 2 M ------------------------------------------------------------------------------------------
+// Work-item t owns Z[t + 1024 b], b < 32.  The pair stage handles k = t + 1024 q, q < 16 (k < M/2) together with M - k,
+// which is the partner work-item's slot 31 - q (work-item 1024 - t; for t = 0: slot 32 - q of work-item 0 itself): the
+// UPPER 16 slots of every work-item travel through the first half of the plane, one component at a time, at their natural
+// index k' - M/2.
+template <bool TO_PARTNER>
+__device__ __forceinline__ void sp_pair_exchange (float2 (&up)[16], float* __restrict__ plane, int t)
+{
+    // TO_PARTNER == false: `up` holds my own upper slots (k' = t + 1024 (16 + q)); on return the values at M - k, k = t + 1024 q
+    // TO_PARTNER == true : `up` holds the values I computed for M - k; on return my own upper slots
+    // Two address families, each ONE base + compile-time offsets (H = M/2):
+    //   own side     index k' - H = t + 1024 q            -> phys = t + t/32 + 1056 q
+    //   mirror side  index (M - k) - H = H - t - 1024 q    -> phys = (-t) + floor(-t / 32) + 16896 - 1056 q
+    // The one irregular pair, k = 0 <-> M/2 (work-item 0, q = 0), lives at own-side index 0; the mirror formula gives H
+    // for it, so work-item 0 keeps a copy there.
+    float* __restrict__ own = plane + (t + (t >> 5));
+    float* __restrict__ mir = plane + ((-t) + ((-t) >> 5) + 16896);
+    float* __restrict__ wr = TO_PARTNER ? mir : own;
+    const float* __restrict__ rd = TO_PARTNER ? own : mir;
+    constexpr int ws = TO_PARTNER ? -1056 : 1056, rs = -ws;
+    float* __restrict__ patch = TO_PARTNER ? plane : plane + 16896;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+        wr[q * ws] = up[q].x;
+    if (t == 0)
+        *patch = up[0].x;
+    __syncthreads();
+    float rx[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+        rx[q] = rd[q * rs];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+        wr[q * ws] = up[q].y;
+    if (t == 0)
+        *patch = up[0].y;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+        up[q] = make_float2 (rx[q], rd[q * rs]);
+}
+
+// forward: N real samples (as M complex points z[n] = x[2n] + i x[2n+1]) -> packed spectrum (real_kernels.hpp)
+__global__ __launch_bounds__ (kSplitT) void r2c_split_kernel (const float2* __restrict__ in,
+                                                            float2* __restrict__ out,
+                                                            const float2* __restrict__ tw,
+                                                            const float2* __restrict__ wtab,
+                                                            unsigned batch,
+                                                            unsigned in_stride,
+                                                            unsigned out_stride)
+{
+    extern __shared__ __attribute__ ((aligned (16))) float sp_plane[];
+    constexpr int M = kSplitN;
+    const int t0 = threadIdx.x;
+    for (unsigned g = blockIdx.x; g < batch; g += gridDim.x)
+    {
+        int t = t0;
+        CFFT_LAUNDER_INDEX (t);
+        const float2* __restrict__ src = in + (size_t) g * in_stride;
+        float2* __restrict__ dst = out + (size_t) g * out_stride;
+        float2 v[32];
+#pragma unroll
+        for (int a = 0; a < 32; ++a)
+            v[a] = gload (&src[(unsigned) (t + 1024 * a)]);
+        sp_core (v, tw, sp_plane, t);
+        int ts = t0;
+        CFFT_LAUNDER_INDEX (ts);
+        float2 up[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            up[q] = v[16 + q];
+        sp_pair_exchange<false> (up, sp_plane, ts);
+        CFFT_PHASE_FENCE();
+        // four rounds of four pairs: the pair twiddles of a round (8 VGPRs) next to the 64 that hold Z[k] and Z[M - k]
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+        {
+            float2 pw[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                pw[q] = wtab[ts + 1024 * (4 * h + q)];
+#pragma unroll
+            for (int q8 = 0; q8 < 4; ++q8)
+            {
+                const int q = 4 * h + q8;
+                const int k = ts + 1024 * q;
+                const float2 A = v[q], Zp = up[q];
+                float2 Xk, Xp;
+                real_split_pair (A, Zp, pw[q8], Xk, Xp);
+                if (k == 0)
+                {
+                    Xk = make_float2 (A.x + A.y, A.x - A.y); // [X0.re, X(N/2).re]
+                    Xp = make_float2 (Zp.x, -Zp.y);          // X[M/2] = conj(Z[M/2])
+                }
+                gstore (&dst[(unsigned) k], Xk);
+                gstore (&dst[(unsigned) (k == 0 ? M / 2 : M - k)], Xp);
+            }
+            CFFT_PHASE_FENCE();
+        }
+    }
+}
+
+// backward: packed spectrum -> N real samples (unscaled)
+__global__ __launch_bounds__ (kSplitT) void c2r_split_kernel (const float2* __restrict__ in,
+                                                            float2* __restrict__ out,
+                                                            const float2* __restrict__ tw,
+                                                            const float2* __restrict__ wtab,
+                                                            unsigned batch,
+                                                            unsigned in_stride,
+                                                            unsigned out_stride)
+{
+    extern __shared__ __attribute__ ((aligned (16))) float sp_plane[];
+    constexpr int M = kSplitN;
+    const int t0 = threadIdx.x;
+    for (unsigned g = blockIdx.x; g < batch; g += gridDim.x)
+    {
+        int t = t0;
+        CFFT_LAUNDER_INDEX (t);
+        const float2* __restrict__ src = in + (size_t) g * in_stride;
+        float2* __restrict__ dst = out + (size_t) g * out_stride;
+        float2 v[32], up[16];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+        {
+            // two rounds of eight pairs (48 VGPRs of operands each)
+            float2 a[8], xp[8], pw[8];
+#pragma unroll
+            for (int q8 = 0; q8 < 8; ++q8)
+            {
+                const int k = t + 1024 * (8 * h + q8);
+                a[q8] = gload (&src[(unsigned) k]);
+                xp[q8] = gload (&src[(unsigned) (k == 0 ? M / 2 : M - k)]);
+                pw[q8] = wtab[k];
+            }
+#pragma unroll
+            for (int q8 = 0; q8 < 8; ++q8)
+            {
+                const int q = 8 * h + q8;
+                const int k = t + 1024 * q;
+                float2 zk, zp;
+                real_merge_pair (a[q8], xp[q8], pw[q8], zk, zp);
+                if (k == 0)
+                {
+                    zk = make_float2 (a[q8].x + a[q8].y, a[q8].x - a[q8].y); // Z[0] = (X0 + XM) + i (X0 - XM)
+                    zp = make_float2 (2.f * xp[q8].x, -2.f * xp[q8].y);      // Z[M/2] = 2 conj(X[M/2])
+                }
+                // re <-> im swapped: the inverse DFT is swap(DFT(swap(.)))
+                v[q] = make_float2 (zk.y, zk.x);
+                up[q] = make_float2 (zp.y, zp.x);
+            }
+        }
+        sp_pair_exchange<true> (up, sp_plane, t);
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            v[16 + q] = up[q];
+        sp_core (v, tw, sp_plane, t);
+        int ts = t0;
+        CFFT_LAUNDER_INDEX (ts);
+#pragma unroll
+        for (int b = 0; b < 32; ++b)
+            gstore (&dst[(unsigned) (ts + 1024 * b)], make_float2 (v[b].y, v[b].x));
+    }
+}
+} // namespace cfft

@@ -50,7 +50,7 @@ bool core_radices (int n, int radix[4])
 void split_large (int n_complex, int& n1, int& n2)
 {
     n1 = n2 = 0;
-    if (n_complex <= kMaxCoreN)
+    if (n_complex <= kMaxCoreN || n_complex == kSplitCoreN)
         return;
     int lg = 0;
     while ((1 << lg) < n_complex)
@@ -223,6 +223,18 @@ bool build_host_tables (int N, int transform, HostTables& out)
         if (! core_plan_desc (nc, d))
             return false;
         append_stage_twiddles (d, out.stage_twiddles);
+        return true;
+    }
+    if (nc == kSplitCoreN)
+    {
+        // split-plane single pass, 32 x 32 x 32: per twiddled stage (p = 32, then 1024) ten rows [j][k], k < p, of
+        // W_{32 p}^{a k} with a = 1..7 (j = 0..6) and a = 8, 16, 24 (j = 7..9)   (split_plane_kernels.hpp)
+        out.core_n = nc;
+        static const int a_of_j[10] = { 1, 2, 3, 4, 5, 6, 7, 8, 16, 24 };
+        for (int p : { 32, 1024 })
+            for (int j = 0; j < 10; ++j)
+                for (int k = 0; k < p; ++k)
+                    out.stage_twiddles.push_back (unit_root ((long long) a_of_j[j] * k, (long long) p * 32));
         return true;
     }
 
