@@ -43,6 +43,7 @@ PROTOTYPES = {
     "fft_gpu_stream_synchronize": (_i, [_vp]),
     "fft_gpu_last_error": (C.c_char_p, []),
     "fft_gpu_set_option": (_i, [C.c_char_p, C.c_long]),
+    "fft_gpu_release_stream_resources": (_i, [_vp]),
     "fft_gpu_size_supported": (_i, [_i, _i]),
     "fft_gpu_plan_describe": (_i, [_i, _i, C.POINTER(C.c_int)]),
     "fft_gpu_setup_size": (_i, [_vp]),
@@ -59,6 +60,9 @@ PROTOTYPES = {
     "fft_accumulate_batch": (_i, [_vp, _fp, _fp, _fp, _sz, _vp]),
     "fft_convolve_frames_batch": (_i, [_vp, _fp, _fp, _fp, _f, _sz, _vp]),
     "fft_transform_host_batch": (_i, [_vp, _fp, _fp, _sz, _i]),
+    "fft_gpu_shard_range": (_i, [_sz, _i, _i, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "fft_transform_batch_multi_gpu": (_i, [C.POINTER(C.c_void_p), _i, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), _i]),
+    "fft_gather_multi_gpu": (_i, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_size_t), _i, C.POINTER(C.c_void_p), C.POINTER(C.c_int), _i]),
     "fft_conv_engine_create": (_vp, [_i, _i, _fp, _i, _i, _vp]),
     "fft_conv_engine_process": (_i, [_vp, _fp, _fp, _vp]),
     "fft_conv_engine_reset": (_i, [_vp, _vp]),
@@ -75,6 +79,13 @@ def load(path: str = LIB_PATH, strict: bool = True) -> C.CDLL:
             f"{path} not found: build it with `make -C chowdsp_fft_amd/csrc` "
             "(or python -c 'import __graft_entry__ as g; g.build()'). There is no fallback path."
         )
+    # PyTorch-ROCm ships its own copy of the HIP runtime.  A process that uses both (tests, bench.py) must end up with ONE
+    # runtime: load torch's first, so that this library's libamdhip64 dependency resolves to the copy already in the
+    # process (loading ours first and torch's second leaves the second one without devices).  C / C++ hosts have no torch.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path, mode=getattr(os, "RTLD_LOCAL", 0) | getattr(os, "RTLD_NOW", 2))
     for name, (res, args) in PROTOTYPES.items():
         if not strict and not hasattr(lib, name):

@@ -257,6 +257,34 @@ class ConvEngine:
             pass
 
 
+def shard_range(total_frames: int, shards: int, rank: int):
+    """fft_gpu_shard_range: (first frame, frame count) of block `rank` (same rule as sharding.shard_range)"""
+    first, count = C.c_size_t(0), C.c_size_t(0)
+    _check(_lib.lib().fft_gpu_shard_range(total_frames, shards, rank, C.byref(first), C.byref(count)), "fft_gpu_shard_range")
+    return first.value, count.value
+
+
+def fft_transform_batch_multi_gpu(setups, inputs, outputs, counts, direction: int) -> None:
+    """fft_transform_batch_multi_gpu: shard d = counts[d] frames of inputs[d] -> outputs[d] on the device of setups[d]"""
+    n = len(setups)
+    vp = C.c_void_p * n
+    _check(_lib.lib().fft_transform_batch_multi_gpu(vp(*setups), n, vp(*[_ptr(a) for a in inputs]), vp(*[_ptr(a) for a in outputs]),
+                                                    (C.c_size_t * n)(*counts), direction), "fft_transform_batch_multi_gpu")
+
+
+def fft_gather_multi_gpu(shards, shard_devices, dsts, dst_devices) -> None:
+    """fft_gather_multi_gpu: every shard tensor is copied, in order, into every non-None destination tensor"""
+    n, m = len(shards), len(dsts)
+    vp = C.c_void_p
+    _check(_lib.lib().fft_gather_multi_gpu((vp * n)(*[_ptr(a) for a in shards]), (C.c_int * n)(*shard_devices),
+                                           (C.c_size_t * n)(*[a.numel() for a in shards]), n,
+                                           (vp * m)(*[_ptr(a) for a in dsts]), (C.c_int * m)(*dst_devices), m), "fft_gather_multi_gpu")
+
+
+def release_stream_resources(stream=None) -> int:
+    return int(_lib.lib().fft_gpu_release_stream_resources(_stream_handle(stream)))
+
+
 def set_option(name: str, value: int) -> None:
     """fft_gpu_set_option: run-time knobs of the library (chowdsp_fft_gpu.h)"""
     _check(_lib.lib().fft_gpu_set_option(name.encode(), int(value)), f"fft_gpu_set_option({name})")

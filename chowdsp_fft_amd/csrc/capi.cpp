@@ -191,6 +191,13 @@ Lanes* get_lanes (int device, hipStream_t stream, size_t bytes_each)
     }
     if (L.bytes < bytes_each)
     {
+        // growing means waiting for the stream and freeing: neither is legal while the stream is being captured into a graph
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (L.ws[0] != nullptr && hipStreamIsCapturing (stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+        {
+            set_last_error ("two-pass workspace would have to grow during stream capture: run the same call once outside the capture first");
+            return nullptr;
+        }
         for (int k = 0; k < 2; ++k)
         {
             if (L.ws[k] != nullptr)
@@ -277,6 +284,12 @@ Lanes* get_fused (int device, hipStream_t stream, size_t ws_bytes)
     }
     if (L.fused_ws_bytes < ws_bytes)
     {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (L.fused_ws != nullptr && hipStreamIsCapturing (stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+        {
+            set_last_error ("two-pass workspace would have to grow during stream capture: run the same call once outside the capture first");
+            return nullptr;
+        }
         if (L.fused_ws != nullptr)
         {
             (void) hipStreamSynchronize (stream);
@@ -828,6 +841,49 @@ int fft_gpu_plan_describe (int N, fft_transform_t transform, int desc[8])
     return FFT_GPU_OK;
 }
 
+int fft_gpu_release_stream_resources (void* stream)
+{
+    // what the two-pass plans cached for (any device, this stream): two helper streams, three events, the workspaces, the
+    // one-launch form's queue state.  Call it before destroying a stream (a re-used handle would inherit the entry) or to
+    // give the memory back; the next two-pass call on the stream builds a fresh set.
+    std::lock_guard<std::mutex> lock (g_ws_mutex);
+    int released = 0;
+    for (auto it = g_lanes.begin(); it != g_lanes.end();)
+    {
+        if (it->first.second != (hipStream_t) stream)
+        {
+            ++it;
+            continue;
+        }
+        const DeviceGuard guard (it->first.first);
+        Lanes& L = it->second;
+        (void) hipStreamSynchronize ((hipStream_t) stream);
+        for (int k = 0; k < 2; ++k)
+        {
+            if (L.lane[k] != nullptr)
+            {
+                (void) hipStreamSynchronize (L.lane[k]);
+                (void) hipStreamDestroy (L.lane[k]);
+            }
+            if (L.done[k] != nullptr)
+                (void) hipEventDestroy (L.done[k]);
+            if (L.ws[k] != nullptr)
+                (void) hipFree (L.ws[k]);
+        }
+        if (L.start != nullptr)
+            (void) hipEventDestroy (L.start);
+        if (L.fused_ws != nullptr)
+            (void) hipFree (L.fused_ws);
+        if (L.fused_state != nullptr)
+            (void) hipFree (L.fused_state);
+        if (L.fused_err_host != nullptr)
+            (void) hipHostFree (L.fused_err_host);
+        it = g_lanes.erase (it);
+        ++released;
+    }
+    return released;
+}
+
 int fft_gpu_set_option (const char* name, long value)
 {
     if (name == nullptr)
@@ -877,7 +933,14 @@ size_t fft_gpu_workspace_bytes (void* setup, size_t batch)
     if (s == nullptr || s->tables->core_n == complex_len (s) || (s->tables->gen_ns > 0 && s->tables->mixed_n2 == 0))
         return 0;
     const size_t frame_bytes = (size_t) complex_len (s) * sizeof (float2);
+    int n1 = 0, n2 = 0;
+    if (s->tables->mixed_n2 == 0)
+        split_large (complex_len (s), n1, n2);
+    if (s->transform == FFT_COMPLEX && fused_enabled() && fused_supported (n1, n2) && batch >= fused_min_batch())
+        return fused_workspace_bytes (complex_len (s), fused_slots()) + fused_state_bytes();
     size_t chunk = workspace_cap() / (size_t) lane_count() / frame_bytes;
+    if (s->transform == FFT_REAL)
+        chunk /= pair_chunk_divisor(); // the pair stage's operands share the cache with the two workspaces
     if (chunk < 1)
         chunk = 1;
     if (chunk > batch)

@@ -54,6 +54,13 @@ int fft_gpu_stream_synchronize (void* stream);
 /* Last HIP error string seen by this thread inside the library ("" if none). */
 const char* fft_gpu_last_error (void);
 
+/* Two-pass plans cache, per (device, stream) they are called on, two helper streams, three events and their
+   workspaces (fft_gpu_workspace_bytes).  This releases what is cached for `stream` (on every device): call it before
+   destroying the stream -- a recycled handle would inherit the entry -- or to give the memory back.  Waits for the stream.
+   Returns the number of entries released.  A workspace that would have to GROW while its stream is being captured into
+   a hipGraph makes the call fail with FFT_GPU_ENOMEM (run the same call once outside the capture first). */
+int fft_gpu_release_stream_resources (void* stream);
+
 /* Run-time options (process-wide; initial values come from the environment variables named in INTEGRATION.md):
      "fused_two_pass"   1 / 0: run two-pass sizes that have a one-launch form (N = 65536 complex) in one launch with the
                         inter-pass hand-off inside an XCD's L2, or always as two launches per chunk
@@ -116,6 +123,21 @@ int fft_accumulate_batch (void* setup, const float* a, const float* b, float* ab
    traffic is one read + one write per frame.  Every other supported size runs the same three steps as separate
    launches with `y` holding the spectra in between (x == y allowed either way). */
 int fft_convolve_frames_batch (void* setup, const float* x, const float* dft_filter, float* y, float scaling, size_t batch, void* stream);
+
+/* ---- several devices in one process (SURVEY section 8 row e) ------------------------------------------------------
+   Frames are independent: a batch is cut into contiguous blocks, one per device, plans are replicated (one setup created
+   on each device after fft_gpu_set_device), and nothing is exchanged while transforming.
+   fft_gpu_shard_range: block `rank` of `shards` = frames [*first, *first + *count); blocks differ by at most one frame. */
+int fft_gpu_shard_range (size_t total_frames, int shards, int rank, size_t* first, size_t* count);
+/* `shards` x fft_transform_batch, shard d on the device of setups[d] (device pointers of that device, counts[d] frames),
+   each from its own host thread on that device's own stream, all at once.  Synchronous: every shard is complete on
+   return.  Several shards may name the same device. */
+int fft_transform_batch_multi_gpu (void* const* setups, int shards, const float* const* inputs, float* const* outputs, const size_t* counts, fft_direction_t direction);
+/* Collect result shards: shard s (shard_floats[s] floats on device shard_devices[s]) is copied behind the shards before
+   it into EVERY non-NULL destination dst_ptrs[d] (a buffer of sum(shard_floats) floats on device dst_devices[d]) --
+   an all-gather when every device is a destination, a gather-to-root when one is.  Each (source, destination) pair is
+   one direct peer copy on its own stream, all pairs in flight together.  Synchronous. */
+int fft_gather_multi_gpu (const float* const* shard_ptrs, const int* shard_devices, const size_t* shard_floats, int shards, float* const* dst_ptrs, const int* dst_devices, int ndst);
 
 /* ---- host-memory streaming mode ------------------------------------------------
    `batch` x fft_transform for callers whose frames live in HOST memory (what every reference caller has:
