@@ -346,7 +346,12 @@ int big_c2c_chunked (Setup* s, int nc, bool inverse, const float2* in, float2* o
         }
         return cf::FFT_GPU_OK;
     }
-    const size_t frame_bytes = (size_t) nc * sizeof (float2);
+    size_t frame_bytes = (size_t) nc * sizeof (float2);
+    if (mixed) // a ragged last column tile pads the workspace frame
+    {
+        const size_t ca = (size_t) s->tables->mixed_ca, m1 = (size_t) s->tables->mixed_n1, m2 = (size_t) s->tables->mixed_n2;
+        frame_bytes = ((m1 + ca - 1) / ca) * ca * m2 * sizeof (float2);
+    }
     const int want_lanes = lane_count();
     // the cap covers BOTH workspaces, so that they fit the Infinity Cache together
     size_t chunk = workspace_cap() / (size_t) want_lanes / frame_bytes;
@@ -799,6 +804,17 @@ int fft_gpu_plan_describe (int N, fft_transform_t transform, int desc[8])
     if ((nc & (nc - 1)) != 0)
     {
         int m1 = 0, m2 = 0;
+        if (nc > 20000 && ! split_mixed (nc, m1, m2) && split_general (nc, m1, m2))
+        {
+            // general two-pass form: generic n2-point columns and generic n1-point rows
+            desc[0] = nc;
+            desc[1] = 2;
+            desc[2] = m1;
+            desc[3] = m2;
+            for (int i = 0; i < 4; ++i)
+                desc[4 + i] = 0;
+            return FFT_GPU_OK;
+        }
         if (nc > 20000 && split_mixed (nc, m1, m2))
         {
             // long mixed-radix frame: two passes, generic n2-point columns then power-of-two n1-point rows (radices of n1)
@@ -824,6 +840,19 @@ int fft_gpu_plan_describe (int N, fft_transform_t transform, int desc[8])
         return FFT_GPU_OK;
     }
     int n1 = 0, n2 = 0;
+    if (nc > (1 << 20))
+    {
+        // powers of two beyond 2^20: the general two-pass form
+        if (! split_general (nc, n1, n2))
+            return FFT_GPU_EINVAL;
+        desc[0] = nc;
+        desc[1] = 2;
+        desc[2] = n1;
+        desc[3] = n2;
+        for (int i = 0; i < 4; ++i)
+            desc[4 + i] = 0;
+        return FFT_GPU_OK;
+    }
     split_large (nc, n1, n2);
     int radix[4] = { 0, 0, 0, 0 };
     if (n1 == 256 && n2 == 256)

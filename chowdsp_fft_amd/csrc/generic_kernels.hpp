@@ -480,28 +480,29 @@ __global__ __launch_bounds__ (256) void pass_a_generic_kernel (const float2* __r
                                                               unsigned n1,
                                                               unsigned batch,
                                                               size_t in_stride,
-                                                              unsigned lfs) // frame stride inside an image: n2 + 1, or n2 where the padded images would not fit the CU's LDS
+                                                              unsigned lfs, // frame stride inside an image: n2 + 1, or n2 where the padded images would not fit the CU's LDS
+                                                              size_t ws_frame_len) // float2 per frame in the workspace: tiles * n2 * CA (>= n1 * n2: the last tile may be ragged)
 {
     extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
     const int tid = threadIdx.x;
     const int n2 = plan.n;
     float2* bufA = smem;
     float2* bufB = smem + (size_t) CA * lfs;
-    const unsigned tiles = n1 / CA;
-    const size_t frame_len = (size_t) n1 * n2;
+    const unsigned tiles = (n1 + CA - 1) / CA;
     const size_t nwork = (size_t) batch * tiles;
     for (size_t w = blockIdx.x; w < nwork; w += gridDim.x)
     {
         const unsigned f = (unsigned) (w / tiles);
         const unsigned tile = (unsigned) (w % tiles);
+        const int valid = (int) min ((unsigned) CA, n1 - tile * CA); // columns of this tile that exist (n1 need not be a multiple of CA)
         const float2* __restrict__ src = in + (size_t) f * in_stride + (size_t) tile * CA;
-        float2* __restrict__ dst = work + (size_t) f * frame_len + (size_t) tile * ((size_t) n2 * CA);
+        float2* __restrict__ dst = work + (size_t) f * ws_frame_len + (size_t) tile * ((size_t) n2 * CA);
         const float2* __restrict__ twp = big_tw + (size_t) tile * ((size_t) n2 * CA);
         __syncthreads(); // previous tile fully stored
         for (int e = tid; e < CA * n2; e += 256)
         {
             const int c = e % CA, j = e / CA;
-            const float2 x = gload (&src[(size_t) j * n1 + c]);
+            const float2 x = c < valid ? gload (&src[(size_t) j * n1 + c]) : make_float2 (0.f, 0.f);
             bufA[c * lfs + j] = SWAP_IN ? make_float2 (x.y, x.x) : x;
         }
         __syncthreads();
@@ -509,7 +510,60 @@ __global__ __launch_bounds__ (256) void pass_a_generic_kernel (const float2* __r
         for (int e = tid; e < CA * n2; e += 256)
         {
             const int c = e % CA, k = e / CA;
-            dst[e] = cmul (res[c * lfs + k], twp[e]); // plain store: the workspace should stay cached
+            dst[e] = cmul (res[c * lfs + k], twp[e]); // plain store: the workspace should stay cached (padding columns: zeros)
+        }
+    }
+}
+
+// Row pass of the same plans when the row length n1 is not a power of two either (and for powers of two beyond the
+// compile-time cores): n1-point FFTs of CB adjacent rows kb with the run-time stage list, read from pass A's tile-major
+// workspace [tile tA][kb][c] (CA columns per tile), stored transposed to X[n2 ka + kb].  n2 need not be a multiple of CB.
+template <bool SWAP_OUT, int CB>
+__global__ __launch_bounds__ (256) void pass_b_generic_kernel (const float2* __restrict__ work,
+                                                              float2* __restrict__ out,
+                                                              const float2* __restrict__ twtab,
+                                                              GenericPlan plan, // n = n1, frames = CB
+                                                              unsigned n2,
+                                                              unsigned ca, // pass A's tile width
+                                                              unsigned batch,
+                                                              size_t out_stride,
+                                                              unsigned lfs,
+                                                              size_t ws_frame_len)
+{
+    extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
+    const int tid = threadIdx.x;
+    const int n1 = plan.n;
+    float2* bufA = smem;
+    float2* bufB = smem + (size_t) CB * lfs;
+    const unsigned tiles = (n2 + CB - 1) / CB;
+    const size_t nwork = (size_t) batch * tiles;
+    for (size_t w = blockIdx.x; w < nwork; w += gridDim.x)
+    {
+        const unsigned f = (unsigned) (w / tiles);
+        const unsigned tile = (unsigned) (w % tiles);
+        const unsigned kb0 = tile * CB;
+        const int valid = (int) min ((unsigned) CB, n2 - kb0);
+        const float2* __restrict__ src = work + (size_t) f * ws_frame_len;
+        float2* __restrict__ dst = out + (size_t) f * out_stride + kb0;
+        __syncthreads();
+        // element (row kbl, column a): c = a % ca fastest (contiguous in the workspace), then the row, then pass A's tile
+        for (int e = tid; e < CB * n1; e += 256)
+        {
+            const unsigned a = (unsigned) e % (unsigned) n1, kbl = (unsigned) e / (unsigned) n1;
+            const unsigned tA = a / ca, c = a % ca;
+            const float2 x = (int) kbl < valid ? src[((size_t) tA * n2 + kb0 + kbl) * ca + c] : make_float2 (0.f, 0.f);
+            bufA[kbl * lfs + a] = x;
+        }
+        __syncthreads();
+        const float2* res = generic_core<256, false, false, false> (plan, twtab, bufA, bufB, nullptr, nullptr, CB, tid, lfs);
+        for (int e = tid; e < CB * n1; e += 256)
+        {
+            const int c = e % CB, k = e / CB;
+            if (c < valid)
+            {
+                const float2 y = res[c * lfs + k];
+                gstore (&dst[(size_t) k * n2 + c], SWAP_OUT ? make_float2 (y.y, y.x) : y);
+            }
         }
     }
 }

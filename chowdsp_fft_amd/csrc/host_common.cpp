@@ -118,6 +118,13 @@ const DeviceTables* acquire_tables (int device, int N, int transform)
     t->mixed_n2 = h.mixed_n2;
     t->mixed_tw1_offset = h.mixed_tw1_offset;
     t->mixed_ca = h.mixed_ca;
+    t->mixed_cb = h.mixed_cb;
+    t->gen2_ns = (int) h.generic2_radix.size();
+    for (int i = 0; i < t->gen2_ns; ++i)
+    {
+        t->gen2_radix[i] = h.generic2_radix[(size_t) i];
+        t->gen2_tw_offset[i] = h.generic2_tw_offset[(size_t) i];
+    }
     t->stage_twiddles = upload (h.stage_twiddles);
     t->real_twiddles = upload (h.real_twiddles);
     t->big_twiddles = upload (h.big_twiddles);

@@ -50,6 +50,11 @@ struct DeviceTables
     // long mixed-radix plans: two passes, gen_* describe the n2-point column FFT, the n1-point row core's table starts at
     // stage_twiddles + mixed_tw1_offset; both 0 otherwise
     int mixed_n1 = 0, mixed_n2 = 0, mixed_tw1_offset = 0, mixed_ca = 0;
+    // general form (rows generic too): mixed_cb > 0, gen2_* = the n1-point row FFT's stage list
+    int mixed_cb = 0;
+    int gen2_ns = 0;
+    int gen2_radix[10] = { 0 };
+    int gen2_tw_offset[10] = { 0 };
 };
 
 // The plan header.  Lives either in a block we allocated (fft_new_setup) or in caller memory

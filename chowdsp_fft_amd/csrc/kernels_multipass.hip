@@ -209,7 +209,7 @@ hipError_t launch_mixed_big_c2c (const DeviceTables& t, bool inverse, const floa
     if (batch == 0)
         return hipSuccess;
     const int n1 = t.mixed_n1, n2 = t.mixed_n2;
-    if (batch > 0x7FFFFFFFull || n1 < 64 || n2 < 16 || t.gen_ns < 1 || t.gen_ns > kGenericMaxStages)
+    if (batch > 0x7FFFFFFFull || n1 < 2 || n2 < 2 || t.gen_ns < 1 || t.gen_ns > kGenericMaxStages)
         return hipErrorInvalidValue;
     const size_t frame_len = (size_t) n1 * (size_t) n2;
     in_stride = in_stride ? in_stride : frame_len;
@@ -218,7 +218,7 @@ hipError_t launch_mixed_big_c2c (const DeviceTables& t, bool inverse, const floa
     plan.n = n2;
     plan.ns = t.gen_ns;
     const int ca = t.mixed_ca;
-    if (ca != 16 && ca != 8)
+    if (ca != 16 && ca != 8 && ca != 4)
         return hipErrorInvalidValue;
     plan.frames = ca;
     plan.in_stride = plan.out_stride = (unsigned) n2;
@@ -238,16 +238,50 @@ hipError_t launch_mixed_big_c2c (const DeviceTables& t, bool inverse, const floa
     const size_t lds = (size_t) 2 * ca * lfs * sizeof (float2);
     if (lds > dev.lds_per_cu)
         return hipErrorInvalidValue;
+    const size_t ws_frame_len = (size_t) ((n1 + ca - 1) / ca) * (size_t) ca * (size_t) n2; // = n1 * n2 unless the last tile is ragged
     auto ka = ca == 16 ? (inverse ? pass_a_generic_kernel<true, 16> : pass_a_generic_kernel<false, 16>)
-                       : (inverse ? pass_a_generic_kernel<true, 8> : pass_a_generic_kernel<false, 8>);
-    unsigned grid = persistent_grid (ka, 256, lds, batch * (size_t) (n1 / ca));
+              : ca == 8 ? (inverse ? pass_a_generic_kernel<true, 8> : pass_a_generic_kernel<false, 8>)
+                        : (inverse ? pass_a_generic_kernel<true, 4> : pass_a_generic_kernel<false, 4>);
+    unsigned grid = persistent_grid (ka, 256, lds, batch * (size_t) ((n1 + ca - 1) / ca));
     if (grid == 0)
         return hipErrorNoDevice;
     grid = std::max (1u, grid / (unsigned) grid_divisor);
-    hipLaunchKernelGGL (ka, dim3 (grid), dim3 (256), lds, stream, in, work, (const float2*) t.stage_twiddles, (const float2*) t.big_twiddles, plan, (unsigned) n1, (unsigned) batch, in_stride, lfs);
+    hipLaunchKernelGGL (ka, dim3 (grid), dim3 (256), lds, stream, in, work, (const float2*) t.stage_twiddles, (const float2*) t.big_twiddles, plan, (unsigned) n1, (unsigned) batch, in_stride, lfs, ws_frame_len);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return e;
+    if (t.mixed_cb > 0)
+    {
+        // general form: the n1-point rows by the generic kernel as well
+        const int cb = t.mixed_cb;
+        if (t.gen2_ns < 1 || t.gen2_ns > kGenericMaxStages || (cb != 16 && cb != 8 && cb != 4))
+            return hipErrorInvalidValue;
+        GenericPlan pb {};
+        pb.n = n1;
+        pb.ns = t.gen2_ns;
+        pb.frames = cb;
+        pb.in_stride = pb.out_stride = (unsigned) n1;
+        for (int i = 0; i < t.gen2_ns; ++i)
+        {
+            pb.radix[i] = t.gen2_radix[i];
+            pb.tw_offset[i] = t.gen2_tw_offset[i];
+        }
+        unsigned lfsb = (unsigned) n1 + 1u;
+        if ((size_t) 2 * cb * lfsb * sizeof (float2) > dev.lds_per_cu)
+            lfsb = (unsigned) n1;
+        const size_t ldsb = (size_t) 2 * cb * lfsb * sizeof (float2);
+        if (ldsb > dev.lds_per_cu)
+            return hipErrorInvalidValue;
+        auto kb = cb == 16 ? (inverse ? pass_b_generic_kernel<true, 16> : pass_b_generic_kernel<false, 16>)
+                  : cb == 8 ? (inverse ? pass_b_generic_kernel<true, 8> : pass_b_generic_kernel<false, 8>)
+                            : (inverse ? pass_b_generic_kernel<true, 4> : pass_b_generic_kernel<false, 4>);
+        unsigned gridb = persistent_grid (kb, 256, ldsb, batch * (size_t) ((n2 + cb - 1) / cb));
+        if (gridb == 0)
+            return hipErrorNoDevice;
+        gridb = std::max (1u, gridb / (unsigned) grid_divisor);
+        hipLaunchKernelGGL (kb, dim3 (gridb), dim3 (256), ldsb, stream, (const float2*) work, out, (const float2*) t.stage_twiddles, pb, (unsigned) n2, (unsigned) ca, (unsigned) batch, out_stride, lfsb, ws_frame_len);
+        return hipGetLastError();
+    }
     const float2* tw1 = t.stage_twiddles + t.mixed_tw1_offset;
     e = hipErrorInvalidValue;
     if (inverse)
@@ -270,10 +304,8 @@ hipError_t launch_real_pair (bool forward, const float2* in, float2* out, const 
     DeviceInfo dev;
     if (! current_device_info (dev))
         return hipErrorNoDevice;
-    if ((m / 2) % 256 != 0)
-        return hipErrorInvalidValue; // only used for M > kMaxCoreN
-    const size_t total = batch * (m / 2);
-    const unsigned grid = (unsigned) std::max<size_t> (1, std::min<size_t> (total / 256, (size_t) dev.num_cus * 16));
+    const size_t total = batch * ((size_t) (m / 2 + 255) / 256);
+    const unsigned grid = (unsigned) std::max<size_t> (1, std::min<size_t> (total, (size_t) dev.num_cus * 16));
     if (forward)
         hipLaunchKernelGGL (real_pair_kernel<true>, dim3 (grid), dim3 (256), 0, stream, in, out, real_tw, m, (unsigned) batch, in_stride, out_stride);
     else

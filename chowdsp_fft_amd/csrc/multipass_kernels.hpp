@@ -182,7 +182,7 @@ __global__ __launch_bounds__ (BLOCK) void pass_b_kernel (const float2* __restric
     }
 }
 
-// Pair stage of the real transform as a stand-alone streaming kernel (N/2 > 4096 only).
+// Pair stage of the real transform as a stand-alone streaming kernel (long frames only; any even M).
 // FORWARD: Z (M complex, canonical) -> packed X, in place allowed.  BACKWARD: packed X -> Z.
 template <bool FORWARD>
 __global__ __launch_bounds__ (256) void real_pair_kernel (const float2* __restrict__ in,
@@ -195,13 +195,15 @@ __global__ __launch_bounds__ (256) void real_pair_kernel (const float2* __restri
 {
     // work item = (frame, chunk of 256 pairs): the frame / chunk split is workgroup-uniform (scalar) arithmetic, every
     // work-item then handles pair k = chunk * 256 + tid: ascending k and descending M - k, both lane-contiguous
-    const unsigned half = M / 2; // pairs per frame, k = 0 .. M/2-1 (M >= 8192 here: a multiple of 256)
-    const unsigned chunks = half / 256;
+    const unsigned half = M / 2; // pairs per frame, k = 0 .. M/2-1 (k = 0 pairs Z[0] with Z[M/2])
+    const unsigned chunks = (half + 255u) / 256u;
     const size_t nwork = (size_t) batch * chunks;
     for (size_t w = blockIdx.x; w < nwork; w += gridDim.x)
     {
         const unsigned f = (unsigned) (w / chunks);
         const unsigned k = (unsigned) (w % chunks) * 256u + threadIdx.x;
+        if (k >= half)
+            continue;
         const unsigned kp = (k == 0 ? half : M - k);
         const float2* __restrict__ src = in + (size_t) f * in_stride;
         float2* __restrict__ dst = out + (size_t) f * out_stride;

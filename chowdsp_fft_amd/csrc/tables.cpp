@@ -9,8 +9,6 @@ namespace cfft::host
 static void generic_radices (int n, std::vector<int>& radix, int frames_override);
 namespace
 {
-constexpr int kMaxLog2 = 20;
-
 bool is_pow2 (int n) { return n > 0 && (n & (n - 1)) == 0; }
 
 float2 unit_root (long long num, long long den) // exp(-2*pi*i*num/den)
@@ -84,6 +82,23 @@ bool split_mixed (int n_complex, int& n1, int& n2)
     return false;
 }
 
+bool split_general (int n_complex, int& n1, int& n2)
+{
+    n1 = n2 = 0;
+    if (n_complex <= 0)
+        return false;
+    // the divisor closest to sqrt(n) from below becomes the column length n2, the cofactor the row length n1
+    int best = 0;
+    for (int d = 1; (long long) d * d <= (long long) n_complex; ++d)
+        if (n_complex % d == 0)
+            best = d;
+    if (best <= 1)
+        return false;
+    n2 = best;
+    n1 = n_complex / best;
+    return n1 <= kGeneralMaxFactor && n2 >= 2;
+}
+
 // 2^a 3^b 5^c ?  (the reference's accepted prime factors, simd/chowdsp_fft_impl_common.hpp:51-82)
 static bool is_235_smooth (int n)
 {
@@ -104,17 +119,17 @@ bool size_supported (int N, int transform)
     const bool real = (transform == 0 /* FFT_REAL */);
     if (N <= 0 || N % (real ? 32 : 16) != 0)
         return false;
-    if (is_pow2 (N))
-        return N <= (1 << kMaxLog2);
-    // mixed-radix sizes run LDS-resident in the generic kernel: bounded by what two frame images need
-    if (! is_235_smooth (N))
-        return false;
     const int nc = real ? N / 2 : N;
+    if (! is_235_smooth (N) || nc > kMaxComplexLen)
+        return false;
+    if (is_pow2 (N))
+        return true; // single pass up to 32768 complex points, two passes beyond
+    // mixed-radix sizes run LDS-resident in the generic kernel: bounded by what the frame image needs
     if (nc <= kGenericMaxComplexLen)
         return true;
-    // longer frames: two passes (generic columns x power-of-two rows) where such a split exists
+    // longer frames: two passes -- generic columns x power-of-two rows where such a split exists, else generic x generic
     int n1 = 0, n2 = 0;
-    return split_mixed (nc, n1, n2);
+    return split_mixed (nc, n1, n2) || split_general (nc, n1, n2);
 }
 
 // stage radices of the generic kernel for a 2^a 3^b 5^c length: fives, threes, then the power of two in as few
@@ -163,6 +178,46 @@ bool build_host_tables (int N, int transform, HostTables& out)
             out.real_twiddles.push_back (unit_root (k, N));
     }
 
+    int gs1 = 0, gs2 = 0;
+    if ((! is_pow2 (nc) && nc > kGenericMaxComplexLen && ! split_mixed (nc, gs1, gs2)) || (is_pow2 (nc) && nc > (1 << 20)))
+    {
+        // general two-pass form: nc = n1 * n2, n2-point column FFTs and n1-point row FFTs both by the generic kernel
+        int n1 = 0, n2 = 0;
+        if (! split_general (nc, n1, n2))
+            return false;
+        out.core_n = 0;
+        out.mixed_n1 = n1;
+        out.mixed_n2 = n2;
+        const int ca = general_tile_width (n2), cb = general_tile_width (n1);
+        out.mixed_ca = ca;
+        out.mixed_cb = cb;
+        const auto add_list = [&out] (int n, int frames, std::vector<int>& radix, std::vector<int>& offs) {
+            generic_radices (n, radix, frames);
+            int p = 1;
+            for (int r : radix)
+            {
+                offs.push_back ((int) out.stage_twiddles.size());
+                for (int a = 1; a < r; ++a)
+                    for (int k = 0; k < p; ++k)
+                        out.stage_twiddles.push_back (unit_root ((long long) a * k, (long long) p * r));
+                p *= r;
+            }
+            return p == n && radix.size() <= 10;
+        };
+        if (! add_list (n2, ca, out.generic_radix, out.generic_tw_offset) || ! add_list (n1, cb, out.generic2_radix, out.generic2_tw_offset))
+            return false;
+        // W_nc^{a*k2} in the workspace's tile-major order [tile tA][k2][c], a = tA*ca + c; columns past n1 (ragged last tile): 1
+        const int tiles = (n1 + ca - 1) / ca;
+        out.big_twiddles.reserve ((size_t) tiles * n2 * ca);
+        for (int ta = 0; ta < tiles; ++ta)
+            for (int k2 = 0; k2 < n2; ++k2)
+                for (int c = 0; c < ca; ++c)
+                {
+                    const int a = ta * ca + c;
+                    out.big_twiddles.push_back (a < n1 ? unit_root ((long long) a * k2, nc) : make_float2 (1.f, 0.f));
+                }
+        return true;
+    }
     if (! is_pow2 (nc) && nc > kGenericMaxComplexLen)
     {
         // long mixed-radix frame: nc = n1 * n2, generic n2-point column FFTs then power-of-two n1-point row FFTs

@@ -21,7 +21,11 @@ struct HostTables
     std::vector<int> generic_tw_offset; // ... and the offset of each stage's table inside stage_twiddles
     // long mixed-radix plans (complex length > 20000): two passes, n2-point generic column FFTs (the radices above)
     // then n1-point power-of-two row FFTs whose stage table starts at mixed_tw1_offset inside stage_twiddles
-    int mixed_n1 = 0, mixed_n2 = 0, mixed_tw1_offset = 0, mixed_ca = 0; // mixed_ca: columns per pass-A tile (16 or 8)
+    int mixed_n1 = 0, mixed_n2 = 0, mixed_tw1_offset = 0, mixed_ca = 0; // mixed_ca: columns per pass-A tile (16, 8 or 4)
+    // "general" form of the same plans (no power-of-two row length with a compile-time core): the rows run the generic kernel
+    // too, with their own stage list; mixed_cb rows per pass-B tile; both tile widths may leave a ragged last tile
+    std::vector<int> generic2_radix, generic2_tw_offset;
+    int mixed_cb = 0;
 };
 
 // Validates (N, transform) and fills the tables.  false = unsupported size.
@@ -64,6 +68,14 @@ void split_large (int n_complex, int& n1, int& n2);
 // * 2^j the generic column length (a multiple of 16, at most kMixedMaxN2) and n1 a power of two in [64, 1024].
 // false if no such split exists (then the size is not supported).
 bool split_mixed (int n_complex, int& n1, int& n2);
+// The general split for every other accepted length up to kMaxComplexLen (2^a 3^b 5^c, powers of two beyond 2^20
+// included): n = n1 * n2 with both factors 2-3-5-smooth and as close to sqrt(n) as possible; columns AND rows run the
+// generic kernel.  false only if a factor would exceed kGeneralMaxFactor (never below 2^21).
+bool split_general (int n_complex, int& n1, int& n2);
+static constexpr int kGeneralMaxFactor = 2559; // two LDS images of 4 frames of n + 1 points
+static constexpr int kMaxComplexLen = 1 << 21;
+// tile width (columns or rows) for a frame length n of the generic passes: as wide as two padded LDS images allow
+inline int general_tile_width (int n) { return n <= 639 ? 16 : (n <= 1279 ? 8 : 4); }
 // columns per pass-A tile of the mixed two-pass plans: 16 (128-byte rows) while two LDS images of 16 padded columns,
 // 2 * 16 * (n2 + 1) * 8 bytes, fit the CU's 160 KiB (n2 <= 639), else 8 (n2 <= 1280; n2 = 1280 runs unpadded)
 static constexpr int kMixedMaxN2Wide = 639;

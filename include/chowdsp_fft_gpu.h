@@ -71,15 +71,21 @@ int fft_gpu_release_stream_resources (void* stream);
 int fft_gpu_set_option (const char* name, long value);
 
 /* ---- plan introspection -------------------------------------------------------------------------- */
-/* 1 if fft_new_setup would accept (N, transform) on a machine with a usable device, else 0.  Pure host
-   logic (no GPU needed); the rule is the reference's SSE size rule (N % 16 complex / N % 32 real, N = 2^a 3^b 5^c;
-   reference simd/chowdsp_fft_impl_common.hpp:168-177, 216-225) with powers of two up to 2^20, mixed-radix
-   sizes up to a complex length of 20000, and longer mixed-radix sizes that factor as (odd part * 2^j <= 1280,
-   j >= 4) x (power of two in 64..1024), e.g. 24576 = 48 x 512, 46080 = 720 x 64. */
+/* 1 if fft_new_setup would accept (N, transform) on a machine with a usable device, else 0.  Pure host logic (no GPU
+   needed).  The rule is the reference's SSE size rule -- N % 16 == 0 (complex) / N % 32 == 0 (real), N = 2^a 3^b 5^c
+   (reference simd/chowdsp_fft_impl_common.hpp:168-177, 216-225) -- for every such N up to a complex length of 2^21
+   (complex N <= 2097152, real N <= 4194304); the reference itself has no upper bound, longer frames return NULL here.
+   How a size runs: fft_gpu_plan_describe. */
 int fft_gpu_size_supported (int N, fft_transform_t transform);
-/* How (N, transform) is executed.  Fills desc[0..7] = { complex length transformed, number of passes
-   through device memory (1 = LDS-resident, 2 = two-pass), n1, n2 (two-pass split, else 0), then up to
-   four stage radices of the LDS-resident core (of the n2 core for two-pass plans), 0-padded }.
+/* How (N, transform) is executed.  Fills desc[0..7] = { complex length transformed, number of passes through device
+   memory (1 = the frame stays on chip, 2 = two-pass), n1, n2 (two-pass split, else 0), then up to four stage radices of
+   the on-chip core (of the n2 core for two-pass plans; 0-padded; all 0 where both passes use run-time radix lists) }.
+     one pass : powers of two up to 32768 complex points (16384: radix <= 16 stages in an LDS image; 32768: three radix-32
+                stages, exchanges one component at a time), other sizes up to 20000 complex points (run-time radix list)
+     two pass : 65536 ... 2^20: power-of-two columns x power-of-two rows (65536 in ONE launch for large batches);
+                other lengths: generic columns x power-of-two rows where N = (odd * 2^j <= 1280, j >= 4) x (2^6..2^10)
+                exists (24576 = 48 x 512), else generic columns x generic rows, both factors near sqrt(N)
+                (20736 = 144 x 144, 2^21 = 2048 x 1024)
    Returns 0, or FFT_GPU_EINVAL for an unsupported size.  Pure host logic. */
 int fft_gpu_plan_describe (int N, fft_transform_t transform, int desc[8]);
 int fft_gpu_setup_size (void* setup);              /* N, or negative error */

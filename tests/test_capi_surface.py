@@ -71,36 +71,65 @@ def test_bytes_required_is_never_below_the_reference_figure():
     assert api.fft_bytes_required(16, api.FFT_REAL) >= 128  # room for the plan header even for tiny N
 
 
+def _smooth(n):
+    for f in (2, 3, 5):
+        while n % f == 0:
+            n //= f
+    return n == 1
+
+
 def test_size_rule_host_logic():
-    """the reference's rule (common.hpp:168-177, 216-225): N % 16 (complex) / N % 32 (real) and no prime
-    factor other than 2, 3, 5; powers of two up to 2^20, mixed-radix sizes in one pass up to a complex length of 20000, longer ones where a two-pass split exists"""
-
-    def smooth(n):
-        for f in (2, 3, 5):
-            while n % f == 0:
-                n //= f
-        return n == 1
-
+    """the reference's rule (common.hpp:168-177, 216-225): N % 16 (complex) / N % 32 (real) and no prime factor other than
+    2, 3, 5 -- accepted for EVERY such N up to a complex length of 2^21 (real: N <= 2^22)"""
     for n in range(1, 2000):
-        assert api.size_supported(n, api.FFT_COMPLEX) == (n % 16 == 0 and smooth(n)), n
-        assert api.size_supported(n, api.FFT_REAL) == (n % 32 == 0 and smooth(n)), n
-    for n in (0, -16, 24, 112, 176, 1 << 21, 3 << 19):
+        assert api.size_supported(n, api.FFT_COMPLEX) == (n % 16 == 0 and _smooth(n)), n
+        assert api.size_supported(n, api.FFT_REAL) == (n % 32 == 0 and _smooth(n)), n
+    for n in (0, -16, 24, 112, 176, 7 << 18, 1 << 22, 3 << 21):
         assert not api.size_supported(n, api.FFT_COMPLEX)
     # the reference's "Other sizes" test list (test/test.cpp:279-285)
     for n in (96, 192, 384, 480, 640, 768, 9216):
         assert api.size_supported(n, api.FFT_COMPLEX) and api.size_supported(n, api.FFT_REAL)
-    assert api.size_supported(1 << 20, api.FFT_REAL)
+    assert api.size_supported(1 << 20, api.FFT_REAL) and api.size_supported(1 << 21, api.FFT_COMPLEX) and api.size_supported(1 << 22, api.FFT_REAL)
     # mixed-radix frames: one pass (in-place stages in one LDS image) up to a complex length of 20000, longer ones in two
-    # passes when N = (odd part * 2^j <= 1280, j >= 4) * (power of two in 64..1024) exists
+    # passes: generic columns x power-of-two rows where N = (odd part * 2^j <= 1280, j >= 4) * (power of two in 64..1024)
+    # exists, else generic columns x generic rows with both factors near sqrt(N)
     for n in (10240, 10368, 11520, 12288, 13824, 19200):
         assert api.size_supported(n, api.FFT_COMPLEX), n
         assert api.plan_describe(n, api.FFT_COMPLEX)["passes"] == 1
     assert api.size_supported(2 * 245760, api.FFT_REAL)
     assert api.plan_describe(24576, api.FFT_COMPLEX) == {"complex_len": 24576, "passes": 2, "n1": 512, "n2": 48, "radices": [8, 8, 8]}
     assert api.size_supported(46080, api.FFT_COMPLEX)  # 720 x 64, 8-wide column tiles
-    for n in (20736, 41472):  # 81 * 256, 81 * 512: odd part > 80, no such split -> NULL
-        assert not api.size_supported(n, api.FFT_COMPLEX), n
+    d = api.plan_describe(20736, api.FFT_COMPLEX)  # 81 * 256: no power-of-two row length -> 144 x 144, both passes generic
+    assert (d["passes"], d["n1"], d["n2"]) == (2, 144, 144)
+    d = api.plan_describe(1 << 21, api.FFT_COMPLEX)
+    assert (d["passes"], d["n1"] * d["n2"]) == (2, 1 << 21) and max(d["n1"], d["n2"]) <= 2048
     assert api.size_supported(2 * 9216, api.FFT_REAL)
+
+
+def test_accepted_size_set_equals_the_reference_rule_up_to_2_21():
+    """every N <= 2^21: accepted <=> N % 16 == 0 (complex) / N % 32 == 0 (real) and N = 2^a 3^b 5^c -- the reference's
+    accepted set (the oracle's new_setup is spot-checked against the same rule in test_oracle_accepts_the_same_sizes)"""
+    accepted = 0
+    for n in range(16, (1 << 21) + 1, 16):
+        want = _smooth(n)
+        assert api.size_supported(n, api.FFT_COMPLEX) == want, n
+        assert api.size_supported(n, api.FFT_REAL) == (want and n % 32 == 0), n
+        accepted += want
+        if want:
+            d = api.plan_describe(n, api.FFT_COMPLEX)
+            assert d is not None and d["complex_len"] == n, n
+    assert accepted == 332
+
+
+def test_oracle_accepts_the_same_sizes(oracle):
+    import oracle_lib as ol
+
+    for n in (16, 32, 48, 80, 112, 20736, 41472, 62208, 34992, 50000, 100000, 18 * 16, 22 * 16, 7 * 64, 1 << 17):
+        for tr, atr in ((ol.COMPLEX, api.FFT_COMPLEX), (ol.REAL, api.FFT_REAL)):
+            so = oracle.new_setup(n, tr)
+            assert (so is not None) == api.size_supported(n, atr), (n, tr)
+            if so is not None:
+                oracle.destroy_setup(so)
 
 
 def test_plan_describe_host_logic():

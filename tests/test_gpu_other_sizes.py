@@ -19,6 +19,9 @@ MORE_SIZES = [48, 80, 160, 240, 320, 720, 1440, 2000, 2304, 3072, 5120, 6400, 76
 # 655360 = 640 x 1024 and 1310720 = 1280 x 1024: the column lengths at the edge of the CU's 160 KiB LDS (two padded
 # 16-column images of 640 points are 164096 B; two padded 8-column images of 1280 points 163968 B)
 LONG_MIXED_SIZES = [12288, 15360, 18432, 20480, 24576, 25600, 46080, 61440, 76800, 98304, 245760, 655360, 1310720]
+# lengths without a power-of-two row factor (odd part > 80, or too few factors of two): generic columns x generic rows with
+# ragged tiles where a factor is not a multiple of the tile width; and the power of two beyond 2^20
+GENERAL_TWO_PASS_SIZES = [20736, 41472, 62208, 34992, 50000, 100000, 405000, 1 << 21]
 
 
 def _gpu(gpu, s, x, direction):
@@ -51,12 +54,13 @@ def _exact(x, n, tr, direction):
     return np.fft.irfft(spec, n=n, axis=1) * n
 
 
-@pytest.mark.parametrize("n", REFERENCE_OTHER_SIZES + MORE_SIZES + LONG_MIXED_SIZES)
+@pytest.mark.parametrize("n", REFERENCE_OTHER_SIZES + MORE_SIZES + LONG_MIXED_SIZES + GENERAL_TWO_PASS_SIZES)
 @pytest.mark.parametrize("tr", [COMPLEX, REAL])
 def test_other_sizes_batch_vs_oracle(gpu, oracle, n, tr):
     api = gpu[0]
-    if n in LONG_MIXED_SIZES and not api.size_supported(n, tr):
-        pytest.skip("no two-pass split for this transform's complex length (documented gap, test_long_mixed_sizes_without_a_split)")
+    if tr == REAL and n % 32 != 0:
+        assert oracle.new_setup(n, tr) is None and api.fft_new_setup(n, tr) is None  # rejected by the reference as well
+        return
     so = oracle.new_setup(n, tr)
     s = api.fft_new_setup(n, tr)
     assert (s is None) == (so is None), "accepted-size rule differs from the reference's"
@@ -140,16 +144,21 @@ def test_reference_other_sizes_sequence_host_pointers(gpu, oracle, n, tr, preall
     api.aligned_free(wp)
 
 
-def test_long_mixed_sizes_without_a_split(gpu, oracle):
-    """documented gap: the reference plans any 2^a 3^b 5^c length; this backend returns NULL where the complex length is
-    > 9216 and has no (odd part * 2^j <= 1280) x (power of two in 64..1024) factorisation"""
+def test_every_long_size_the_reference_plans_gets_a_plan(gpu, oracle):
+    """the reference plans any 2^a 3^b 5^c length (simd/chowdsp_fft_impl_common.hpp:51-82, 216-225); so does this backend,
+    up to a complex length of 2^21 (beyond that: NULL, documented in include/chowdsp_fft.h)"""
     api = gpu[0]
-    for n in (20736, 41472):
+    for n in (20736, 41472, 62208, 1 << 21):
         so = oracle.new_setup(n, COMPLEX)
         assert so is not None
         oracle.destroy_setup(so)
-        assert api.fft_new_setup(n, api.FFT_COMPLEX) is None
-        assert api.fft_new_setup(2 * n, api.FFT_REAL) is None
+        s = api.fft_new_setup(n, api.FFT_COMPLEX)
+        assert s is not None
+        api.fft_destroy_setup(s)
+        s = api.fft_new_setup(2 * n, api.FFT_REAL)
+        assert s is not None
+        api.fft_destroy_setup(s)
+    assert api.fft_new_setup(1 << 22, api.FFT_COMPLEX) is None
 
 
 def test_other_size_convolution_ops(gpu, oracle):
