@@ -56,6 +56,7 @@ PROTOTYPES = {
     "fft_transform_batch": (_i, [_vp, _fp, _fp, _sz, _i, _vp]),
     "fft_transform_batch_strided": (_i, [_vp, _fp, _sz, _fp, _sz, _sz, _i, _vp]),
     "fft_transform_unordered_batch": (_i, [_vp, _fp, _fp, _sz, _i, _vp]),
+    "fft_transform_2d_batch": (_i, [_vp, _i, _fp, _fp, _sz, _i, _vp]),
     "fft_convolve_unordered_batch": (_i, [_vp, _fp, _fp, _fp, _f, _sz, _i, _vp]),
     "fft_accumulate_batch": (_i, [_vp, _fp, _fp, _fp, _sz, _vp]),
     "fft_convolve_frames_batch": (_i, [_vp, _fp, _fp, _fp, _f, _sz, _vp]),

@@ -147,6 +147,11 @@ def fft_transform_batch_strided(setup, input, in_stride: int, output, out_stride
            "fft_transform_batch_strided")
 
 
+def fft_transform_2d_batch(setup, rows: int, input, output, batch: int, direction: int, stream=None) -> None:
+    _check(_lib.lib().fft_transform_2d_batch(setup, rows, _ptr(input), _ptr(output), batch, direction, _stream_handle(stream)),
+           "fft_transform_2d_batch")
+
+
 def fft_transform_unordered_batch(setup, input, output, direction: int, batch: int | None = None, stream=None) -> None:
     b = _batch_of(setup, input) if batch is None else batch
     _check(_lib.lib().fft_transform_unordered_batch(setup, _ptr(input), _ptr(output), b, direction, _stream_handle(stream)),

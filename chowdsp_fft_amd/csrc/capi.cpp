@@ -1015,6 +1015,38 @@ int fft_transform_batch_strided (void* setup, const float* input, size_t in_stri
     return run_transform (s, input, output, batch, direction, (hipStream_t) stream, in_stride, out_stride);
 }
 
+// 2-D.  Row pass = the ordinary batched transform of batch * rows frames of `cols` points; column pass in place.
+int fft_transform_2d_batch (void* setup, int rows, const float* input, float* output, size_t batch, fft_direction_t direction, void* stream)
+{
+    Setup* s = as_setup (setup);
+    if (s == nullptr || input == nullptr || output == nullptr || rows < 1)
+        return FFT_GPU_EINVAL;
+    if (s->transform != FFT_COMPLEX)
+    {
+        set_last_error ("fft_transform_2d_batch: needs a COMPLEX setup (N = the row length)");
+        return FFT_GPU_EINVAL;
+    }
+    if (batch > ((size_t) 1 << 40) / (size_t) rows)
+        return FFT_GPU_EINVAL;
+    const DeviceGuard guard (s->device);
+    const DeviceTables* ct = rows > 1 ? acquire_column_tables (s->device, rows) : nullptr;
+    if (rows > 1 && ct == nullptr)
+    {
+        set_last_error ("fft_transform_2d_batch: the number of rows must be 2^a 3^b 5^c and at most 2559");
+        return FFT_GPU_EINVAL;
+    }
+    const int rc = run_transform (s, input, output, batch * (size_t) rows, direction, (hipStream_t) stream);
+    if (rc != FFT_GPU_OK || rows == 1)
+        return rc;
+    const hipError_t e = launch_column_fft (direction == FFT_BACKWARD, rows, s->N, *ct, (float2*) output, batch, (hipStream_t) stream);
+    if (e != hipSuccess)
+    {
+        set_last_error ("fft_transform_2d_batch: column pass launch", e);
+        return FFT_GPU_ELAUNCH;
+    }
+    return FFT_GPU_OK;
+}
+
 int fft_transform_unordered_batch (void* setup, const float* input, float* output, size_t batch, fft_direction_t direction, void* stream)
 {
     return fft_transform_batch (setup, input, output, batch, direction, stream);

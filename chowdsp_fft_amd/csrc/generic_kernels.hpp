@@ -567,4 +567,52 @@ __global__ __launch_bounds__ (256) void pass_b_generic_kernel (const float2* __r
         }
     }
 }
+
+// ---- 2-D transforms: the column pass ---------------------------------------------------------
+// `batch` row-major [rows][cols] complex arrays whose rows have already been transformed: rows-point FFTs along every
+// column, in place.  Same tile scheme as the two-pass column pass above -- C adjacent columns staged through LDS so that
+// every global access touches C * 8 contiguous bytes, the FFTs by the run-time stage list -- without the inter-pass
+// twiddle, and stored back where it came from.  cols need not be a multiple of C.
+template <bool SWAP, int C>
+__global__ __launch_bounds__ (256) void column_fft_kernel (float2* __restrict__ data,
+                                                          const float2* __restrict__ twtab,
+                                                          GenericPlan plan, // n = rows, frames = C
+                                                          unsigned cols,
+                                                          unsigned batch,
+                                                          size_t array_stride, // float2 between consecutive arrays
+                                                          unsigned lfs)
+{
+    extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
+    const int tid = threadIdx.x;
+    const int rows = plan.n;
+    float2* bufA = smem;
+    float2* bufB = smem + (size_t) C * lfs;
+    const unsigned tiles = (cols + C - 1) / C;
+    const size_t nwork = (size_t) batch * tiles;
+    for (size_t w = blockIdx.x; w < nwork; w += gridDim.x)
+    {
+        const unsigned f = (unsigned) (w / tiles);
+        const unsigned tile = (unsigned) (w % tiles);
+        const int valid = (int) min ((unsigned) C, cols - tile * C);
+        float2* __restrict__ base = data + (size_t) f * array_stride + (size_t) tile * C;
+        __syncthreads(); // previous tile fully stored
+        for (int e = tid; e < C * rows; e += 256)
+        {
+            const int c = e % C, j = e / C;
+            const float2 x = c < valid ? gload (&base[(size_t) j * cols + c]) : make_float2 (0.f, 0.f);
+            bufA[c * lfs + j] = SWAP ? make_float2 (x.y, x.x) : x;
+        }
+        __syncthreads();
+        const float2* res = generic_core<256, false, false, false> (plan, twtab, bufA, bufB, nullptr, nullptr, C, tid, lfs);
+        for (int e = tid; e < C * rows; e += 256)
+        {
+            const int c = e % C, k = e / C;
+            if (c < valid)
+            {
+                const float2 y = res[c * lfs + k];
+                gstore (&base[(size_t) k * cols + c], SWAP ? make_float2 (y.y, y.x) : y);
+            }
+        }
+    }
+}
 } // namespace cfft

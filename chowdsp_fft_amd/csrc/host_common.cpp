@@ -92,6 +92,37 @@ int blocks_per_cu_cached (const void* kernel, int threads, size_t lds_bytes)
     return n;
 }
 
+const DeviceTables* acquire_column_tables (int device, int rows)
+{
+    std::lock_guard<std::mutex> lock (g_cache_mutex);
+    const auto key = std::make_tuple (device, rows, 2 /* neither FFT_REAL nor FFT_COMPLEX: column pass */);
+    auto it = g_tables.find (key);
+    if (it != g_tables.end())
+        return it->second;
+    HostTables h;
+    if (! build_column_tables (rows, h))
+    {
+        set_last_error ("unsupported column length");
+        return nullptr;
+    }
+    auto* t = new DeviceTables();
+    t->gen_ns = (int) h.generic_radix.size();
+    for (int i = 0; i < t->gen_ns; ++i)
+    {
+        t->gen_radix[i] = h.generic_radix[(size_t) i];
+        t->gen_tw_offset[i] = h.generic_tw_offset[(size_t) i];
+    }
+    t->stage_twiddles = upload (h.stage_twiddles);
+    if (t->stage_twiddles == nullptr)
+    {
+        set_last_error ("device table upload failed");
+        delete t;
+        return nullptr;
+    }
+    g_tables.emplace (key, t);
+    return t;
+}
+
 const DeviceTables* acquire_tables (int device, int N, int transform)
 {
     std::lock_guard<std::mutex> lock (g_cache_mutex);

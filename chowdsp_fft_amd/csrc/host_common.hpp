@@ -78,6 +78,9 @@ inline Setup* as_setup (void* p)
 }
 
 const DeviceTables* acquire_tables (int device, int N, int transform);
+// stage list + tables of the 2-D transform's column pass (rows-point FFTs of a tile of columns); nullptr if `rows` is not
+// 2-3-5-smooth or does not fit a column tile (tables.hpp kGeneralMaxFactor)
+const DeviceTables* acquire_column_tables (int device, int rows);
 // RAII: run on the device the plan's tables live on, whatever device the calling thread has current
 struct DeviceGuard
 {

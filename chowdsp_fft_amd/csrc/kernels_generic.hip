@@ -108,4 +108,41 @@ hipError_t launch_generic (int mode, bool inverse, int nc, const DeviceTables& t
         default: return hipErrorInvalidValue;
     }
 }
+
+// column pass of the 2-D transform: rows-point FFTs along the columns of `batch` [rows][cols] arrays, in place
+hipError_t launch_column_fft (bool inverse, int rows, int cols, const DeviceTables& t, float2* data, size_t batch, hipStream_t stream)
+{
+    if (batch == 0)
+        return hipSuccess;
+    if (batch > 0x7FFFFFFFull || rows < 2 || cols < 1 || t.gen_ns < 1 || t.gen_ns > kGenericMaxStages)
+        return hipErrorInvalidValue;
+    DeviceInfo dev;
+    if (! current_device_info (dev))
+        return hipErrorNoDevice;
+    const int c = general_tile_width (rows);
+    GenericPlan plan {};
+    plan.n = rows;
+    plan.ns = t.gen_ns;
+    plan.frames = c;
+    plan.in_stride = plan.out_stride = (unsigned) rows;
+    for (int i = 0; i < t.gen_ns; ++i)
+    {
+        plan.radix[i] = t.gen_radix[i];
+        plan.tw_offset[i] = t.gen_tw_offset[i];
+    }
+    unsigned lfs = (unsigned) rows + 1u;
+    if ((size_t) 2 * c * lfs * sizeof (float2) > dev.lds_per_cu)
+        lfs = (unsigned) rows;
+    const size_t lds = (size_t) 2 * c * lfs * sizeof (float2);
+    if (lds > dev.lds_per_cu)
+        return hipErrorInvalidValue;
+    auto k = c == 16 ? (inverse ? column_fft_kernel<true, 16> : column_fft_kernel<false, 16>)
+             : c == 8 ? (inverse ? column_fft_kernel<true, 8> : column_fft_kernel<false, 8>)
+                      : (inverse ? column_fft_kernel<true, 4> : column_fft_kernel<false, 4>);
+    const unsigned grid = persistent_grid (k, 256, lds, batch * (size_t) ((cols + c - 1) / c));
+    if (grid == 0)
+        return hipErrorNoDevice;
+    hipLaunchKernelGGL (k, dim3 (grid), dim3 (256), lds, stream, data, (const float2*) t.stage_twiddles, plan, (unsigned) cols, (unsigned) batch, (size_t) rows * (size_t) cols, lfs);
+    return hipGetLastError();
+}
 } // namespace cfft::host

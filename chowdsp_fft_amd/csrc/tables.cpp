@@ -163,6 +163,26 @@ static void generic_radices (int n, std::vector<int>& radix, int frames_override
     }
 }
 
+bool build_column_tables (int rows, HostTables& out)
+{
+    if (rows < 2 || rows > kGeneralMaxFactor || ! is_235_smooth (rows))
+        return false;
+    out.core_n = 0;
+    generic_radices (rows, out.generic_radix, general_tile_width (rows));
+    int p = 1;
+    for (int r : out.generic_radix)
+    {
+        out.generic_tw_offset.push_back ((int) out.stage_twiddles.size());
+        for (int a = 1; a < r; ++a)
+            for (int k = 0; k < p; ++k)
+                out.stage_twiddles.push_back (unit_root ((long long) a * k, (long long) p * r));
+        p *= r;
+    }
+    if (out.stage_twiddles.empty())
+        out.stage_twiddles.push_back (make_float2 (1.f, 0.f)); // single-stage plans read no twiddles; keep the table non-empty
+    return p == rows && out.generic_radix.size() <= 10;
+}
+
 bool build_host_tables (int N, int transform, HostTables& out)
 {
     if (! size_supported (N, transform))

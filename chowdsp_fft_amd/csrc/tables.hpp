@@ -31,6 +31,10 @@ struct HostTables
 // Validates (N, transform) and fills the tables.  false = unsupported size.
 bool build_host_tables (int N, int transform, HostTables& out);
 
+// Column pass of the 2-D transform: stage list (for general_tile_width (rows) frames per workgroup) and tables of a
+// rows-point FFT, rows = 2^a 3^b 5^c, 2 <= rows <= kGeneralMaxFactor.  false otherwise.
+bool build_column_tables (int rows, HostTables& out);
+
 // Size policy shared with the C API.
 bool size_supported (int N, int transform);
 // stage radices of the LDS-resident core of length n (0-padded); false if n has no core plan

@@ -108,6 +108,14 @@ int fft_transform_batch (void* setup, const float* input, float* output, size_t 
    In place (input == output) needs in_stride == out_stride; any other overlap is FFT_GPU_EINVAL. */
 int fft_transform_batch_strided (void* setup, const float* input, size_t in_stride, float* output, size_t out_stride, size_t batch, fft_direction_t direction, void* stream);
 
+/* 2-D complex transform (the reference has no 2-D entry point -- its callers would loop
+   fft_transform over the rows and over gathered columns): `batch` row-major [rows][cols] complex arrays, cols = the N of
+   `setup` (a COMPLEX plan), rows = 2^a 3^b 5^c <= 2559.  A cols-point transform along every row (the ordinary batched
+   transform of batch * rows frames), then a rows-point transform along every column (tiles of adjacent columns staged
+   through LDS), in place on `output`; unscaled like every transform here: BACKWARD(FORWARD(x)) = rows * cols * x.
+   input == output allowed. */
+int fft_transform_2d_batch (void* setup, int rows, const float* input, float* output, size_t batch, fft_direction_t direction, void* stream);
+
 /* `batch` x fft_transform_unordered (reference chowdsp_fft.h:145; ordered = 0). */
 int fft_transform_unordered_batch (void* setup, const float* input, float* output, size_t batch, fft_direction_t direction, void* stream);
 
