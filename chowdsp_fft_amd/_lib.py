@@ -44,6 +44,8 @@ PROTOTYPES = {
     "fft_gpu_last_error": (C.c_char_p, []),
     "fft_gpu_set_option": (_i, [C.c_char_p, C.c_long]),
     "fft_gpu_release_stream_resources": (_i, [_vp]),
+    "fft_gpu_defer_begin": (_i, []),
+    "fft_gpu_defer_flush": (_i, []),
     "fft_gpu_size_supported": (_i, [_i, _i]),
     "fft_gpu_plan_describe": (_i, [_i, _i, C.POINTER(C.c_int)]),
     "fft_gpu_setup_size": (_i, [_vp]),

@@ -286,6 +286,14 @@ def fft_gather_multi_gpu(shards, shard_devices, dsts, dst_devices) -> None:
                                            (vp * m)(*[_ptr(a) for a in dsts]), (C.c_int * m)(*dst_devices), m), "fft_gather_multi_gpu")
 
 
+def defer_begin() -> None:
+    _check(_lib.lib().fft_gpu_defer_begin(), "fft_gpu_defer_begin")
+
+
+def defer_flush() -> None:
+    _check(_lib.lib().fft_gpu_defer_flush(), "fft_gpu_defer_flush")
+
+
 def release_stream_resources(stream=None) -> int:
     return int(_lib.lib().fft_gpu_release_stream_resources(_stream_handle(stream)))
 

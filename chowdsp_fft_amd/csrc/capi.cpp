@@ -488,6 +488,164 @@ int run_convolve (Setup* s, const float* a, const float* b, float* ab, float sca
     return cf::FFT_GPU_OK;
 }
 
+// ---- call coalescing for the legacy single-frame symbols ---------------------------------------
+// A caller that can only make one-frame calls with host pointers pays a launch, two PCIe crossings and a synchronisation
+// per frame (about 21 us at N = 4096).  Between fft_gpu_defer_begin() and fft_gpu_defer_flush() the calling thread's
+// fft_transform / fft_transform_unordered calls are RECORDED instead; the flush gathers every recorded input into pinned
+// memory, runs one batched transform per (plan, direction), and scatters the results.  Semantics stay those of the calls
+// executed one after the other: a call whose input or output overlaps the OUTPUT of a recorded call (it depends on it)
+// flushes first; inputs are all read before any output is written, and outputs are written in call order.
+struct DeferredCall
+{
+    Setup* s;
+    const float* in;
+    float* out;
+    int dir;
+};
+struct DeferredQueue
+{
+    bool active = false;
+    std::vector<DeferredCall> calls;
+    size_t floats = 0;
+    float* pin = nullptr; // pinned staging: inputs, then outputs
+    size_t pin_floats = 0;
+    float* dev = nullptr;
+    size_t dev_floats = 0;
+    int dev_device = -1;
+    ~DeferredQueue()
+    {
+        if (pin != nullptr)
+            (void) hipHostFree (pin);
+        if (dev != nullptr)
+            (void) hipFree (dev);
+    }
+};
+thread_local DeferredQueue g_deferred;
+constexpr size_t kDeferredMaxFloats = (size_t) 32 << 20; // 128 MiB of frames: flush by itself beyond that
+
+int deferred_flush()
+{
+    DeferredQueue& q = g_deferred;
+    if (q.calls.empty())
+        return cf::FFT_GPU_OK;
+    std::vector<DeferredCall> calls;
+    calls.swap (q.calls);
+    const size_t total = q.floats;
+    q.floats = 0;
+    // groups of calls that share plan and direction, in order of first appearance
+    std::vector<std::pair<Setup*, int>> groups;
+    for (const DeferredCall& c : calls)
+    {
+        bool seen = false;
+        for (const auto& g : groups)
+            seen = seen || (g.first == c.s && g.second == c.dir);
+        if (! seen)
+            groups.emplace_back (c.s, c.dir);
+    }
+    if (q.pin_floats < 2 * total)
+    {
+        if (q.pin != nullptr)
+            (void) hipHostFree (q.pin);
+        q.pin = nullptr;
+        q.pin_floats = 0;
+        if (hipHostMalloc ((void**) &q.pin, 2 * total * sizeof (float), hipHostMallocDefault) != hipSuccess)
+        {
+            set_last_error ("fft_gpu_defer_flush: pinned staging allocation failed");
+            return cf::FFT_GPU_ENOMEM;
+        }
+        q.pin_floats = 2 * total;
+    }
+    // 1. every input, grouped (so that a group is one contiguous batch), before any output is written
+    float* pin_in = q.pin;
+    float* pin_out = q.pin + total;
+    std::vector<size_t> offset (calls.size());
+    size_t pos = 0;
+    for (const auto& g : groups)
+        for (size_t i = 0; i < calls.size(); ++i)
+            if (calls[i].s == g.first && calls[i].dir == g.second)
+            {
+                const size_t nf = frame_floats (calls[i].s);
+                std::memcpy (pin_in + pos, calls[i].in, nf * sizeof (float));
+                offset[i] = pos;
+                pos += nf;
+            }
+    // 2. one batched transform per group, device memory of the plan's device, copies and kernels on the null stream
+    int rc = cf::FFT_GPU_OK;
+    pos = 0;
+    for (const auto& g : groups)
+    {
+        Setup* s = g.first;
+        const size_t nf = frame_floats (s);
+        size_t count = 0;
+        for (const DeferredCall& c : calls)
+            count += (c.s == s && c.dir == g.second) ? 1 : 0;
+        const DeviceGuard guard (s->device);
+        if (q.dev_floats < 2 * count * nf || q.dev_device != s->device)
+        {
+            if (q.dev != nullptr)
+                (void) hipFree (q.dev);
+            q.dev = nullptr;
+            q.dev_floats = 0;
+            if (hipMalloc ((void**) &q.dev, 2 * count * nf * sizeof (float)) != hipSuccess)
+            {
+                set_last_error ("fft_gpu_defer_flush: device staging allocation failed");
+                return cf::FFT_GPU_ENOMEM;
+            }
+            q.dev_floats = 2 * count * nf;
+            q.dev_device = s->device;
+        }
+        float* din = q.dev;
+        float* dout = q.dev + count * nf;
+        if (hipMemcpyAsync (din, pin_in + pos, count * nf * sizeof (float), hipMemcpyHostToDevice, nullptr) != hipSuccess)
+            rc = cf::FFT_GPU_ELAUNCH;
+        if (rc == cf::FFT_GPU_OK)
+            rc = run_transform (s, din, dout, count, (cf::fft_direction_t) g.second, nullptr, 0, 0);
+        if (rc == cf::FFT_GPU_OK && hipMemcpyAsync (pin_out + pos, dout, count * nf * sizeof (float), hipMemcpyDeviceToHost, nullptr) != hipSuccess)
+            rc = cf::FFT_GPU_ELAUNCH;
+        if (rc == cf::FFT_GPU_OK && hipStreamSynchronize (nullptr) != hipSuccess)
+            rc = cf::FFT_GPU_ELAUNCH;
+        if (rc != cf::FFT_GPU_OK)
+        {
+            set_last_error ("fft_gpu_defer_flush: a batched transform failed; the recorded calls' outputs were not written");
+            return rc;
+        }
+        pos += count * nf;
+    }
+    // 3. results, in call order (a later call that wrote the same buffer wins, as it would have)
+    for (size_t i = 0; i < calls.size(); ++i)
+        std::memcpy (calls[i].out, pin_out + offset[i], frame_floats (calls[i].s) * sizeof (float));
+    return cf::FFT_GPU_OK;
+}
+
+// true: the call was recorded (deferred mode, host pointers)
+bool deferred_record (Setup* s, const float* input, float* output, cf::fft_direction_t direction)
+{
+    DeferredQueue& q = g_deferred;
+    if (! q.active)
+        return false;
+    const size_t nf = frame_floats (s);
+    const char *ib = (const char*) input, *ob = (const char*) output;
+    const size_t bytes = nf * sizeof (float);
+    // a call that reads or rewrites what a recorded call is going to write depends on it: run what is recorded first
+    for (const DeferredCall& c : q.calls)
+    {
+        const char* cb = (const char*) c.out;
+        const size_t cbytes = frame_floats (c.s) * sizeof (float);
+        const bool in_hits = ib < cb + cbytes && cb < ib + bytes;
+        const bool out_hits = ob < cb + cbytes && cb < ob + bytes;
+        if (in_hits || (out_hits && c.out != output))
+        {
+            (void) deferred_flush();
+            break;
+        }
+    }
+    if (q.floats + nf > kDeferredMaxFloats)
+        (void) deferred_flush();
+    q.calls.push_back (DeferredCall { s, input, output, (int) direction });
+    q.floats += nf;
+    return true;
+}
+
 // legacy single-frame entry: host pointers are staged, device pointers used in place; synchronous.
 // The reference's entry points return void (chowdsp_fft.h:138-160): a failure cannot be reported through the return
 // value, so every early return records its reason for fft_gpu_last_error().
@@ -505,6 +663,12 @@ void legacy_transform (void* setup, const float* input, float* output, cf::fft_d
     const DeviceGuard guard (s->device);
     const size_t nf = frame_floats (s);
     const bool in_dev = is_device_pointer (input), out_dev = is_device_pointer (output);
+    if (g_deferred.active)
+    {
+        if (! in_dev && ! out_dev && deferred_record (s, input, output, direction))
+            return; // runs at fft_gpu_defer_flush()
+        (void) deferred_flush(); // a call that cannot be recorded keeps its place in the order
+    }
     if (in_dev && out_dev)
     {
         if (run_transform (s, input, output, 1, direction, nullptr) == cf::FFT_GPU_OK)
@@ -552,6 +716,8 @@ template <class Op>
 void legacy_elementwise (Setup* s, const float* a, const float* b, float* ab, size_t nf, Op&& op, bool ab_is_input)
 {
     const DeviceGuard guard (s->device); // whole body: see legacy_transform
+    if (g_deferred.active)
+        (void) deferred_flush(); // convolve / accumulate are not recorded: they keep their place in the order
     const bool a_dev = is_device_pointer (a), b_dev = is_device_pointer (b), ab_dev = is_device_pointer (ab);
     if (! a_dev && ! b_dev && ! ab_dev && nf * sizeof (float) <= zerocopy_max_bytes())
     {
@@ -868,6 +1034,19 @@ int fft_gpu_plan_describe (int N, fft_transform_t transform, int desc[8])
     for (int i = 0; i < 4; ++i)
         desc[4 + i] = radix[i];
     return FFT_GPU_OK;
+}
+
+int fft_gpu_defer_begin (void)
+{
+    g_deferred.active = true;
+    return FFT_GPU_OK;
+}
+
+int fft_gpu_defer_flush (void)
+{
+    const int rc = deferred_flush();
+    g_deferred.active = false;
+    return rc;
 }
 
 int fft_gpu_release_stream_resources (void* stream)

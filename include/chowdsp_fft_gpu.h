@@ -162,6 +162,17 @@ int fft_gather_multi_gpu (const float* const* shard_ptrs, const int* shard_devic
    is in `output` on return.  input == output is allowed.  PCIe-bound by construction. */
 int fft_transform_host_batch (void* setup, const float* input, float* output, size_t batch, fft_direction_t direction);
 
+/* Call coalescing for callers that can only make single-frame legacy calls with host pointers (second part of row f3).
+   Between fft_gpu_defer_begin() and fft_gpu_defer_flush() the calling thread's fft_transform / fft_transform_unordered
+   calls are recorded instead of executed; the flush gathers the recorded inputs into pinned memory, runs ONE batched
+   transform per (setup, direction) and writes the outputs.  The observable result is that of the calls executed in order:
+   a call whose input or output overlaps the output of a recorded call flushes first (so a forward / backward pair on one
+   buffer is not coalesced -- independent frames are); fft_convolve_unordered / fft_accumulate and calls with device
+   pointers flush and then run as usual.  Until the flush returns the recorded inputs must stay valid and unmodified and
+   the outputs are not written.  Per thread; 128 MiB of recorded frames flush by themselves. */
+int fft_gpu_defer_begin (void);
+int fft_gpu_defer_flush (void);
+
 /* ---- JUCE FFT-engine layouts on the device (second half of row f3) ------------------------------------------
    Batched counterparts of the three methods of the reference's JUCE adapter
    (chowdsp_fft_juce/chowdsp_fft_juce.cpp:32-86): same buffer shapes, layout and scaling, `batch` device buffers

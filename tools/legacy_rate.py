@@ -24,6 +24,22 @@ for n, tr, name in ((4096, api.FFT_COMPLEX, "complex"), (1024, api.FFT_REAL, "re
     dt = time.perf_counter() - t0
     print(f"legacy fft_transform, host pointers, N={n} {name}: {dt / calls * 1e6:8.1f} us/call  {calls / dt:10.0f} FFT/s  "
           f"({2 * nf * 4 * calls / dt / 1e9:.3f} GB/s over PCIe incl. launch + sync)")
+    # call coalescing: the same single-frame calls on independent buffers, recorded and flushed as one batch
+    nq = 512 if n <= 4096 else 64
+    xs = [api.aligned_array(nf) for _ in range(nq)]
+    ys = [api.aligned_array(nf) for _ in range(nq)]
+    for xa, _ in xs:
+        xa[:] = x
+    for _ in range(2):
+        t0 = time.perf_counter()
+        api.defer_begin()
+        for (xa, _), (ya, _) in zip(xs, ys):
+            api.fft_transform(s, xa, ya, None, api.FFT_FORWARD)
+        api.defer_flush()
+        dtq = time.perf_counter() - t0
+    print(f"coalesced legacy calls (defer_begin/flush), N={n} {name}: {dtq / nq * 1e6:8.2f} us/call {nq / dtq:10.0f} FFT/s  ({nq} calls per flush, incl. the Python call overhead)")
+    for _, pp in xs + ys:
+        api.aligned_free(pp)
     # the streaming mode: the same frames in ONE call, pinned in place, two-stream pipeline
     nb = max(64, (512 << 20) // (4 * nf))
     X = np.random.default_rng(1).uniform(-1, 1, (nb, nf)).astype(np.float32)
