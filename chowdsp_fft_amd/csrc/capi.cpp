@@ -1109,6 +1109,8 @@ int fft_gpu_set_option (const char* name, long value)
     }
     else if (std::strcmp (name, "fused_slots") == 0 && value > o.lag.load() && value <= 8)
         o.slots = value;
+    else if (std::strcmp (name, "wave4096") == 0)
+        set_wave4096 (value != 0);
     else
     {
         set_last_error ("fft_gpu_set_option: unknown option or value out of range");

@@ -37,7 +37,7 @@ hipError_t launch_real_split (bool forward, const float2* in, float2* out, const
         return hipSuccess;
     if (batch > 0x7FFFFFFFull || in_stride > 0xFFFFFFFFull || out_stride > 0xFFFFFFFFull)
         return hipErrorInvalidValue;
-    auto kernel = forward ? r2c_split_kernel : c2r_split_kernel;
+    auto kernel = forward ? r2c_split_kernel<0> : c2r_split_kernel<0>;
     const unsigned grid = persistent_grid (kernel, kSplitT, kSplitLdsBytes, batch);
     if (grid == 0)
         return hipErrorNoDevice;

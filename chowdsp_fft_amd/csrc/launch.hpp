@@ -16,6 +16,8 @@ static constexpr size_t kMaxFrameStride = (size_t) 1 << 24;
 // batched complex FFT, interleaved in/out, in may equal out
 hipError_t launch_c2c (int n, bool inverse, const float2* in, float2* out, const float2* stage_tw, size_t batch, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
 
+void set_wave4096 (bool on); // N = 4096 complex: one wavefront per frame (wave_kernels.hpp) instead of the workgroup plan
+
 // batched real FFT of N = 2*m real points through the m-point core (m = 16..4096)
 hipError_t launch_r2c (int m, const float2* in, float2* out, const float2* stage_tw, const float2* real_tw, size_t batch, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
 hipError_t launch_c2r (int m, const float2* in, float2* out, const float2* stage_tw, const float2* real_tw, size_t batch, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);

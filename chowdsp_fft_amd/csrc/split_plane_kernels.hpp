@@ -272,6 +272,7 @@ __device__ __forceinline__ void sp_pair_exchange (float2 (&up)[16], float* __res
 }
 
 // forward: N real samples (as M complex points z[n] = x[2n] + i x[2n+1]) -> packed spectrum (real_kernels.hpp)
+template <int UNUSED = 0> // (a template only so that the header can be included from more than one translation unit)
 __global__ __launch_bounds__ (kSplitT) void r2c_split_kernel (const float2* __restrict__ in,
                                                             float2* __restrict__ out,
                                                             const float2* __restrict__ tw,
@@ -332,6 +333,7 @@ __global__ __launch_bounds__ (kSplitT) void r2c_split_kernel (const float2* __re
 }
 
 // backward: packed spectrum -> N real samples (unscaled)
+template <int UNUSED = 0>
 __global__ __launch_bounds__ (kSplitT) void c2r_split_kernel (const float2* __restrict__ in,
                                                             float2* __restrict__ out,
                                                             const float2* __restrict__ tw,

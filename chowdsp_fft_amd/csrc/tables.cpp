@@ -298,6 +298,16 @@ bool build_host_tables (int N, int transform, HostTables& out)
         if (! core_plan_desc (nc, d))
             return false;
         append_stage_twiddles (d, out.stage_twiddles);
+        if (nc == 4096)
+        {
+            // one-wavefront-per-frame form (wave_kernels.hpp), 64 x 64: W_4096^(a t), t < 64, rows a = 1..7 then 8, 16, .. 56
+            for (int a = 1; a < 8; ++a)
+                for (int t = 0; t < 64; ++t)
+                    out.stage_twiddles.push_back (unit_root ((long long) a * t, 4096));
+            for (int a = 8; a < 64; a += 8)
+                for (int t = 0; t < 64; ++t)
+                    out.stage_twiddles.push_back (unit_root ((long long) a * t, 4096));
+        }
         return true;
     }
     if (nc == kSplitCoreN)

@@ -67,6 +67,8 @@ int fft_gpu_release_stream_resources (void* stream);
      "fused_min_batch"  smallest batch that takes the one-launch form (default 2048)
      "fused_lag", "fused_slots"   queue depth of the one-launch form (steps between a frame's two passes; workspace
                         frames per XCD, > lag)
+     "wave4096"         1: N = 4096 complex transforms run one wavefront per frame (two radix-64 stages in registers, one
+                        wave-private exchange) instead of one 256-work-item workgroup per frame; same rate, default 0
    Returns 0, or FFT_GPU_EINVAL for an unknown name / a value out of range. */
 int fft_gpu_set_option (const char* name, long value);
 

@@ -378,3 +378,31 @@ def test_two_streams_share_one_setup(gpu, oracle):
     assert_frames_close(y2.cpu().numpy(), want, what="stream 2")
     api.fft_destroy_setup(s)
     oracle.destroy_setup(so)
+
+
+def test_wave_per_frame_form_of_n4096(gpu, oracle):
+    """option "wave4096": one wavefront per 4096-point frame (csrc/wave_kernels.hpp) -- same results as the workgroup plan"""
+    api, torch, dev = gpu
+    n, batch = 4096, 37
+    s, so = api.fft_new_setup(n, api.FFT_COMPLEX), oracle.new_setup(n, COMPLEX)
+    x = ol.uniform(batch * 2 * n, 4242).reshape(batch, 2 * n)
+    want_f = oracle.transform_batch(so, x, FORWARD)
+    want_b = oracle.transform_batch(so, want_f, BACKWARD)
+    api.set_option("wave4096", 1)
+    try:
+        assert_frames_close(_gpu_transform(gpu, s, x, api.FFT_FORWARD), want_f, what="wave-per-frame fwd")
+        assert_frames_close(_gpu_transform(gpu, s, want_f, api.FFT_BACKWARD), want_b, what="wave-per-frame bwd")
+        # strided frames take the same kernel
+        stride = 2 * n + 32
+        buf = torch.zeros((batch, stride), device=dev)
+        buf[:, :2 * n] = torch.from_numpy(x).to(dev)
+        out = torch.full((batch, stride), 9.0, device=dev)
+        api.fft_transform_batch_strided(s, buf, stride, out, stride, batch, api.FFT_FORWARD)
+        torch.cuda.synchronize()
+        o = out.cpu().numpy()
+        assert_frames_close(o[:, :2 * n], want_f, what="wave-per-frame strided")
+        assert np.all(o[:, 2 * n:] == 9.0)
+    finally:
+        api.set_option("wave4096", 0)
+    api.fft_destroy_setup(s)
+    oracle.destroy_setup(so)
