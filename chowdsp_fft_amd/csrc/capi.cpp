@@ -413,6 +413,54 @@ int big_c2c_chunked (Setup* s, int nc, bool inverse, const float2* in, float2* o
     return cf::FFT_GPU_OK;
 }
 
+// long real frames by the real four-step: the same chunked two-lane pipeline as big_c2c_chunked, two launches per chunk
+int big_real4_chunked (Setup* s, bool inverse, const float2* in, float2* out, size_t batch, hipStream_t stream, size_t is2, size_t os2)
+{
+    const DeviceTables* t = s->tables;
+    const int r1 = t->real4_r1, r2 = t->real4_r2;
+    const size_t frame_bytes = real4_workspace_frame_len (r1, r2) * sizeof (float2);
+    const int want_lanes = lane_count();
+    size_t chunk = workspace_cap() / (size_t) want_lanes / frame_bytes;
+    if (chunk < 1)
+        chunk = 1;
+    if (chunk > batch)
+        chunk = batch;
+    std::lock_guard<std::mutex> lock (g_ws_mutex);
+    Lanes* L = get_lanes (s->device, stream, chunk * frame_bytes);
+    if (L == nullptr)
+        return cf::FFT_GPU_ENOMEM;
+    const size_t nchunks = (batch + chunk - 1) / chunk;
+    const int lanes = (nchunks >= 2) ? want_lanes : 1;
+    if (lanes == 2)
+    {
+        CFFT_HIP_TRY (hipEventRecord (L->start, stream), cf::FFT_GPU_ELAUNCH);
+        for (int k = 0; k < 2; ++k)
+            CFFT_HIP_TRY (hipStreamWaitEvent (L->lane[k], L->start, 0), cf::FFT_GPU_ELAUNCH);
+    }
+    size_t i = 0;
+    for (size_t f0 = 0; f0 < batch; f0 += chunk, ++i)
+    {
+        const size_t nb = (batch - f0 < chunk) ? batch - f0 : chunk;
+        const int k = (lanes == 2) ? (int) (i & 1) : 0;
+        const hipStream_t st = (lanes == 2) ? L->lane[k] : stream;
+        const hipError_t e = launch_real4 (r1, r2, inverse, in + f0 * is2, L->ws[k], out + f0 * os2, t->stage_twiddles, t->big_twiddles, nb, lanes, st, is2, os2);
+        if (e != hipSuccess)
+        {
+            set_last_error ("real four-step kernel launch", e);
+            return cf::FFT_GPU_ELAUNCH;
+        }
+    }
+    if (lanes == 2)
+    {
+        for (int k = 0; k < 2; ++k)
+        {
+            CFFT_HIP_TRY (hipEventRecord (L->done[k], L->lane[k]), cf::FFT_GPU_ELAUNCH);
+            CFFT_HIP_TRY (hipStreamWaitEvent (stream, L->done[k], 0), cf::FFT_GPU_ELAUNCH);
+        }
+    }
+    return cf::FFT_GPU_OK;
+}
+
 // in_stride / out_stride: floats between consecutive frames (0 = packed); validated by the caller
 int run_transform (Setup* s, const float* in, float* out, size_t batch, cf::fft_direction_t dir, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0)
 {
@@ -428,6 +476,8 @@ int run_transform (Setup* s, const float* in, float* out, size_t batch, cf::fft_
     // strides in float2, always explicit from here on
     const size_t is2 = in_stride ? in_stride / 2 : (size_t) nc, os2 = out_stride ? out_stride / 2 : (size_t) nc;
     hipError_t e = hipSuccess;
+    if (t->real4_r1 > 0)
+        return big_real4_chunked (s, inverse, cin, cout, batch, stream, is2, os2);
     if (t->mixed_n2 > 0)
     {
         // long mixed-radix frame (complex length > 20000): two passes; real frames add the pair stage per chunk
@@ -967,6 +1017,21 @@ int fft_gpu_plan_describe (int N, fft_transform_t transform, int desc[8])
     if (desc == nullptr || ! size_supported (N, (int) transform))
         return FFT_GPU_EINVAL;
     const int nc = (transform == FFT_COMPLEX) ? N : N / 2;
+    int q1 = 0, q2 = 0;
+    if (transform == FFT_REAL && split_real4 (N, q1, q2))
+    {
+        // long real frame: the four-step algorithm on the N real samples themselves, N = q1 x q2 (rows x columns)
+        int rr[4] = { 0, 0, 0, 0 };
+        if (! core_radices (q2, rr))
+            return FFT_GPU_EINVAL;
+        desc[0] = nc;
+        desc[1] = 2;
+        desc[2] = q1;
+        desc[3] = q2;
+        for (int i = 0; i < 4; ++i)
+            desc[4 + i] = rr[i];
+        return FFT_GPU_OK;
+    }
     if ((nc & (nc - 1)) != 0)
     {
         int m1 = 0, m2 = 0;
@@ -1142,14 +1207,16 @@ size_t fft_gpu_workspace_bytes (void* setup, size_t batch)
     Setup* s = as_setup (setup);
     if (s == nullptr || s->tables->core_n == complex_len (s) || (s->tables->gen_ns > 0 && s->tables->mixed_n2 == 0))
         return 0;
-    const size_t frame_bytes = (size_t) complex_len (s) * sizeof (float2);
+    size_t frame_bytes = (size_t) complex_len (s) * sizeof (float2);
+    if (s->tables->real4_r1 > 0)
+        frame_bytes = real4_workspace_frame_len (s->tables->real4_r1, s->tables->real4_r2) * sizeof (float2);
     int n1 = 0, n2 = 0;
     if (s->tables->mixed_n2 == 0)
         split_large (complex_len (s), n1, n2);
     if (s->transform == FFT_COMPLEX && fused_enabled() && fused_supported (n1, n2) && batch >= fused_min_batch())
         return fused_workspace_bytes (complex_len (s), fused_slots()) + fused_state_bytes();
     size_t chunk = workspace_cap() / (size_t) lane_count() / frame_bytes;
-    if (s->transform == FFT_REAL)
+    if (s->transform == FFT_REAL && s->tables->real4_r1 == 0)
         chunk /= pair_chunk_divisor(); // the pair stage's operands share the cache with the two workspaces
     if (chunk < 1)
         chunk = 1;

@@ -143,6 +143,104 @@ hipError_t launch_big_c2c (int n1, int n2, bool inverse, const float2* in, float
     return e;
 }
 
+// ---- long REAL frames: the four-step algorithm on the real data (multipass_kernels.hpp), two sweeps instead of three ----
+namespace
+{
+template <int R2>
+hipError_t real4_pass_a (int n1c, const float2* in, float2* work, const float2* tw2, const float2* big_tw, size_t batch, int div, hipStream_t stream, size_t in_stride, size_t ws_len)
+{
+    using TG = TileGeom<R2>;
+    static_assert (TG::C == 16, "the real four-step tiles are 16 complex = 32 real columns wide");
+    auto kernel = pass_a_real_kernel<typename TG::P, TG::C, TG::BLOCK>;
+    unsigned grid = persistent_grid (kernel, TG::BLOCK, TG::lds_bytes, batch * (size_t) (n1c / TG::C));
+    if (grid == 0)
+        return hipErrorNoDevice;
+    grid = std::max (1u, grid / (unsigned) div);
+    hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (TG::BLOCK), TG::lds_bytes, stream, in, work, tw2, big_tw, (unsigned) n1c, (unsigned) batch, in_stride, ws_len);
+    return hipGetLastError();
+}
+template <int R1>
+hipError_t real4_pass_b (int r2, const float2* work, float2* out, const float2* tw1, size_t batch, int div, hipStream_t stream, size_t out_stride, size_t ws_len)
+{
+    using TG = TileGeom<R1>;
+    static_assert (TG::C == 16, "row tiles of 16");
+    auto kernel = pass_b_real_kernel<typename TG::P, TG::C, TG::BLOCK>;
+    const size_t tiles = ((size_t) r2 / 2 + 1 + TG::C - 1) / TG::C;
+    unsigned grid = persistent_grid (kernel, TG::BLOCK, TG::lds_bytes, batch * tiles);
+    if (grid == 0)
+        return hipErrorNoDevice;
+    grid = std::max (1u, grid / (unsigned) div);
+    hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (TG::BLOCK), TG::lds_bytes, stream, work, out, tw1, (unsigned) r2, (unsigned) batch, out_stride, ws_len);
+    return hipGetLastError();
+}
+template <int R1>
+hipError_t real4_pass_b_inv (int r2, const float2* in, float2* work, const float2* tw1, const float2* big_tw, size_t batch, int div, hipStream_t stream, size_t in_stride, size_t ws_len)
+{
+    using TG = TileGeom<R1>;
+    auto kernel = pass_b_real_inv_kernel<typename TG::P, TG::C, TG::BLOCK>;
+    const size_t tiles = ((size_t) r2 / 2 + 1 + TG::C - 1) / TG::C;
+    unsigned grid = persistent_grid (kernel, TG::BLOCK, TG::lds_bytes, batch * tiles);
+    if (grid == 0)
+        return hipErrorNoDevice;
+    grid = std::max (1u, grid / (unsigned) div);
+    hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (TG::BLOCK), TG::lds_bytes, stream, in, work, tw1, big_tw, (unsigned) r2, (unsigned) batch, in_stride, ws_len);
+    return hipGetLastError();
+}
+template <int R2>
+hipError_t real4_pass_a_inv (int n1c, const float2* work, float2* out, const float2* tw2, size_t batch, int div, hipStream_t stream, size_t out_stride, size_t ws_len)
+{
+    using TG = TileGeom<R2>;
+    auto kernel = pass_a_real_inv_kernel<typename TG::P, TG::C, TG::BLOCK>;
+    unsigned grid = persistent_grid (kernel, TG::BLOCK, TG::lds_bytes, batch * (size_t) (n1c / TG::C));
+    if (grid == 0)
+        return hipErrorNoDevice;
+    grid = std::max (1u, grid / (unsigned) div);
+    hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (TG::BLOCK), TG::lds_bytes, stream, work, out, tw2, (unsigned) n1c, (unsigned) batch, out_stride, ws_len);
+    return hipGetLastError();
+}
+#define CFFT_DISPATCH_REAL4(n, CALL)                         \
+    switch (n)                                               \
+    {                                                        \
+        case 256: { constexpr int N_ = 256; CALL; } break;   \
+        case 512: { constexpr int N_ = 512; CALL; } break;   \
+        case 1024: { constexpr int N_ = 1024; CALL; } break; \
+        default: return hipErrorInvalidValue;                \
+    }
+} // namespace
+
+size_t real4_workspace_frame_len (int r1, int r2) { return (size_t) r1 * (size_t) (r2 / 2 + 1); }
+
+hipError_t launch_real4 (int r1, int r2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, size_t batch, int grid_divisor, hipStream_t stream, size_t in_stride, size_t out_stride)
+{
+    if (batch == 0)
+        return hipSuccess;
+    if (batch > 0x7FFFFFFFull)
+        return hipErrorInvalidValue;
+    const size_t m = (size_t) r1 * (size_t) r2 / 2; // float2 per frame on the caller's side
+    in_stride = in_stride ? in_stride : m;
+    out_stride = out_stride ? out_stride : m;
+    const size_t ws_len = real4_workspace_frame_len (r1, r2);
+    const float2* tw2 = stage_tw;                          // R2-point column core
+    const float2* tw1 = stage_tw + stage_table_len (r2);   // R1-point row core
+    const int n1c = r1 / 2;
+    hipError_t e = hipErrorInvalidValue;
+    if (! inverse)
+    {
+        CFFT_DISPATCH_REAL4 (r2, e = (real4_pass_a<N_> (n1c, in, work, tw2, big_tw, batch, grid_divisor, stream, in_stride, ws_len)));
+        if (e != hipSuccess)
+            return e;
+        CFFT_DISPATCH_REAL4 (r1, e = (real4_pass_b<N_> (r2, work, out, tw1, batch, grid_divisor, stream, out_stride, ws_len)));
+    }
+    else
+    {
+        CFFT_DISPATCH_REAL4 (r1, e = (real4_pass_b_inv<N_> (r2, in, work, tw1, big_tw, batch, grid_divisor, stream, in_stride, ws_len)));
+        if (e != hipSuccess)
+            return e;
+        CFFT_DISPATCH_REAL4 (r2, e = (real4_pass_a_inv<N_> (n1c, work, out, tw2, batch, grid_divisor, stream, out_stride, ws_len)));
+    }
+    return e;
+}
+
 // ---- both passes in one launch, hand-off inside an XCD's L2 (fused_twopass_kernels.hpp) -------------------------------
 size_t fused_state_bytes() { return sizeof (FusedState); }
 size_t fused_workspace_bytes (int nc, int slots) { return (size_t) kFusedMaxXcc * (size_t) slots * (size_t) nc * sizeof (float2); }

@@ -53,6 +53,11 @@ hipError_t launch_conv_frames_real (int m, const float2* in, const float2* H, fl
 // stage_tw holds the n2-core table followed by the n1-core table.  grid_divisor: 2 when two launches are meant
 // to share the GPU (two-lane pipeline), else 1.
 hipError_t launch_big_c2c (int n1, int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, size_t batch, int grid_divisor, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
+// long REAL frames (N = r1 * r2 samples, both powers of two in 256..1024): the four-step algorithm on the real data, two
+// sweeps (real columns as pairs -> rows -> packed spectrum; backward the other way round).  in / out: the real frame and the
+// packed spectrum, both as N/2 float2; work: real4_workspace_frame_len() float2 per frame.
+size_t real4_workspace_frame_len (int r1, int r2);
+hipError_t launch_real4 (int r1, int r2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, size_t batch, int grid_divisor, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
 // the same two passes in ONE launch with the intermediate handed over inside an XCD's L2 (fused_twopass_kernels.hpp):
 // `state` = fused_state_bytes() of device memory (zeroed by the launcher on `stream`), `work` = fused_workspace_bytes()
 bool fused_supported (int n1, int n2);

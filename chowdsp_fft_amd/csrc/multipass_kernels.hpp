@@ -182,6 +182,279 @@ __global__ __launch_bounds__ (BLOCK) void pass_b_kernel (const float2* __restric
     }
 }
 
+// =====================================================================================================
+// REAL frames too long for one pass (N = 2^17 .. 2^20 samples): the four-step algorithm on the real data itself,
+// N = R1 x R2, instead of a complex two-pass transform of N/2 points followed by a third sweep for the pair stage.
+//
+//   n = a + R1 b,  k = R2 ka + kb:   X[R2 ka + kb] = sum_a W_R1^{a ka} [ W_N^{a kb} C_a[kb] ],   C_a = DFT_R2 of column a
+//
+// The columns are real, so two adjacent ones are transformed as ONE complex column -- z_c[b] = x[2c + R1 b] + i x[2c+1 + R1 b]
+// is exactly the float2 at index c + (R1/2) b of the frame -- and separated afterwards,
+//     C_2c[kb] = (Z_c[kb] + conj Z_c[R2 - kb]) / 2,     C_2c+1[kb] = (Z_c[kb] - conj Z_c[R2 - kb]) / (2 i),
+// which needs Z_c[kb] and Z_c[R2 - kb] of the SAME column: both are in the tile's LDS image.  Being spectra of real data,
+// C_a[R2 - kb] = conj C_a[kb]: only the rows kb = 0 .. R2/2 are kept (the intermediate is N/2 + R1 complex values, the size of
+// the real frame), and each of them yields, after its R1-point row transform, R1 bins of the packed spectrum: the bins
+// k = R2 ka + kb < N/2 directly, the others as the conjugates of X[N - k].  Two sweeps over the data instead of three.
+// The reference does this with FFTPACK real passes + pffft_real_finalize on 4 lanes (simd/chowdsp_fft_impl_sse.cpp:552-966).
+//
+// Workspace per frame: [column tile tA][row kb <= R2/2][32]: the 32 real columns of a tile, a = 32 tA + al.
+// =====================================================================================================
+template <class P, int CA, int BLOCK>
+__global__ __launch_bounds__ (BLOCK) void pass_a_real_kernel (const float2* __restrict__ in, // the real frame as N/2 float2
+                                                           float2* __restrict__ work,
+                                                           const float2* __restrict__ stage_tw,
+                                                           const float2* __restrict__ big_tw, // [tA][kb][c][2]: W_N^{a kb}, a = 2 (CA tA + c) + {0, 1}
+                                                           unsigned n1c, // complex columns = R1 / 2
+                                                           unsigned batch,
+                                                           size_t in_stride,
+                                                           size_t ws_frame_len)
+{
+    extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
+    constexpr int n2 = P::N, NR = n2 / 2 + 1;
+    constexpr int FS = TileFrame<n2>::stride;
+    const int tid = threadIdx.x;
+    const int team = tid / P::T;
+    const int t = tid % P::T;
+    TwiddleRegs<P> tw;
+    if constexpr (! TileStreamsTwiddles<P, BLOCK>::value)
+        load_twiddles<P> (tw, stage_tw, t);
+    const unsigned tiles = n1c / CA;
+    const size_t nwork = (size_t) batch * tiles;
+    for (size_t w = blockIdx.x; w < nwork; w += gridDim.x)
+    {
+        const unsigned f = (unsigned) (w / tiles);
+        const unsigned tile = (unsigned) (w % tiles);
+        const float2* __restrict__ src = in + (size_t) f * in_stride + (size_t) tile * CA;
+        float4* __restrict__ dst = reinterpret_cast<float4*> (work + (size_t) f * ws_frame_len + (size_t) tile * ((size_t) NR * CA * 2));
+        const float4* __restrict__ twp = reinterpret_cast<const float4*> (big_tw + (size_t) tile * ((size_t) NR * CA * 2));
+        __syncthreads(); // previous tile fully stored
+#pragma unroll 4
+        for (int e = tid; e < CA * n2; e += BLOCK)
+        {
+            const int c = e % CA, j = e / CA;
+            smem[c * FS + lds_phys (j)] = gload (&src[(size_t) j * n1c + c]);
+        }
+        __syncthreads();
+        tile_fft_frames<P, CA, BLOCK> (smem, tw, stage_tw, team, t);
+        __syncthreads();
+#pragma unroll 2
+        for (int e = tid; e < CA * NR; e += BLOCK)
+        {
+            const int c = e % CA, kb = e / CA;
+            const float2 zk = smem[c * FS + lds_phys (kb)];
+            const float2 zm = smem[c * FS + lds_phys ((n2 - kb) & (n2 - 1))];
+            // even column: (zk + conj zm) / 2;  odd column: (zk - conj zm) / (2 i)
+            const float2 ce = make_float2 (0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+            const float2 co = make_float2 (0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));
+            const float4 w4 = twp[e];
+            const float2 re = cmul (ce, make_float2 (w4.x, w4.y)), ro = cmul (co, make_float2 (w4.z, w4.w));
+            dst[e] = make_float4 (re.x, re.y, ro.x, ro.y); // plain store: the workspace should stay cached
+        }
+    }
+}
+
+// Row pass: R1-point transforms of CB adjacent rows kb (of the R2/2 + 1 kept), stored into the packed spectrum
+// P[0] = (X0, X_{N/2}), P[k] = X[k] (0 < k < N/2): bins R2 ka + kb with ka < R1/2 directly, the upper half of every inner
+// row as conjugates at N - k = R2 (R1 - 1 - ka) + (R2 - kb).
+template <class P, int CB, int BLOCK>
+__global__ __launch_bounds__ (BLOCK) void pass_b_real_kernel (const float2* __restrict__ work,
+                                                           float2* __restrict__ out,
+                                                           const float2* __restrict__ stage_tw,
+                                                           unsigned n2, // R2
+                                                           unsigned batch,
+                                                           size_t out_stride,
+                                                           size_t ws_frame_len)
+{
+    extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
+    constexpr int R1 = P::N;
+    constexpr int FS = TileFrame<R1>::stride;
+    const int tid = threadIdx.x;
+    const int team = tid / P::T;
+    const int t = tid % P::T;
+    TwiddleRegs<P> tw;
+    if constexpr (! TileStreamsTwiddles<P, BLOCK>::value)
+        load_twiddles<P> (tw, stage_tw, t);
+    const unsigned NR = n2 / 2 + 1;
+    const unsigned tiles = (NR + CB - 1) / CB;
+    const size_t nwork = (size_t) batch * tiles;
+    for (size_t w = blockIdx.x; w < nwork; w += gridDim.x)
+    {
+        const unsigned f = (unsigned) (w / tiles);
+        const unsigned tile = (unsigned) (w % tiles);
+        const unsigned kb0 = tile * CB;
+        const int valid = (int) min ((unsigned) CB, NR - kb0);
+        const float2* __restrict__ src = work + (size_t) f * ws_frame_len;
+        float2* __restrict__ dst = out + (size_t) f * out_stride;
+        __syncthreads();
+#pragma unroll 4
+        for (int e = tid; e < CB * R1; e += BLOCK)
+        {
+            // al fastest (32 contiguous values), then the tile's row, then pass A's tile
+            const unsigned al = (unsigned) e & 31u;
+            const unsigned kbl = ((unsigned) e >> 5) % CB;
+            const unsigned tA = ((unsigned) e >> 5) / CB;
+            const float2 x = (int) kbl < valid ? src[((size_t) tA * NR + kb0 + kbl) * 32 + al] : make_float2 (0.f, 0.f);
+            smem[kbl * FS + lds_phys ((int) (tA * 32 + al))] = x;
+        }
+        __syncthreads();
+        tile_fft_frames<P, CB, BLOCK> (smem, tw, stage_tw, team, t);
+        __syncthreads();
+#pragma unroll 4
+        for (int e = tid; e < CB * R1; e += BLOCK)
+        {
+            const int c = e % CB, k = e / CB;
+            if (c >= valid)
+                continue;
+            const unsigned kb = kb0 + (unsigned) c;
+            const float2 y = smem[c * FS + lds_phys (k)];
+            if (k < R1 / 2)
+            {
+                if (kb == 0 && k == 0)
+                    gstore (&dst[0], make_float2 (y.x, smem[c * FS + lds_phys (R1 / 2)].x)); // (X0, X_{N/2}): both real
+                else
+                    gstore (&dst[(size_t) k * n2 + kb], y);
+            }
+            else if (kb != 0 && 2 * kb != n2)
+                gstore (&dst[(size_t) (R1 - 1 - k) * n2 + (n2 - kb)], make_float2 (y.x, -y.y));
+        }
+    }
+}
+
+// Backward, first sweep: the rows.  Row kb (0 .. R2/2) of the spectrum is gathered from the packed input -- bins
+// R2 ka + kb directly for ka < R1/2, conj P[R2 (R1 - 1 - ka) + R2 - kb] for the rest (rows 0 and R2/2 are their own
+// mirrors: conj P[R2 (R1 - ka)] resp. the same formula) --, transformed backward (re <-> im swap on both sides), times
+// conj W_N^{a kb}, into the workspace.
+template <class P, int CB, int BLOCK>
+__global__ __launch_bounds__ (BLOCK) void pass_b_real_inv_kernel (const float2* __restrict__ in, // packed spectrum
+                                                               float2* __restrict__ work,
+                                                               const float2* __restrict__ stage_tw,
+                                                               const float2* __restrict__ big_tw, // as pass_a_real_kernel's
+                                                               unsigned n2,
+                                                               unsigned batch,
+                                                               size_t in_stride,
+                                                               size_t ws_frame_len)
+{
+    extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
+    constexpr int R1 = P::N;
+    constexpr int FS = TileFrame<R1>::stride;
+    const int tid = threadIdx.x;
+    const int team = tid / P::T;
+    const int t = tid % P::T;
+    TwiddleRegs<P> tw;
+    if constexpr (! TileStreamsTwiddles<P, BLOCK>::value)
+        load_twiddles<P> (tw, stage_tw, t);
+    const unsigned NR = n2 / 2 + 1;
+    const unsigned tiles = (NR + CB - 1) / CB;
+    const size_t nwork = (size_t) batch * tiles;
+    for (size_t w = blockIdx.x; w < nwork; w += gridDim.x)
+    {
+        const unsigned f = (unsigned) (w / tiles);
+        const unsigned tile = (unsigned) (w % tiles);
+        const unsigned kb0 = tile * CB;
+        const int valid = (int) min ((unsigned) CB, NR - kb0);
+        const float2* __restrict__ src = in + (size_t) f * in_stride;
+        float2* __restrict__ dst = work + (size_t) f * ws_frame_len;
+        __syncthreads();
+#pragma unroll 4
+        for (int e = tid; e < CB * R1; e += BLOCK)
+        {
+            const int c = e % CB, k = e / CB; // row fastest: CB contiguous bins per access
+            float2 x = make_float2 (0.f, 0.f);
+            if (c < valid)
+            {
+                const unsigned kb = kb0 + (unsigned) c;
+                if (k < R1 / 2)
+                {
+                    x = gload (&src[(size_t) k * n2 + kb]);
+                    if (kb == 0 && k == 0)
+                        x = make_float2 (x.x, 0.f); // X0 (its slot's second float is X_{N/2})
+                }
+                else if (kb == 0 && k == R1 / 2)
+                    x = make_float2 (gload (&src[0]).y, 0.f); // X_{N/2}
+                else
+                {
+                    // X[R2 k + kb] = conj X[N - R2 k - kb];  rows 0 and R2/2 mirror onto themselves
+                    const size_t m = (kb == 0) ? (size_t) (R1 - k) * n2 : (size_t) (R1 - 1 - k) * n2 + (n2 - kb);
+                    const float2 p = gload (&src[m]);
+                    x = make_float2 (p.x, -p.y);
+                }
+            }
+            smem[c * FS + lds_phys (k)] = make_float2 (x.y, x.x); // swapped: backward = swap . forward . swap
+        }
+        __syncthreads();
+        tile_fft_frames<P, CB, BLOCK> (smem, tw, stage_tw, team, t);
+        __syncthreads();
+#pragma unroll 4
+        for (int e = tid; e < CB * R1; e += BLOCK)
+        {
+            const unsigned al = (unsigned) e & 31u;
+            const unsigned kbl = ((unsigned) e >> 5) % CB;
+            const unsigned tA = ((unsigned) e >> 5) / CB;
+            if ((int) kbl < valid)
+            {
+                const float2 ys = smem[kbl * FS + lds_phys ((int) (tA * 32 + al))];
+                const size_t idx = ((size_t) tA * NR + kb0 + kbl) * 32 + al;
+                dst[idx] = cmulc (make_float2 (ys.y, ys.x), big_tw[idx]); // un-swap, times conj W_N^{a kb}
+            }
+        }
+    }
+}
+
+// Backward, second sweep: the columns.  For the complex column c = the real columns 2c, 2c + 1:
+// Z_c[kb] = C_2c[kb] + i C_2c+1[kb] for kb <= R2/2 and conj C_2c[R2 - kb] + i conj C_2c+1[R2 - kb] above; backward
+// transform over kb, stored as the float2 column c of the real frame.
+template <class P, int CA, int BLOCK>
+__global__ __launch_bounds__ (BLOCK) void pass_a_real_inv_kernel (const float2* __restrict__ work,
+                                                               float2* __restrict__ out, // the real frame as N/2 float2
+                                                               const float2* __restrict__ stage_tw,
+                                                               unsigned n1c,
+                                                               unsigned batch,
+                                                               size_t out_stride,
+                                                               size_t ws_frame_len)
+{
+    extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
+    constexpr int n2 = P::N, NR = n2 / 2 + 1;
+    constexpr int FS = TileFrame<n2>::stride;
+    const int tid = threadIdx.x;
+    const int team = tid / P::T;
+    const int t = tid % P::T;
+    TwiddleRegs<P> tw;
+    if constexpr (! TileStreamsTwiddles<P, BLOCK>::value)
+        load_twiddles<P> (tw, stage_tw, t);
+    const unsigned tiles = n1c / CA;
+    const size_t nwork = (size_t) batch * tiles;
+    for (size_t w = blockIdx.x; w < nwork; w += gridDim.x)
+    {
+        const unsigned f = (unsigned) (w / tiles);
+        const unsigned tile = (unsigned) (w % tiles);
+        const float4* __restrict__ src = reinterpret_cast<const float4*> (work + (size_t) f * ws_frame_len + (size_t) tile * ((size_t) NR * CA * 2));
+        float2* __restrict__ dst = out + (size_t) f * out_stride + (size_t) tile * CA;
+        __syncthreads();
+#pragma unroll 2
+        for (int e = tid; e < CA * NR; e += BLOCK)
+        {
+            const int c = e % CA, kb = e / CA;
+            const float4 p = src[e]; // (C_2c[kb], C_2c+1[kb])
+            // Z[kb] = Ce + i Co, Z[R2 - kb] = conj Ce + i conj Co; stored swapped for the backward transform
+            const float2 zk = make_float2 (p.x - p.w, p.y + p.z);
+            const float2 zm = make_float2 (p.x + p.w, p.z - p.y);
+            smem[c * FS + lds_phys (kb)] = make_float2 (zk.y, zk.x);
+            if (kb != 0 && 2 * kb != n2)
+                smem[c * FS + lds_phys (n2 - kb)] = make_float2 (zm.y, zm.x);
+        }
+        __syncthreads();
+        tile_fft_frames<P, CA, BLOCK> (smem, tw, stage_tw, team, t);
+        __syncthreads();
+#pragma unroll 4
+        for (int e = tid; e < CA * n2; e += BLOCK)
+        {
+            const int c = e % CA, j = e / CA;
+            const float2 y = smem[c * FS + lds_phys (j)];
+            gstore (&dst[(size_t) j * n1c + c], make_float2 (y.y, y.x));
+        }
+    }
+}
+
 // Pair stage of the real transform as a stand-alone streaming kernel (long frames only; any even M).
 // FORWARD: Z (M complex, canonical) -> packed X, in place allowed.  BACKWARD: packed X -> Z.
 template <bool FORWARD>

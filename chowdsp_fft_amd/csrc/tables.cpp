@@ -82,6 +82,19 @@ bool split_mixed (int n_complex, int& n1, int& n2)
     return false;
 }
 
+bool split_real4 (int n_real, int& r1, int& r2)
+{
+    r1 = r2 = 0;
+    if (n_real < (1 << 17) || n_real > (1 << 20) || ! is_pow2 (n_real))
+        return false;
+    int lg = 0;
+    while ((1 << lg) < n_real)
+        ++lg;
+    r2 = 1 << (lg / 2);        // column length
+    r1 = 1 << (lg - lg / 2);   // row length
+    return true;
+}
+
 bool split_general (int n_complex, int& n1, int& n2)
 {
     n1 = n2 = 0;
@@ -291,6 +304,27 @@ bool build_host_tables (int N, int transform, HostTables& out)
         return p == nc && out.generic_radix.size() <= 10;
     }
 
+    int q1 = 0, q2 = 0;
+    if (real && split_real4 (N, q1, q2))
+    {
+        // long real frame: four-step on the real data.  Stage tables of the two cores (columns first), then W_N^{a kb} in the
+        // workspace's order [column tile tA][kb <= r2/2][32], a = 32 tA + al
+        PlanDesc dc, dr;
+        if (! core_plan_desc (q2, dc) || ! core_plan_desc (q1, dr))
+            return false;
+        out.core_n = 0;
+        out.real4_r1 = q1;
+        out.real4_r2 = q2;
+        append_stage_twiddles (dc, out.stage_twiddles);
+        append_stage_twiddles (dr, out.stage_twiddles);
+        const int nr = q2 / 2 + 1;
+        out.big_twiddles.reserve ((size_t) q1 * nr);
+        for (int ta = 0; ta < q1 / 32; ++ta)
+            for (int kb = 0; kb < nr; ++kb)
+                for (int al = 0; al < 32; ++al)
+                    out.big_twiddles.push_back (unit_root ((long long) (ta * 32 + al) * kb, N));
+        return true;
+    }
     PlanDesc d;
     if (nc <= kMaxCoreN)
     {

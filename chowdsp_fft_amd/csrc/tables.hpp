@@ -26,6 +26,7 @@ struct HostTables
     // too, with their own stage list; mixed_cb rows per pass-B tile; both tile widths may leave a ragged last tile
     std::vector<int> generic2_radix, generic2_tw_offset;
     int mixed_cb = 0;
+    int real4_r1 = 0, real4_r2 = 0; // long real frames: real four-step N = r1 * r2 (multipass_kernels.hpp)
 };
 
 // Validates (N, transform) and fills the tables.  false = unsupported size.
@@ -34,6 +35,9 @@ bool build_host_tables (int N, int transform, HostTables& out);
 // Column pass of the 2-D transform: stage list (for general_tile_width (rows) frames per workgroup) and tables of a
 // rows-point FFT, rows = 2^a 3^b 5^c, 2 <= rows <= kGeneralMaxFactor.  false otherwise.
 bool build_column_tables (int rows, HostTables& out);
+
+// Real N = 2^17 .. 2^20: the real four-step split N = r1 * r2 (r1 >= r2, both in 256..1024); false for any other N.
+bool split_real4 (int n_real, int& r1, int& r2);
 
 // Size policy shared with the C API.
 bool size_supported (int N, int transform);
