@@ -37,6 +37,8 @@ WORKLOADS = {
     "c2c_n4096_b65536_fwd_inv": (4096, "complex", 65536, "BASELINE configs[1]: N=4096 fp32 complex fwd+inv, batch=65536 per GPU"),
     "real_n1024_b262144_fwd_inv": (1024, "real", 262144, "BASELINE configs[2]: N=1024 fp32 real r2c+c2r, batch=262144 per GPU"),
     "c2c_n65536_b8192_fwd_inv": (65536, "complex", 8192, "BASELINE configs[4]: N=65536 fp32 complex (two-pass), batch=8192 per GPU"),
+    # the same configuration through the one-launch form (option fused_two_pass): the inter-pass hand-off stays in the XCDs' L2
+    "c2c_n65536_b8192_fwd_inv_one_launch": (65536, "complex", 8192, "BASELINE configs[4] through the one-launch, XCD-local two-pass form (fused_two_pass = 1)"),
     "conv_real_n4096_b131072": (4096, "real", 131072, "BASELINE configs[3] per-GPU share: fused fwd->mul->inv frames, N=4096 real, 131072 frames per GPU"),
     # a mixed-radix size from the reference's "Other sizes" list (9216 = 2^10 * 3^2), generic kernel
     "c2c_n9216_b16384_fwd_inv": (9216, "complex", 16384, "mixed-radix N=9216 fp32 complex fwd+inv (generic kernel), batch=16384 per GPU"),
@@ -47,7 +49,7 @@ WORKLOADS = {
 
 DEFAULT_WORKLOAD = "c2c_n4096_b65536_fwd_inv"
 # the other BASELINE.json configurations, reported under "secondary" of the default run's ONE JSON line
-SECONDARY_WORKLOADS = ("real_n1024_b262144_fwd_inv", "conv_real_n4096_b131072", "c2c_n65536_b8192_fwd_inv")
+SECONDARY_WORKLOADS = ("real_n1024_b262144_fwd_inv", "conv_real_n4096_b131072", "c2c_n65536_b8192_fwd_inv", "c2c_n65536_b8192_fwd_inv_one_launch")
 
 
 def cpu_baseline(n: int, transform: str, seconds: float) -> dict:
@@ -106,6 +108,7 @@ def run_workload(workload, args, world, rank, dev, frames_override=0, gather=Fal
         frames = frames_override
     tr = api.FFT_COMPLEX if transform == "complex" else api.FFT_REAL
     frame_floats = 2 * n if transform == "complex" else n
+    api.set_option("fused_two_pass", 1 if workload.endswith("_one_launch") else 0)
     setup = api.fft_new_setup(n, tr)
     if setup is None:
         sys.stderr.write("[bench] fft_new_setup returned NULL\n")
@@ -205,6 +208,7 @@ def run_workload(workload, args, world, rank, dev, frames_override=0, gather=Fal
             "real_n1024_b262144_fwd_inv": "cfft::r2c_kernel<Plan<512,64,8,8,8>, 4, false> and cfft::c2r_kernel<Plan<512,64,8,8,8>, 4, false>",
             "conv_real_n4096_b131072": "cfft::conv_frames_real_kernel_pf<Plan<2048,128,16,16,8>, 1, false>",
             "c2c_n65536_b8192_fwd_inv": "cfft::pass_a256_kernel<INV> + cfft::pass_b256_kernel<INV> per 256-frame chunk (two passes over the frame)",
+            "c2c_n65536_b8192_fwd_inv_one_launch": "cfft::fused256_kernel<INV> (both passes in one launch, per-XCD ticket queues)",
             "c2c_n9216_b16384_fwd_inv": "cfft::generic_kernel<0, INV, 1024>",
             "ols_engine_b2048_p16_c8192": "cfft::ols_block_kernel<Plan<2048,128,16,16,8>, 2>",
         }.get(workload, f"{workload} kernels")
@@ -237,6 +241,7 @@ def run_workload(workload, args, world, rank, dev, frames_override=0, gather=Fal
         if gather_info:
             line["gather_xgmi"] = gather_info
     api.fft_destroy_setup(setup)
+    api.set_option("fused_two_pass", 0)
     del x, y, z, engine
     torch.cuda.empty_cache()
     return line

@@ -286,7 +286,7 @@ __global__ __launch_bounds__ (BLOCK) void pass_b_real_kernel (const float2* __re
         const float2* __restrict__ src = work + (size_t) f * ws_frame_len;
         float2* __restrict__ dst = out + (size_t) f * out_stride;
         __syncthreads();
-#pragma unroll 4
+#pragma unroll 2
         for (int e = tid; e < CB * R1; e += BLOCK)
         {
             // al fastest (32 contiguous values), then the tile's row, then pass A's tile
@@ -299,7 +299,7 @@ __global__ __launch_bounds__ (BLOCK) void pass_b_real_kernel (const float2* __re
         __syncthreads();
         tile_fft_frames<P, CB, BLOCK> (smem, tw, stage_tw, team, t);
         __syncthreads();
-#pragma unroll 4
+#pragma unroll 2
         for (int e = tid; e < CB * R1; e += BLOCK)
         {
             const int c = e % CB, k = e / CB;
@@ -355,7 +355,7 @@ __global__ __launch_bounds__ (BLOCK) void pass_b_real_inv_kernel (const float2* 
         const float2* __restrict__ src = in + (size_t) f * in_stride;
         float2* __restrict__ dst = work + (size_t) f * ws_frame_len;
         __syncthreads();
-#pragma unroll 4
+#pragma unroll 1
         for (int e = tid; e < CB * R1; e += BLOCK)
         {
             const int c = e % CB, k = e / CB; // row fastest: CB contiguous bins per access
@@ -384,7 +384,7 @@ __global__ __launch_bounds__ (BLOCK) void pass_b_real_inv_kernel (const float2* 
         __syncthreads();
         tile_fft_frames<P, CB, BLOCK> (smem, tw, stage_tw, team, t);
         __syncthreads();
-#pragma unroll 4
+#pragma unroll 1
         for (int e = tid; e < CB * R1; e += BLOCK)
         {
             const unsigned al = (unsigned) e & 31u;

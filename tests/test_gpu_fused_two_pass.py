@@ -1,6 +1,6 @@
 """The one-launch two-pass form (csrc/fused_twopass_kernels.hpp): both passes of N = 65536 complex in ONE kernel, the
 inter-pass hand-off inside an XCD's L2, work handed out by per-XCD ticket queues.  Forced on for every batch size here
-(by default only batches >= 2048 take it): parity with the oracle, and agreement with the two-launch form, for
+(an option, off by default; when on, batches >= 2048 take it): parity with the oracle, and agreement with the two-launch form, for
 batches that fill the queue's pipeline only partly, exactly, and many times over; both directions; in place; strided.
 """
 import numpy as np
@@ -23,7 +23,7 @@ def fused_on(gpu):
     yield api
     api.set_option("fused_min_batch", 2048)
     api.set_option("fused_lag", 4)
-    api.set_option("fused_two_pass", 1)
+    api.set_option("fused_two_pass", 0)  # the library default
 
 
 def _run(gpu, s, x, direction, fused):
@@ -33,7 +33,7 @@ def _run(gpu, s, x, direction, fused):
     yd = torch.empty_like(xd)
     api.fft_transform_batch(s, xd, yd, direction)
     torch.cuda.synchronize()
-    api.set_option("fused_two_pass", 1)
+    api.set_option("fused_two_pass", 1)  # the state the fused_on fixture set up
     return yd.cpu().numpy()
 
 

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Rate table: every power of two (complex 2^4..2^21, real 2^5..2^21) and a few mixed-radix lengths, forward + backward,
+device-resident batches of about 1 GiB, HIP events.  Algorithmic bytes = 16 N per complex transform, 8 N per real one."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from chowdsp_fft_amd import api  # noqa: E402
+
+dev = torch.device("cuda:0")
+sizes = [(1 << lg, True) for lg in range(4, 22)] + [(1 << lg, False) for lg in range(5, 22)]
+sizes += [(n, True) for n in (480, 640, 768, 1536, 5120, 9216, 19200, 20736, 46080, 245760)] + [(9216, False), (41472, False)]
+for n, cplx in sizes:
+    nf = 2 * n if cplx else n
+    batch = max(1, (1 << 28) // nf)  # 1 GiB of fp32 per buffer
+    s = api.fft_new_setup(n, api.FFT_COMPLEX if cplx else api.FFT_REAL)
+    if s is None:
+        print(f"{'c' if cplx else 'r'}{n}: not supported")
+        continue
+    x = torch.rand((batch, nf), device=dev) * 2 - 1
+    y = torch.empty_like(x)
+    z = torch.empty_like(x)
+    for _ in range(3):
+        api.fft_transform_batch(s, x, y, api.FFT_FORWARD)
+        api.fft_transform_batch(s, y, z, api.FFT_BACKWARD)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 8
+    e0.record()
+    for _ in range(reps):
+        api.fft_transform_batch(s, x, y, api.FFT_FORWARD)
+        api.fft_transform_batch(s, y, z, api.FFT_BACKWARD)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / (2 * reps)
+    err = float((z[:4] / n - x[:4]).abs().max())
+    gbs = batch * nf * 8 / ms / 1e6
+    print(f"{'c' if cplx else 'r'}{n:<8d} batch {batch:<9d} {ms:8.4f} ms/launch  {gbs:7.0f} GB/s  frac {gbs / 8000:5.3f}   round-trip err {err:.1e}")
+    api.fft_destroy_setup(s)
+    del x, y, z
