@@ -259,6 +259,20 @@ FusedOptions& fused_options()
     static FusedOptions o;
     return o;
 }
+// "split16384" / CHOWDSP_FFT_SPLIT16384: N = 16384 complex / real N = 32768 through the split-plane kernels (frame in registers,
+// exchanges one component at a time; 512 work-items) instead of the interleaved-image plan with streamed twiddles
+std::atomic<int> g_split16384 { -1 };
+bool split16384_enabled()
+{
+    int v = g_split16384.load();
+    if (v < 0)
+    {
+        const char* e = std::getenv ("CHOWDSP_FFT_SPLIT16384");
+        v = (e != nullptr && e[0] == '0') ? 0 : 1;
+        g_split16384 = v;
+    }
+    return v != 0;
+}
 bool fused_enabled() { return fused_options().enabled.load() != 0; }
 size_t fused_min_batch() { return (size_t) fused_options().min_batch.load(); }
 int fused_lag() { return (int) fused_options().lag.load(); }
@@ -497,12 +511,20 @@ int run_transform (Setup* s, const float* in, float* out, size_t batch, cf::fft_
     {
         if (! lds_resident)
             return big_c2c_chunked (s, nc, inverse, cin, cout, batch, stream, is2, os2);
-        e = (nc == cfft::kSplitCoreN) ? launch_c2c_split (inverse, cin, cout, t->stage_twiddles, batch, stream, is2, os2)
-                                      : launch_c2c (nc, inverse, cin, cout, t->stage_twiddles, batch, stream, is2, os2);
+        if (nc == cfft::kSplitCoreN)
+            e = launch_c2c_split (nc, inverse, cin, cout, t->stage_twiddles, batch, stream, is2, os2);
+        else if (nc == 16384 && split16384_enabled())
+            e = launch_c2c_split (nc, inverse, cin, cout, t->stage_twiddles + cfft::CorePlan<16384>::type::tw_total, batch, stream, is2, os2);
+        else
+            e = launch_c2c (nc, inverse, cin, cout, t->stage_twiddles, batch, stream, is2, os2);
     }
     else if (lds_resident && nc == cfft::kSplitCoreN)
     {
-        e = launch_real_split (! inverse, cin, cout, t->stage_twiddles, t->real_twiddles, batch, stream, is2, os2);
+        e = launch_real_split (nc, ! inverse, cin, cout, t->stage_twiddles, t->real_twiddles, batch, stream, is2, os2);
+    }
+    else if (lds_resident && nc == 16384 && split16384_enabled())
+    {
+        e = launch_real_split (nc, ! inverse, cin, cout, t->stage_twiddles + cfft::CorePlan<16384>::type::tw_total, t->real_twiddles, batch, stream, is2, os2);
     }
     else if (lds_resident)
     {
@@ -1178,6 +1200,8 @@ int fft_gpu_set_option (const char* name, long value)
         o.slots = value;
     else if (std::strcmp (name, "wave4096") == 0)
         set_wave4096 (value != 0);
+    else if (std::strcmp (name, "split16384") == 0)
+        g_split16384 = value != 0 ? 1 : 0;
     else
     {
         set_last_error ("fft_gpu_set_option: unknown option or value out of range");

@@ -6,43 +6,67 @@ namespace cfft::host
 {
 namespace
 {
-template <class K>
-hipError_t launch_split (K kernel, const float2* in, float2* out, const float2* tw, const float2* rtw, bool real, size_t batch, hipStream_t stream, size_t in_stride, size_t out_stride)
+template <class G, class K>
+hipError_t launch_split (K kernel, size_t batch, hipStream_t stream, size_t in_stride, size_t out_stride, unsigned& grid, unsigned& is, unsigned& os)
 {
-    if (batch == 0)
-        return hipSuccess;
     if (batch > 0x7FFFFFFFull || in_stride > 0xFFFFFFFFull || out_stride > 0xFFFFFFFFull)
         return hipErrorInvalidValue;
-    // one 1024-thread workgroup per CU (132 KiB of LDS): persistent over the batch
-    const unsigned grid = persistent_grid (kernel, kSplitT, kSplitLdsBytes, batch);
+    // persistent over the batch: one 1024-thread workgroup (132 KiB of LDS) or two 512-thread ones (66 KiB each) per CU
+    grid = persistent_grid (kernel, G::T, G::lds_bytes, batch);
     if (grid == 0)
         return hipErrorNoDevice;
-    const unsigned is = in_stride ? (unsigned) in_stride : (unsigned) kSplitN, os = out_stride ? (unsigned) out_stride : (unsigned) kSplitN;
-    (void) real;
-    (void) rtw;
-    hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (kSplitT), kSplitLdsBytes, stream, in, out, tw, (unsigned) batch, is, os);
+    is = in_stride ? (unsigned) in_stride : (unsigned) G::N;
+    os = out_stride ? (unsigned) out_stride : (unsigned) G::N;
+    (void) stream;
+    return hipSuccess;
+}
+
+template <class G>
+hipError_t c2c_split (bool inverse, const float2* in, float2* out, const float2* tw, size_t batch, hipStream_t stream, size_t in_stride, size_t out_stride)
+{
+    auto kernel = inverse ? c2c_split_kernel<G, true> : c2c_split_kernel<G, false>;
+    unsigned grid = 0, is = 0, os = 0;
+    const hipError_t e = launch_split<G> (kernel, batch, stream, in_stride, out_stride, grid, is, os);
+    if (e != hipSuccess)
+        return e;
+    hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (G::T), G::lds_bytes, stream, in, out, tw, (unsigned) batch, is, os);
+    return hipGetLastError();
+}
+
+template <class G>
+hipError_t real_split (bool forward, const float2* in, float2* out, const float2* tw, const float2* real_tw, size_t batch, hipStream_t stream, size_t in_stride, size_t out_stride)
+{
+    auto kernel = forward ? r2c_split_kernel<G> : c2r_split_kernel<G>;
+    unsigned grid = 0, is = 0, os = 0;
+    const hipError_t e = launch_split<G> (kernel, batch, stream, in_stride, out_stride, grid, is, os);
+    if (e != hipSuccess)
+        return e;
+    hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (G::T), G::lds_bytes, stream, in, out, tw, real_tw, (unsigned) batch, is, os);
     return hipGetLastError();
 }
 } // namespace
 
-hipError_t launch_c2c_split (bool inverse, const float2* in, float2* out, const float2* tw, size_t batch, hipStream_t stream, size_t in_stride, size_t out_stride)
-{
-    return inverse ? launch_split (c2c_split_kernel<true>, in, out, tw, nullptr, false, batch, stream, in_stride, out_stride)
-                   : launch_split (c2c_split_kernel<false>, in, out, tw, nullptr, false, batch, stream, in_stride, out_stride);
-}
+bool split_plane_length (int n) { return n == SplitGeom<1024>::N || n == SplitGeom<512>::N; }
 
-hipError_t launch_real_split (bool forward, const float2* in, float2* out, const float2* tw, const float2* real_tw, size_t batch, hipStream_t stream, size_t in_stride, size_t out_stride)
+hipError_t launch_c2c_split (int n, bool inverse, const float2* in, float2* out, const float2* tw, size_t batch, hipStream_t stream, size_t in_stride, size_t out_stride)
 {
     if (batch == 0)
         return hipSuccess;
-    if (batch > 0x7FFFFFFFull || in_stride > 0xFFFFFFFFull || out_stride > 0xFFFFFFFFull)
-        return hipErrorInvalidValue;
-    auto kernel = forward ? r2c_split_kernel<0> : c2r_split_kernel<0>;
-    const unsigned grid = persistent_grid (kernel, kSplitT, kSplitLdsBytes, batch);
-    if (grid == 0)
-        return hipErrorNoDevice;
-    const unsigned is = in_stride ? (unsigned) in_stride : (unsigned) kSplitN, os = out_stride ? (unsigned) out_stride : (unsigned) kSplitN;
-    hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (kSplitT), kSplitLdsBytes, stream, in, out, tw, real_tw, (unsigned) batch, is, os);
-    return hipGetLastError();
+    if (n == SplitGeom<1024>::N)
+        return c2c_split<SplitGeom<1024>> (inverse, in, out, tw, batch, stream, in_stride, out_stride);
+    if (n == SplitGeom<512>::N)
+        return c2c_split<SplitGeom<512>> (inverse, in, out, tw, batch, stream, in_stride, out_stride);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_real_split (int m, bool forward, const float2* in, float2* out, const float2* tw, const float2* real_tw, size_t batch, hipStream_t stream, size_t in_stride, size_t out_stride)
+{
+    if (batch == 0)
+        return hipSuccess;
+    if (m == SplitGeom<1024>::N)
+        return real_split<SplitGeom<1024>> (forward, in, out, tw, real_tw, batch, stream, in_stride, out_stride);
+    if (m == SplitGeom<512>::N)
+        return real_split<SplitGeom<512>> (forward, in, out, tw, real_tw, batch, stream, in_stride, out_stride);
+    return hipErrorInvalidValue;
 }
 } // namespace cfft::host

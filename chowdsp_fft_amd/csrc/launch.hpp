@@ -24,8 +24,10 @@ hipError_t launch_c2r (int m, const float2* in, float2* out, const float2* stage
 
 // N = 32768 complex points / real N = 65536 in one pass, the Stockham exchanges one component at a time through a 132 KiB
 // LDS plane (split_plane_kernels.hpp); `tw` = the split-plane table (tables.cpp), strides in float2 (0 = packed)
-hipError_t launch_c2c_split (bool inverse, const float2* in, float2* out, const float2* tw, size_t batch, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
-hipError_t launch_real_split (bool forward, const float2* in, float2* out, const float2* tw, const float2* real_tw, size_t batch, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
+// (n / m = 32768 or 16384 complex points)
+bool split_plane_length (int n);
+hipError_t launch_c2c_split (int n, bool inverse, const float2* in, float2* out, const float2* tw, size_t batch, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
+hipError_t launch_real_split (int m, bool forward, const float2* in, float2* out, const float2* tw, const float2* real_tw, size_t batch, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
 
 // ab += a*b*scaling on `batch` frames of `cplx_per_frame` complex values; real_packed: bin 0 is (DC, Nyquist)
 hipError_t launch_conv_mac (bool real_packed, const float* a, const float* b, float* ab, float scaling, size_t cplx_per_frame, size_t batch, bool b_is_shared, hipStream_t stream, bool accumulate = true);

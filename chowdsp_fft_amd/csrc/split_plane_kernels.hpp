@@ -1,5 +1,7 @@
 // N = 32768 complex points (and real N = 65536 on top of it) in ONE pass over HBM.
 //
+// (Since round 2 also N = 16384 / real N = 32768 with 512 work-items: SplitGeom below.)
+//
 // A 32768-point frame is 256 KiB: its interleaved LDS image does not fit the CU's 160 KiB, which is why round 1 ran it as
 // two passes through device memory (2 x the traffic, 2.9 TB/s).  Here one 1024-thread workgroup keeps the whole frame in
 // registers -- 32 complex points per work-item -- and the two Stockham exchanges go through LDS ONE COMPONENT AT A TIME:
@@ -21,15 +23,28 @@
 
 namespace cfft
 {
-constexpr int kSplitN = 32768;   // complex points per frame
-constexpr int kSplitT = 1024;    // work-items per frame
-constexpr int kSplitR = 32;      // points per work-item = the radix of every stage
-constexpr int kSplitPlaneFloats = kSplitN + (kSplitN >> 5); // one float per point, one float of padding after every 32
-constexpr size_t kSplitLdsBytes = (size_t) kSplitPlaneFloats * sizeof (float);
-// twiddle table layout: stage 1 (p = 32) then stage 2 (p = 1024); per stage [j][k], j = 0..6: a = 1..7, j = 7..9: a = 8, 16, 24
-constexpr int kSplitTwStage1 = 0;
-constexpr int kSplitTwStage2 = 10 * 32;
-constexpr int kSplitTwTotal = 10 * 32 + 10 * 1024;
+// Geometry for T work-items per frame, 32 points each: N = 32 T.
+//   T = 1024: N = 32768 = 32 x 32 x 32                      (one workgroup per CU, 132 KiB plane)
+//   T =  512: N = 16384 = 32 x 32 x 16, the last stage as two radix-16 butterflies per work-item
+//             (two workgroups per CU, 66 KiB plane each; replaces the interleaved-image plan with streamed twiddles)
+// Invariant: register slot c of work-item t holds element t + T c -- on input, after each exchange and on output.
+template <int T_>
+struct SplitGeom
+{
+    static constexpr int T = T_;
+    static constexpr int N = 32 * T_;
+    static constexpr int LAST = N / 1024;                    // radix of the last stage: 32 or 16
+    static constexpr int RS = T_ + T_ / 32;                  // physical distance of consecutive slots in the plane
+    static constexpr int plane_floats = N + N / 32;          // one float per point, one float of padding after every 32
+    static constexpr size_t lds_bytes = (size_t) plane_floats * sizeof (float);
+    // twiddle table: stage 1 (p = 32): [10][32] rows a = 1..7, 8, 16, 24 of W_1024^(a k); stage 2 (p = 1024):
+    // LAST = 32: [10][1024] the same rows of W_N^(a k); LAST = 16: [6][1024] rows a = 1, 2, 3, 4, 8, 12
+    static constexpr int tw_stage2 = 10 * 32;
+    static constexpr int tw_rows2 = LAST == 32 ? 10 : 6;
+    static constexpr int tw_total = tw_stage2 + tw_rows2 * 1024;
+};
+constexpr int kSplitN = SplitGeom<1024>::N;   // the longest frame of this family
+constexpr int kSplitT = 1024;
 
 __device__ __forceinline__ constexpr int sp_phys (int idx) { return idx + (idx >> 5); }
 
@@ -120,36 +135,91 @@ __device__ __forceinline__ void fft_reg32 (float2 (&u)[32], const float2 (&w)[10
         u[i] = o[i];
 }
 
-// the 10 twiddles of work-item t's butterfly in stage S (1 or 2)
-template <int S>
+// the 10 twiddles of work-item t's radix-32 butterfly in stage S (1, or 2 when the last stage is radix 32)
+template <class G, int S>
 __device__ __forceinline__ void sp_load_twiddles (float2 (&w)[10], const float2* __restrict__ tw, int t)
 {
     constexpr int p = (S == 1) ? 32 : 1024;
-    constexpr int off = (S == 1) ? kSplitTwStage1 : kSplitTwStage2;
+    constexpr int off = (S == 1) ? 0 : G::tw_stage2;
     const int k = t & (p - 1);
 #pragma unroll
     for (int j = 0; j < 10; ++j)
         w[j] = tw[off + j * p + k];
+}
+// the 2 x 6 twiddles of work-item t's two radix-16 butterflies (k = t and t + 512) of the last stage of N = 16384
+template <class G>
+__device__ __forceinline__ void sp_load_twiddles16 (float2 (&w)[2][6], const float2* __restrict__ tw, int t)
+{
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            w[q][j] = tw[G::tw_stage2 + j * 1024 + t + 512 * q];
+}
+
+// 16-point forward DFT with the stage twiddle W^(a k) applied first, a = n1 + 4 n2 (fft_reg<16> is 4 x 4):
+// w[0..2] = W^(n1 k), n1 = 1..3, applied after the inner transforms; w[3..5] = W^(4 n2 k), n2 = 1..3, before them.
+__device__ __forceinline__ void fft_reg16_tw (float2 (&u)[16], const float2 (&w)[6])
+{
+#pragma unroll
+    for (int n2 = 1; n2 < 4; ++n2)
+#pragma unroll
+        for (int n1 = 0; n1 < 4; ++n1)
+            u[n1 + 4 * n2] = cmul (u[n1 + 4 * n2], w[3 + n2 - 1]);
+    bfly4 (u[0], u[4], u[8], u[12]);
+    bfly4 (u[1], u[5], u[9], u[13]);
+    bfly4 (u[2], u[6], u[10], u[14]);
+    bfly4 (u[3], u[7], u[11], u[15]);
+#pragma unroll
+    for (int n1 = 1; n1 < 4; ++n1)
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2)
+            u[n1 + 4 * k2] = cmul (u[n1 + 4 * k2], w[n1 - 1]);
+    const float2 w1 = make_float2 (kCosPi8, -kSinPi8); // W16^1
+    const float2 w3 = make_float2 (kSinPi8, -kCosPi8); // W16^3
+    u[5] = cmul (u[5], w1);
+    u[6] = mul_w8_1 (u[6]);
+    u[7] = cmul (u[7], w3);
+    u[9] = mul_w8_1 (u[9]);
+    u[10] = mul_mi (u[10]);
+    u[11] = mul_w8_3 (u[11]);
+    u[13] = cmul (u[13], w3);
+    u[14] = mul_w8_3 (u[14]);
+    {
+        const float2 tt = cmul (u[15], w1);
+        u[15] = make_float2 (-tt.x, -tt.y);
+    }
+    bfly4 (u[0], u[1], u[2], u[3]);
+    bfly4 (u[4], u[5], u[6], u[7]);
+    bfly4 (u[8], u[9], u[10], u[11]);
+    bfly4 (u[12], u[13], u[14], u[15]);
+    float2 tt;
+    tt = u[1]; u[1] = u[4]; u[4] = tt;
+    tt = u[2]; u[2] = u[8]; u[8] = tt;
+    tt = u[3]; u[3] = u[12]; u[12] = tt;
+    tt = u[6]; u[6] = u[9]; u[9] = tt;
+    tt = u[7]; u[7] = u[13]; u[13] = tt;
+    tt = u[11]; u[11] = u[14]; u[14] = tt;
 }
 
 // Stockham exchange after stage S - 1 (p = product of the radices so far: 32^S / 32 ... P_ = 1 after stage 0, 32 after
 // stage 1), one component at a time through the plane.  Bank check (ds_*_b32: 32 banks per 32-lane group): the writes go
 // to phys (j + b p) with bank (t + b) mod 32, the reads to phys (t + 1024 a) with bank (t + t / 32) mod 32 -- both
 // conflict-free over 32 consecutive t.
-template <int P_>
+template <class G, int P_>
 __device__ __forceinline__ void sp_exchange (float2 (&v)[32], float* __restrict__ plane, int t)
 {
     // Addresses written out as ONE base per side + compile-time offsets (so that they fold into the instructions'
     // immediate fields instead of costing a VGPR each):
     //   write  phys (j + b p):  p = 1:  j = 32 t          -> 33 t + b
     //                           p = 32: j = 32 (t - k) + k -> 33 (t - k) + k + 33 b        (k = t mod 32)
-    //   read   phys (t + 1024 a) = t + t / 32 + 1056 a
+    //   read   phys (t + T c) = t + t / 32 + (T + T / 32) c
     const int k = t & (P_ - 1);
     float* __restrict__ wp = plane + ((P_ == 1) ? 33 * t : 33 * (t - k) + k);
     constexpr int ws = (P_ == 1) ? 1 : 33;
     const float* __restrict__ rp0 = plane + (t + (t >> 5));
-    int r1 = t + (t >> 5) + 16 * 1056; // ds offsets are 16 bits: a second base for the upper half, kept from being folded
-    CFFT_LAUNDER_INDEX (r1);           // back into the first one (which costs one address VGPR per read instead)
+    int r1 = t + (t >> 5) + 16 * G::RS; // ds offsets are 16 bits: a second base for the upper half, kept from being folded
+    CFFT_LAUNDER_INDEX (r1);            // back into the first one (which costs one address VGPR per read instead)
     const float* __restrict__ rp1 = plane + r1;
     __syncthreads(); // whoever read the plane last (previous exchange, previous frame) is done
 #pragma unroll
@@ -159,8 +229,8 @@ __device__ __forceinline__ void sp_exchange (float2 (&v)[32], float* __restrict_
 #pragma unroll
     for (int a = 0; a < 16; ++a)
     {
-        v[a].x = rp0[a * 1056];
-        v[a + 16].x = rp1[a * 1056];
+        v[a].x = rp0[a * G::RS];
+        v[a + 16].x = rp1[a * G::RS];
     }
     __syncthreads();
 #pragma unroll
@@ -170,33 +240,58 @@ __device__ __forceinline__ void sp_exchange (float2 (&v)[32], float* __restrict_
 #pragma unroll
     for (int a = 0; a < 16; ++a)
     {
-        v[a].y = rp0[a * 1056];
-        v[a + 16].y = rp1[a * 1056];
+        v[a].y = rp0[a * G::RS];
+        v[a + 16].y = rp1[a * G::RS];
     }
 }
 
-// v (input order: v[a] = x[t + 1024 a]) -> v[b] = X[t + 1024 b]
+// v (v[c] = x[t + T c]) -> v[c] = X[t + T c]
+template <class G>
 __device__ __forceinline__ void sp_core (float2 (&v)[32], const float2* __restrict__ tw, float* __restrict__ plane, int t)
 {
     float2 w[10];
     fft_reg32<false> (v, w);
     CFFT_PHASE_FENCE();
-    sp_load_twiddles<1> (w, tw, t);
-    sp_exchange<1> (v, plane, t);
+    sp_load_twiddles<G, 1> (w, tw, t);
+    sp_exchange<G, 1> (v, plane, t);
     CFFT_PHASE_FENCE();
     fft_reg32<true> (v, w);
     CFFT_PHASE_FENCE();
     CFFT_LAUNDER_INDEX (t);
-    sp_load_twiddles<2> (w, tw, t);
-    sp_exchange<32> (v, plane, t);
-    CFFT_PHASE_FENCE();
-    fft_reg32<true> (v, w);
+    if constexpr (G::LAST == 32)
+    {
+        sp_load_twiddles<G, 2> (w, tw, t);
+        sp_exchange<G, 32> (v, plane, t);
+        CFFT_PHASE_FENCE();
+        fft_reg32<true> (v, w);
+    }
+    else
+    {
+        // N = 16384: 1024 radix-16 butterflies, two per work-item: butterfly q works on the slots c = q + 2 a (elements
+        // t + 512 q + 1024 a) and leaves X[t + 512 q + 1024 b] in slot q + 2 b
+        float2 w16[2][6];
+        sp_load_twiddles16<G> (w16, tw, t);
+        sp_exchange<G, 32> (v, plane, t);
+        CFFT_PHASE_FENCE();
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+        {
+            float2 u[16];
+#pragma unroll
+            for (int a = 0; a < 16; ++a)
+                u[a] = v[q + 2 * a];
+            fft_reg16_tw (u, w16[q]);
+#pragma unroll
+            for (int b = 0; b < 16; ++b)
+                v[q + 2 * b] = u[b];
+        }
+    }
     CFFT_PHASE_FENCE();
 }
 
 // ---- complex ------------------------------------------------------------------------------------------------------
-template <bool INV>
-__global__ __launch_bounds__ (kSplitT) void c2c_split_kernel (const float2* __restrict__ in,
+template <class G, bool INV>
+__global__ __launch_bounds__ (G::T) void c2c_split_kernel (const float2* __restrict__ in,
                                                             float2* __restrict__ out,
                                                             const float2* __restrict__ tw,
                                                             unsigned batch,
@@ -215,39 +310,39 @@ __global__ __launch_bounds__ (kSplitT) void c2c_split_kernel (const float2* __re
 #pragma unroll
         for (int a = 0; a < 32; ++a)
         {
-            const float2 x = gload (&src[(unsigned) (t + 1024 * a)]);
+            const float2 x = gload (&src[(unsigned) (t + G::T * a)]);
             v[a] = INV ? make_float2 (x.y, x.x) : x;
         }
-        sp_core (v, tw, sp_plane, t);
+        sp_core<G> (v, tw, sp_plane, t);
         int ts = t0;
         CFFT_LAUNDER_INDEX (ts); // the store addresses are formed here, not at the top of the loop (where they would be spilled)
 #pragma unroll
         for (int b = 0; b < 32; ++b)
-            gstore (&dst[(unsigned) (ts + 1024 * b)], INV ? make_float2 (v[b].y, v[b].x) : v[b]);
+            gstore (&dst[(unsigned) (ts + G::T * b)], INV ? make_float2 (v[b].y, v[b].x) : v[b]);
     }
 }
 
-// ---- real, N = 65536 = 2 M ------------------------------------------------------------------------------------------
-// Work-item t owns Z[t + 1024 b], b < 32.  The pair stage handles k = t + 1024 q, q < 16 (k < M/2) together with M - k,
-// which is the partner work-item's slot 31 - q (work-item 1024 - t; for t = 0: slot 32 - q of work-item 0 itself): the
+// ---- real, N = 2 M (65536 or 32768 samples) -----------------------------------------------------------------------------
+// Work-item t owns Z[t + T b], b < 32.  The pair stage handles k = t + T q, q < 16 (k < M/2) together with M - k,
+// which is the partner work-item's slot 31 - q (work-item T - t; for t = 0: slot 32 - q of work-item 0 itself): the
 // UPPER 16 slots of every work-item travel through the first half of the plane, one component at a time, at their natural
 // index k' - M/2.
-template <bool TO_PARTNER>
+template <class G, bool TO_PARTNER>
 __device__ __forceinline__ void sp_pair_exchange (float2 (&up)[16], float* __restrict__ plane, int t)
 {
-    // TO_PARTNER == false: `up` holds my own upper slots (k' = t + 1024 (16 + q)); on return the values at M - k, k = t + 1024 q
+    // TO_PARTNER == false: `up` holds my own upper slots (k' = t + T (16 + q)); on return the values at M - k, k = t + T q
     // TO_PARTNER == true : `up` holds the values I computed for M - k; on return my own upper slots
-    // Two address families, each ONE base + compile-time offsets (H = M/2):
-    //   own side     index k' - H = t + 1024 q            -> phys = t + t/32 + 1056 q
-    //   mirror side  index (M - k) - H = H - t - 1024 q    -> phys = (-t) + floor(-t / 32) + 16896 - 1056 q
+    // Two address families, each ONE base + compile-time offsets (H = M/2 = 16 T, RS = T + T/32):
+    //   own side     index k' - H = t + T q            -> phys = t + t/32 + RS q
+    //   mirror side  index (M - k) - H = H - t - T q    -> phys = (-t) + floor(-t / 32) + 16 RS - RS q
     // The one irregular pair, k = 0 <-> M/2 (work-item 0, q = 0), lives at own-side index 0; the mirror formula gives H
     // for it, so work-item 0 keeps a copy there.
     float* __restrict__ own = plane + (t + (t >> 5));
-    float* __restrict__ mir = plane + ((-t) + ((-t) >> 5) + 16896);
+    float* __restrict__ mir = plane + ((-t) + ((-t) >> 5) + 16 * G::RS);
     float* __restrict__ wr = TO_PARTNER ? mir : own;
     const float* __restrict__ rd = TO_PARTNER ? own : mir;
-    constexpr int ws = TO_PARTNER ? -1056 : 1056, rs = -ws;
-    float* __restrict__ patch = TO_PARTNER ? plane : plane + 16896;
+    constexpr int ws = TO_PARTNER ? -G::RS : G::RS, rs = -ws;
+    float* __restrict__ patch = TO_PARTNER ? plane : plane + 16 * G::RS;
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < 16; ++q)
@@ -272,8 +367,8 @@ __device__ __forceinline__ void sp_pair_exchange (float2 (&up)[16], float* __res
 }
 
 // forward: N real samples (as M complex points z[n] = x[2n] + i x[2n+1]) -> packed spectrum (real_kernels.hpp)
-template <int UNUSED = 0> // (a template only so that the header can be included from more than one translation unit)
-__global__ __launch_bounds__ (kSplitT) void r2c_split_kernel (const float2* __restrict__ in,
+template <class G>
+__global__ __launch_bounds__ (G::T) void r2c_split_kernel (const float2* __restrict__ in,
                                                             float2* __restrict__ out,
                                                             const float2* __restrict__ tw,
                                                             const float2* __restrict__ wtab,
@@ -282,7 +377,7 @@ __global__ __launch_bounds__ (kSplitT) void r2c_split_kernel (const float2* __re
                                                             unsigned out_stride)
 {
     extern __shared__ __attribute__ ((aligned (16))) float sp_plane[];
-    constexpr int M = kSplitN;
+    constexpr int M = G::N;
     const int t0 = threadIdx.x;
     for (unsigned g = blockIdx.x; g < batch; g += gridDim.x)
     {
@@ -293,15 +388,15 @@ __global__ __launch_bounds__ (kSplitT) void r2c_split_kernel (const float2* __re
         float2 v[32];
 #pragma unroll
         for (int a = 0; a < 32; ++a)
-            v[a] = gload (&src[(unsigned) (t + 1024 * a)]);
-        sp_core (v, tw, sp_plane, t);
+            v[a] = gload (&src[(unsigned) (t + G::T * a)]);
+        sp_core<G> (v, tw, sp_plane, t);
         int ts = t0;
         CFFT_LAUNDER_INDEX (ts);
         float2 up[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q)
             up[q] = v[16 + q];
-        sp_pair_exchange<false> (up, sp_plane, ts);
+        sp_pair_exchange<G, false> (up, sp_plane, ts);
         CFFT_PHASE_FENCE();
         // four rounds of four pairs: the pair twiddles of a round (8 VGPRs) next to the 64 that hold Z[k] and Z[M - k]
 #pragma unroll
@@ -310,12 +405,12 @@ __global__ __launch_bounds__ (kSplitT) void r2c_split_kernel (const float2* __re
             float2 pw[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                pw[q] = wtab[ts + 1024 * (4 * h + q)];
+                pw[q] = wtab[ts + G::T * (4 * h + q)];
 #pragma unroll
             for (int q8 = 0; q8 < 4; ++q8)
             {
                 const int q = 4 * h + q8;
-                const int k = ts + 1024 * q;
+                const int k = ts + G::T * q;
                 const float2 A = v[q], Zp = up[q];
                 float2 Xk, Xp;
                 real_split_pair (A, Zp, pw[q8], Xk, Xp);
@@ -333,8 +428,8 @@ __global__ __launch_bounds__ (kSplitT) void r2c_split_kernel (const float2* __re
 }
 
 // backward: packed spectrum -> N real samples (unscaled)
-template <int UNUSED = 0>
-__global__ __launch_bounds__ (kSplitT) void c2r_split_kernel (const float2* __restrict__ in,
+template <class G>
+__global__ __launch_bounds__ (G::T) void c2r_split_kernel (const float2* __restrict__ in,
                                                             float2* __restrict__ out,
                                                             const float2* __restrict__ tw,
                                                             const float2* __restrict__ wtab,
@@ -343,7 +438,7 @@ __global__ __launch_bounds__ (kSplitT) void c2r_split_kernel (const float2* __re
                                                             unsigned out_stride)
 {
     extern __shared__ __attribute__ ((aligned (16))) float sp_plane[];
-    constexpr int M = kSplitN;
+    constexpr int M = G::N;
     const int t0 = threadIdx.x;
     for (unsigned g = blockIdx.x; g < batch; g += gridDim.x)
     {
@@ -360,7 +455,7 @@ __global__ __launch_bounds__ (kSplitT) void c2r_split_kernel (const float2* __re
 #pragma unroll
             for (int q8 = 0; q8 < 8; ++q8)
             {
-                const int k = t + 1024 * (8 * h + q8);
+                const int k = t + G::T * (8 * h + q8);
                 a[q8] = gload (&src[(unsigned) k]);
                 xp[q8] = gload (&src[(unsigned) (k == 0 ? M / 2 : M - k)]);
                 pw[q8] = wtab[k];
@@ -369,7 +464,7 @@ __global__ __launch_bounds__ (kSplitT) void c2r_split_kernel (const float2* __re
             for (int q8 = 0; q8 < 8; ++q8)
             {
                 const int q = 8 * h + q8;
-                const int k = t + 1024 * q;
+                const int k = t + G::T * q;
                 float2 zk, zp;
                 real_merge_pair (a[q8], xp[q8], pw[q8], zk, zp);
                 if (k == 0)
@@ -382,16 +477,16 @@ __global__ __launch_bounds__ (kSplitT) void c2r_split_kernel (const float2* __re
                 up[q] = make_float2 (zp.y, zp.x);
             }
         }
-        sp_pair_exchange<true> (up, sp_plane, t);
+        sp_pair_exchange<G, true> (up, sp_plane, t);
 #pragma unroll
         for (int q = 0; q < 16; ++q)
             v[16 + q] = up[q];
-        sp_core (v, tw, sp_plane, t);
+        sp_core<G> (v, tw, sp_plane, t);
         int ts = t0;
         CFFT_LAUNDER_INDEX (ts);
 #pragma unroll
         for (int b = 0; b < 32; ++b)
-            gstore (&dst[(unsigned) (ts + 1024 * b)], make_float2 (v[b].y, v[b].x));
+            gstore (&dst[(unsigned) (ts + G::T * b)], make_float2 (v[b].y, v[b].x));
     }
 }
 } // namespace cfft

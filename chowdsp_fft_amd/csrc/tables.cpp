@@ -18,6 +18,22 @@ float2 unit_root (long long num, long long den) // exp(-2*pi*i*num/den)
     return make_float2 ((float) std::cos (a), (float) std::sin (a));
 }
 
+// split-plane single pass (split_plane_kernels.hpp), N = 32 T: per twiddled stage rows [j][k], k < p, of W_{r p}^{a k}:
+// stage 1 (p = 32, r = 32): a = 1..7, 8, 16, 24; stage 2 (p = 1024): the same ten rows for r = 32 (N = 32768), or
+// a = 1, 2, 3, 4, 8, 12 for r = 16 (N = 16384)
+void append_split_plane_twiddles (int n, std::vector<float2>& out)
+{
+    static const int a32[10] = { 1, 2, 3, 4, 5, 6, 7, 8, 16, 24 };
+    static const int a16[6] = { 1, 2, 3, 4, 8, 12 };
+    for (int j = 0; j < 10; ++j)
+        for (int k = 0; k < 32; ++k)
+            out.push_back (unit_root ((long long) a32[j] * k, 1024));
+    const int last = n / 1024;
+    for (int j = 0; j < (last == 32 ? 10 : 6); ++j)
+        for (int k = 0; k < 1024; ++k)
+            out.push_back (unit_root ((long long) (last == 32 ? a32[j] : a16[j]) * k, n));
+}
+
 void append_stage_twiddles (const PlanDesc& d, std::vector<float2>& out)
 {
     // stage s >= 1 : (r-1) * p entries, [a-1][k] = W_{p*r}^{a*k}
@@ -332,6 +348,8 @@ bool build_host_tables (int N, int transform, HostTables& out)
         if (! core_plan_desc (nc, d))
             return false;
         append_stage_twiddles (d, out.stage_twiddles);
+        if (nc == 16384) // the split-plane form of this length: its table follows the interleaved-image plan's
+            append_split_plane_twiddles (nc, out.stage_twiddles);
         if (nc == 4096)
         {
             // one-wavefront-per-frame form (wave_kernels.hpp), 64 x 64: W_4096^(a t), t < 64, rows a = 1..7 then 8, 16, .. 56
@@ -346,14 +364,9 @@ bool build_host_tables (int N, int transform, HostTables& out)
     }
     if (nc == kSplitCoreN)
     {
-        // split-plane single pass, 32 x 32 x 32: per twiddled stage (p = 32, then 1024) ten rows [j][k], k < p, of
-        // W_{32 p}^{a k} with a = 1..7 (j = 0..6) and a = 8, 16, 24 (j = 7..9)   (split_plane_kernels.hpp)
+        // split-plane single pass, 32 x 32 x 32 (split_plane_kernels.hpp)
         out.core_n = nc;
-        static const int a_of_j[10] = { 1, 2, 3, 4, 5, 6, 7, 8, 16, 24 };
-        for (int p : { 32, 1024 })
-            for (int j = 0; j < 10; ++j)
-                for (int k = 0; k < p; ++k)
-                    out.stage_twiddles.push_back (unit_root ((long long) a_of_j[j] * k, (long long) p * 32));
+        append_split_plane_twiddles (nc, out.stage_twiddles);
         return true;
     }
 
