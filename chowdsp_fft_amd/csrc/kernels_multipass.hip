@@ -23,23 +23,13 @@ struct TileGeom
     static constexpr int BLOCK = (N >= CFFT_TILE_BLOCK_MIN_N && C * P::T > 256) ? (C * P::T > 1024 ? 1024 : C * P::T) : 256;
 };
 
-template <class K>
-hipError_t ensure_lds (K kernel, size_t bytes)
-{
-    if (bytes > 64 * 1024)
-        return hipFuncSetAttribute ((const void*) kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes);
-    return hipSuccess;
-}
-
+// (the dynamic-LDS cap of a kernel is raised once per kernel, device and size by persistent_grid -> blocks_per_cu_cached)
 // pass A: n2-point column FFTs (+ inter-pass twiddle), in -> work (tile-major)
 template <int N2, bool INV>
 hipError_t pass_a (int n1, const float2* in, float2* work, const float2* tw2, const float2* big_tw, size_t batch, int div, hipStream_t stream, size_t in_stride)
 {
     using TG = TileGeom<N2>;
     auto kernel = pass_a_kernel<typename TG::P, TG::C, INV, TG::BLOCK>;
-    hipError_t e = ensure_lds (kernel, TG::lds_bytes);
-    if (e != hipSuccess)
-        return e;
     const size_t tiles = (size_t) (n1 / TG::C);
     unsigned grid = persistent_grid (kernel, TG::BLOCK, TG::lds_bytes, batch * tiles);
     if (grid == 0)
@@ -55,9 +45,6 @@ hipError_t pass_b (int n2, const float2* work, float2* out, const float2* tw1, s
 {
     using TG = TileGeom<N1>;
     auto kernel = pass_b_kernel<typename TG::P, TG::C, INV, TG::BLOCK>;
-    hipError_t e = ensure_lds (kernel, TG::lds_bytes);
-    if (e != hipSuccess)
-        return e;
     const size_t tiles = (size_t) (n2 / TG::C);
     unsigned grid = persistent_grid (kernel, TG::BLOCK, TG::lds_bytes, batch * tiles);
     if (grid == 0)
