@@ -409,7 +409,9 @@ int big_c2c_chunked (Setup* s, int nc, bool inverse, const float2* in, float2* o
         }
         if (e == hipSuccess)
             e = mixed ? launch_mixed_big_c2c (*s->tables, inverse, cin, L->ws[k], out + f0 * os2, nb, lanes, st, cis, os2)
-                      : launch_big_c2c (n1, n2, inverse, cin, L->ws[k], out + f0 * os2, s->tables->stage_twiddles, s->tables->big_twiddles, nb, lanes, st, cis, os2);
+                : s->tables->fast_n1 > 0
+                    ? launch_fast_c2c (n1, n2, inverse, cin, L->ws[k], out + f0 * os2, s->tables->stage_twiddles, s->tables->big_twiddles, nb, lanes, st, cis, os2)
+                    : launch_big_c2c (n1, n2, inverse, cin, L->ws[k], out + f0 * os2, s->tables->stage_twiddles, s->tables->big_twiddles, nb, lanes, st, cis, os2);
         if (e == hipSuccess && pair > 0)
             e = launch_real_pair (true, out + f0 * os2, out + f0 * os2, s->tables->real_twiddles, (unsigned) nc, nb, st, os2, os2);
         if (e != hipSuccess)
@@ -434,7 +436,7 @@ int big_real4_chunked (Setup* s, bool inverse, const float2* in, float2* out, si
 {
     const DeviceTables* t = s->tables;
     const int r1 = t->real4_r1, r2 = t->real4_r2;
-    const size_t frame_bytes = real4_workspace_frame_len (r1, r2) * sizeof (float2);
+    const size_t frame_bytes = (t->real4_fast ? real4_fast_workspace_frame_len (r1, r2) : real4_workspace_frame_len (r1, r2)) * sizeof (float2);
     const int want_lanes = lane_count();
     size_t chunk = workspace_cap() / (size_t) want_lanes / frame_bytes;
     if (chunk < 1)
@@ -459,7 +461,9 @@ int big_real4_chunked (Setup* s, bool inverse, const float2* in, float2* out, si
         const size_t nb = (batch - f0 < chunk) ? batch - f0 : chunk;
         const int k = (lanes == 2) ? (int) (i & 1) : 0;
         const hipStream_t st = (lanes == 2) ? L->lane[k] : stream;
-        const hipError_t e = launch_real4 (r1, r2, inverse, in + f0 * is2, L->ws[k], out + f0 * os2, t->stage_twiddles, t->big_twiddles, nb, lanes, st, is2, os2);
+        const hipError_t e = t->real4_fast
+                                 ? launch_real4_fast (r1, r2, inverse, in + f0 * is2, L->ws[k], out + f0 * os2, t->stage_twiddles, t->big_twiddles, nb, lanes, st, is2, os2)
+                                 : launch_real4 (r1, r2, inverse, in + f0 * is2, L->ws[k], out + f0 * os2, t->stage_twiddles, t->big_twiddles, nb, lanes, st, is2, os2);
         if (e != hipSuccess)
         {
             set_last_error ("real four-step kernel launch", e);
@@ -1235,7 +1239,8 @@ size_t fft_gpu_workspace_bytes (void* setup, size_t batch)
         return 0;
     size_t frame_bytes = (size_t) complex_len (s) * sizeof (float2);
     if (s->tables->real4_r1 > 0)
-        frame_bytes = real4_workspace_frame_len (s->tables->real4_r1, s->tables->real4_r2) * sizeof (float2);
+        frame_bytes = (s->tables->real4_fast ? real4_fast_workspace_frame_len (s->tables->real4_r1, s->tables->real4_r2)
+                                             : real4_workspace_frame_len (s->tables->real4_r1, s->tables->real4_r2)) * sizeof (float2);
     int n1 = 0, n2 = 0;
     if (s->tables->mixed_n2 == 0)
         split_large (complex_len (s), n1, n2);

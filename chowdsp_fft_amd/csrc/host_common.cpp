@@ -150,8 +150,11 @@ const DeviceTables* acquire_tables (int device, int N, int transform)
     t->mixed_tw1_offset = h.mixed_tw1_offset;
     t->mixed_ca = h.mixed_ca;
     t->mixed_cb = h.mixed_cb;
+    t->fast_n1 = h.fast_n1;
+    t->fast_n2 = h.fast_n2;
     t->real4_r1 = h.real4_r1;
     t->real4_r2 = h.real4_r2;
+    t->real4_fast = h.real4_fast;
     t->gen2_ns = (int) h.generic2_radix.size();
     for (int i = 0; i < t->gen2_ns; ++i)
     {

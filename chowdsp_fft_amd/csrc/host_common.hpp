@@ -50,8 +50,11 @@ struct DeviceTables
     // long mixed-radix plans: two passes, gen_* describe the n2-point column FFT, the n1-point row core's table starts at
     // stage_twiddles + mixed_tw1_offset; both 0 otherwise
     int mixed_n1 = 0, mixed_n2 = 0, mixed_tw1_offset = 0, mixed_ca = 0;
+    // N = 2^17 .. 2^20 complex by the register-direct passes (tile_fast_kernels.hpp): fast_n1 x fast_n2, else 0
+    int fast_n1 = 0, fast_n2 = 0;
     // long real frames by the real four-step (N = real4_r1 * real4_r2), else 0
     int real4_r1 = 0, real4_r2 = 0;
+    int real4_fast = 0; // ... on the register-direct tiles (tile_fast_kernels.hpp) instead of the LDS-staged ones
     // general form (rows generic too): mixed_cb > 0, gen2_* = the n1-point row FFT's stage list
     int mixed_cb = 0;
     int gen2_ns = 0;

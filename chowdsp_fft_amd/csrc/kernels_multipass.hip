@@ -2,6 +2,7 @@
 #include "launch_util.hpp"
 #include "multipass_kernels.hpp"
 #include "fused_twopass_kernels.hpp"
+#include "tile_fast_kernels.hpp"
 #include "generic_kernels.hpp"
 #include "tables.hpp"
 
@@ -126,6 +127,123 @@ hipError_t launch_big_c2c (int n1, int n2, bool inverse, const float2* in, float
         if (e != hipSuccess)
             return e;
         CFFT_DISPATCH_BIG (n1, e = (pass_b<N_, false> (n2, work, out, tw1, batch, grid_divisor, stream, out_stride)));
+    }
+    return e;
+}
+
+// ---- N = 2^17 .. 2^20 complex: register-direct passes (tile_fast_kernels.hpp) ------------------------------------------
+namespace
+{
+template <int N2, bool INV>
+hipError_t fast_pass_a (int n1, const float2* in, float2* work, const float2* tw2, const float2* big_tw, size_t batch, int div, hipStream_t stream, size_t in_stride)
+{
+    using FT = FastTile<N2>;
+    auto kernel = pass_a_fast_kernel<N2, INV>;
+    unsigned grid = persistent_grid (kernel, FT::threads, FT::lds_bytes, batch * (size_t) (n1 / 16));
+    if (grid == 0)
+        return hipErrorNoDevice;
+    grid = std::max (1u, grid / (unsigned) div);
+    hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (FT::threads), FT::lds_bytes, stream, in, work, tw2, big_tw, (unsigned) n1, (unsigned) batch, in_stride);
+    return hipGetLastError();
+}
+template <int N1, bool INV>
+hipError_t fast_pass_b (int n2, const float2* work, float2* out, const float2* tw1, size_t batch, int div, hipStream_t stream, size_t out_stride)
+{
+    using FT = FastTile<N1>;
+    auto kernel = pass_b_fast_kernel<N1, INV>;
+    unsigned grid = persistent_grid (kernel, FT::threads, FT::lds_bytes, batch * (size_t) (n2 / 16));
+    if (grid == 0)
+        return hipErrorNoDevice;
+    grid = std::max (1u, grid / (unsigned) div);
+    hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (FT::threads), FT::lds_bytes, stream, work, out, tw1, (unsigned) n2, (unsigned) batch, out_stride);
+    return hipGetLastError();
+}
+#define CFFT_DISPATCH_FAST(n, CALL)                          \
+    switch (n)                                               \
+    {                                                        \
+        case 256: { constexpr int N_ = 256; CALL; } break;   \
+        case 512: { constexpr int N_ = 512; CALL; } break;   \
+        case 1024: { constexpr int N_ = 1024; CALL; } break; \
+        default: return hipErrorInvalidValue;                \
+    }
+} // namespace
+
+int fast_tile_table_rows (int n) { return n == 1024 ? 10 : (n == 512 ? 6 : (n == 256 ? 4 : 0)); }
+
+size_t real4_fast_workspace_frame_len (int r1, int r2) { return (size_t) r1 * (size_t) (r2 / 2 + 16); }
+
+// long REAL frames on the register-direct tiles: N = r1 x r2 samples, r1, r2 in {256, 512, 1024}
+hipError_t launch_real4_fast (int r1, int r2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, size_t batch, int grid_divisor, hipStream_t stream, size_t in_stride, size_t out_stride)
+{
+    if (batch == 0)
+        return hipSuccess;
+    if (batch > 0x7FFFFFFFull || fast_tile_table_rows (r1) == 0 || fast_tile_table_rows (r2) == 0)
+        return hipErrorInvalidValue;
+    const size_t m = (size_t) r1 * (size_t) r2 / 2;
+    in_stride = in_stride ? in_stride : m;
+    out_stride = out_stride ? out_stride : m;
+    const float2* tw2 = stage_tw;
+    const float2* tw1 = stage_tw + fast_tile_table_rows (r2) * 32;
+    const float2* big_fwd = big_tw;                                              // [a][kb < r2/2 + 16]
+    const float2* big_inv = big_tw + real4_fast_workspace_frame_len (r1, r2);   // [kb <= r2/2][a]
+    const int n1c = r1 / 2;
+    const unsigned div = (unsigned) grid_divisor;
+    const size_t tiles_a = (size_t) (n1c / 16), tiles_b = (size_t) ((r2 / 2 + 16) / 16);
+#define CFFT_REAL4_FAST_LAUNCH(KERNEL, NN, TILES, ...)                                                              \
+    {                                                                                                               \
+        using FT = FastTile<NN>;                                                                                    \
+        auto k_ = KERNEL<NN>;                                                                                       \
+        unsigned grid_ = persistent_grid (k_, FT::threads, FT::lds_bytes, batch * (TILES));                         \
+        if (grid_ == 0)                                                                                             \
+            return hipErrorNoDevice;                                                                                \
+        grid_ = std::max (1u, grid_ / div);                                                                         \
+        hipLaunchKernelGGL (k_, dim3 (grid_), dim3 (FT::threads), FT::lds_bytes, stream, __VA_ARGS__);              \
+        e = hipGetLastError();                                                                                      \
+    }
+    hipError_t e = hipErrorInvalidValue;
+    if (! inverse)
+    {
+        CFFT_DISPATCH_FAST (r2, CFFT_REAL4_FAST_LAUNCH (pass_a_real_fast_kernel, N_, tiles_a, in, work, tw2, big_fwd, (unsigned) n1c, (unsigned) batch, in_stride));
+        if (e != hipSuccess)
+            return e;
+        CFFT_DISPATCH_FAST (r1, CFFT_REAL4_FAST_LAUNCH (pass_b_real_fast_kernel, N_, tiles_b, (const float2*) work, out, tw1, (unsigned) r2, (unsigned) batch, out_stride));
+    }
+    else
+    {
+        CFFT_DISPATCH_FAST (r1, CFFT_REAL4_FAST_LAUNCH (pass_b_real_inv_fast_kernel, N_, tiles_b, in, work, tw1, big_inv, (unsigned) r2, (unsigned) batch, in_stride));
+        if (e != hipSuccess)
+            return e;
+        CFFT_DISPATCH_FAST (r2, CFFT_REAL4_FAST_LAUNCH (pass_a_real_inv_fast_kernel, N_, tiles_a, (const float2*) work, out, tw2, (unsigned) n1c, (unsigned) batch, out_stride));
+    }
+#undef CFFT_REAL4_FAST_LAUNCH
+    return e;
+}
+
+hipError_t launch_fast_c2c (int n1, int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, size_t batch, int grid_divisor, hipStream_t stream, size_t in_stride, size_t out_stride)
+{
+    if (batch == 0)
+        return hipSuccess;
+    if (batch > 0x7FFFFFFFull || fast_tile_table_rows (n1) == 0 || fast_tile_table_rows (n2) == 0)
+        return hipErrorInvalidValue;
+    const size_t frame_len = (size_t) n1 * (size_t) n2;
+    in_stride = in_stride ? in_stride : frame_len;
+    out_stride = out_stride ? out_stride : frame_len;
+    const float2* tw2 = stage_tw;                                   // n2 core (columns)
+    const float2* tw1 = stage_tw + fast_tile_table_rows (n2) * 32;  // n1 core (rows)
+    hipError_t e = hipErrorInvalidValue;
+    if (inverse)
+    {
+        CFFT_DISPATCH_FAST (n2, e = (fast_pass_a<N_, true> (n1, in, work, tw2, big_tw, batch, grid_divisor, stream, in_stride)));
+        if (e != hipSuccess)
+            return e;
+        CFFT_DISPATCH_FAST (n1, e = (fast_pass_b<N_, true> (n2, work, out, tw1, batch, grid_divisor, stream, out_stride)));
+    }
+    else
+    {
+        CFFT_DISPATCH_FAST (n2, e = (fast_pass_a<N_, false> (n1, in, work, tw2, big_tw, batch, grid_divisor, stream, in_stride)));
+        if (e != hipSuccess)
+            return e;
+        CFFT_DISPATCH_FAST (n1, e = (fast_pass_b<N_, false> (n2, work, out, tw1, batch, grid_divisor, stream, out_stride)));
     }
     return e;
 }

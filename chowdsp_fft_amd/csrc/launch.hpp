@@ -55,6 +55,15 @@ hipError_t launch_conv_frames_real (int m, const float2* in, const float2* H, fl
 // stage_tw holds the n2-core table followed by the n1-core table.  grid_divisor: 2 when two launches are meant
 // to share the GPU (two-lane pipeline), else 1.
 hipError_t launch_big_c2c (int n1, int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, size_t batch, int grid_divisor, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
+// N = 2^17 .. 2^20 complex, n1 and n2 in {256, 512, 1024}: register-direct passes (tile_fast_kernels.hpp).  stage_tw = the
+// factorised stage-1 rows of the n2 core, then of the n1 core (fast_tile_table_rows (n) x 32 entries each); big_tw and the
+// workspace in plain [a][kb] order
+int fast_tile_table_rows (int n);
+hipError_t launch_fast_c2c (int n1, int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, size_t batch, int grid_divisor, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
+// ... and long REAL frames on the same tiles (real four-step; big_tw = forward table [a][kb < r2/2 + 16] followed by the
+// backward table [kb <= r2/2][a]; work: real4_fast_workspace_frame_len() float2 per frame)
+size_t real4_fast_workspace_frame_len (int r1, int r2);
+hipError_t launch_real4_fast (int r1, int r2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, size_t batch, int grid_divisor, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
 // long REAL frames (N = r1 * r2 samples, both powers of two in 256..1024): the four-step algorithm on the real data, two
 // sweeps (real columns as pairs -> rows -> packed spectrum; backward the other way round).  in / out: the real frame and the
 // packed spectrum, both as N/2 float2; work: real4_workspace_frame_len() float2 per frame.

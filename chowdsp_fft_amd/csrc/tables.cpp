@@ -3,6 +3,7 @@
 #include "plans.hpp"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace cfft::host
 {
@@ -325,6 +326,38 @@ bool build_host_tables (int N, int transform, HostTables& out)
     {
         // long real frame: four-step on the real data.  Stage tables of the two cores (columns first), then W_N^{a kb} in the
         // workspace's order [column tile tA][kb <= r2/2][32], a = 32 tA + al
+        const char* evr = std::getenv ("CHOWDSP_FFT_FAST_TILES");
+        // measured (forward, TB/s algorithmic, register-direct vs LDS-staged tiles): 2^17 2.36 vs 2.13, 2^18 2.19 vs 1.88,
+        // 2^19 2.12 vs 1.69, 2^20 1.79 vs 1.85 (its column pass reads 1024 rows 4 KiB apart): the last one keeps the staged tiles
+        if (! (evr != nullptr && evr[0] == '0') && N < (1 << 20))
+        {
+            // register-direct tiles (tile_fast_kernels.hpp): factorised stage-1 rows of the column core (q2) then of the row
+            // core (q1); forward inter-pass table [a][kb < q2/2 + 16] (W_N^{a kb}, padding rows 1), backward table [kb <= q2/2][a]
+            const auto rows = [] (int n) { return n == 1024 ? 10 : (n == 512 ? 6 : 4); };
+            static const int a32[10] = { 1, 2, 3, 4, 5, 6, 7, 8, 16, 24 };
+            static const int a16[6] = { 1, 2, 3, 4, 8, 12 };
+            static const int a8[4] = { 1, 2, 3, 4 };
+            out.core_n = 0;
+            out.real4_r1 = q1;
+            out.real4_r2 = q2;
+            out.real4_fast = 1;
+            for (int n : { q2, q1 })
+            {
+                const int* al = n == 1024 ? a32 : (n == 512 ? a16 : a8);
+                for (int j = 0; j < rows (n); ++j)
+                    for (int k = 0; k < 32; ++k)
+                        out.stage_twiddles.push_back (unit_root ((long long) al[j] * k, n));
+            }
+            const int nr = q2 / 2 + 1, nrp = q2 / 2 + 16;
+            out.big_twiddles.reserve ((size_t) q1 * nrp + (size_t) nr * q1);
+            for (int a = 0; a < q1; ++a)
+                for (int kb = 0; kb < nrp; ++kb)
+                    out.big_twiddles.push_back (kb < nr ? unit_root ((long long) a * kb, N) : make_float2 (1.f, 0.f));
+            for (int kb = 0; kb < nr; ++kb)
+                for (int a = 0; a < q1; ++a)
+                    out.big_twiddles.push_back (unit_root ((long long) a * kb, N));
+            return true;
+        }
         PlanDesc dc, dr;
         if (! core_plan_desc (q2, dc) || ! core_plan_desc (q1, dr))
             return false;
@@ -370,6 +403,38 @@ bool build_host_tables (int N, int transform, HostTables& out)
         return true;
     }
 
+    {
+        // N = 2^17 .. 2^20 complex: register-direct passes (tile_fast_kernels.hpp) unless CHOWDSP_FFT_FAST_TILES=0
+        int f1 = 0, f2 = 0;
+        split_large (nc, f1, f2);
+        const char* ev = std::getenv ("CHOWDSP_FFT_FAST_TILES");
+        const bool off = ev != nullptr && ev[0] == '0';
+        const auto rows = [] (int n) { return n == 1024 ? 10 : (n == 512 ? 6 : (n == 256 ? 4 : 0)); };
+        const char* e16 = std::getenv ("CHOWDSP_FFT_FAST_TILES_65536"); // experiment: N = 65536 through these kernels too
+        const int min_nc = (e16 != nullptr && e16[0] == '1') ? (1 << 16) : (1 << 17);
+        if (! real && ! off && nc >= min_nc && rows (f1) != 0 && rows (f2) != 0)
+        {
+            out.core_n = 0;
+            out.fast_n1 = f1;
+            out.fast_n2 = f2;
+            // stage-1 rows [j][k < 32] of W_n^(a k): n = 1024: a = 1..7, 8, 16, 24; 512: 1, 2, 3, 4, 8, 12; 256: 1, 2, 3, 4
+            static const int a32[10] = { 1, 2, 3, 4, 5, 6, 7, 8, 16, 24 };
+            static const int a16[6] = { 1, 2, 3, 4, 8, 12 };
+            static const int a8[4] = { 1, 2, 3, 4 };
+            for (int n : { f2, f1 })
+            {
+                const int* al = n == 1024 ? a32 : (n == 512 ? a16 : a8);
+                for (int j = 0; j < rows (n); ++j)
+                    for (int k = 0; k < 32; ++k)
+                        out.stage_twiddles.push_back (unit_root ((long long) al[j] * k, n));
+            }
+            out.big_twiddles.reserve ((size_t) nc);
+            for (int a = 0; a < f1; ++a)
+                for (int kb = 0; kb < f2; ++kb)
+                    out.big_twiddles.push_back (unit_root ((long long) a * kb, nc));
+            return true;
+        }
+    }
     // multi-pass: nc = n1 * n2.  stage tables of the two cores are stored back to back
     // (n2 core first), the inter-pass twiddle W_nc^{a*k2}, a < n1, k2 < n2, in tile-major order.
     int n1 = 0, n2 = 0;

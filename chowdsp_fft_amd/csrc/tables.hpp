@@ -26,7 +26,9 @@ struct HostTables
     // too, with their own stage list; mixed_cb rows per pass-B tile; both tile widths may leave a ragged last tile
     std::vector<int> generic2_radix, generic2_tw_offset;
     int mixed_cb = 0;
+    int fast_n1 = 0, fast_n2 = 0;   // complex 2^17 .. 2^20: register-direct passes (tile_fast_kernels.hpp)
     int real4_r1 = 0, real4_r2 = 0; // long real frames: real four-step N = r1 * r2 (multipass_kernels.hpp)
+    int real4_fast = 0;             // ... on the register-direct tiles (tile_fast_kernels.hpp)
 };
 
 // Validates (N, transform) and fills the tables.  false = unsupported size.

@@ -1,0 +1,556 @@
+// Two-pass (four-step) transforms of N = n1 x n2 = 2^17 .. 2^20 points: both passes register-direct.
+//
+// multipass_kernels.hpp's generic tile kernels stage a tile through LDS three times (coalesced load -> per-frame LDS
+// FFT with 2-4 exchanges -> coalesced store) and run at 2.0-2.35 TB/s; its 256 x 256 fast path (global loads straight into
+// VGPRs, two register stages, ONE exchange) is 40 % faster per pass.  This file is that fast path for core lengths
+// n = 256, 512 and 1024, built like split_plane_kernels.hpp:
+//   * a tile = 16 adjacent columns (pass A) / rows (pass B); a column is handled by a TEAM of n/32 work-items with 32 points
+//     each, the 16 teams INTERLEAVED across lanes (lane = column + 16 * team member), so that one wave-instruction touches
+//     4 x 128 contiguous bytes of the strided side;
+//   * n = 32 x (n/32): stage 0 = one radix-32 butterfly per work-item, stage 1 = 32 butterflies of radix n/32 per column
+//     (32 / (n/32) per work-item), ONE exchange between them through LDS, one component at a time (the plane of a tile is
+//     16 x (n + n/32) floats: 68 KiB for n = 1024, two workgroups per CU);
+//   * pass A re-maps its work-items across the exchange (lanes then run along the butterfly index, 32 consecutive output
+//     indices kb per half-wave), which makes the plain layout W[a][kb] of the intermediate contiguous for pass A's stores
+//     (256 bytes per half-wave) AND for pass B's loads (16 rows kb of one column a: 128 bytes);
+//   * stage-1 twiddles W_n^(a k) in registers, factorised like the butterflies (split_plane_kernels.hpp): 10 / 6 / 4 values
+//     per butterfly index for n = 1024 / 512 / 256.
+// Replaces, per frame, the reference's in-cache pass loop (cfftf1_ps, simd/chowdsp_fft_impl_sse.cpp:372-432;
+// chowdsp_fft.h:131-134 on scratch for large N).
+#pragma once
+#include "split_plane_kernels.hpp"
+
+namespace cfft
+{
+template <int N_>
+struct FastTile
+{
+    static constexpr int n = N_;
+    static constexpr int Tn = N_ / 32;        // work-items per column / row
+    static constexpr int R1 = N_ / 32;        // radix of stage 1
+    static constexpr int Q = 32 / Tn;         // stage-1 butterflies per work-item
+    static constexpr int threads = 16 * Tn;   // 128 / 256 / 512
+    // distance of consecutive teams' images in the plane: >= n + n/32 and = 2 (mod 32), so that the 16 teams x 2 team
+    // members of a half-wave fall on 32 different banks (bank = 2 c + member + const)
+    static constexpr int S = ((N_ + N_ / 32 + 31) / 32) * 32 + 2;
+    static constexpr size_t lds_bytes = (size_t) 16 * S * sizeof (float);
+    // minimum waves per SIMD asked of the compiler: two 512-thread workgroups per CU for n = 1024 (4 waves per SIMD, 128
+    // VGPRs), CFFT_FAST_TILE_WAVES overrides (A/B)
+#ifndef CFFT_FAST_TILE_WAVES
+#define CFFT_FAST_TILE_WAVES 0
+#endif
+    static constexpr int min_waves = CFFT_FAST_TILE_WAVES > 0 ? CFFT_FAST_TILE_WAVES : 2; // (4 for n = 1024 spills: 2^19 -11 %)
+    static constexpr int tw_rows = R1 == 32 ? 10 : (R1 == 16 ? 6 : 4); // rows [j][k < 32] of the stage-1 table
+};
+
+// 8-point forward DFT with the stage twiddle W^(a k) applied first, a = n1 + 4 n2 (fft_reg<8> is 2 (n2) x 4 (n1)):
+// w[0..2] = W^(n1 k), n1 = 1..3, after the inner 2-point transforms; w[3] = W^(4 k) before them.
+__device__ __forceinline__ void fft_reg8_tw (float2 (&u)[8], const float2 (&w)[4])
+{
+#pragma unroll
+    for (int n1 = 0; n1 < 4; ++n1)
+        u[n1 + 4] = cmul (u[n1 + 4], w[3]);
+    bfly2 (u[0], u[4]);
+    bfly2 (u[1], u[5]);
+    bfly2 (u[2], u[6]);
+    bfly2 (u[3], u[7]);
+    // now u[n1] = A[n1][k2 = 0], u[n1 + 4] = A[n1][k2 = 1]
+#pragma unroll
+    for (int n1 = 1; n1 < 4; ++n1)
+    {
+        u[n1] = cmul (u[n1], w[n1 - 1]);
+        u[n1 + 4] = cmul (u[n1 + 4], w[n1 - 1]);
+    }
+    u[5] = mul_w8_1 (u[5]);
+    u[6] = mul_mi (u[6]);
+    u[7] = mul_w8_3 (u[7]);
+    bfly4 (u[0], u[1], u[2], u[3]);
+    bfly4 (u[4], u[5], u[6], u[7]);
+    const float2 e0 = u[0], e1 = u[1], e2 = u[2], e3 = u[3];
+    const float2 o0 = u[4], o1 = u[5], o2 = u[6], o3 = u[7];
+    u[0] = e0; u[1] = o0; u[2] = e1; u[3] = o1;
+    u[4] = e2; u[5] = o2; u[6] = e3; u[7] = o3;
+}
+
+// the stage-1 twiddles of butterfly index i (rows [j][i] of the table)
+template <class FT>
+__device__ __forceinline__ void ft_load_twiddles (float2 (&w)[10], const float2* __restrict__ tw, int i)
+{
+#pragma unroll
+    for (int j = 0; j < FT::tw_rows; ++j)
+        w[j] = tw[j * 32 + i];
+}
+
+// the stage-1 butterfly number q (radix FT::R1) on v[q R1 .. q R1 + R1)
+template <class FT, int Q_>
+__device__ __forceinline__ void ft_stage1 (float2 (&v)[32], const float2 (&w)[10])
+{
+    float2 u[FT::R1];
+#pragma unroll
+    for (int a = 0; a < FT::R1; ++a)
+        u[a] = v[Q_ * FT::R1 + a];
+    if constexpr (FT::R1 == 32)
+        fft_reg32<true> (u, w);
+    else if constexpr (FT::R1 == 16)
+    {
+        const float2 w6[6] = { w[0], w[1], w[2], w[3], w[4], w[5] };
+        fft_reg16_tw (u, w6);
+    }
+    else
+    {
+        const float2 w4[4] = { w[0], w[1], w[2], w[3] };
+        fft_reg8_tw (u, w4);
+    }
+#pragma unroll
+    for (int a = 0; a < FT::R1; ++a)
+        v[Q_ * FT::R1 + a] = u[a];
+}
+template <class FT>
+__device__ __forceinline__ void ft_stage1_all (float2 (&v)[32], const float2 (&w0)[10], const float2 (&w1)[10], const float2 (&w2)[10], const float2 (&w3)[10])
+{
+    ft_stage1<FT, 0> (v, w0);
+    if constexpr (FT::Q > 1)
+        ft_stage1<FT, 1> (v, w1);
+    if constexpr (FT::Q > 2)
+    {
+        ft_stage1<FT, 2> (v, w2);
+        ft_stage1<FT, 3> (v, w3);
+    }
+}
+
+// The exchange.  Stage-0 role (c, m): team c = tid & 15, member m = tid >> 4, holds Y_c[32 m + b] in v[b].
+// Stage-1 role: SWAPPED (pass A): butterfly i = tid & 31 of the columns cc_q = (tid >> 5) + (Tn / 2) q;
+//               plain   (pass B): butterflies i_q = m + Tn q of team c.   v[q R1 + a] = X[i + 32 a].
+// Addresses: team image at c S; write phys (32 m + b) = 33 m + b; read phys (i + 32 a) = i + 33 a  (i < 32).
+template <class FT, bool SWAPPED>
+__device__ __forceinline__ void ft_exchange (float2 (&v)[32], float* __restrict__ plane, int tid)
+{
+    const int c = tid & 15, m = tid >> 4;
+    float* __restrict__ wp = plane + c * FT::S + 33 * m;
+    const float* __restrict__ rp = SWAPPED ? plane + (tid >> 5) * FT::S + (tid & 31) : plane + c * FT::S + m;
+    constexpr int rq = SWAPPED ? (FT::Tn / 2) * FT::S : FT::Tn; // distance between a work-item's butterflies q
+    __syncthreads(); // the previous tile's reads of the plane are finished
+#pragma unroll
+    for (int b = 0; b < 32; ++b)
+        wp[b] = v[b].x;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < FT::Q; ++q)
+#pragma unroll
+        for (int a = 0; a < FT::R1; ++a)
+            v[q * FT::R1 + a].x = rp[q * rq + 33 * a];
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 32; ++b)
+        wp[b] = v[b].y;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < FT::Q; ++q)
+#pragma unroll
+        for (int a = 0; a < FT::R1; ++a)
+            v[q * FT::R1 + a].y = rp[q * rq + 33 * a];
+}
+
+// ---- pass A: n2-point column FFTs of 16 adjacent columns, times W_N^{a kb}, into W[a][kb] ------------------------------
+template <int N2, bool SWAP_IN>
+__global__ __launch_bounds__ (FastTile<N2>::threads, FastTile<N2>::min_waves) void pass_a_fast_kernel (const float2* __restrict__ in,
+                                                                           float2* __restrict__ work,
+                                                                           const float2* __restrict__ stage_tw, // [rows][32] of the n2 core
+                                                                           const float2* __restrict__ big_tw,   // [a][kb] = W_N^{a kb}
+                                                                           unsigned n1,
+                                                                           unsigned batch,
+                                                                           size_t in_stride)
+{
+    using FT = FastTile<N2>;
+    extern __shared__ __attribute__ ((aligned (16))) float ft_plane[];
+    const int tid0 = threadIdx.x;
+    float2 w[10];
+    ft_load_twiddles<FT> (w, stage_tw, tid0 & 31); // stage-1 role: butterfly index i = tid & 31
+    const unsigned tiles = n1 / 16;
+    const size_t frame_len = (size_t) n1 * N2;
+    const size_t nwork = (size_t) batch * tiles;
+    for (size_t wk = blockIdx.x; wk < nwork; wk += gridDim.x)
+    {
+        int tid = tid0;
+        CFFT_LAUNDER_INDEX (tid);
+        const unsigned f = (unsigned) (wk / tiles);
+        const unsigned a0 = (unsigned) (wk % tiles) * 16u;
+        const float2* __restrict__ src = in + (size_t) f * in_stride + a0 + (unsigned) (tid & 15);
+        const unsigned m = (unsigned) tid >> 4;
+        float2 v[32];
+#pragma unroll
+        for (int a = 0; a < 32; ++a)
+        {
+            const float2 x = gload (&src[(size_t) (m + FT::Tn * a) * n1]);
+            v[a] = SWAP_IN ? make_float2 (x.y, x.x) : x;
+        }
+        CFFT_PHASE_FENCE();
+        fft_reg32<false> (v, w);
+        CFFT_PHASE_FENCE();
+        ft_exchange<FT, true> (v, ft_plane, tid);
+        CFFT_PHASE_FENCE();
+        ft_stage1_all<FT> (v, w, w, w, w);
+        CFFT_PHASE_FENCE();
+        // column cc_q, output indices kb = i + 32 b: 32 consecutive kb per half-wave
+        int ts = tid0;
+        CFFT_LAUNDER_INDEX (ts);
+        const unsigned i = (unsigned) ts & 31u;
+#pragma unroll
+        for (int q = 0; q < FT::Q; ++q)
+        {
+            const unsigned a = a0 + ((unsigned) ts >> 5) + (unsigned) (FT::Tn / 2) * q;
+            const float2* __restrict__ twp = big_tw + (size_t) a * N2 + i;
+            float2* __restrict__ dst = work + (size_t) f * frame_len + (size_t) a * N2 + i;
+#pragma unroll
+            for (int b = 0; b < FT::R1; ++b)
+                dst[32 * b] = cmul (v[q * FT::R1 + b], twp[32 * b]); // plain store: the workspace should stay cached
+        }
+    }
+}
+
+// ---- pass B: n1-point row FFTs of 16 adjacent rows kb, transposed store X[n2 ka + kb] ----------------------------------
+template <int N1, bool SWAP_OUT>
+__global__ __launch_bounds__ (FastTile<N1>::threads, FastTile<N1>::min_waves) void pass_b_fast_kernel (const float2* __restrict__ work,
+                                                                           float2* __restrict__ out,
+                                                                           const float2* __restrict__ stage_tw, // [rows][32] of the n1 core
+                                                                           unsigned n2,
+                                                                           unsigned batch,
+                                                                           size_t out_stride)
+{
+    using FT = FastTile<N1>;
+    extern __shared__ __attribute__ ((aligned (16))) float ft_plane[];
+    const int tid0 = threadIdx.x;
+    float2 w[FT::Q][10];
+#pragma unroll
+    for (int q = 0; q < FT::Q; ++q)
+        ft_load_twiddles<FT> (w[q], stage_tw, (tid0 >> 4) + FT::Tn * q); // butterfly index i_q = member + Tn q
+    const unsigned tiles = n2 / 16;
+    const size_t frame_len = (size_t) N1 * n2;
+    const size_t nwork = (size_t) batch * tiles;
+    for (size_t wk = blockIdx.x; wk < nwork; wk += gridDim.x)
+    {
+        int tid = tid0;
+        CFFT_LAUNDER_INDEX (tid);
+        const unsigned f = (unsigned) (wk / tiles);
+        const unsigned kb0 = (unsigned) (wk % tiles) * 16u;
+        const unsigned m = (unsigned) tid >> 4;
+        const float2* __restrict__ src = work + (size_t) f * frame_len + kb0 + (unsigned) (tid & 15);
+        float2 v[32];
+#pragma unroll
+        for (int a = 0; a < 32; ++a)
+            v[a] = src[(size_t) (m + FT::Tn * a) * n2];
+        CFFT_PHASE_FENCE();
+        fft_reg32<false> (v, w[0]);
+        CFFT_PHASE_FENCE();
+        ft_exchange<FT, false> (v, ft_plane, tid);
+        CFFT_PHASE_FENCE();
+        ft_stage1_all<FT> (v, w[0], w[FT::Q > 1 ? 1 : 0], w[FT::Q > 2 ? 2 : 0], w[FT::Q > 2 ? 3 : 0]);
+        CFFT_PHASE_FENCE();
+        int ts = tid0;
+        CFFT_LAUNDER_INDEX (ts);
+        float2* __restrict__ dst = out + (size_t) f * out_stride + kb0 + ((unsigned) ts & 15u);
+        const unsigned ms = (unsigned) ts >> 4;
+#pragma unroll
+        for (int q = 0; q < FT::Q; ++q)
+#pragma unroll
+            for (int b = 0; b < FT::R1; ++b)
+            {
+                const float2 y = v[q * FT::R1 + b];
+                gstore (&dst[(size_t) (ms + FT::Tn * q + 32 * b) * n2], SWAP_OUT ? make_float2 (y.y, y.x) : y);
+            }
+    }
+}
+
+// =====================================================================================================
+// Long REAL frames (N = R1 x R2 = 2^17 .. 2^20 samples) on the same register-direct tiles: the real four-step of
+// multipass_kernels.hpp (pairs of real columns as complex columns, separation, rows kb <= R2/2 only, packed spectrum
+// written directly) with the column / row transforms done as above.
+//   forward : pass A (columns, re-mapped across the exchange) -> Wf[a][kb], NRp = R2/2 + 16 entries per real column a
+//             pass B (rows) -> packed spectrum
+//   backward: pass B (rows, re-mapped) -> Wi[kb][a];  pass A (columns) -> the real frame
+// The partner Z_c[R2 - kb] of the separation sits in the SAME 32-lane group as Z_c[kb] after the re-mapping (butterfly index
+// 32 - i, slot R1c - 1 - b): one ds_bpermute per component, no LDS traffic, no barrier.
+// =====================================================================================================
+template <int N2>
+__global__ __launch_bounds__ (FastTile<N2>::threads, FastTile<N2>::min_waves) void pass_a_real_fast_kernel (const float2* __restrict__ in, // real frame as N/2 float2
+                                                                                                       float2* __restrict__ work, // Wf[a][kb]
+                                                                                                       const float2* __restrict__ stage_tw,
+                                                                                                       const float2* __restrict__ big_tw, // [a][kb < NRp]
+                                                                                                       unsigned n1c, // complex columns = R1 / 2
+                                                                                                       unsigned batch,
+                                                                                                       size_t in_stride)
+{
+    using FT = FastTile<N2>;
+    constexpr unsigned NRp = N2 / 2 + 16;
+    extern __shared__ __attribute__ ((aligned (16))) float ft_plane[];
+    const int tid0 = threadIdx.x;
+    float2 w[10];
+    ft_load_twiddles<FT> (w, stage_tw, tid0 & 31);
+    const unsigned tiles = n1c / 16;
+    const size_t ws_len = (size_t) (2 * n1c) * NRp;
+    const size_t nwork = (size_t) batch * tiles;
+    for (size_t wk = blockIdx.x; wk < nwork; wk += gridDim.x)
+    {
+        int tid = tid0;
+        CFFT_LAUNDER_INDEX (tid);
+        const unsigned f = (unsigned) (wk / tiles);
+        const unsigned a0 = (unsigned) (wk % tiles) * 16u;
+        const float2* __restrict__ src = in + (size_t) f * in_stride + a0 + (unsigned) (tid & 15);
+        const unsigned m = (unsigned) tid >> 4;
+        float2 v[32];
+#pragma unroll
+        for (int a = 0; a < 32; ++a)
+            v[a] = gload (&src[(size_t) (m + FT::Tn * a) * n1c]);
+        CFFT_PHASE_FENCE();
+        fft_reg32<false> (v, w);
+        CFFT_PHASE_FENCE();
+        ft_exchange<FT, true> (v, ft_plane, tid);
+        CFFT_PHASE_FENCE();
+        ft_stage1_all<FT> (v, w, w, w, w);
+        CFFT_PHASE_FENCE();
+        int ts = tid0;
+        CFFT_LAUNDER_INDEX (ts);
+        const unsigned i = (unsigned) ts & 31u;
+        const int partner = (int) ((32u - i) & 31u);
+#pragma unroll
+        for (int q = 0; q < FT::Q; ++q)
+        {
+            const unsigned cc = a0 + ((unsigned) ts >> 5) + (unsigned) (FT::Tn / 2) * q; // complex column = real columns 2 cc, 2 cc + 1
+            const size_t row_e = (size_t) (2 * cc) * NRp + i, row_o = row_e + NRp;
+            float2* __restrict__ dst = work + (size_t) f * ws_len;
+#pragma unroll
+            for (int b = 0; b <= FT::R1 / 2; ++b)
+            {
+                // kb = i + 32 b <= R2 / 2: b < R1c / 2 for every lane, b = R1c / 2 for i = 0 only
+                const float2 zk = v[q * FT::R1 + (b % FT::R1)];
+                const float2 own = v[q * FT::R1 + ((FT::R1 - b) % FT::R1)];          // lane 0: Z[R2 - 32 b] is its own slot R1c - b
+                const float2 oth = v[q * FT::R1 + ((2 * FT::R1 - 1 - b) % FT::R1)];  // others: slot R1c - 1 - b of lane 32 - i
+                float2 zm = make_float2 (__shfl (oth.x, partner, 32), __shfl (oth.y, partner, 32));
+                if (i == 0)
+                    zm = own;
+                if (b < FT::R1 / 2 || i == 0)
+                {
+                    const float2 ce = make_float2 (0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+                    const float2 co = make_float2 (0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));
+                    dst[row_e + 32 * b] = cmul (ce, big_tw[row_e + 32 * b]);
+                    dst[row_o + 32 * b] = cmul (co, big_tw[row_o + 32 * b]);
+                }
+            }
+        }
+    }
+}
+
+template <int R1_>
+__global__ __launch_bounds__ (FastTile<R1_>::threads, FastTile<R1_>::min_waves) void pass_b_real_fast_kernel (const float2* __restrict__ work, // Wf[a][kb]
+                                                                                                         float2* __restrict__ out, // packed spectrum
+                                                                                                         const float2* __restrict__ stage_tw,
+                                                                                                         unsigned n2, // R2
+                                                                                                         unsigned batch,
+                                                                                                         size_t out_stride)
+{
+    using FT = FastTile<R1_>;
+    extern __shared__ __attribute__ ((aligned (16))) float ft_plane[];
+    const int tid0 = threadIdx.x;
+    float2 w[FT::Q][10];
+#pragma unroll
+    for (int q = 0; q < FT::Q; ++q)
+        ft_load_twiddles<FT> (w[q], stage_tw, (tid0 >> 4) + FT::Tn * q);
+    const unsigned NR = n2 / 2 + 1, NRp = n2 / 2 + 16;
+    const unsigned tiles = NRp / 16;
+    const size_t ws_len = (size_t) R1_ * NRp;
+    const size_t nwork = (size_t) batch * tiles;
+    for (size_t wk = blockIdx.x; wk < nwork; wk += gridDim.x)
+    {
+        int tid = tid0;
+        CFFT_LAUNDER_INDEX (tid);
+        const unsigned f = (unsigned) (wk / tiles);
+        const unsigned kb = (unsigned) (wk % tiles) * 16u + ((unsigned) tid & 15u);
+        const bool row_ok = kb < NR;
+        const unsigned m = (unsigned) tid >> 4;
+        const float2* __restrict__ src = work + (size_t) f * ws_len + kb;
+        float2 v[32];
+#pragma unroll
+        for (int a = 0; a < 32; ++a)
+            v[a] = row_ok ? src[(size_t) (m + FT::Tn * a) * NRp] : make_float2 (0.f, 0.f);
+        CFFT_PHASE_FENCE();
+        fft_reg32<false> (v, w[0]);
+        CFFT_PHASE_FENCE();
+        ft_exchange<FT, false> (v, ft_plane, tid);
+        CFFT_PHASE_FENCE();
+        ft_stage1_all<FT> (v, w[0], w[FT::Q > 1 ? 1 : 0], w[FT::Q > 2 ? 2 : 0], w[FT::Q > 2 ? 3 : 0]);
+        CFFT_PHASE_FENCE();
+        int ts = tid0;
+        CFFT_LAUNDER_INDEX (ts);
+        const unsigned ms = (unsigned) ts >> 4;
+        float2* __restrict__ dst = out + (size_t) f * out_stride;
+        if (row_ok)
+        {
+            const bool inner = kb != 0 && 2 * kb != n2; // rows 0 and R2/2 are their own mirrors
+#pragma unroll
+            for (int q = 0; q < FT::Q; ++q)
+#pragma unroll
+                for (int b = 0; b < FT::R1; ++b)
+                {
+                    const unsigned ka = ms + (unsigned) (FT::Tn * q + 32 * b);
+                    const float2 y = v[q * FT::R1 + b];
+                    if (32 * b + FT::Tn * q < R1_ / 2) // ka < R1 / 2 for every member (Tn q + 32 b is a multiple of Tn; ms < Tn)
+                    {
+                        if (q == 0 && b == 0 && kb == 0 && ms == 0)
+                            gstore (&dst[0], make_float2 (y.x, v[FT::R1 / 2].x)); // (X0, X_{N/2}): Y_0[0] and Y_0[R1/2], both real, both here
+                        else
+                            gstore (&dst[(size_t) ka * n2 + kb], y);
+                    }
+                    else if (inner)
+                        gstore (&dst[(size_t) (R1_ - 1 - ka) * n2 + (n2 - kb)], make_float2 (y.x, -y.y));
+                }
+        }
+    }
+}
+
+// backward, first sweep: rows gathered from the packed spectrum (conjugate mirror for ka >= R1/2), transformed backward,
+// times conj W_N^{a kb}, into Wi[kb][a] (work-items re-mapped across the exchange: lanes along a)
+template <int R1_>
+__global__ __launch_bounds__ (FastTile<R1_>::threads, FastTile<R1_>::min_waves) void pass_b_real_inv_fast_kernel (const float2* __restrict__ in, // packed spectrum
+                                                                                                             float2* __restrict__ work, // Wi[kb][a]
+                                                                                                             const float2* __restrict__ stage_tw,
+                                                                                                             const float2* __restrict__ big_tw, // [kb][a]
+                                                                                                             unsigned n2,
+                                                                                                             unsigned batch,
+                                                                                                             size_t in_stride)
+{
+    using FT = FastTile<R1_>;
+    extern __shared__ __attribute__ ((aligned (16))) float ft_plane[];
+    const int tid0 = threadIdx.x;
+    float2 w[10];
+    ft_load_twiddles<FT> (w, stage_tw, tid0 & 31);
+    const unsigned NR = n2 / 2 + 1, NRp = n2 / 2 + 16;
+    const unsigned tiles = NRp / 16;
+    const size_t ws_len = (size_t) R1_ * NRp;
+    const size_t nwork = (size_t) batch * tiles;
+    for (size_t wk = blockIdx.x; wk < nwork; wk += gridDim.x)
+    {
+        int tid = tid0;
+        CFFT_LAUNDER_INDEX (tid);
+        const unsigned f = (unsigned) (wk / tiles);
+        const unsigned kb0 = (unsigned) (wk % tiles) * 16u;
+        const unsigned kb = kb0 + ((unsigned) tid & 15u);
+        const bool row_ok = kb < NR;
+        const unsigned m = (unsigned) tid >> 4;
+        const float2* __restrict__ src = in + (size_t) f * in_stride;
+        float2 v[32];
+#pragma unroll
+        for (int a = 0; a < 32; ++a)
+        {
+            const unsigned ka = m + (unsigned) (FT::Tn * a);
+            float2 x = make_float2 (0.f, 0.f);
+            if (row_ok)
+            {
+                if (FT::Tn * a < R1_ / 2) // ka < R1 / 2
+                {
+                    x = gload (&src[(size_t) ka * n2 + kb]);
+                    if (a == 0 && kb == 0 && m == 0)
+                        x = make_float2 (x.x, 0.f); // X0 (the slot's second float is X_{N/2})
+                }
+                else if (FT::Tn * a == R1_ / 2 && kb == 0 && m == 0)
+                    x = make_float2 (gload (&src[0]).y, 0.f); // X_{N/2}
+                else
+                {
+                    const size_t mi = (kb == 0) ? (size_t) (R1_ - ka) * n2 : (size_t) (R1_ - 1 - ka) * n2 + (n2 - kb);
+                    const float2 p = gload (&src[mi]);
+                    x = make_float2 (p.x, -p.y);
+                }
+            }
+            v[a] = make_float2 (x.y, x.x); // swapped: backward = swap . forward . swap
+        }
+        CFFT_PHASE_FENCE();
+        fft_reg32<false> (v, w);
+        CFFT_PHASE_FENCE();
+        ft_exchange<FT, true> (v, ft_plane, tid);
+        CFFT_PHASE_FENCE();
+        ft_stage1_all<FT> (v, w, w, w, w);
+        CFFT_PHASE_FENCE();
+        int ts = tid0;
+        CFFT_LAUNDER_INDEX (ts);
+        const unsigned i = (unsigned) ts & 31u;
+#pragma unroll
+        for (int q = 0; q < FT::Q; ++q)
+        {
+            const unsigned row = kb0 + ((unsigned) ts >> 5) + (unsigned) (FT::Tn / 2) * q;
+            if (row < NR)
+            {
+                const size_t base = (size_t) row * R1_ + i;
+                float2* __restrict__ dst = work + (size_t) f * ws_len + base;
+                const float2* __restrict__ twp = big_tw + base;
+#pragma unroll
+                for (int b = 0; b < FT::R1; ++b)
+                {
+                    const float2 ys = v[q * FT::R1 + b];
+                    dst[32 * b] = cmulc (make_float2 (ys.y, ys.x), twp[32 * b]); // un-swap, times conj W_N^{a kb}
+                }
+            }
+        }
+    }
+}
+
+// backward, second sweep: columns.  Z_c[kb] = C_2c[kb] + i C_2c+1[kb] (kb <= R2/2), conj C_2c[R2-kb] + i conj C_2c+1[R2-kb] above.
+template <int N2>
+__global__ __launch_bounds__ (FastTile<N2>::threads, FastTile<N2>::min_waves) void pass_a_real_inv_fast_kernel (const float2* __restrict__ work, // Wi[kb][a]
+                                                                                                           float2* __restrict__ out, // real frame as N/2 float2
+                                                                                                           const float2* __restrict__ stage_tw,
+                                                                                                           unsigned n1c,
+                                                                                                           unsigned batch,
+                                                                                                           size_t out_stride)
+{
+    using FT = FastTile<N2>;
+    constexpr unsigned NRp = N2 / 2 + 16;
+    extern __shared__ __attribute__ ((aligned (16))) float ft_plane[];
+    const int tid0 = threadIdx.x;
+    float2 w[FT::Q][10];
+#pragma unroll
+    for (int q = 0; q < FT::Q; ++q)
+        ft_load_twiddles<FT> (w[q], stage_tw, (tid0 >> 4) + FT::Tn * q);
+    const unsigned tiles = n1c / 16;
+    const size_t ws_len = (size_t) (2 * n1c) * NRp;
+    const size_t nwork = (size_t) batch * tiles;
+    for (size_t wk = blockIdx.x; wk < nwork; wk += gridDim.x)
+    {
+        int tid = tid0;
+        CFFT_LAUNDER_INDEX (tid);
+        const unsigned f = (unsigned) (wk / tiles);
+        const unsigned a0 = (unsigned) (wk % tiles) * 16u;
+        const unsigned m = (unsigned) tid >> 4;
+        // (C_2c, C_2c+1) of row kb: one float4 at Wi[kb][2 (a0 + c)]
+        const float4* __restrict__ src = reinterpret_cast<const float4*> (work + (size_t) f * ws_len) + a0 + ((unsigned) tid & 15u);
+        float2 v[32];
+#pragma unroll
+        for (int a = 0; a < 32; ++a)
+        {
+            const unsigned kb = m + (unsigned) (FT::Tn * a);
+            const bool upper = (unsigned) (FT::Tn * a) > (unsigned) (N2 / 2) || ((unsigned) (FT::Tn * a) == (unsigned) (N2 / 2) && m != 0);
+            const unsigned row = upper ? N2 - kb : kb;
+            const float4 p = src[(size_t) row * n1c];
+            const float2 z = upper ? make_float2 (p.x + p.w, p.z - p.y) : make_float2 (p.x - p.w, p.y + p.z);
+            v[a] = make_float2 (z.y, z.x); // swapped for the backward transform
+        }
+        CFFT_PHASE_FENCE();
+        fft_reg32<false> (v, w[0]);
+        CFFT_PHASE_FENCE();
+        ft_exchange<FT, false> (v, ft_plane, tid);
+        CFFT_PHASE_FENCE();
+        ft_stage1_all<FT> (v, w[0], w[FT::Q > 1 ? 1 : 0], w[FT::Q > 2 ? 2 : 0], w[FT::Q > 2 ? 3 : 0]);
+        CFFT_PHASE_FENCE();
+        int ts = tid0;
+        CFFT_LAUNDER_INDEX (ts);
+        float2* __restrict__ dst = out + (size_t) f * out_stride + a0 + ((unsigned) ts & 15u);
+        const unsigned ms = (unsigned) ts >> 4;
+#pragma unroll
+        for (int q = 0; q < FT::Q; ++q)
+#pragma unroll
+            for (int b = 0; b < FT::R1; ++b)
+            {
+                const float2 y = v[q * FT::R1 + b];
+                gstore (&dst[(size_t) (ms + FT::Tn * q + 32 * b) * n1c], make_float2 (y.y, y.x));
+            }
+    }
+}
+} // namespace cfft
