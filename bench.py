@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the hot path on MI355X, one JSON line on stdout (rank 0).
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 50 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
@@ -250,8 +250,8 @@ def run_workload(workload, args, world, rank, dev, frames_override=0, gather=Fal
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--frames-per-gpu", type=int, default=0, help="override the workload's batch (debugging only)")
     ap.add_argument("--cpu-seconds", type=float, default=4.0, help="seconds per CPU-baseline regime (3 regimes)")

@@ -594,8 +594,25 @@ __global__ __launch_bounds__ (256) void pass_a256_kernel (const float2* __restri
         const size_t base_ = (size_t) (((W) % tiles) * 16) * 256 + c1 * 16 + i1;                   \
         float2* __restrict__ dst_ = work + (size_t) ((W) / tiles) * N + base_;                     \
         const float2* __restrict__ twp_ = big_tw + base_;                                          \
-        _Pragma ("unroll") for (int b = 0; b < 16; ++b)                                            \
-            dst_[b * 256] = cmul (V[b], twp_[b * 256]);                                            \
+        /* twiddles four at a time, one group ahead of the stores: gfx9 counts loads and stores in ONE in-order counter, */ \
+        /* so "load W; wait; store" per element makes every wait drain the previous store (tools/isa_vmem_scan.py); with  */ \
+        /* group g + 1 requested before group g is stored a wait only covers older loads                                  */ \
+        float2 bw_[2][4];                                                                          \
+        CFFT_PHASE_FENCE();                                                                        \
+        _Pragma ("unroll") for (int b = 0; b < 4; ++b)                                             \
+            bw_[0][b] = twp_[b * 256];                                                             \
+        _Pragma ("unroll") for (int g_ = 0; g_ < 4; ++g_)                                          \
+        {                                                                                          \
+            if (g_ < 3)                                                                            \
+            {                                                                                      \
+                _Pragma ("unroll") for (int b = 0; b < 4; ++b)                                     \
+                    bw_[(g_ + 1) & 1][b] = twp_[(b + 4 * (g_ + 1)) * 256];                         \
+            }                                                                                      \
+            CFFT_PHASE_FENCE();                                                                    \
+            _Pragma ("unroll") for (int b = 0; b < 4; ++b)                                         \
+                dst_[(b + 4 * g_) * 256] = cmul (V[b + 4 * g_], bw_[g_ & 1][b]);                   \
+            CFFT_PHASE_FENCE();                                                                    \
+        }                                                                                          \
     }
     {
         float2 v[16];
@@ -652,6 +669,7 @@ __global__ __launch_bounds__ (256) void pass_b256_kernel (const float2* __restri
         const unsigned wn_ = (W) + gridDim.x;                                                      \
         if (wn_ < nwork)                                                                           \
             CFFT_B256_LOAD (wn_, nre, nim)                                                         \
+        CFFT_PHASE_FENCE(); /* the next tile's loads stay ahead of this tile's transform */       \
         fft256_two_stage (V, w, smem, kbl, t, kbl, t);                                             \
         float2* __restrict__ dst_ = out + (size_t) ((W) / tiles) * out_stride + ((W) % tiles) * 16 + kbl; \
         _Pragma ("unroll") for (int b = 0; b < 16; ++b)                                            \

@@ -20,6 +20,9 @@
 #pragma once
 #include "split_plane_kernels.hpp"
 
+#ifndef CFFT_PARF_GROUP
+#define CFFT_PARF_GROUP(N2) ((N2) >= 1024 ? 4 : 2)
+#endif
 namespace cfft
 {
 template <int N_>
@@ -70,6 +73,16 @@ __device__ __forceinline__ void fft_reg8_tw (float2 (&u)[8], const float2 (&w)[4
     const float2 o0 = u[4], o1 = u[5], o2 = u[6], o3 = u[7];
     u[0] = e0; u[1] = o0; u[2] = e1; u[3] = o1;
     u[4] = e2; u[5] = o2; u[6] = e3; u[7] = o3;
+}
+
+// XCD-aware order of work items (speed only; any bijection is correct): blocks are dealt round-robin over the 8 XCDs, so
+// block b and b + 8 share an L2.  Item v of the persistent loop (v = blockIdx + k gridDim, gridDim a multiple of 8 on a full
+// chip) is mapped so that the items one XCD works through are CONSECUTIVE tiles: the rows whose mirrored halves straddle a
+// 128-byte line then share that line inside one L2 instead of fetching / writing it from two.
+__device__ __forceinline__ size_t xcd_order (size_t v, size_t nwork)
+{
+    const size_t per = (nwork + 7) / 8;
+    return (v % 8) * per + v / 8;
 }
 
 // the stage-1 twiddles of butterfly index i (rows [j][i] of the table)
@@ -312,31 +325,66 @@ __global__ __launch_bounds__ (FastTile<N2>::threads, FastTile<N2>::min_waves) vo
         CFFT_LAUNDER_INDEX (ts);
         const unsigned i = (unsigned) ts & 31u;
         const int partner = (int) ((32u - i) & 31u);
+        // Steps (q, b) in groups of four, the two twiddles of a group requested one group ahead of its stores: gfx9 counts loads
+        // and stores in one in-order counter, so a twiddle load issued after a store and waited for at once drains that store
+        // (tools/isa_vmem_scan.py; it cost the N2 = 1024 form a store round trip per element).
+        constexpr int NB = FT::R1 / 2 + 1, STEPS = FT::Q * NB, GROUP = CFFT_PARF_GROUP (N2), NG = (STEPS + GROUP - 1) / GROUP;
+        float2* __restrict__ dst = work + (size_t) f * ws_len;
+        const unsigned cc0 = a0 + ((unsigned) ts >> 5);
+        float2 te[2][GROUP], to[2][GROUP];
+#define CFFT_PARF_LOAD(G, SLOT)                                                                                          \
+    _Pragma ("unroll") for (int c = 0; c < GROUP; ++c)                                                                   \
+    {                                                                                                                    \
+        constexpr int dummy_ = 0;                                                                                        \
+        const int st_ = (G) * GROUP + c + dummy_;                                                                        \
+        if (st_ < STEPS)                                                                                                 \
+        {                                                                                                                \
+            const int q_ = st_ / NB, b_ = st_ % NB;                                                                      \
+            const size_t re_ = (size_t) (2 * (cc0 + (unsigned) (FT::Tn / 2) * q_)) * NRp + i;                            \
+            const size_t off_ = (b_ < FT::R1 / 2 || i == 0) ? (size_t) (32 * b_) : 0; /* lanes that do not store read slot 0 */ \
+            te[SLOT][c] = big_tw[re_ + off_];                                                                            \
+            to[SLOT][c] = big_tw[re_ + NRp + off_];                                                                      \
+        }                                                                                                                \
+    }
+        CFFT_PARF_LOAD (0, 0)
 #pragma unroll
-        for (int q = 0; q < FT::Q; ++q)
+        for (int g = 0; g < NG; ++g)
         {
-            const unsigned cc = a0 + ((unsigned) ts >> 5) + (unsigned) (FT::Tn / 2) * q; // complex column = real columns 2 cc, 2 cc + 1
-            const size_t row_e = (size_t) (2 * cc) * NRp + i, row_o = row_e + NRp;
-            float2* __restrict__ dst = work + (size_t) f * ws_len;
-#pragma unroll
-            for (int b = 0; b <= FT::R1 / 2; ++b)
+            if (g + 1 < NG)
             {
-                // kb = i + 32 b <= R2 / 2: b < R1c / 2 for every lane, b = R1c / 2 for i = 0 only
-                const float2 zk = v[q * FT::R1 + (b % FT::R1)];
-                const float2 own = v[q * FT::R1 + ((FT::R1 - b) % FT::R1)];          // lane 0: Z[R2 - 32 b] is its own slot R1c - b
-                const float2 oth = v[q * FT::R1 + ((2 * FT::R1 - 1 - b) % FT::R1)];  // others: slot R1c - 1 - b of lane 32 - i
-                float2 zm = make_float2 (__shfl (oth.x, partner, 32), __shfl (oth.y, partner, 32));
-                if (i == 0)
-                    zm = own;
-                if (b < FT::R1 / 2 || i == 0)
+                if ((g & 1) == 0)
+                    CFFT_PARF_LOAD (g + 1, 1)
+                else
+                    CFFT_PARF_LOAD (g + 1, 0)
+            }
+            CFFT_PHASE_FENCE();
+#pragma unroll
+            for (int c = 0; c < GROUP; ++c)
+            {
+                const int st = g * GROUP + c;
+                if (st < STEPS)
                 {
-                    const float2 ce = make_float2 (0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
-                    const float2 co = make_float2 (0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));
-                    dst[row_e + 32 * b] = cmul (ce, big_tw[row_e + 32 * b]);
-                    dst[row_o + 32 * b] = cmul (co, big_tw[row_o + 32 * b]);
+                    const int q = st / NB, b = st % NB;
+                    const size_t row_e = (size_t) (2 * (cc0 + (unsigned) (FT::Tn / 2) * q)) * NRp + i, row_o = row_e + NRp;
+                    // kb = i + 32 b <= R2 / 2: b < R1c / 2 for every lane, b = R1c / 2 for i = 0 only
+                    const float2 zk = v[q * FT::R1 + (b % FT::R1)];
+                    const float2 own = v[q * FT::R1 + ((FT::R1 - b) % FT::R1)];         // lane 0: Z[R2 - 32 b] is its own slot R1c - b
+                    const float2 oth = v[q * FT::R1 + ((2 * FT::R1 - 1 - b) % FT::R1)]; // others: slot R1c - 1 - b of lane 32 - i
+                    float2 zm = make_float2 (__shfl (oth.x, partner, 32), __shfl (oth.y, partner, 32));
+                    if (i == 0)
+                        zm = own;
+                    if (b < FT::R1 / 2 || i == 0)
+                    {
+                        const float2 ce = make_float2 (0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+                        const float2 co = make_float2 (0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));
+                        dst[row_e + 32 * b] = cmul (ce, te[g & 1][c]);
+                        dst[row_o + 32 * b] = cmul (co, to[g & 1][c]);
+                    }
                 }
             }
+            CFFT_PHASE_FENCE();
         }
+#undef CFFT_PARF_LOAD
     }
 }
 
@@ -359,8 +407,12 @@ __global__ __launch_bounds__ (FastTile<R1_>::threads, FastTile<R1_>::min_waves) 
     const unsigned tiles = NRp / 16;
     const size_t ws_len = (size_t) R1_ * NRp;
     const size_t nwork = (size_t) batch * tiles;
-    for (size_t wk = blockIdx.x; wk < nwork; wk += gridDim.x)
+    const size_t nloop = ((nwork + 7) / 8) * 8;
+    for (size_t wv = blockIdx.x; wv < nloop; wv += gridDim.x)
     {
+        const size_t wk = xcd_order (wv, nwork);
+        if (wk >= nwork)
+            continue;
         int tid = tid0;
         CFFT_LAUNDER_INDEX (tid);
         const unsigned f = (unsigned) (wk / tiles);
@@ -427,8 +479,12 @@ __global__ __launch_bounds__ (FastTile<R1_>::threads, FastTile<R1_>::min_waves) 
     const unsigned tiles = NRp / 16;
     const size_t ws_len = (size_t) R1_ * NRp;
     const size_t nwork = (size_t) batch * tiles;
-    for (size_t wk = blockIdx.x; wk < nwork; wk += gridDim.x)
+    const size_t nloop = ((nwork + 7) / 8) * 8;
+    for (size_t wv = blockIdx.x; wv < nloop; wv += gridDim.x)
     {
+        const size_t wk = xcd_order (wv, nwork);
+        if (wk >= nwork)
+            continue;
         int tid = tid0;
         CFFT_LAUNDER_INDEX (tid);
         const unsigned f = (unsigned) (wk / tiles);
@@ -437,28 +493,28 @@ __global__ __launch_bounds__ (FastTile<R1_>::threads, FastTile<R1_>::min_waves) 
         const bool row_ok = kb < NR;
         const unsigned m = (unsigned) tid >> 4;
         const float2* __restrict__ src = in + (size_t) f * in_stride;
+        // Every load is issued unconditionally (rows past NR read row 0 and are never stored): a load inside a divergent
+        // branch is followed by its own s_waitcnt, which serialises the 32 round trips of a tile.
+        const unsigned kbl = row_ok ? kb : 0u;
+        const bool first = (kbl == 0u) && (m == 0u); // holds X0 / X_{N/2} of the packed layout
         float2 v[32];
 #pragma unroll
         for (int a = 0; a < 32; ++a)
         {
             const unsigned ka = m + (unsigned) (FT::Tn * a);
-            float2 x = make_float2 (0.f, 0.f);
-            if (row_ok)
+            float2 x;
+            if (FT::Tn * a < R1_ / 2) // ka < R1 / 2: P[n2 ka + kb]
             {
-                if (FT::Tn * a < R1_ / 2) // ka < R1 / 2
-                {
-                    x = gload (&src[(size_t) ka * n2 + kb]);
-                    if (a == 0 && kb == 0 && m == 0)
-                        x = make_float2 (x.x, 0.f); // X0 (the slot's second float is X_{N/2})
-                }
-                else if (FT::Tn * a == R1_ / 2 && kb == 0 && m == 0)
-                    x = make_float2 (gload (&src[0]).y, 0.f); // X_{N/2}
-                else
-                {
-                    const size_t mi = (kb == 0) ? (size_t) (R1_ - ka) * n2 : (size_t) (R1_ - 1 - ka) * n2 + (n2 - kb);
-                    const float2 p = gload (&src[mi]);
-                    x = make_float2 (p.x, -p.y);
-                }
+                x = gload (&src[(size_t) ka * n2 + kbl]);
+                if (a == 0)
+                    x.y = first ? 0.f : x.y; // X0 (the slot's second float is X_{N/2})
+            }
+            else // conj P[n2 (R1 - 1 - ka) + n2 - kb]; X_{N/2} for (ka, kb) = (R1 / 2, 0)
+            {
+                const bool nyq = (FT::Tn * a == R1_ / 2) && first;
+                const size_t mi = nyq ? (size_t) 0 : (size_t) (R1_ - ka) * n2 - kbl;
+                const float2 p = gload (&src[mi]);
+                x = make_float2 (nyq ? p.y : p.x, nyq ? 0.f : -p.y);
             }
             v[a] = make_float2 (x.y, x.x); // swapped: backward = swap . forward . swap
         }
@@ -522,15 +578,29 @@ __global__ __launch_bounds__ (FastTile<N2>::threads, FastTile<N2>::min_waves) vo
         // (C_2c, C_2c+1) of row kb: one float4 at Wi[kb][2 (a0 + c)]
         const float4* __restrict__ src = reinterpret_cast<const float4*> (work + (size_t) f * ws_len) + a0 + ((unsigned) tid & 15u);
         float2 v[32];
+        // two batches of 16 float4 loads, each issued as a group before any of its values is used (left alone, the scheduler
+        // trades the loads' 128 registers for one wait per load: 32 serial round trips per tile)
 #pragma unroll
-        for (int a = 0; a < 32; ++a)
+        for (int h = 0; h < 2; ++h)
         {
-            const unsigned kb = m + (unsigned) (FT::Tn * a);
-            const bool upper = (unsigned) (FT::Tn * a) > (unsigned) (N2 / 2) || ((unsigned) (FT::Tn * a) == (unsigned) (N2 / 2) && m != 0);
-            const unsigned row = upper ? N2 - kb : kb;
-            const float4 p = src[(size_t) row * n1c];
-            const float2 z = upper ? make_float2 (p.x + p.w, p.z - p.y) : make_float2 (p.x - p.w, p.y + p.z);
-            v[a] = make_float2 (z.y, z.x); // swapped for the backward transform
+            float4 p[16];
+#pragma unroll
+            for (int a = 0; a < 16; ++a)
+            {
+                const unsigned kb = m + (unsigned) (FT::Tn * (a + 16 * h));
+                const bool upper = (unsigned) (FT::Tn * (a + 16 * h)) > (unsigned) (N2 / 2) || ((unsigned) (FT::Tn * (a + 16 * h)) == (unsigned) (N2 / 2) && m != 0);
+                const unsigned row = upper ? N2 - kb : kb;
+                p[a] = src[(size_t) row * n1c];
+            }
+            CFFT_PHASE_FENCE();
+#pragma unroll
+            for (int a = 0; a < 16; ++a)
+            {
+                const bool upper = (unsigned) (FT::Tn * (a + 16 * h)) > (unsigned) (N2 / 2) || ((unsigned) (FT::Tn * (a + 16 * h)) == (unsigned) (N2 / 2) && m != 0);
+                const float2 z = upper ? make_float2 (p[a].x + p[a].w, p[a].z - p[a].y) : make_float2 (p[a].x - p[a].w, p[a].y + p[a].z);
+                v[a + 16 * h] = make_float2 (z.y, z.x); // swapped for the backward transform
+            }
+            CFFT_PHASE_FENCE();
         }
         CFFT_PHASE_FENCE();
         fft_reg32<false> (v, w[0]);
