@@ -26,6 +26,8 @@ struct GenericPlan
     unsigned in_stride, out_stride;   // float2 between consecutive frames in global memory (n for packed batches)
     int radix[kGenericMaxStages];     // each in {2, 3, 4, 5, 8, 16}
     int tw_offset[kGenericMaxStages]; // float2 offset of the stage's table: (radix-1) * p entries, [a-1][k]
+    int lds_stages;                   // generic_inplace_kernel: the tables of stages [0, lds_stages) ride in LDS behind the image
+    int lds_tw_len;                   // ... that many float2 (the tables are contiguous from tw_offset[0])
 };
 
 template <>
@@ -130,14 +132,15 @@ __device__ __forceinline__ void generic_stage_dispatch (int r, const float2* __r
 template <int BLOCK, bool IN_GLOBAL, bool OUT_GLOBAL, bool SWAP>
 __device__ __forceinline__ float2* generic_core (const GenericPlan& plan, const float2* __restrict__ twtab, float2* a, float2* b,
                                                   const float2* __restrict__ gin, float2* __restrict__ gout, int nframes, int tid,
-                                                  unsigned lfs)
+                                                  unsigned lfs, int tw_base = 0)
 {
+    // tw_base: table offset of twtab[0] (plan.tw_offset[0] when twtab is the workgroup's LDS copy of this plan's n - 1 twiddles)
     float2 *src = a, *dst = b;
     int p = 1;
     for (int s = 0; s < plan.ns; ++s)
     {
         const int r = plan.radix[s];
-        const float2* tw = twtab + plan.tw_offset[s];
+        const float2* tw = twtab + (plan.tw_offset[s] - tw_base);
         const bool first = IN_GLOBAL && s == 0, last = OUT_GLOBAL && s == plan.ns - 1;
         if (first && last)
             generic_stage_dispatch<BLOCK, 3, SWAP> (r, gin, gout, tw, plan.n, p, nframes, tid, plan.in_stride, plan.out_stride, lfs);
@@ -159,7 +162,10 @@ __device__ __forceinline__ float2* generic_core (const GenericPlan& plan, const 
 
 // MODE 0: complex <-> complex (INV: backward).  MODE 1: real forward (packed spectrum out).  MODE 2: real backward.
 // For the real modes plan.n = N/2 and wtab holds W_N^k, k <= N/4 (pair stage formulas: real_kernels.hpp).
-template <int MODE, bool INV, int BLOCK>
+// TWLDS: the plan's stage twiddles (n - 1 values: sum of (r - 1) p over the stages) are copied to LDS once per workgroup, behind
+// the two images.  From L2 they cost 25-35 % (MI355X, n = 480 .. 1536: every butterfly waits for its own twiddle loads, and in
+// the last stage -- gfx9 counts loads and stores in one in-order counter -- for the previous butterfly's stores as well).
+template <int MODE, bool INV, int BLOCK, bool TWLDS>
 __global__ __launch_bounds__ (BLOCK) void generic_kernel (const float2* __restrict__ in,
                                                          float2* __restrict__ out,
                                                          const float2* __restrict__ twtab,
@@ -174,6 +180,13 @@ __global__ __launch_bounds__ (BLOCK) void generic_kernel (const float2* __restri
     const int half = n / 2 + 1; // pair-stage work items per frame: k = 0 .. n/2
     float2* bufA = smem;
     float2* bufB = smem + (size_t) F * n;
+    float2* twl = smem + (size_t) 2 * F * n;
+    if constexpr (TWLDS)
+    {
+        for (int i = tid; i < n - 1; i += BLOCK)
+            twl[i] = twtab[plan.tw_offset[0] + i];
+        // the first barrier of the group loop orders these writes before any stage
+    }
     const unsigned ngroups = (batch + F - 1) / F;
     for (unsigned g = blockIdx.x; g < ngroups; g += gridDim.x)
     {
@@ -213,7 +226,11 @@ __global__ __launch_bounds__ (BLOCK) void generic_kernel (const float2* __restri
         if (MODE == 2)
             __syncthreads();
         constexpr bool IN_GLOBAL = (MODE != 2), OUT_GLOBAL = (MODE != 1);
-        const float2* res = generic_core<BLOCK, IN_GLOBAL, OUT_GLOBAL, (MODE == 2) || INV> (plan, twtab, bufA, bufB, src, dst, nframes, tid, (unsigned) n);
+        const float2* res;
+        if constexpr (TWLDS)
+            res = generic_core<BLOCK, IN_GLOBAL, OUT_GLOBAL, (MODE == 2) || INV> (plan, twl, bufA, bufB, src, dst, nframes, tid, (unsigned) n, plan.tw_offset[0]);
+        else
+            res = generic_core<BLOCK, IN_GLOBAL, OUT_GLOBAL, (MODE == 2) || INV> (plan, twtab, bufA, bufB, src, dst, nframes, tid, (unsigned) n);
         if (MODE == 1)
         {
             for (int idx = tid; idx < nframes * half; idx += BLOCK)
@@ -368,8 +385,10 @@ __device__ __forceinline__ void inplace_stage_dispatch (int r, const float2* __r
     }
 }
 
-template <int BLOCK, bool IN_GLOBAL, bool OUT_GLOBAL, bool SWAP>
-__device__ __forceinline__ void inplace_core (const GenericPlan& plan, const float2* __restrict__ twtab, float2* buf,
+// TWLDS: stages [0, plan.lds_stages) take their twiddles from the workgroup's LDS copy `twl` (twl[0] = table entry
+// plan.tw_offset[0]), the rest from the table in L2.  Two call sites per kind of stage so that each keeps its address space.
+template <int BLOCK, bool IN_GLOBAL, bool OUT_GLOBAL, bool SWAP, bool TWLDS>
+__device__ __forceinline__ void inplace_core (const GenericPlan& plan, const float2* __restrict__ twtab, const float2* twl, float2* buf,
                                               const float2* __restrict__ gin, float2* __restrict__ gout, int tid)
 {
     int p = 1;
@@ -379,9 +398,17 @@ __device__ __forceinline__ void inplace_core (const GenericPlan& plan, const flo
         const float2* tw = twtab + plan.tw_offset[s];
         const bool first = IN_GLOBAL && s == 0, last = OUT_GLOBAL && s == plan.ns - 1;
         if (first && last)
-            inplace_stage_dispatch<BLOCK, 3, SWAP> (r, gin, gout, buf, tw, plan.n, p, tid);
+            inplace_stage_dispatch<BLOCK, 3, SWAP> (r, gin, gout, buf, tw, plan.n, p, tid); // p == 1: no twiddles
         else if (first)
             inplace_stage_dispatch<BLOCK, 1, SWAP> (r, gin, gout, buf, tw, plan.n, p, tid);
+        else if (TWLDS && s < plan.lds_stages)
+        {
+            const float2* tl = twl + (plan.tw_offset[s] - plan.tw_offset[0]);
+            if (last)
+                inplace_stage_dispatch<BLOCK, 2, SWAP> (r, gin, gout, buf, tl, plan.n, p, tid);
+            else
+                inplace_stage_dispatch<BLOCK, 0, false> (r, gin, gout, buf, tl, plan.n, p, tid);
+        }
         else if (last)
             inplace_stage_dispatch<BLOCK, 2, SWAP> (r, gin, gout, buf, tw, plan.n, p, tid);
         else
@@ -391,7 +418,7 @@ __device__ __forceinline__ void inplace_core (const GenericPlan& plan, const flo
 }
 
 // same MODEs as generic_kernel; one frame per workgroup pass
-template <int MODE, bool INV, int BLOCK>
+template <int MODE, bool INV, int BLOCK, bool TWLDS>
 __global__ __launch_bounds__ (BLOCK) void generic_inplace_kernel (const float2* __restrict__ in,
                                                                  float2* __restrict__ out,
                                                                  const float2* __restrict__ twtab,
@@ -404,6 +431,13 @@ __global__ __launch_bounds__ (BLOCK) void generic_inplace_kernel (const float2* 
     const int n = plan.n;
     const int half = n / 2 + 1;
     float2* buf = smem;
+    float2* twl = smem + n;
+    if constexpr (TWLDS)
+    {
+        for (int i = tid; i < plan.lds_tw_len; i += BLOCK)
+            twl[i] = twtab[plan.tw_offset[0] + i];
+        // the first barrier of the frame loop orders these writes before any stage
+    }
     for (unsigned g = blockIdx.x; g < batch; g += gridDim.x)
     {
         const float2* __restrict__ src = in + (size_t) g * plan.in_stride;
@@ -436,7 +470,7 @@ __global__ __launch_bounds__ (BLOCK) void generic_inplace_kernel (const float2* 
             __syncthreads();
         }
         constexpr bool IN_GLOBAL = (MODE != 2), OUT_GLOBAL = (MODE != 1);
-        inplace_core<BLOCK, IN_GLOBAL, OUT_GLOBAL, (MODE == 2) || INV> (plan, twtab, buf, src, dst, tid);
+        inplace_core<BLOCK, IN_GLOBAL, OUT_GLOBAL, (MODE == 2) || INV, TWLDS> (plan, twtab, twl, buf, src, dst, tid);
         if (MODE == 1)
         {
             for (int k = tid; k < half; k += BLOCK)

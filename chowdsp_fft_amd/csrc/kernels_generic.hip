@@ -9,11 +9,21 @@ namespace cfft::host
 {
 namespace
 {
-template <int MODE, bool INV, int BLOCK>
-hipError_t launch_generic_mb (const GenericPlan& plan, const DeviceTables& t, const float2* in, float2* out, size_t batch, hipStream_t stream)
+// CHOWDSP_FFT_GENERIC_TW_LDS: 0 = stage twiddles from L2 everywhere (the round-1 form), default 1 = from LDS where they fit
+inline bool generic_tw_lds_enabled()
 {
-    auto kernel = generic_kernel<MODE, INV, BLOCK>;
-    const size_t lds = (size_t) 2 * plan.frames * plan.n * sizeof (float2);
+    static const bool off = [] {
+        const char* e = std::getenv ("CHOWDSP_FFT_GENERIC_TW_LDS");
+        return e != nullptr && std::atoi (e) == 0;
+    }();
+    return ! off;
+}
+
+template <int MODE, bool INV, int BLOCK, bool TWLDS>
+hipError_t launch_generic_mb_tw (const GenericPlan& plan, const DeviceTables& t, const float2* in, float2* out, size_t batch, hipStream_t stream)
+{
+    auto kernel = generic_kernel<MODE, INV, BLOCK, TWLDS>;
+    const size_t lds = ((size_t) 2 * plan.frames * plan.n + (TWLDS ? (size_t) plan.n : 0)) * sizeof (float2);
     if (lds > 64 * 1024)
     {
         const hipError_t e = hipFuncSetAttribute ((const void*) kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
@@ -28,16 +38,69 @@ hipError_t launch_generic_mb (const GenericPlan& plan, const DeviceTables& t, co
     return hipGetLastError();
 }
 
+// the stage twiddles ride in LDS wherever the n - 1 values fit behind the two images (generic_kernels.hpp: TWLDS)
 template <int MODE, bool INV, int BLOCK>
-hipError_t launch_generic_inplace (const GenericPlan& plan, const DeviceTables& t, const float2* in, float2* out, size_t batch, hipStream_t stream)
+hipError_t launch_generic_mb (const GenericPlan& plan, const DeviceTables& t, const float2* in, float2* out, size_t batch, hipStream_t stream)
 {
-    auto kernel = generic_inplace_kernel<MODE, INV, BLOCK>;
-    const size_t lds = (size_t) plan.n * sizeof (float2);
+    DeviceInfo dev;
+    if (! current_device_info (dev))
+        return hipErrorNoDevice;
+    const size_t with_table = ((size_t) 2 * plan.frames * plan.n + (size_t) plan.n) * sizeof (float2);
+    if (generic_tw_lds_enabled() && with_table <= dev.lds_per_cu)
+        return launch_generic_mb_tw<MODE, INV, BLOCK, true> (plan, t, in, out, batch, stream);
+    return launch_generic_mb_tw<MODE, INV, BLOCK, false> (plan, t, in, out, batch, stream);
+}
+
+template <int MODE, bool INV, int BLOCK, bool TWLDS>
+hipError_t launch_generic_inplace_tw (const GenericPlan& plan, const DeviceTables& t, const float2* in, float2* out, size_t batch, hipStream_t stream)
+{
+    auto kernel = generic_inplace_kernel<MODE, INV, BLOCK, TWLDS>;
+    const size_t lds = ((size_t) plan.n + (TWLDS ? (size_t) plan.lds_tw_len : 0)) * sizeof (float2);
     const unsigned grid = persistent_grid (kernel, BLOCK, lds, batch); // raises the dynamic-LDS cap when lds > 64 KiB
     if (grid == 0)
         return hipErrorNoDevice;
     hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (BLOCK), lds, stream, in, out, (const float2*) t.stage_twiddles, (const float2*) t.real_twiddles, plan, (unsigned) batch);
     return hipGetLastError();
+}
+
+// The tables of as many leading stages as fit ride in LDS behind the image (generic_kernels.hpp: TWLDS) -- as long as that
+// costs no workgroup per CU: the budget is the CU's LDS divided by the workgroups the plain kernel gets, and the table
+// kernel (a few more registers) must reach the same count with its larger allocation.
+template <int MODE, bool INV, int BLOCK>
+hipError_t launch_generic_inplace (GenericPlan plan, const DeviceTables& t, const float2* in, float2* out, size_t batch, hipStream_t stream)
+{
+    DeviceInfo dev;
+    if (! current_device_info (dev))
+        return hipErrorNoDevice;
+    plan.lds_stages = 0;
+    plan.lds_tw_len = 0;
+    if (generic_tw_lds_enabled())
+    {
+        const size_t image = (size_t) plan.n * sizeof (float2);
+        const int wgs = blocks_per_cu_cached ((const void*) generic_inplace_kernel<MODE, INV, BLOCK, false>, BLOCK, image);
+        const size_t per_wg = dev.lds_per_cu / (size_t) std::max (1, wgs);
+        const size_t room = per_wg > image ? (per_wg - image) / sizeof (float2) : 0;
+        int p = 1;
+        size_t len = 0;
+        int stages = 0;
+        for (int s = 0; s < plan.ns; ++s)
+        {
+            const size_t stage_len = (size_t) (plan.radix[s] - 1) * (size_t) p;
+            if (len + stage_len > room)
+                break;
+            len += stage_len;
+            stages = s + 1;
+            p *= plan.radix[s];
+        }
+        if (stages > 1 // stage 0 has no twiddles (p == 1)
+            && blocks_per_cu_cached ((const void*) generic_inplace_kernel<MODE, INV, BLOCK, true>, BLOCK, image + len * sizeof (float2)) >= wgs)
+        {
+            plan.lds_stages = stages;
+            plan.lds_tw_len = (int) len;
+            return launch_generic_inplace_tw<MODE, INV, BLOCK, true> (plan, t, in, out, batch, stream);
+        }
+    }
+    return launch_generic_inplace_tw<MODE, INV, BLOCK, false> (plan, t, in, out, batch, stream);
 }
 
 template <int MODE, bool INV>

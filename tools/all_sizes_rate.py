@@ -12,6 +12,8 @@ from chowdsp_fft_amd import api  # noqa: E402
 dev = torch.device("cuda:0")
 sizes = [(1 << lg, True) for lg in range(4, 22)] + [(1 << lg, False) for lg in range(5, 22)]
 sizes += [(n, True) for n in (480, 640, 768, 1536, 5120, 9216, 19200, 20736, 46080, 245760)] + [(9216, False), (41472, False)]
+if len(sys.argv) > 1:  # subset: "c480,c768,r9216"
+    sizes = [(int(t[1:]), t[0] == "c") for t in sys.argv[1].split(",")]
 for n, cplx in sizes:
     nf = 2 * n if cplx else n
     batch = max(1, (1 << 28) // nf)  # 1 GiB of fp32 per buffer
