@@ -4,7 +4,11 @@
 // adapter's method does for one: same buffer shapes, same scaling, same layout.
 #include "../../include/chowdsp_fft_gpu.h"
 
+#include "host_common.hpp"
 #include "launch.hpp"
+#include "tables.hpp"
+
+#include <cstdlib>
 
 using namespace cfft::host;
 namespace cf = chowdsp::fft;
@@ -15,6 +19,33 @@ int fail (const char* what, hipError_t e)
 {
     set_last_error (what, e);
     return cf::FFT_GPU_ELAUNCH;
+}
+
+// One launch: the layout conversion is the pair stage's own load / store pattern (real_kernels.hpp: LAYOUT) for every
+// power-of-two N whose half-length core is a plain LDS-resident plan (N <= 16384: every block size an audio host asks a
+// JUCE engine for).  Returns FFT_GPU_OK, an error, or +1 = "no fused form for this setup" (longer / mixed-radix frames: the
+// caller converts in a second launch).
+int fused_real (void* setup, float* inout, size_t batch, bool forward, bool mirror, hipStream_t stream, const char* what)
+{
+    static const bool off = [] {
+        const char* e = std::getenv ("CHOWDSP_FFT_JUCE_FUSED");
+        return e != nullptr && std::atoi (e) == 0;
+    }();
+    Setup* s = as_setup (setup);
+    if (off || s == nullptr || s->tables == nullptr)
+        return 1;
+    const DeviceTables* t = s->tables;
+    const int m = s->N / 2;
+    if (t->gen_ns > 0 || t->real4_r1 > 0 || t->mixed_n2 > 0 || t->core_n != m || m > 8192 || (m & (m - 1)) != 0)
+        return 1;
+    const DeviceGuard guard (s->device);
+    const hipError_t e = launch_real_juce (m, forward, (float2*) inout, t->stage_twiddles, t->real_twiddles, batch, stream, mirror, 1.0f / (float) s->N);
+    if (e == hipErrorNotSupported)
+    {
+        (void) hipGetLastError();
+        return 1;
+    }
+    return e == hipSuccess ? cf::FFT_GPU_OK : fail (what, e);
 }
 } // namespace
 
@@ -45,6 +76,11 @@ int fft_juce_real_forward_batch (void* setup_real, float* inout, size_t batch, i
     const int n = fft_gpu_setup_size (setup_real);
     if (n < 0 || fft_gpu_setup_is_real (setup_real) != 1 || inout == nullptr)
         return FFT_GPU_EINVAL;
+    if (batch == 0)
+        return FFT_GPU_OK;
+    const int fused = fused_real (setup_real, inout, batch, true, ignore_negative_freqs == 0, (hipStream_t) stream, "fft_juce_real_forward_batch: fused launch");
+    if (fused <= 0)
+        return fused;
     const int rc = fft_transform_batch_strided (setup_real, inout, 2 * (size_t) n, inout, 2 * (size_t) n, batch, FFT_FORWARD, stream);
     if (rc != FFT_GPU_OK)
         return rc;
@@ -61,6 +97,11 @@ int fft_juce_real_inverse_batch (void* setup_real, float* inout, size_t batch, v
     const int n = fft_gpu_setup_size (setup_real);
     if (n < 0 || fft_gpu_setup_is_real (setup_real) != 1 || inout == nullptr)
         return FFT_GPU_EINVAL;
+    if (batch == 0)
+        return FFT_GPU_OK;
+    const int fused = fused_real (setup_real, inout, batch, false, false, (hipStream_t) stream, "fft_juce_real_inverse_batch: fused launch");
+    if (fused <= 0)
+        return fused;
     hipError_t e;
     {
         const DeviceGuard guard (fft_gpu_setup_device (setup_real));

@@ -6,6 +6,37 @@ namespace cfft::host
 {
 namespace
 {
+// the JUCE engine's layouts fused into the pair stage (real_kernels.hpp: LAYOUT): frames of 2 M complex slots, in place
+template <int M, bool FWD>
+hipError_t launch_real_juce_m (float2* inout, const float2* tw, const float2* rtw, size_t batch, hipStream_t stream, bool mirror, float scale)
+{
+    using P = typename CorePlan<M>::type;
+    using G = Geometry<P>;
+    if constexpr (M >= kStreamedCoreN)
+        return hipErrorNotSupported; // the caller keeps the two-launch form for these lengths
+    else
+    {
+        const size_t ngroups = (batch + G::FPB - 1) / G::FPB;
+        if constexpr (FWD)
+        {
+            auto kernel = mirror ? &r2c_kernel<P, G::FPB, true, 2> : &r2c_kernel<P, G::FPB, true, 1>;
+            const unsigned grid = persistent_grid (kernel, G::threads, G::lds_bytes_real, ngroups);
+            if (grid == 0)
+                return hipErrorNoDevice;
+            hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (G::threads), G::lds_bytes_real, stream, (const float2*) inout, inout, tw, rtw, (unsigned) batch, (unsigned) (2 * M), (unsigned) (2 * M));
+        }
+        else
+        {
+            auto kernel = &c2r_kernel<P, G::FPB, true, 1>;
+            const unsigned grid = persistent_grid (kernel, G::threads, G::lds_bytes_real, ngroups);
+            if (grid == 0)
+                return hipErrorNoDevice;
+            hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (G::threads), G::lds_bytes_real, stream, (const float2*) inout, inout, tw, rtw, (unsigned) batch, (unsigned) (2 * M), (unsigned) (2 * M), scale);
+        }
+        return hipGetLastError();
+    }
+}
+
 template <int M, bool FWD>
 hipError_t launch_real_m (const float2* in, float2* out, const float2* tw, const float2* rtw, size_t batch, hipStream_t stream, unsigned in_stride, unsigned out_stride)
 {
@@ -75,7 +106,7 @@ hipError_t launch_real_m (const float2* in, float2* out, const float2* tw, const
         const unsigned grid = persistent_grid (kernel, G::threads, G::lds_bytes_real, ngroups);
         if (grid == 0)
             return hipErrorNoDevice;
-        hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (G::threads), G::lds_bytes_real, stream, in, out, tw, rtw, (unsigned) batch, in_stride ? in_stride : (unsigned) M, out_stride ? out_stride : (unsigned) M);
+        hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (G::threads), G::lds_bytes_real, stream, in, out, tw, rtw, (unsigned) batch, in_stride ? in_stride : (unsigned) M, out_stride ? out_stride : (unsigned) M, 1.0f);
     }
     return hipGetLastError();
     }
@@ -90,6 +121,23 @@ hipError_t launch_r2c (int m, const float2* in, float2* out, const float2* stage
         return hipErrorInvalidValue;
     CFFT_DISPATCH_CORE_N (m, return (launch_real_m<N_, true> (in, out, stage_tw, real_tw, batch, stream, (unsigned) in_stride, (unsigned) out_stride)));
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_real_juce (int m, bool forward, float2* inout, const float2* stage_tw, const float2* real_tw, size_t batch, hipStream_t stream, bool mirror, float scale)
+{
+    if (batch == 0)
+        return hipSuccess;
+    if (batch > 0x7FFFFFFFull || (size_t) 2 * (size_t) m > kMaxFrameStride)
+        return hipErrorInvalidValue;
+    if (forward)
+    {
+        CFFT_DISPATCH_CORE_N (m, return (launch_real_juce_m<N_, true> (inout, stage_tw, real_tw, batch, stream, mirror, scale)));
+    }
+    else
+    {
+        CFFT_DISPATCH_CORE_N (m, return (launch_real_juce_m<N_, false> (inout, stage_tw, real_tw, batch, stream, mirror, scale)));
+    }
+    return hipErrorNotSupported;
 }
 
 hipError_t launch_c2r (int m, const float2* in, float2* out, const float2* stage_tw, const float2* real_tw, size_t batch, hipStream_t stream, size_t in_stride, size_t out_stride)

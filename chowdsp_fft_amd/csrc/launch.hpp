@@ -87,6 +87,9 @@ hipError_t launch_generic (int mode, bool inverse, int nc, const DeviceTables& t
 hipError_t launch_column_fft (bool inverse, int rows, int cols, const DeviceTables& t, float2* data, size_t batch, hipStream_t stream);
 
 // layout conversions of the JUCE-engine adapter (kernels_layout.hip); data = batch frames of 2*m float2
+// real transform with the JUCE engine's layout fused into the pair stage, in place on frames of 4 m floats; hipErrorNotSupported
+// for core lengths without a fused form (the caller then converts in a second launch)
+hipError_t launch_real_juce (int m, bool forward, float2* inout, const float2* stage_tw, const float2* real_tw, size_t batch, hipStream_t stream, bool mirror, float scale);
 hipError_t launch_juce_unpack (float2* data, unsigned m, size_t batch, bool mirror, hipStream_t stream);
 hipError_t launch_juce_pack_scale (float2* data, unsigned m, size_t batch, float scale, hipStream_t stream);
 hipError_t launch_scale (float* data, size_t count, float scale, hipStream_t stream); // count % 4 == 0

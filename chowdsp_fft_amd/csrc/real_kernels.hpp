@@ -76,7 +76,11 @@ __device__ __forceinline__ void real_merge_pair (float2 A, float2 Xmk, float2 w,
 
 // ---- r2c -----------------------------------------------------------------------------------------
 // P is the plan of the M = N/2 point complex core.
-template <class P, int FPB, bool STRIDED>
+// LAYOUT 0: the packed spectrum.  LAYOUT 1 / 2: the JUCE engine's interleaved layout written by the pair stage itself
+// (chowdsp_fft_juce/chowdsp_fft_juce.cpp:57-66): frames of 2 M complex slots, c[0] = (X0, 0), c[k] = X_k, c[M] = (X_{N/2}, 0),
+// and for LAYOUT 2 also c[2 M - k] = conj X_k -- the same values through a different store pattern, in place of a second
+// launch over the frames.
+template <class P, int FPB, bool STRIDED, int LAYOUT = 0>
 __global__ __launch_bounds__ (P::T* FPB) void r2c_kernel (const float2* __restrict__ in,
                                                          float2* __restrict__ out,
                                                          const float2* __restrict__ twtab,
@@ -134,6 +138,7 @@ __global__ __launch_bounds__ (P::T* FPB) void r2c_kernel (const float2* __restri
         lds_store_output_order<P> (v, lds, t);
         team_sync<P::T>();
 
+        float2 hi_k[(STAGED && LAYOUT == 2) ? P::R / 2 : 1], hi_p[(STAGED && LAYOUT == 2) ? P::R / 2 : 1]; // the conjugate half's values
 #pragma unroll
         for (int q = 0; q < P::R / 2; ++q)
         {
@@ -150,19 +155,62 @@ __global__ __launch_bounds__ (P::T* FPB) void r2c_kernel (const float2* __restri
             }
             if constexpr (STAGED)
             {
-                stage[team_base + (unsigned) k] = Xk;
+                // LAYOUT 1 / 2: bins 0 .. M - 1 leave through the staged copy like the packed spectrum; bin M on its own
+                // (LAYOUT 1) or with the conjugate half in a second staged copy below (LAYOUT 2)
+                stage[team_base + (unsigned) k] = (LAYOUT != 0 && k == 0) ? make_float2 (Xk.x, 0.f) : Xk;
                 stage[team_base + (unsigned) (k == 0 ? M / 2 : M - k)] = Xp;
+                if (LAYOUT == 1 && k == 0 && active)
+                    gstore (&dst[team_out + (unsigned) M], make_float2 (Xk.y, 0.f));
+                if constexpr (LAYOUT == 2)
+                {
+                    hi_k[q] = (k == 0) ? make_float2 (Xk.y, 0.f) : make_float2 (Xp.x, -Xp.y);  // slot M + k = conj X_{M-k}
+                    hi_p[q] = (k == 0) ? make_float2 (Xp.x, -Xp.y) : make_float2 (Xk.x, -Xk.y); // slot M + (M - k) = conj X_k
+                }
             }
             else if (active)
             {
-                gstore (&dst[team_out + (unsigned) k], Xk);
-                gstore (&dst[team_out + (unsigned) (k == 0 ? M / 2 : M - k)], Xp);
+                const unsigned kp = (unsigned) (k == 0 ? M / 2 : M - k);
+                if constexpr (LAYOUT == 0)
+                {
+                    gstore (&dst[team_out + (unsigned) k], Xk);
+                    gstore (&dst[team_out + kp], Xp);
+                }
+                else
+                {
+                    if (k == 0)
+                    {
+                        gstore (&dst[team_out], make_float2 (Xk.x, 0.f));
+                        gstore (&dst[team_out + (unsigned) M], make_float2 (Xk.y, 0.f));
+                    }
+                    else
+                    {
+                        gstore (&dst[team_out + (unsigned) k], Xk);
+                        if constexpr (LAYOUT == 2)
+                            gstore (&dst[team_out + (unsigned) (2 * M - k)], make_float2 (Xk.x, -Xk.y));
+                    }
+                    gstore (&dst[team_out + kp], Xp);
+                    if constexpr (LAYOUT == 2)
+                        gstore (&dst[team_out + (unsigned) (2 * M) - kp], make_float2 (Xp.x, -Xp.y));
+                }
             }
         }
         if constexpr (STAGED)
         {
             __syncthreads();
             stage_out_strided<P::T * FPB, FPB * M, M> (dst, out_stride, stage, valid, tid);
+            if constexpr (LAYOUT == 2)
+            {
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < P::R / 2; ++q)
+                {
+                    const int k = t + P::T * q;
+                    stage[team_base + (unsigned) k] = hi_k[q];
+                    stage[team_base + (unsigned) (k == 0 ? M / 2 : M - k)] = hi_p[q];
+                }
+                __syncthreads();
+                stage_out_strided<P::T * FPB, FPB * M, M> (dst + M, out_stride, stage, valid, tid);
+            }
         }
     }
 }
@@ -286,14 +334,18 @@ __global__ __launch_bounds__ (P::T* FPB) void r2c_kernel_pf (const float2* __res
 }
 
 // ---- c2r -----------------------------------------------------------------------------------------
-template <class P, int FPB, bool STRIDED>
+// LAYOUT 1: the spectrum comes in the JUCE engine's interleaved layout (X0 = c[0].re, X_{N/2} = c[M].re,
+// chowdsp_fft_juce.cpp:71-73) and the signal is stored times `scale` (the adapter's 1/N, :85) -- one launch instead of a
+// repacking pass over the frames before the transform.
+template <class P, int FPB, bool STRIDED, int LAYOUT = 0>
 __global__ __launch_bounds__ (P::T* FPB) void c2r_kernel (const float2* __restrict__ in,
                                                          float2* __restrict__ out,
                                                          const float2* __restrict__ twtab,
                                                          const float2* __restrict__ wtab,
                                                          unsigned batch,
                                                          unsigned in_stride_arg,
-                                                         unsigned out_stride_arg)
+                                                         unsigned out_stride_arg,
+                                                         float scale)
 {
     CFFT_FRAME_STRIDES (STRIDED, P::N);
     extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
@@ -333,10 +385,15 @@ __global__ __launch_bounds__ (P::T* FPB) void c2r_kernel (const float2* __restri
         {
             const int k = t + P::T * q;
             const int kq = (k == 0 ? M / 2 : M - k);
-            const float2 A = STAGED ? stage[team_base + (unsigned) k]
-                                    : (active ? gload (&src[team_in + (unsigned) k]) : make_float2 (0.f, 0.f));
+            float2 A = STAGED ? stage[team_base + (unsigned) k]
+                              : (active ? gload (&src[team_in + (unsigned) k]) : make_float2 (0.f, 0.f));
             const float2 Xp = STAGED ? stage[team_base + (unsigned) kq]
                                      : (active ? gload (&src[team_in + (unsigned) kq]) : make_float2 (0.f, 0.f));
+            if constexpr (LAYOUT == 1)
+            {
+                if (k == 0)
+                    A.y = active ? gload (&src[team_in + (unsigned) M]).x : 0.f; // packed slot 0 = (X0.re, X_{N/2}.re)
+            }
             real_merge_pair (A, Xp, pw.w[q], zk[q], zp[q]);
             if (k == 0)
             {
@@ -358,6 +415,12 @@ __global__ __launch_bounds__ (P::T* FPB) void c2r_kernel (const float2* __restri
         lds_load_input_order<P> (v, lds, t);
         team_sync<P::T>();
         fft_core<P> (v, tw, lds, t);
+        if constexpr (LAYOUT != 0)
+        {
+#pragma unroll
+            for (int s = 0; s < P::R; ++s)
+                v[s] = make_float2 (v[s].x * scale, v[s].y * scale);
+        }
         if constexpr (STAGED)
         {
 #pragma unroll

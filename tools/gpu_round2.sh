@@ -42,4 +42,7 @@ done
 echo "== all-sizes rate table"
 timeout 900 python tools/all_sizes_rate.py > "$OUT/all_sizes.txt" 2>/dev/null || true
 tail -5 "$OUT/all_sizes.txt"
+echo "== JUCE-engine adapter: fused layouts vs the two-launch form"
+{ echo "# fused (default)"; timeout 200 python tools/juce_rate.py 5 7 9 10 12 14; echo "# CHOWDSP_FFT_JUCE_FUSED=0 (two launches)"; CHOWDSP_FFT_JUCE_FUSED=0 timeout 200 python tools/juce_rate.py 5 7 9 10 12 14; } > "$OUT/juce_rates.txt" 2>/dev/null || true
+tail -4 "$OUT/juce_rates.txt"
 echo "== done"
