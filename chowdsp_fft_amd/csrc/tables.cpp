@@ -327,9 +327,9 @@ bool build_host_tables (int N, int transform, HostTables& out)
         // long real frame: four-step on the real data.  Stage tables of the two cores (columns first), then W_N^{a kb} in the
         // workspace's order [column tile tA][kb <= r2/2][32], a = 32 tA + al
         const char* evr = std::getenv ("CHOWDSP_FFT_FAST_TILES");
-        // measured (forward, TB/s algorithmic, register-direct vs LDS-staged tiles): 2^17 2.36 vs 2.13, 2^18 2.19 vs 1.88,
-        // 2^19 2.12 vs 1.69, 2^20 1.79 vs 1.85 (its column pass reads 1024 rows 4 KiB apart): the last one keeps the staged tiles
-        if (! (evr != nullptr && evr[0] == '0') && N < (1 << 20))
+        // measured (forward / backward, TB/s algorithmic, register-direct vs LDS-staged tiles): 2^17 2.4 / 2.6 vs 2.1, 2^18 2.3 / 2.6
+        // vs 1.9, 2^19 2.3 / 2.4 vs 1.7, 2^20 2.1 / 2.2 vs 1.8 / 1.5
+        if (! (evr != nullptr && evr[0] == '0'))
         {
             // register-direct tiles (tile_fast_kernels.hpp): factorised stage-1 rows of the column core (q2) then of the row
             // core (q1); forward inter-pass table [a][kb < q2/2 + 16] (W_N^{a kb}, padding rows 1), backward table [kb <= q2/2][a]

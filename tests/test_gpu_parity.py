@@ -91,13 +91,15 @@ def test_two_pass_sizes_vs_oracle(gpu, oracle, n, tr):
 
 
 def test_one_million_point_frames(gpu, oracle):
-    """largest accepted size (2^20): one frame, complex and real"""
+    """2^20 (the largest size of the power-of-two tile kernels): forward and backward, complex and real, two frames"""
     api = gpu[0]
     for tr in (COMPLEX, REAL):
         n = 1 << 20
-        x = ol.uniform(_frame(n, tr), 5).reshape(1, -1)
+        x = ol.uniform(2 * _frame(n, tr), 5).reshape(2, -1)
         s, so = api.fft_new_setup(n, tr), oracle.new_setup(n, tr)
-        assert_frames_close(_gpu_transform(gpu, s, x, api.FFT_FORWARD), oracle.transform_batch(so, x, FORWARD), what="2^20")
+        want_f = oracle.transform_batch(so, x, FORWARD)
+        assert_frames_close(_gpu_transform(gpu, s, x, api.FFT_FORWARD), want_f, what="2^20 fwd")
+        assert_frames_close(_gpu_transform(gpu, s, want_f, api.FFT_BACKWARD), oracle.transform_batch(so, want_f, BACKWARD), what="2^20 bwd")
         api.fft_destroy_setup(s)
         oracle.destroy_setup(so)
 
