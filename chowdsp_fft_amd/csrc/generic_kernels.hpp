@@ -505,8 +505,9 @@ __global__ __launch_bounds__ (BLOCK) void generic_inplace_kernel (const float2* 
 // writes them, times W_N^{a kb}, in the same tile-major workspace layout as pass_a_kernel; pass B is then the ordinary
 // power-of-two pass_b_kernel.  LDS: two images of 16 frames of n2 + 1 points (the + 1 keeps the 16 lanes that walk
 // across frames while the tile is loaded / stored off each other's banks).
-template <bool SWAP_IN, int CA>
-__global__ __launch_bounds__ (256) void pass_a_generic_kernel (const float2* __restrict__ in,
+// BLOCK: 256 work-items, or 1024 where the two images leave room for only one workgroup per CU (4 waves would be all a CU has)
+template <bool SWAP_IN, int CA, int BLOCK>
+__global__ __launch_bounds__ (BLOCK) void pass_a_generic_kernel (const float2* __restrict__ in,
                                                               float2* __restrict__ work,
                                                               const float2* __restrict__ twtab,
                                                               const float2* __restrict__ big_tw,
@@ -533,15 +534,15 @@ __global__ __launch_bounds__ (256) void pass_a_generic_kernel (const float2* __r
         float2* __restrict__ dst = work + (size_t) f * ws_frame_len + (size_t) tile * ((size_t) n2 * CA);
         const float2* __restrict__ twp = big_tw + (size_t) tile * ((size_t) n2 * CA);
         __syncthreads(); // previous tile fully stored
-        for (int e = tid; e < CA * n2; e += 256)
+        for (int e = tid; e < CA * n2; e += BLOCK)
         {
             const int c = e % CA, j = e / CA;
             const float2 x = c < valid ? gload (&src[(size_t) j * n1 + c]) : make_float2 (0.f, 0.f);
             bufA[c * lfs + j] = SWAP_IN ? make_float2 (x.y, x.x) : x;
         }
         __syncthreads();
-        const float2* res = generic_core<256, false, false, false> (plan, twtab, bufA, bufB, nullptr, nullptr, CA, tid, lfs);
-        for (int e = tid; e < CA * n2; e += 256)
+        const float2* res = generic_core<BLOCK, false, false, false> (plan, twtab, bufA, bufB, nullptr, nullptr, CA, tid, lfs);
+        for (int e = tid; e < CA * n2; e += BLOCK)
         {
             const int c = e % CA, k = e / CA;
             dst[e] = cmul (res[c * lfs + k], twp[e]); // plain store: the workspace should stay cached (padding columns: zeros)
@@ -552,8 +553,8 @@ __global__ __launch_bounds__ (256) void pass_a_generic_kernel (const float2* __r
 // Row pass of the same plans when the row length n1 is not a power of two either (and for powers of two beyond the
 // compile-time cores): n1-point FFTs of CB adjacent rows kb with the run-time stage list, read from pass A's tile-major
 // workspace [tile tA][kb][c] (CA columns per tile), stored transposed to X[n2 ka + kb].  n2 need not be a multiple of CB.
-template <bool SWAP_OUT, int CB>
-__global__ __launch_bounds__ (256) void pass_b_generic_kernel (const float2* __restrict__ work,
+template <bool SWAP_OUT, int CB, int BLOCK>
+__global__ __launch_bounds__ (BLOCK) void pass_b_generic_kernel (const float2* __restrict__ work,
                                                               float2* __restrict__ out,
                                                               const float2* __restrict__ twtab,
                                                               GenericPlan plan, // n = n1, frames = CB
@@ -581,7 +582,7 @@ __global__ __launch_bounds__ (256) void pass_b_generic_kernel (const float2* __r
         float2* __restrict__ dst = out + (size_t) f * out_stride + kb0;
         __syncthreads();
         // element (row kbl, column a): c = a % ca fastest (contiguous in the workspace), then the row, then pass A's tile
-        for (int e = tid; e < CB * n1; e += 256)
+        for (int e = tid; e < CB * n1; e += BLOCK)
         {
             const unsigned a = (unsigned) e % (unsigned) n1, kbl = (unsigned) e / (unsigned) n1;
             const unsigned tA = a / ca, c = a % ca;
@@ -589,8 +590,8 @@ __global__ __launch_bounds__ (256) void pass_b_generic_kernel (const float2* __r
             bufA[kbl * lfs + a] = x;
         }
         __syncthreads();
-        const float2* res = generic_core<256, false, false, false> (plan, twtab, bufA, bufB, nullptr, nullptr, CB, tid, lfs);
-        for (int e = tid; e < CB * n1; e += 256)
+        const float2* res = generic_core<BLOCK, false, false, false> (plan, twtab, bufA, bufB, nullptr, nullptr, CB, tid, lfs);
+        for (int e = tid; e < CB * n1; e += BLOCK)
         {
             const int c = e % CB, k = e / CB;
             if (c < valid)
@@ -607,8 +608,8 @@ __global__ __launch_bounds__ (256) void pass_b_generic_kernel (const float2* __r
 // column, in place.  Same tile scheme as the two-pass column pass above -- C adjacent columns staged through LDS so that
 // every global access touches C * 8 contiguous bytes, the FFTs by the run-time stage list -- without the inter-pass
 // twiddle, and stored back where it came from.  cols need not be a multiple of C.
-template <bool SWAP, int C>
-__global__ __launch_bounds__ (256) void column_fft_kernel (float2* __restrict__ data,
+template <bool SWAP, int C, int BLOCK>
+__global__ __launch_bounds__ (BLOCK) void column_fft_kernel (float2* __restrict__ data,
                                                           const float2* __restrict__ twtab,
                                                           GenericPlan plan, // n = rows, frames = C
                                                           unsigned cols,
@@ -630,15 +631,15 @@ __global__ __launch_bounds__ (256) void column_fft_kernel (float2* __restrict__ 
         const int valid = (int) min ((unsigned) C, cols - tile * C);
         float2* __restrict__ base = data + (size_t) f * array_stride + (size_t) tile * C;
         __syncthreads(); // previous tile fully stored
-        for (int e = tid; e < C * rows; e += 256)
+        for (int e = tid; e < C * rows; e += BLOCK)
         {
             const int c = e % C, j = e / C;
             const float2 x = c < valid ? gload (&base[(size_t) j * cols + c]) : make_float2 (0.f, 0.f);
             bufA[c * lfs + j] = SWAP ? make_float2 (x.y, x.x) : x;
         }
         __syncthreads();
-        const float2* res = generic_core<256, false, false, false> (plan, twtab, bufA, bufB, nullptr, nullptr, C, tid, lfs);
-        for (int e = tid; e < C * rows; e += 256)
+        const float2* res = generic_core<BLOCK, false, false, false> (plan, twtab, bufA, bufB, nullptr, nullptr, C, tid, lfs);
+        for (int e = tid; e < C * rows; e += BLOCK)
         {
             const int c = e % C, k = e / C;
             if (c < valid)

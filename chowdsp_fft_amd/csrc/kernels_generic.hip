@@ -199,13 +199,18 @@ hipError_t launch_column_fft (bool inverse, int rows, int cols, const DeviceTabl
     const size_t lds = (size_t) 2 * c * lfs * sizeof (float2);
     if (lds > dev.lds_per_cu)
         return hipErrorInvalidValue;
-    auto k = c == 16 ? (inverse ? column_fft_kernel<true, 16> : column_fft_kernel<false, 16>)
-             : c == 8 ? (inverse ? column_fft_kernel<true, 8> : column_fft_kernel<false, 8>)
-                      : (inverse ? column_fft_kernel<true, 4> : column_fft_kernel<false, 4>);
-    const unsigned grid = persistent_grid (k, 256, lds, batch * (size_t) ((cols + c - 1) / c));
+    const int block = generic_tile_block (lds, dev.lds_per_cu);
+    auto k256 = c == 16 ? (inverse ? column_fft_kernel<true, 16, 256> : column_fft_kernel<false, 16, 256>)
+                : c == 8 ? (inverse ? column_fft_kernel<true, 8, 256> : column_fft_kernel<false, 8, 256>)
+                         : (inverse ? column_fft_kernel<true, 4, 256> : column_fft_kernel<false, 4, 256>);
+    auto k1024 = c == 16 ? (inverse ? column_fft_kernel<true, 16, 1024> : column_fft_kernel<false, 16, 1024>)
+                 : c == 8 ? (inverse ? column_fft_kernel<true, 8, 1024> : column_fft_kernel<false, 8, 1024>)
+                          : (inverse ? column_fft_kernel<true, 4, 1024> : column_fft_kernel<false, 4, 1024>);
+    auto k = block == 1024 ? k1024 : k256;
+    const unsigned grid = persistent_grid (k, block, lds, batch * (size_t) ((cols + c - 1) / c));
     if (grid == 0)
         return hipErrorNoDevice;
-    hipLaunchKernelGGL (k, dim3 (grid), dim3 (256), lds, stream, data, (const float2*) t.stage_twiddles, plan, (unsigned) cols, (unsigned) batch, (size_t) rows * (size_t) cols, lfs);
+    hipLaunchKernelGGL (k, dim3 (grid), dim3 (block), lds, stream, data, (const float2*) t.stage_twiddles, plan, (unsigned) cols, (unsigned) batch, (size_t) rows * (size_t) cols, lfs);
     return hipGetLastError();
 }
 } // namespace cfft::host

@@ -442,14 +442,19 @@ hipError_t launch_mixed_big_c2c (const DeviceTables& t, bool inverse, const floa
     if (lds > dev.lds_per_cu)
         return hipErrorInvalidValue;
     const size_t ws_frame_len = (size_t) ((n1 + ca - 1) / ca) * (size_t) ca * (size_t) n2; // = n1 * n2 unless the last tile is ragged
-    auto ka = ca == 16 ? (inverse ? pass_a_generic_kernel<true, 16> : pass_a_generic_kernel<false, 16>)
-              : ca == 8 ? (inverse ? pass_a_generic_kernel<true, 8> : pass_a_generic_kernel<false, 8>)
-                        : (inverse ? pass_a_generic_kernel<true, 4> : pass_a_generic_kernel<false, 4>);
-    unsigned grid = persistent_grid (ka, 256, lds, batch * (size_t) ((n1 + ca - 1) / ca));
+    const int block_a = generic_tile_block (lds, dev.lds_per_cu);
+    auto ka256 = ca == 16 ? (inverse ? pass_a_generic_kernel<true, 16, 256> : pass_a_generic_kernel<false, 16, 256>)
+                 : ca == 8 ? (inverse ? pass_a_generic_kernel<true, 8, 256> : pass_a_generic_kernel<false, 8, 256>)
+                           : (inverse ? pass_a_generic_kernel<true, 4, 256> : pass_a_generic_kernel<false, 4, 256>);
+    auto ka1024 = ca == 16 ? (inverse ? pass_a_generic_kernel<true, 16, 1024> : pass_a_generic_kernel<false, 16, 1024>)
+                  : ca == 8 ? (inverse ? pass_a_generic_kernel<true, 8, 1024> : pass_a_generic_kernel<false, 8, 1024>)
+                            : (inverse ? pass_a_generic_kernel<true, 4, 1024> : pass_a_generic_kernel<false, 4, 1024>);
+    auto ka = block_a == 1024 ? ka1024 : ka256;
+    unsigned grid = persistent_grid (ka, block_a, lds, batch * (size_t) ((n1 + ca - 1) / ca));
     if (grid == 0)
         return hipErrorNoDevice;
     grid = std::max (1u, grid / (unsigned) grid_divisor);
-    hipLaunchKernelGGL (ka, dim3 (grid), dim3 (256), lds, stream, in, work, (const float2*) t.stage_twiddles, (const float2*) t.big_twiddles, plan, (unsigned) n1, (unsigned) batch, in_stride, lfs, ws_frame_len);
+    hipLaunchKernelGGL (ka, dim3 (grid), dim3 (block_a), lds, stream, in, work, (const float2*) t.stage_twiddles, (const float2*) t.big_twiddles, plan, (unsigned) n1, (unsigned) batch, in_stride, lfs, ws_frame_len);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return e;
@@ -475,14 +480,19 @@ hipError_t launch_mixed_big_c2c (const DeviceTables& t, bool inverse, const floa
         const size_t ldsb = (size_t) 2 * cb * lfsb * sizeof (float2);
         if (ldsb > dev.lds_per_cu)
             return hipErrorInvalidValue;
-        auto kb = cb == 16 ? (inverse ? pass_b_generic_kernel<true, 16> : pass_b_generic_kernel<false, 16>)
-                  : cb == 8 ? (inverse ? pass_b_generic_kernel<true, 8> : pass_b_generic_kernel<false, 8>)
-                            : (inverse ? pass_b_generic_kernel<true, 4> : pass_b_generic_kernel<false, 4>);
-        unsigned gridb = persistent_grid (kb, 256, ldsb, batch * (size_t) ((n2 + cb - 1) / cb));
+        const int block_b = generic_tile_block (ldsb, dev.lds_per_cu);
+        auto kb256 = cb == 16 ? (inverse ? pass_b_generic_kernel<true, 16, 256> : pass_b_generic_kernel<false, 16, 256>)
+                     : cb == 8 ? (inverse ? pass_b_generic_kernel<true, 8, 256> : pass_b_generic_kernel<false, 8, 256>)
+                               : (inverse ? pass_b_generic_kernel<true, 4, 256> : pass_b_generic_kernel<false, 4, 256>);
+        auto kb1024 = cb == 16 ? (inverse ? pass_b_generic_kernel<true, 16, 1024> : pass_b_generic_kernel<false, 16, 1024>)
+                      : cb == 8 ? (inverse ? pass_b_generic_kernel<true, 8, 1024> : pass_b_generic_kernel<false, 8, 1024>)
+                                : (inverse ? pass_b_generic_kernel<true, 4, 1024> : pass_b_generic_kernel<false, 4, 1024>);
+        auto kb = block_b == 1024 ? kb1024 : kb256;
+        unsigned gridb = persistent_grid (kb, block_b, ldsb, batch * (size_t) ((n2 + cb - 1) / cb));
         if (gridb == 0)
             return hipErrorNoDevice;
         gridb = std::max (1u, gridb / (unsigned) grid_divisor);
-        hipLaunchKernelGGL (kb, dim3 (gridb), dim3 (256), ldsb, stream, (const float2*) work, out, (const float2*) t.stage_twiddles, pb, (unsigned) n2, (unsigned) ca, (unsigned) batch, out_stride, lfsb, ws_frame_len);
+        hipLaunchKernelGGL (kb, dim3 (gridb), dim3 (block_b), ldsb, stream, (const float2*) work, out, (const float2*) t.stage_twiddles, pb, (unsigned) n2, (unsigned) ca, (unsigned) batch, out_stride, lfsb, ws_frame_len);
         return hipGetLastError();
     }
     const float2* tw1 = t.stage_twiddles + t.mixed_tw1_offset;

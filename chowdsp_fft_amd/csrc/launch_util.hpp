@@ -1,5 +1,6 @@
 // Helpers shared by the kernels_*.hip launch files.
 #pragma once
+#include <cstdlib>
 #include "launch.hpp"
 #include "plans.hpp"
 
@@ -20,6 +21,23 @@ inline unsigned persistent_grid (K kernel, int threads, size_t lds_bytes, size_t
     const int per_cu = blocks_per_cu_cached ((const void*) kernel, threads, lds_bytes);
     const size_t resident = (size_t) dev.num_cus * (size_t) per_cu;
     return (unsigned) std::max<size_t> (1, std::min (work_items, resident));
+}
+
+// work-items per workgroup of the generic tile kernels (pass_a_generic / pass_b_generic / column_fft): 1024 where the two LDS
+// images leave room for fewer than four workgroups per CU -- with 256 that CU would run 4 .. 12 waves.  CHOWDSP_FFT_GENERIC_TILE_BLOCK
+// (256 / 1024) overrides for experiments.
+inline int generic_tile_block (size_t lds_bytes, size_t lds_per_cu)
+{
+    static const int forced = [] {
+        const char* e = std::getenv ("CHOWDSP_FFT_GENERIC_TILE_BLOCK");
+        const int v = e != nullptr ? std::atoi (e) : 0;
+        return (v == 256 || v == 1024) ? v : 0;
+    }();
+    if (forced != 0)
+        return forced;
+    // measured (MI355X, complex, fraction of 8 TB/s with 256 / 1024): 46080 0.10 / 0.18, 61440 0.15 / 0.19, 245760 0.15 / 0.18,
+    // 655360 0.11 / 0.18, 2^21 0.07 / 0.10 -- but 20736 (two 18 KiB images, four workgroups per CU) 0.16 / 0.12
+    return 4 * lds_bytes > lds_per_cu ? 1024 : 256;
 }
 
 // run-time n -> compile-time plan dispatch
