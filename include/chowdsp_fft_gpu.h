@@ -179,7 +179,8 @@ int fft_gpu_defer_flush (void);
 /* ---- JUCE FFT-engine layouts on the device (second half of row f3) ------------------------------------------
    Batched counterparts of the three methods of the reference's JUCE adapter
    (chowdsp_fft_juce/chowdsp_fft_juce.cpp:32-86): same buffer shapes, layout and scaling, `batch` device buffers
-   per call instead of one host buffer.
+   per call instead of one host buffer.  For power-of-two N <= 16384 the real methods are ONE launch: the layout is the
+   transform's own store / load pattern; longer and mixed-radix frames run the transform and a layout kernel.
    perform: complex transform, output != or == input, the inverse scaled by 1/N (:32-45). */
 int fft_juce_perform_batch (void* setup_complex, const float* input, float* output, size_t batch, int inverse, void* stream);
 /* performRealOnlyForwardTransform (:47-67): `batch` buffers of 2N floats with the N samples at the start of each;
