@@ -24,7 +24,7 @@ struct GenericPlan
     int ns;                           // number of stages
     int frames;                       // frames per workgroup pass (F)
     unsigned in_stride, out_stride;   // float2 between consecutive frames in global memory (n for packed batches)
-    int radix[kGenericMaxStages];     // each in {2, 3, 4, 5, 8, 16}
+    int radix[kGenericMaxStages];     // each in {2, 3, 4, 5, 6, 8, 9, 10, 12, 15, 16}
     int tw_offset[kGenericMaxStages]; // float2 offset of the stage's table: (radix-1) * p entries, [a-1][k]
     int lds_stages;                   // generic_inplace_kernel: the tables of stages [0, lds_stages) ride in LDS behind the image
     int lds_tw_len;                   // ... that many float2 (the tables are contiguous from tw_offset[0])
@@ -62,6 +62,132 @@ __device__ __forceinline__ void fft_reg<5> (float2 (&u)[5])
     u[3] = make_float2 (m2.x - q2.y, m2.y + q2.x);
 }
 
+// ---- composite radices 6, 9, 10, 12, 15 (round 2) ---------------------------------------------------------------------
+// One stage of radix A * B instead of a stage of radix A and a stage of radix B: one LDS round trip less per merged pair
+// (N = 9216: 3 3 16 8 8 -> 12 12 8 8; 96: 3 8 4 -> 12 8; 1536: 3 8 8 8 -> 12 16 8; 480: 5 3 8 4 -> 15 8 4).  Cooley-Tukey
+// inside the registers, n = n1 + A n2, k = B k1 + k2:
+//     X[B k1 + k2] = sum_{n1 < A} W_A^{n1 k1} [ W_{AB}^{n1 k2} sum_{n2 < B} x[n1 + A n2] W_B^{n2 k2} ]
+// with the inner twiddles W_{AB}^m as compile-time constants (evaluated in double by the constexpr series below).
+namespace ct
+{
+constexpr double kPi = 3.14159265358979323846264338327950288;
+constexpr double sin_series (double x) // |x| <= pi/4
+{
+    const double x2 = x * x;
+    double term = x, sum = x;
+    for (int i = 1; i < 12; ++i)
+    {
+        term *= -x2 / (double) ((2 * i) * (2 * i + 1));
+        sum += term;
+    }
+    return sum;
+}
+constexpr double cos_series (double x) // |x| <= pi/4
+{
+    const double x2 = x * x;
+    double term = 1.0, sum = 1.0;
+    for (int i = 1; i < 12; ++i)
+    {
+        term *= -x2 / (double) ((2 * i - 1) * (2 * i));
+        sum += term;
+    }
+    return sum;
+}
+// cos / sin of 2 pi num / den by octant reduction (exact symmetries, series argument <= pi/4)
+constexpr double cos_2pi (int num, int den)
+{
+    num %= den;
+    if (num < 0)
+        num += den;
+    if (2 * num > den) // cos(2 pi - t) = cos t
+        num = den - num;
+    if (4 * num > den) // cos(pi - t) = -cos t
+        return -cos_2pi (den - 2 * num, 2 * den);
+    // 0 <= 2 pi num / den <= pi/2
+    if (8 * num > den) // cos t = sin(pi/2 - t)
+        return sin_series (kPi / 2.0 - 2.0 * kPi * (double) num / (double) den);
+    return cos_series (2.0 * kPi * (double) num / (double) den);
+}
+constexpr double sin_2pi (int num, int den) { return cos_2pi (4 * num - den, 4 * den); } // sin t = cos(t - pi/2)
+template <int DEN, int M>
+__device__ __forceinline__ float2 mul_root (float2 u) // u * exp(-2 pi i M / DEN)
+{
+    constexpr int m = ((M % DEN) + DEN) % DEN;
+    if constexpr (m == 0)
+        return u;
+    else if constexpr (4 * m == DEN)
+        return make_float2 (u.y, -u.x);
+    else if constexpr (2 * m == DEN)
+        return make_float2 (-u.x, -u.y);
+    else if constexpr (4 * m == 3 * DEN)
+        return make_float2 (-u.y, u.x);
+    else
+    {
+        constexpr float c = (float) cos_2pi (m, DEN), sn = (float) sin_2pi (m, DEN);
+        return cmul (u, make_float2 (c, -sn));
+    }
+}
+template <int A, int B, int N1, int K2>
+__device__ __forceinline__ void inner_twiddle_row (float2 (&y)[A * B])
+{
+    if constexpr (K2 < B)
+    {
+        y[N1 + A * K2] = mul_root<A * B, N1 * K2> (y[N1 + A * K2]);
+        inner_twiddle_row<A, B, N1, K2 + 1> (y);
+    }
+}
+template <int A, int B, int N1>
+__device__ __forceinline__ void inner_twiddles (float2 (&y)[A * B])
+{
+    if constexpr (N1 < A)
+    {
+        inner_twiddle_row<A, B, N1, 1> (y);
+        inner_twiddles<A, B, N1 + 1> (y);
+    }
+}
+// natural order in and out
+template <int A, int B>
+__device__ __forceinline__ void fft_reg_ct (float2 (&u)[A * B])
+{
+    // B-point transforms over n2 for each n1: y[n1 + A k2]
+#pragma unroll
+    for (int n1 = 0; n1 < A; ++n1)
+    {
+        float2 t[B];
+#pragma unroll
+        for (int n2 = 0; n2 < B; ++n2)
+            t[n2] = u[n1 + A * n2];
+        fft_reg<B> (t);
+#pragma unroll
+        for (int k2 = 0; k2 < B; ++k2)
+            u[n1 + A * k2] = t[k2];
+    }
+    inner_twiddles<A, B, 1> (u);
+    // A-point transforms over n1 for each k2: X[B k1 + k2]
+    float2 o[A * B];
+#pragma unroll
+    for (int k2 = 0; k2 < B; ++k2)
+    {
+        float2 t[A];
+#pragma unroll
+        for (int n1 = 0; n1 < A; ++n1)
+            t[n1] = u[n1 + A * k2];
+        fft_reg<A> (t);
+#pragma unroll
+        for (int k1 = 0; k1 < A; ++k1)
+            o[B * k1 + k2] = t[k1];
+    }
+#pragma unroll
+    for (int i = 0; i < A * B; ++i)
+        u[i] = o[i];
+}
+} // namespace ct
+template <> __device__ __forceinline__ void fft_reg<6> (float2 (&u)[6]) { ct::fft_reg_ct<3, 2> (u); }
+template <> __device__ __forceinline__ void fft_reg<9> (float2 (&u)[9]) { ct::fft_reg_ct<3, 3> (u); }
+template <> __device__ __forceinline__ void fft_reg<10> (float2 (&u)[10]) { ct::fft_reg_ct<5, 2> (u); }
+template <> __device__ __forceinline__ void fft_reg<12> (float2 (&u)[12]) { ct::fft_reg_ct<3, 4> (u); }
+template <> __device__ __forceinline__ void fft_reg<15> (float2 (&u)[15]) { ct::fft_reg_ct<5, 3> (u); }
+
 // One Stockham stage of radix R over `nframes` frames of n points: src -> dst.
 // IO 0: LDS image -> LDS image (frame f at f*n).  IO 1: global memory (frame stride gs, optional re<->im swap) -> LDS:
 // the first stage of a complex transform reads its operands where they are, x[i + a*m] is lane-contiguous.
@@ -73,6 +199,7 @@ __device__ __forceinline__ void generic_stage (const float2* __restrict__ src, f
                                                unsigned gs_in, unsigned gs_out, unsigned lfs)
 {
     // lfs: distance between consecutive frames inside an LDS image (n, or n + 1 where lanes walk across frames)
+    asm volatile ("; generic_stage R=%1 IO=%2" : "+s"(n) : "n"(R), "n"(IO)); // keeps the radix cases' offsets inside their case (see inplace_stage)
     const int m = n / R;
     const bool p_pow2 = (p & (p - 1)) == 0;
     const unsigned fs_in = (IO & 1) ? gs_in : lfs, fs_out = (IO & 2) ? gs_out : lfs;
@@ -121,7 +248,12 @@ __device__ __forceinline__ void generic_stage_dispatch (int r, const float2* __r
         case 3: generic_stage<3, BLOCK, IO, SWAP> (src, dst, tw, n, p, nframes, tid, gs_in, gs_out, lfs); break;
         case 4: generic_stage<4, BLOCK, IO, SWAP> (src, dst, tw, n, p, nframes, tid, gs_in, gs_out, lfs); break;
         case 5: generic_stage<5, BLOCK, IO, SWAP> (src, dst, tw, n, p, nframes, tid, gs_in, gs_out, lfs); break;
+        case 6: generic_stage<6, BLOCK, IO, SWAP> (src, dst, tw, n, p, nframes, tid, gs_in, gs_out, lfs); break;
         case 8: generic_stage<8, BLOCK, IO, SWAP> (src, dst, tw, n, p, nframes, tid, gs_in, gs_out, lfs); break;
+        case 9: generic_stage<9, BLOCK, IO, SWAP> (src, dst, tw, n, p, nframes, tid, gs_in, gs_out, lfs); break;
+        case 10: generic_stage<10, BLOCK, IO, SWAP> (src, dst, tw, n, p, nframes, tid, gs_in, gs_out, lfs); break;
+        case 12: generic_stage<12, BLOCK, IO, SWAP> (src, dst, tw, n, p, nframes, tid, gs_in, gs_out, lfs); break;
+        case 15: generic_stage<15, BLOCK, IO, SWAP> (src, dst, tw, n, p, nframes, tid, gs_in, gs_out, lfs); break;
         default: generic_stage<16, BLOCK, IO, SWAP> (src, dst, tw, n, p, nframes, tid, gs_in, gs_out, lfs); break;
     }
 }
@@ -273,6 +405,10 @@ __device__ __forceinline__ void inplace_stage (const float2* __restrict__ gin, f
                                                const float2* __restrict__ tw, int n, int p, int tid)
 {
     constexpr int J = (kInplaceMaxPoints + R - 1) / R; // butterflies per work-item
+    // n passes through an opaque (volatile) statement: everything below derives from it, so the loop-invariant code motion of
+    // the stage loop cannot lift the operand / twiddle offsets of every radix case out of the loop and hold them all across it
+    // (with eleven radix cases that doubled the kernel's registers: 80 for the worst single case, 179-210 for the kernel).
+    asm volatile ("; inplace_stage R=%1 IO=%2" : "+s"(n) : "n"(R), "n"(IO));
     const int m = n / R;
     if constexpr ((IO & 1) != 0)
     {
@@ -375,13 +511,13 @@ __device__ __forceinline__ void inplace_stage_dispatch (int r, const float2* __r
         case 3: inplace_stage<3, BLOCK, IO, SWAP> (gin, gout, buf, tw, n, p, tid); break;
         case 4: inplace_stage<4, BLOCK, IO, SWAP> (gin, gout, buf, tw, n, p, tid); break;
         case 5: inplace_stage<5, BLOCK, IO, SWAP> (gin, gout, buf, tw, n, p, tid); break;
+        case 6: inplace_stage<6, BLOCK, IO, SWAP> (gin, gout, buf, tw, n, p, tid); break;
         case 8: inplace_stage<8, BLOCK, IO, SWAP> (gin, gout, buf, tw, n, p, tid); break;
-        default:
-            // 1024-thread workgroups (n > 10240) have 128 VGPRs: two radix-16 butterflies in flight do not fit, and the
-            // plans for those lengths are built with radices up to 8 (tables.cpp)
-            if constexpr (BLOCK < 1024)
-                inplace_stage<16, BLOCK, IO, SWAP> (gin, gout, buf, tw, n, p, tid);
-            break;
+        case 9: inplace_stage<9, BLOCK, IO, SWAP> (gin, gout, buf, tw, n, p, tid); break;
+        case 10: inplace_stage<10, BLOCK, IO, SWAP> (gin, gout, buf, tw, n, p, tid); break;
+        case 12: inplace_stage<12, BLOCK, IO, SWAP> (gin, gout, buf, tw, n, p, tid); break;
+        case 15: inplace_stage<15, BLOCK, IO, SWAP> (gin, gout, buf, tw, n, p, tid); break;
+        default: inplace_stage<16, BLOCK, IO, SWAP> (gin, gout, buf, tw, n, p, tid); break;
     }
 }
 
@@ -391,17 +527,25 @@ template <int BLOCK, bool IN_GLOBAL, bool OUT_GLOBAL, bool SWAP, bool TWLDS>
 __device__ __forceinline__ void inplace_core (const GenericPlan& plan, const float2* __restrict__ twtab, const float2* twl, float2* buf,
                                               const float2* __restrict__ gin, float2* __restrict__ gout, int tid)
 {
-    int p = 1;
-    for (int s = 0; s < plan.ns; ++s)
+    int p = 1, s0 = 0;
+    if constexpr (IN_GLOBAL)
+    {
+        // the stage that reads global memory stands outside the stage loop (p == 1: no twiddles): with its radix cases
+        // inside, the loop carried 40 more registers
+        const int r = plan.radix[0];
+        if (OUT_GLOBAL && plan.ns == 1)
+            inplace_stage_dispatch<BLOCK, 3, SWAP> (r, gin, gout, buf, twtab, plan.n, 1, tid);
+        else
+            inplace_stage_dispatch<BLOCK, 1, SWAP> (r, gin, gout, buf, twtab, plan.n, 1, tid);
+        p = r;
+        s0 = 1;
+    }
+    for (int s = s0; s < plan.ns; ++s)
     {
         const int r = plan.radix[s];
         const float2* tw = twtab + plan.tw_offset[s];
-        const bool first = IN_GLOBAL && s == 0, last = OUT_GLOBAL && s == plan.ns - 1;
-        if (first && last)
-            inplace_stage_dispatch<BLOCK, 3, SWAP> (r, gin, gout, buf, tw, plan.n, p, tid); // p == 1: no twiddles
-        else if (first)
-            inplace_stage_dispatch<BLOCK, 1, SWAP> (r, gin, gout, buf, tw, plan.n, p, tid);
-        else if (TWLDS && s < plan.lds_stages)
+        const bool last = OUT_GLOBAL && s == plan.ns - 1;
+        if (TWLDS && s < plan.lds_stages)
         {
             const float2* tl = twl + (plan.tw_offset[s] - plan.tw_offset[0]);
             if (last)
@@ -418,8 +562,9 @@ __device__ __forceinline__ void inplace_core (const GenericPlan& plan, const flo
 }
 
 // same MODEs as generic_kernel; one frame per workgroup pass
+// 512 work-items: at most 128 VGPRs (4 waves per SIMD), so that two workgroups share a CU where their images fit
 template <int MODE, bool INV, int BLOCK, bool TWLDS>
-__global__ __launch_bounds__ (BLOCK) void generic_inplace_kernel (const float2* __restrict__ in,
+__global__ __launch_bounds__ (BLOCK, BLOCK == 512 ? 4 : 1) void generic_inplace_kernel (const float2* __restrict__ in,
                                                                  float2* __restrict__ out,
                                                                  const float2* __restrict__ twtab,
                                                                  const float2* __restrict__ wtab,
@@ -427,14 +572,14 @@ __global__ __launch_bounds__ (BLOCK) void generic_inplace_kernel (const float2* 
                                                                  unsigned batch)
 {
     extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
-    const int tid = threadIdx.x;
+    const int tid0 = threadIdx.x;
     const int n = plan.n;
     const int half = n / 2 + 1;
     float2* buf = smem;
     float2* twl = smem + n;
     if constexpr (TWLDS)
     {
-        for (int i = tid; i < plan.lds_tw_len; i += BLOCK)
+        for (int i = tid0; i < plan.lds_tw_len; i += BLOCK)
             twl[i] = twtab[plan.tw_offset[0] + i];
         // the first barrier of the frame loop orders these writes before any stage
     }
@@ -442,6 +587,8 @@ __global__ __launch_bounds__ (BLOCK) void generic_inplace_kernel (const float2* 
     {
         const float2* __restrict__ src = in + (size_t) g * plan.in_stride;
         float2* __restrict__ dst = out + (size_t) g * plan.out_stride;
+        int tid = tid0;
+        CFFT_LAUNDER_INDEX (tid); // per frame: nothing derived from the work-item index is lifted out of the frame loop and held
         __syncthreads(); // previous frame's reads of the image are finished
         if (MODE == 2)
         {

@@ -114,10 +114,10 @@ hipError_t launch_generic_m (GenericPlan& plan, const DeviceTables& t, const flo
         const char* e = std::getenv ("CHOWDSP_FFT_GENERIC_INPLACE");
         return e != nullptr ? std::atoi (e) : -1;
     }();
-    // measured on MI355X (fwd+inv, in-place vs two images): complex n = 2304 / 3072 / 4608 / 5120: 3.07 / 3.62 / 3.40 / 3.96 vs
-    // 2.65 / 2.92 / 2.39 / 2.51 TB/s; real N = 6144 / 9216 / 18432: 3.27 / 3.16 / 3.15 vs 2.31 / 2.15 / 2.49; but complex
-    // n = 6400 / 7680 / 9216 (512-thread in-place workgroups): 2.40 / 2.58 / 2.62 vs 2.46 / 2.82 / 2.83
-    bool use_inplace = generic_uses_inplace (plan.n) && ! (MODE == 0 && plan.n > 5120 && plan.n <= 9216);
+    // measured on MI355X (fwd+inv, fraction of 8 TB/s, in-place vs two images, round 2 after the stage loop stopped carrying every
+    // radix case's registers): complex n = 2304 / 4608 / 5120 / 6400 / 7680 / 9216: 0.62 / 0.59 / 0.56 / 0.51 / 0.59 / 0.55 vs
+    // 0.44 / 0.36 / 0.38 / 0.41 / 0.40 / 0.43; real N = 6144 / 9216 / 18432: 0.49 / 0.49 / 0.47 vs 0.37 / 0.32 / 0.37
+    bool use_inplace = generic_uses_inplace (plan.n);
     if (force == 0 && plan.n <= 9216)
         use_inplace = false;
     if (force == 1 && plan.n > 2048)

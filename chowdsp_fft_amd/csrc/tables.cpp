@@ -1,5 +1,7 @@
 // Twiddle-table construction (host, double precision, rounded once to fp32).
 #include "tables.hpp"
+#include <algorithm>
+#include <functional>
 #include "plans.hpp"
 
 #include <cmath>
@@ -175,22 +177,73 @@ static void generic_radices (int n, std::vector<int>& radix, int frames_override
         frames = frames_override;
         block = 256;
     }
-    int cap_bits = (frames_override == 0 && block == 1024) ? 3 : 4; // 1024-thread in-place kernel: radices up to 8
+    int cap_bits = 4; // radices up to 16 (the 1024-thread in-place kernel stopped at 8 while its stage loop carried every radix case's offsets)
     while (cap_bits > 2 && (frames * n) >> cap_bits < block / 4)
         --cap_bits;
+    const int cap = 1 << cap_bits;
+    // Fewest stages first (every stage but the first costs an LDS round trip), then the smallest sum of radices (= the most even
+    // split: 2^10 -> 16 8 8, 9216 -> 12 12 8 8), over the radices the kernels have butterflies for.  Composite radices
+    // (6, 9, 10, 12, 15: generic_kernels.hpp) merge a 3 or a 5 with a neighbour instead of giving it a stage of its own.
+    // CHOWDSP_FFT_GENERIC_COMPOSITE=0: the round-1 lists (5s, 3s, then the power of two spread evenly).
+    static const bool composite = [] {
+        const char* e = std::getenv ("CHOWDSP_FFT_GENERIC_COMPOSITE");
+        return ! (e != nullptr && e[0] == '0');
+    }();
+    static const int all[11] = { 16, 15, 12, 10, 9, 8, 6, 5, 4, 3, 2 };
+    std::vector<int> best, cur;
+    int best_sum = 0;
+    const std::function<void (int, int, int)> search = [&] (int rest, int from, int sum) {
+        if (rest == 1)
+        {
+            if (best.empty() || cur.size() < best.size() || (cur.size() == best.size() && sum < best_sum))
+            {
+                best = cur;
+                best_sum = sum;
+            }
+            return;
+        }
+        if (! best.empty() && cur.size() + 1 > best.size())
+            return;
+        for (int i = from; i < 11; ++i)
+        {
+            const int r = all[i];
+            const bool is_composite = (r == 6 || r == 9 || r == 10 || r == 12 || r == 15);
+            if (r > cap || rest % r != 0 || (is_composite && ! composite))
+                continue;
+            cur.push_back (r);
+            search (rest / r, i, sum + r);
+            cur.pop_back();
+        }
+    };
     radix.clear();
-    while (n % 5 == 0) { radix.push_back (5); n /= 5; }
-    while (n % 3 == 0) { radix.push_back (3); n /= 3; }
-    int e = 0;
-    while (n % 2 == 0) { ++e; n /= 2; }
-    int stages = (e + cap_bits - 1) / cap_bits;
-    while (e > 0)
+    if (composite)
+        search (n, 0, 0);
+    if (best.empty())
     {
-        const int bits = (e + stages - 1) / stages;
-        radix.push_back (1 << bits);
-        e -= bits;
-        --stages;
+        // round-1 rule (also the fallback: always succeeds for 2-3-5-smooth n)
+        while (n % 5 == 0) { radix.push_back (5); n /= 5; }
+        while (n % 3 == 0) { radix.push_back (3); n /= 3; }
+        int e = 0;
+        while (n % 2 == 0) { ++e; n /= 2; }
+        int stages = (e + cap_bits - 1) / cap_bits;
+        while (e > 0)
+        {
+            const int bits = (e + stages - 1) / stages;
+            radix.push_back (1 << bits);
+            e -= bits;
+            --stages;
+        }
+        return;
     }
+    // stages with an odd factor first (largest first), then the powers of two, largest first
+    const auto odd_part = [] (int r) { while (r % 2 == 0) r /= 2; return r; };
+    std::stable_sort (best.begin(), best.end(), [&] (int a, int b) {
+        const bool oa = odd_part (a) > 1, ob = odd_part (b) > 1;
+        if (oa != ob)
+            return oa;
+        return a > b;
+    });
+    radix = best;
 }
 
 bool build_column_tables (int rows, HostTables& out)
