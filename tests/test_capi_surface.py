@@ -149,10 +149,32 @@ def test_plan_describe_host_logic():
         if d["passes"] == 2:
             assert d["n1"] * d["n2"] == 1 << lg and 64 <= d["n2"] <= d["n1"] <= 1024
     assert api.plan_describe(24, api.FFT_COMPLEX) is None
-    # mixed-radix sizes: one pass of the generic kernel, radices 5 / 3 first, then the power of two
+    # mixed-radix sizes: one pass of the generic kernel; fewest stages, composite radices (6, 9, 10, 12, 15) merge the odd
+    # factors into their neighbours, stages with an odd factor first
     d = api.plan_describe(480, api.FFT_COMPLEX)
-    assert d == {"complex_len": 480, "passes": 1, "n1": 0, "n2": 0, "radices": [5, 3, 8, 4]}
+    assert (d["complex_len"], d["passes"], d["n1"], d["n2"]) == (480, 1, 0, 0)
+    assert sorted(d["radices"]) == [6, 8, 10] and d["radices"][-1] == 8
+    assert api.plan_describe(9216, api.FFT_COMPLEX)["radices"] == [12, 12, 8, 8]
     assert api.plan_describe(96, api.FFT_REAL)["complex_len"] == 48
+
+
+def test_mixed_radix_plans_multiply_out():
+    """every accepted single-pass mixed-radix length: the stage radices are ones the kernels have butterflies for and their
+    product is the frame length (fft_gpu_plan_describe reports the first four stages)"""
+    allowed = {2, 3, 4, 5, 6, 8, 9, 10, 12, 15, 16}
+    checked = 0
+    for n in range(16, 20001, 16):
+        if not _smooth(n) or n & (n - 1) == 0:
+            continue
+        d = api.plan_describe(n, api.FFT_COMPLEX)
+        assert d is not None and d["passes"] == 1, n
+        prod = 1
+        for r in d["radices"]:
+            assert r in allowed, (n, d["radices"])
+            prod *= r
+        assert n % prod == 0 and (prod == n or len(d["radices"]) == 4), (n, d["radices"])
+        checked += 1
+    assert checked == 82  # the 2-3-5-smooth multiples of 16 up to 20000 that are not powers of two
 
 
 def test_misuse_returns_codes_not_crashes():
