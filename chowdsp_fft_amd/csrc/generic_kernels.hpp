@@ -188,6 +188,12 @@ template <> __device__ __forceinline__ void fft_reg<10> (float2 (&u)[10]) { ct::
 template <> __device__ __forceinline__ void fft_reg<12> (float2 (&u)[12]) { ct::fft_reg_ct<3, 4> (u); }
 template <> __device__ __forceinline__ void fft_reg<15> (float2 (&u)[15]) { ct::fft_reg_ct<5, 3> (u); }
 
+// x / d for 0 <= x < 2^16-ish and a run-time, workgroup-uniform d: one multiply-high with M = floor((2^32 - 1) / d) + 1 (exact while
+// x * d < 2^32: here x < 65536 work items and d <= 20000).  The compiler's 32-bit division is ~35 instructions, and the stage
+// loops need one or two per butterfly -- as much arithmetic as a radix-6 butterfly itself.
+__device__ __forceinline__ unsigned div_magic (unsigned d) { return 0xFFFFFFFFu / d + 1u; } // d >= 2
+__device__ __forceinline__ int fast_div (int x, unsigned magic) { return (int) __umulhi ((unsigned) x, magic); }
+
 // One Stockham stage of radix R over `nframes` frames of n points: src -> dst.
 // IO 0: LDS image -> LDS image (frame f at f*n).  IO 1: global memory (frame stride gs, optional re<->im swap) -> LDS:
 // the first stage of a complex transform reads its operands where they are, x[i + a*m] is lane-contiguous.
@@ -203,12 +209,13 @@ __device__ __forceinline__ void generic_stage (const float2* __restrict__ src, f
     const int m = n / R;
     const bool p_pow2 = (p & (p - 1)) == 0;
     const unsigned fs_in = (IO & 1) ? gs_in : lfs, fs_out = (IO & 2) ? gs_out : lfs;
+    const unsigned magic_m = m > 1 ? div_magic ((unsigned) m) : 0u, magic_p = p > 1 ? div_magic ((unsigned) p) : 0u;
     for (int idx = tid; idx < nframes * m; idx += BLOCK)
     {
         // one frame per workgroup pass (n > 512) and power-of-two p are the common cases: no integer division there
-        const int f = (nframes == 1) ? 0 : idx / m;
+        const int f = (nframes == 1) ? 0 : (m == 1 ? idx : fast_div (idx, magic_m));
         const int i = idx - f * m;
-        const int k = p_pow2 ? (i & (p - 1)) : (i % p);
+        const int k = p_pow2 ? (i & (p - 1)) : (i - fast_div (i, magic_p) * p);
         const int j = (i - k) * R + k;
         const float2* s = src + (size_t) f * fs_in;
         float2* d = dst + (size_t) f * fs_out;
@@ -310,6 +317,7 @@ __global__ __launch_bounds__ (BLOCK) void generic_kernel (const float2* __restri
     const int n = plan.n;
     const int F = plan.frames;
     const int half = n / 2 + 1; // pair-stage work items per frame: k = 0 .. n/2
+    const unsigned magic_half = div_magic ((unsigned) half);
     float2* bufA = smem;
     float2* bufB = smem + (size_t) F * n;
     float2* twl = smem + (size_t) 2 * F * n;
@@ -332,7 +340,7 @@ __global__ __launch_bounds__ (BLOCK) void generic_kernel (const float2* __restri
             // merge pairs straight from global memory (k and n-k), stored re<->im swapped for the inverse core
             for (int idx = tid; idx < nframes * half; idx += BLOCK)
             {
-                const int f = idx / half, k = idx - f * half;
+                const int f = fast_div (idx, magic_half), k = idx - f * half;
                 const int kp = (k == 0) ? 0 : n - k;
                 const float2 A = gload (&src[f * is + k]);
                 const float2 Xp = gload (&src[f * is + kp]);
@@ -367,7 +375,7 @@ __global__ __launch_bounds__ (BLOCK) void generic_kernel (const float2* __restri
         {
             for (int idx = tid; idx < nframes * half; idx += BLOCK)
             {
-                const int f = idx / half, k = idx - f * half;
+                const int f = fast_div (idx, magic_half), k = idx - f * half;
                 const int kp = (k == 0) ? 0 : n - k;
                 const float2 A = res[f * n + k];
                 const float2 Zp = res[f * n + kp];
@@ -458,6 +466,7 @@ __device__ __forceinline__ void inplace_stage (const float2* __restrict__ gin, f
     else
     {
         const bool p_pow2 = (p & (p - 1)) == 0;
+        const unsigned magic_p = p > 1 ? div_magic ((unsigned) p) : 0u;
         float2 u[J][R];
 #pragma unroll
         for (int j = 0; j < J; ++j)
@@ -477,7 +486,7 @@ __device__ __forceinline__ void inplace_stage (const float2* __restrict__ gin, f
             const int i = tid + j * BLOCK;
             if (i < m)
             {
-                const int k = p_pow2 ? (i & (p - 1)) : (i % p);
+                const int k = p_pow2 ? (i & (p - 1)) : (i - fast_div (i, magic_p) * p);
                 const int jj = (i - k) * R + k;
                 if (p > 1)
                 {
@@ -718,6 +727,7 @@ __global__ __launch_bounds__ (BLOCK) void pass_b_generic_kernel (const float2* _
     float2* bufA = smem;
     float2* bufB = smem + (size_t) CB * lfs;
     const unsigned tiles = (n2 + CB - 1) / CB;
+    const unsigned magic_n1 = div_magic ((unsigned) n1), magic_ca = ca > 1 ? div_magic (ca) : 0u;
     const size_t nwork = (size_t) batch * tiles;
     for (size_t w = blockIdx.x; w < nwork; w += gridDim.x)
     {
@@ -731,8 +741,8 @@ __global__ __launch_bounds__ (BLOCK) void pass_b_generic_kernel (const float2* _
         // element (row kbl, column a): c = a % ca fastest (contiguous in the workspace), then the row, then pass A's tile
         for (int e = tid; e < CB * n1; e += BLOCK)
         {
-            const unsigned a = (unsigned) e % (unsigned) n1, kbl = (unsigned) e / (unsigned) n1;
-            const unsigned tA = a / ca, c = a % ca;
+            const unsigned kbl = (unsigned) fast_div (e, magic_n1), a = (unsigned) e - kbl * (unsigned) n1;
+            const unsigned tA = (unsigned) fast_div ((int) a, magic_ca), c = a - tA * ca;
             const float2 x = (int) kbl < valid ? src[((size_t) tA * n2 + kb0 + kbl) * ca + c] : make_float2 (0.f, 0.f);
             bufA[kbl * lfs + a] = x;
         }
