@@ -13,6 +13,8 @@
 #pragma once
 #include "real_kernels.hpp"
 
+#include <type_traits>
+
 namespace cfft
 {
 static constexpr int kGenericMaxStages = 10;
@@ -199,13 +201,15 @@ __device__ __forceinline__ int fast_div (int x, unsigned magic) { return (int) _
 // the first stage of a complex transform reads its operands where they are, x[i + a*m] is lane-contiguous.
 // IO 2: LDS -> global memory: the last stage stores y[j + b*p] straight to the result (lane-contiguous in k).
 // IO 3: global -> global (single-stage plans).
-template <int R, int BLOCK, int IO, bool SWAP>
+// STATIC: n and p are compile-time constants at the call (static_core below): everything derived from them folds.
+template <int R, int BLOCK, int IO, bool SWAP, bool STATIC = false>
 __device__ __forceinline__ void generic_stage (const float2* __restrict__ src, float2* __restrict__ dst,
                                                const float2* __restrict__ tw, int n, int p, int nframes, int tid,
                                                unsigned gs_in, unsigned gs_out, unsigned lfs)
 {
     // lfs: distance between consecutive frames inside an LDS image (n, or n + 1 where lanes walk across frames)
-    asm volatile ("; generic_stage R=%1 IO=%2" : "+s"(n) : "n"(R), "n"(IO)); // keeps the radix cases' offsets inside their case (see inplace_stage)
+    if constexpr (! STATIC)
+        asm volatile ("; generic_stage R=%1 IO=%2" : "+s"(n) : "n"(R), "n"(IO)); // keeps the radix cases' offsets inside their case (see inplace_stage)
     const int m = n / R;
     const bool p_pow2 = (p & (p - 1)) == 0;
     const unsigned fs_in = (IO & 1) ? gs_in : lfs, fs_out = (IO & 2) ? gs_out : lfs;
@@ -299,12 +303,73 @@ __device__ __forceinline__ float2* generic_core (const GenericPlan& plan, const 
     return src;
 }
 
+// ---- compile-time stage lists for the reference's "other sizes" (round 2) -----------------------------------------------
+// test/test.cpp:279-285 transforms 96, 192, 384, 480, 640, 768 (and 9216) complex and real points; their complex lengths and
+// the halves the real transforms ride on -- 48 ... 768 -- get the stage list the planner gives them (tables.cpp; checked at
+// launch, since the twiddle table is laid out by that list) as a template: no radix switch, no stage loop, no run-time
+// division, every offset a constant.  Against the run-time list: about half the vector and a fortieth of the scalar
+// instructions (profiles/r02_sq_counters_mixed_radix.txt).  Every other length keeps the run-time list.
+template <int N_, int... Rs>
+struct StaticPlan
+{
+    static constexpr int n = N_;
+    static constexpr int ns = (int) sizeof...(Rs);
+    static constexpr int radix (int s)
+    {
+        constexpr int r[] = { Rs... };
+        return r[s];
+    }
+    static constexpr int period (int s) // product of the radices before stage s
+    {
+        int p = 1;
+        for (int i = 0; i < s; ++i)
+            p *= radix (i);
+        return p;
+    }
+    static constexpr int tw_offset (int s) // of stage s's table inside the plan's n - 1 twiddles
+    {
+        int o = 0;
+        for (int i = 0; i < s; ++i)
+            o += (radix (i) - 1) * period (i);
+        return o;
+    }
+};
+template <int N_> struct StaticPlanFor { using type = void; };
+template <> struct StaticPlanFor<48> { using type = StaticPlan<48, 6, 8>; };
+template <> struct StaticPlanFor<96> { using type = StaticPlan<96, 12, 8>; };
+template <> struct StaticPlanFor<192> { using type = StaticPlan<192, 12, 16>; };
+template <> struct StaticPlanFor<240> { using type = StaticPlan<240, 15, 16>; };
+template <> struct StaticPlanFor<320> { using type = StaticPlan<320, 5, 8, 8>; };
+template <> struct StaticPlanFor<384> { using type = StaticPlan<384, 6, 8, 8>; };
+template <> struct StaticPlanFor<480> { using type = StaticPlan<480, 10, 6, 8>; };
+template <> struct StaticPlanFor<640> { using type = StaticPlan<640, 10, 8, 8>; };
+template <> struct StaticPlanFor<768> { using type = StaticPlan<768, 12, 8, 8>; };
+
+// all stages of a static plan; twl: the workgroup's LDS copy of the plan's twiddles.  Returns the image that holds the result.
+template <class SP, int BLOCK, bool IN_GLOBAL, bool OUT_GLOBAL, bool SWAP, int S = 0>
+__device__ __forceinline__ float2* static_core (const float2* twl, float2* a, float2* b, const float2* __restrict__ gin, float2* __restrict__ gout,
+                                                int nframes, int tid, unsigned gs_in, unsigned gs_out)
+{
+    if constexpr (S == SP::ns)
+        return a;
+    else
+    {
+        constexpr int R = SP::radix (S), P = SP::period (S);
+        constexpr bool first = IN_GLOBAL && S == 0, last = OUT_GLOBAL && S == SP::ns - 1;
+        constexpr int IO = (first ? 1 : 0) | (last ? 2 : 0);
+        generic_stage<R, BLOCK, IO, IO != 0 && SWAP, true> (first ? gin : a, last ? gout : b, twl + SP::tw_offset (S), SP::n, P, nframes, tid, gs_in, gs_out, (unsigned) SP::n);
+        if constexpr (! last)
+            __syncthreads();
+        return static_core<SP, BLOCK, IN_GLOBAL, OUT_GLOBAL, SWAP, S + 1> (twl, b, a, gin, gout, nframes, tid, gs_in, gs_out);
+    }
+}
+
 // MODE 0: complex <-> complex (INV: backward).  MODE 1: real forward (packed spectrum out).  MODE 2: real backward.
 // For the real modes plan.n = N/2 and wtab holds W_N^k, k <= N/4 (pair stage formulas: real_kernels.hpp).
 // TWLDS: the plan's stage twiddles (n - 1 values: sum of (r - 1) p over the stages) are copied to LDS once per workgroup, behind
 // the two images.  From L2 they cost 25-35 % (MI355X, n = 480 .. 1536: every butterfly waits for its own twiddle loads, and in
 // the last stage -- gfx9 counts loads and stores in one in-order counter -- for the previous butterfly's stores as well).
-template <int MODE, bool INV, int BLOCK, bool TWLDS>
+template <int MODE, bool INV, int BLOCK, bool TWLDS, class SP = void>
 __global__ __launch_bounds__ (BLOCK) void generic_kernel (const float2* __restrict__ in,
                                                          float2* __restrict__ out,
                                                          const float2* __restrict__ twtab,
@@ -314,7 +379,14 @@ __global__ __launch_bounds__ (BLOCK) void generic_kernel (const float2* __restri
 {
     extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
     const int tid = threadIdx.x;
-    const int n = plan.n;
+    constexpr bool STATIC = ! std::is_void<SP>::value; // compile-time stage list (static_core): n is a constant
+    static_assert (! STATIC || TWLDS, "static plans take their twiddles from LDS");
+    const int n = [&] {
+        if constexpr (STATIC)
+            return (int) SP::n;
+        else
+            return plan.n;
+    }();
     const int F = plan.frames;
     const int half = n / 2 + 1; // pair-stage work items per frame: k = 0 .. n/2
     const unsigned magic_half = div_magic ((unsigned) half);
@@ -367,7 +439,9 @@ __global__ __launch_bounds__ (BLOCK) void generic_kernel (const float2* __restri
             __syncthreads();
         constexpr bool IN_GLOBAL = (MODE != 2), OUT_GLOBAL = (MODE != 1);
         const float2* res;
-        if constexpr (TWLDS)
+        if constexpr (STATIC)
+            res = static_core<SP, BLOCK, IN_GLOBAL, OUT_GLOBAL, (MODE == 2) || INV> (twl, bufA, bufB, src, dst, nframes, tid, plan.in_stride, plan.out_stride);
+        else if constexpr (TWLDS)
             res = generic_core<BLOCK, IN_GLOBAL, OUT_GLOBAL, (MODE == 2) || INV> (plan, twl, bufA, bufB, src, dst, nframes, tid, (unsigned) n, plan.tw_offset[0]);
         else
             res = generic_core<BLOCK, IN_GLOBAL, OUT_GLOBAL, (MODE == 2) || INV> (plan, twtab, bufA, bufB, src, dst, nframes, tid, (unsigned) n);

@@ -19,10 +19,10 @@ inline bool generic_tw_lds_enabled()
     return ! off;
 }
 
-template <int MODE, bool INV, int BLOCK, bool TWLDS>
+template <int MODE, bool INV, int BLOCK, bool TWLDS, class SP = void>
 hipError_t launch_generic_mb_tw (const GenericPlan& plan, const DeviceTables& t, const float2* in, float2* out, size_t batch, hipStream_t stream)
 {
-    auto kernel = generic_kernel<MODE, INV, BLOCK, TWLDS>;
+    auto kernel = generic_kernel<MODE, INV, BLOCK, TWLDS, SP>;
     const size_t lds = ((size_t) 2 * plan.frames * plan.n + (TWLDS ? (size_t) plan.n : 0)) * sizeof (float2);
     if (lds > 64 * 1024)
     {
@@ -47,7 +47,41 @@ hipError_t launch_generic_mb (const GenericPlan& plan, const DeviceTables& t, co
         return hipErrorNoDevice;
     const size_t with_table = ((size_t) 2 * plan.frames * plan.n + (size_t) plan.n) * sizeof (float2);
     if (generic_tw_lds_enabled() && with_table <= dev.lds_per_cu)
+    {
+        // the reference's "other sizes" (generic_kernels.hpp: StaticPlanFor): compile-time stage list where the planner's list
+        // (by which the twiddle table is laid out) is the one the template was written for
+        static const bool static_off = [] {
+            const char* e = std::getenv ("CHOWDSP_FFT_GENERIC_STATIC");
+            return e != nullptr && std::atoi (e) == 0;
+        }();
+        if constexpr (BLOCK == 256)
+        {
+            if (! static_off)
+            {
+#define CFFT_TRY_STATIC(N_)                                                                                        \
+    if (plan.n == N_)                                                                                              \
+    {                                                                                                              \
+        using SP = typename StaticPlanFor<N_>::type;                                                               \
+        bool same = plan.ns == SP::ns;                                                                             \
+        for (int i = 0; same && i < SP::ns; ++i)                                                                   \
+            same = plan.radix[i] == SP::radix (i);                                                                 \
+        if (same)                                                                                                  \
+            return launch_generic_mb_tw<MODE, INV, BLOCK, true, SP> (plan, t, in, out, batch, stream);             \
+    }
+                CFFT_TRY_STATIC (48)
+                CFFT_TRY_STATIC (96)
+                CFFT_TRY_STATIC (192)
+                CFFT_TRY_STATIC (240)
+                CFFT_TRY_STATIC (320)
+                CFFT_TRY_STATIC (384)
+                CFFT_TRY_STATIC (480)
+                CFFT_TRY_STATIC (640)
+                CFFT_TRY_STATIC (768)
+#undef CFFT_TRY_STATIC
+            }
+        }
         return launch_generic_mb_tw<MODE, INV, BLOCK, true> (plan, t, in, out, batch, stream);
+    }
     return launch_generic_mb_tw<MODE, INV, BLOCK, false> (plan, t, in, out, batch, stream);
 }
 
