@@ -303,12 +303,14 @@ __device__ __forceinline__ float2* generic_core (const GenericPlan& plan, const 
     return src;
 }
 
-// ---- compile-time stage lists for the reference's "other sizes" (round 2) -----------------------------------------------
-// test/test.cpp:279-285 transforms 96, 192, 384, 480, 640, 768 (and 9216) complex and real points; their complex lengths and
-// the halves the real transforms ride on -- 48 ... 768 -- get the stage list the planner gives them (tables.cpp; checked at
-// launch, since the twiddle table is laid out by that list) as a template: no radix switch, no stage loop, no run-time
-// division, every offset a constant.  Against the run-time list: about half the vector and a fortieth of the scalar
-// instructions (profiles/r02_sq_counters_mixed_radix.txt).  Every other length keeps the run-time list.
+// ---- compile-time stage lists for every mixed-radix length up to 2048 (round 2) --------------------------------------------
+// The reference's "other sizes" (test/test.cpp:279-285: 96, 192, 384, 480, 640, 768 complex and real points, i.e. complex
+// lengths 48 ... 768) and the other 2-3-5-smooth multiples of 16 that the two-image kernel serves -- thirty lengths -- get the
+// stage list the planner gives them (tables.cpp; checked at launch, since the twiddle table is laid out by that list; the list
+// below is generated from fft_gpu_plan_describe) as a template: no radix switch, no stage loop, no run-time division, every
+// offset a constant.  Against the run-time list that is about half the vector and a fortieth of the scalar instructions
+// (profiles/r02_sq_counters_mixed_radix.txt): N = 1920 0.51 -> 0.74 of 8 TB/s, N = 48 0.34 -> 0.52.  Longer frames (the
+// in-place kernel) keep the run-time list.
 template <int N_, int... Rs>
 struct StaticPlan
 {
@@ -336,14 +338,35 @@ struct StaticPlan
 };
 template <int N_> struct StaticPlanFor { using type = void; };
 template <> struct StaticPlanFor<48> { using type = StaticPlan<48, 6, 8>; };
+template <> struct StaticPlanFor<80> { using type = StaticPlan<80, 10, 8>; };
 template <> struct StaticPlanFor<96> { using type = StaticPlan<96, 12, 8>; };
+template <> struct StaticPlanFor<144> { using type = StaticPlan<144, 12, 12>; };
+template <> struct StaticPlanFor<160> { using type = StaticPlan<160, 10, 16>; };
 template <> struct StaticPlanFor<192> { using type = StaticPlan<192, 12, 16>; };
 template <> struct StaticPlanFor<240> { using type = StaticPlan<240, 15, 16>; };
+template <> struct StaticPlanFor<288> { using type = StaticPlan<288, 6, 6, 8>; };
 template <> struct StaticPlanFor<320> { using type = StaticPlan<320, 5, 8, 8>; };
 template <> struct StaticPlanFor<384> { using type = StaticPlan<384, 6, 8, 8>; };
+template <> struct StaticPlanFor<400> { using type = StaticPlan<400, 10, 5, 8>; };
+template <> struct StaticPlanFor<432> { using type = StaticPlan<432, 9, 6, 8>; };
 template <> struct StaticPlanFor<480> { using type = StaticPlan<480, 10, 6, 8>; };
+template <> struct StaticPlanFor<576> { using type = StaticPlan<576, 9, 8, 8>; };
 template <> struct StaticPlanFor<640> { using type = StaticPlan<640, 10, 8, 8>; };
+template <> struct StaticPlanFor<720> { using type = StaticPlan<720, 10, 9, 8>; };
 template <> struct StaticPlanFor<768> { using type = StaticPlan<768, 12, 8, 8>; };
+template <> struct StaticPlanFor<800> { using type = StaticPlan<800, 10, 10, 8>; };
+template <> struct StaticPlanFor<864> { using type = StaticPlan<864, 12, 9, 8>; };
+template <> struct StaticPlanFor<960> { using type = StaticPlan<960, 12, 10, 8>; };
+template <> struct StaticPlanFor<1152> { using type = StaticPlan<1152, 12, 12, 8>; };
+template <> struct StaticPlanFor<1200> { using type = StaticPlan<1200, 12, 10, 10>; };
+template <> struct StaticPlanFor<1280> { using type = StaticPlan<1280, 10, 16, 8>; };
+template <> struct StaticPlanFor<1296> { using type = StaticPlan<1296, 12, 12, 9>; };
+template <> struct StaticPlanFor<1440> { using type = StaticPlan<1440, 12, 12, 10>; };
+template <> struct StaticPlanFor<1536> { using type = StaticPlan<1536, 12, 16, 8>; };
+template <> struct StaticPlanFor<1600> { using type = StaticPlan<1600, 10, 10, 16>; };
+template <> struct StaticPlanFor<1728> { using type = StaticPlan<1728, 12, 12, 12>; };
+template <> struct StaticPlanFor<1920> { using type = StaticPlan<1920, 12, 10, 16>; };
+template <> struct StaticPlanFor<2000> { using type = StaticPlan<2000, 10, 5, 5, 8>; };
 
 // all stages of a static plan; twl: the workgroup's LDS copy of the plan's twiddles.  Returns the image that holds the result.
 template <class SP, int BLOCK, bool IN_GLOBAL, bool OUT_GLOBAL, bool SWAP, int S = 0>

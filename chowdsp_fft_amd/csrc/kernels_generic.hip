@@ -69,14 +69,35 @@ hipError_t launch_generic_mb (const GenericPlan& plan, const DeviceTables& t, co
             return launch_generic_mb_tw<MODE, INV, BLOCK, true, SP> (plan, t, in, out, batch, stream);             \
     }
                 CFFT_TRY_STATIC (48)
+                CFFT_TRY_STATIC (80)
                 CFFT_TRY_STATIC (96)
+                CFFT_TRY_STATIC (144)
+                CFFT_TRY_STATIC (160)
                 CFFT_TRY_STATIC (192)
                 CFFT_TRY_STATIC (240)
+                CFFT_TRY_STATIC (288)
                 CFFT_TRY_STATIC (320)
                 CFFT_TRY_STATIC (384)
+                CFFT_TRY_STATIC (400)
+                CFFT_TRY_STATIC (432)
                 CFFT_TRY_STATIC (480)
+                CFFT_TRY_STATIC (576)
                 CFFT_TRY_STATIC (640)
+                CFFT_TRY_STATIC (720)
                 CFFT_TRY_STATIC (768)
+                CFFT_TRY_STATIC (800)
+                CFFT_TRY_STATIC (864)
+                CFFT_TRY_STATIC (960)
+                CFFT_TRY_STATIC (1152)
+                CFFT_TRY_STATIC (1200)
+                CFFT_TRY_STATIC (1280)
+                CFFT_TRY_STATIC (1296)
+                CFFT_TRY_STATIC (1440)
+                CFFT_TRY_STATIC (1536)
+                CFFT_TRY_STATIC (1600)
+                CFFT_TRY_STATIC (1728)
+                CFFT_TRY_STATIC (1920)
+                CFFT_TRY_STATIC (2000)
 #undef CFFT_TRY_STATIC
             }
         }

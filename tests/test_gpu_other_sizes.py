@@ -13,7 +13,11 @@ from oracle_lib import BACKWARD, COMPLEX, FORWARD, REAL
 pytestmark = pytest.mark.gpu
 
 REFERENCE_OTHER_SIZES = [96, 192, 384, 480, 640, 768, 9216]
-MORE_SIZES = [48, 80, 160, 240, 320, 720, 1440, 2000, 2304, 3072, 5120, 6400, 7680, 8640, 10240, 10368, 11520, 13824, 17280, 19200]
+# every 2-3-5-smooth multiple of 16 up to 2048 that is not a power of two (each has its own compile-time stage list,
+# generic_kernels.hpp: StaticPlanFor; as real frames of N the complex length N / 2 is exercised too), then a spread of longer ones
+STATIC_PLAN_SIZES = [48, 80, 144, 160, 240, 288, 320, 400, 432, 576, 720, 800, 864, 960, 1152, 1200, 1280, 1296, 1440, 1536, 1600, 1728,
+                     1920, 2000]
+MORE_SIZES = STATIC_PLAN_SIZES + [2304, 2400, 2880, 3072, 3200, 3456, 3840, 4000, 5120, 6400, 7680, 8640, 10240, 10368, 11520, 13824, 17280, 19200]
 # complex length > 20000 (and some below, as real frames of twice the length): two passes (generic n2-point column FFTs x power-of-two n1-point row FFTs) where such a split
 # exists; sizes without one (test_long_mixed_sizes_without_a_split) come back NULL although the reference accepts them
 # 655360 = 640 x 1024 and 1310720 = 1280 x 1024: the column lengths at the edge of the CU's 160 KiB LDS (two padded
