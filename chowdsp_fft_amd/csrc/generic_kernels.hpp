@@ -505,7 +505,7 @@ __global__ __launch_bounds__ (BLOCK) void generic_kernel (const float2* __restri
 // CU up to n = 10240 (their load / compute / store phases overlap), and frames of up to 20000 points fit at all.
 static constexpr int kInplaceMaxPoints = 20; // points per work-item and stage
 
-template <int R, int BLOCK, int IO, bool SWAP>
+template <int R, int BLOCK, int IO, bool SWAP, bool STATIC = false>
 __device__ __forceinline__ void inplace_stage (const float2* __restrict__ gin, float2* __restrict__ gout, float2* __restrict__ buf,
                                                const float2* __restrict__ tw, int n, int p, int tid)
 {
@@ -513,7 +513,8 @@ __device__ __forceinline__ void inplace_stage (const float2* __restrict__ gin, f
     // n passes through an opaque (volatile) statement: everything below derives from it, so the loop-invariant code motion of
     // the stage loop cannot lift the operand / twiddle offsets of every radix case out of the loop and hold them all across it
     // (with eleven radix cases that doubled the kernel's registers: 80 for the worst single case, 179-210 for the kernel).
-    asm volatile ("; inplace_stage R=%1 IO=%2" : "+s"(n) : "n"(R), "n"(IO));
+    if constexpr (! STATIC) // (compile-time n and p at the call: static_inplace_core)
+        asm volatile ("; inplace_stage R=%1 IO=%2" : "+s"(n) : "n"(R), "n"(IO));
     const int m = n / R;
     if constexpr ((IO & 1) != 0)
     {
@@ -667,9 +668,40 @@ __device__ __forceinline__ void inplace_core (const GenericPlan& plan, const flo
     }
 }
 
+// The same with a compile-time stage list (StaticPlan): for the long frames of the reference's test list (9216 complex points, and
+// 4608 for the real transform of 9216) and a handful of lengths audio hosts use.  Whether a stage's twiddles come from the LDS
+// copy or from L2 stays a run-time (uniform) choice: the launcher decides how many tables fit.
+template <class SP, int BLOCK, bool IN_GLOBAL, bool OUT_GLOBAL, bool SWAP, bool TWLDS, int S = 0>
+__device__ __forceinline__ void static_inplace_core (const GenericPlan& plan, const float2* __restrict__ twtab, const float2* twl, float2* buf,
+                                                     const float2* __restrict__ gin, float2* __restrict__ gout, int tid)
+{
+    if constexpr (S < SP::ns)
+    {
+        constexpr int R = SP::radix (S), P = SP::period (S);
+        constexpr bool first = IN_GLOBAL && S == 0, last = OUT_GLOBAL && S == SP::ns - 1;
+        constexpr int IO = (first ? 1 : 0) | (last ? 2 : 0);
+        if constexpr (first)
+            inplace_stage<R, BLOCK, IO, SWAP, true> (gin, gout, buf, twtab, SP::n, 1, tid); // p == 1: no twiddles
+        else
+        {
+            bool from_lds = false;
+            if constexpr (TWLDS)
+                from_lds = S < plan.lds_stages;
+            if (from_lds)
+                inplace_stage<R, BLOCK, IO, IO != 0 && SWAP, true> (gin, gout, buf, twl + SP::tw_offset (S), SP::n, P, tid);
+            else
+                inplace_stage<R, BLOCK, IO, IO != 0 && SWAP, true> (gin, gout, buf, twtab + plan.tw_offset[0] + SP::tw_offset (S), SP::n, P, tid);
+        }
+        static_inplace_core<SP, BLOCK, IN_GLOBAL, OUT_GLOBAL, SWAP, TWLDS, S + 1> (plan, twtab, twl, buf, gin, gout, tid);
+    }
+}
+template <int N_> struct StaticInplacePlanFor { using type = void; };
+template <> struct StaticInplacePlanFor<4608> { using type = StaticPlan<4608, 9, 8, 8, 8>; };
+template <> struct StaticInplacePlanFor<9216> { using type = StaticPlan<9216, 12, 12, 8, 8>; };
+
 // same MODEs as generic_kernel; one frame per workgroup pass
 // 512 work-items: at most 128 VGPRs (4 waves per SIMD), so that two workgroups share a CU where their images fit
-template <int MODE, bool INV, int BLOCK, bool TWLDS>
+template <int MODE, bool INV, int BLOCK, bool TWLDS, class SP = void>
 __global__ __launch_bounds__ (BLOCK, BLOCK == 512 ? 4 : 1) void generic_inplace_kernel (const float2* __restrict__ in,
                                                                  float2* __restrict__ out,
                                                                  const float2* __restrict__ twtab,
@@ -679,7 +711,13 @@ __global__ __launch_bounds__ (BLOCK, BLOCK == 512 ? 4 : 1) void generic_inplace_
 {
     extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
     const int tid0 = threadIdx.x;
-    const int n = plan.n;
+    constexpr bool STATIC = ! std::is_void<SP>::value;
+    const int n = [&] {
+        if constexpr (STATIC)
+            return (int) SP::n;
+        else
+            return plan.n;
+    }();
     const int half = n / 2 + 1;
     float2* buf = smem;
     float2* twl = smem + n;
@@ -723,7 +761,10 @@ __global__ __launch_bounds__ (BLOCK, BLOCK == 512 ? 4 : 1) void generic_inplace_
             __syncthreads();
         }
         constexpr bool IN_GLOBAL = (MODE != 2), OUT_GLOBAL = (MODE != 1);
-        inplace_core<BLOCK, IN_GLOBAL, OUT_GLOBAL, (MODE == 2) || INV, TWLDS> (plan, twtab, twl, buf, src, dst, tid);
+        if constexpr (STATIC)
+            static_inplace_core<SP, BLOCK, IN_GLOBAL, OUT_GLOBAL, (MODE == 2) || INV, TWLDS> (plan, twtab, twl, buf, src, dst, tid);
+        else
+            inplace_core<BLOCK, IN_GLOBAL, OUT_GLOBAL, (MODE == 2) || INV, TWLDS> (plan, twtab, twl, buf, src, dst, tid);
         if (MODE == 1)
         {
             for (int k = tid; k < half; k += BLOCK)

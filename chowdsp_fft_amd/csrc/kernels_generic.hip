@@ -106,10 +106,10 @@ hipError_t launch_generic_mb (const GenericPlan& plan, const DeviceTables& t, co
     return launch_generic_mb_tw<MODE, INV, BLOCK, false> (plan, t, in, out, batch, stream);
 }
 
-template <int MODE, bool INV, int BLOCK, bool TWLDS>
+template <int MODE, bool INV, int BLOCK, bool TWLDS, class SP = void>
 hipError_t launch_generic_inplace_tw (const GenericPlan& plan, const DeviceTables& t, const float2* in, float2* out, size_t batch, hipStream_t stream)
 {
-    auto kernel = generic_inplace_kernel<MODE, INV, BLOCK, TWLDS>;
+    auto kernel = generic_inplace_kernel<MODE, INV, BLOCK, TWLDS, SP>;
     const size_t lds = ((size_t) plan.n + (TWLDS ? (size_t) plan.lds_tw_len : 0)) * sizeof (float2);
     const unsigned grid = persistent_grid (kernel, BLOCK, lds, batch); // raises the dynamic-LDS cap when lds > 64 KiB
     if (grid == 0)
@@ -152,6 +152,27 @@ hipError_t launch_generic_inplace (GenericPlan plan, const DeviceTables& t, cons
         {
             plan.lds_stages = stages;
             plan.lds_tw_len = (int) len;
+            // compile-time stage lists (generic_kernels.hpp: StaticInplacePlanFor), where the planner's list is the template's
+            static const bool static_off = [] {
+                const char* e = std::getenv ("CHOWDSP_FFT_GENERIC_STATIC");
+                return e != nullptr && std::atoi (e) == 0;
+            }();
+#define CFFT_TRY_STATIC_INPLACE(N_, B_)                                                                            \
+    if constexpr (BLOCK == B_)                                                                                     \
+    {                                                                                                              \
+        if (plan.n == N_ && ! static_off)                                                                          \
+        {                                                                                                          \
+            using SP = typename StaticInplacePlanFor<N_>::type;                                                    \
+            bool same = plan.ns == SP::ns;                                                                         \
+            for (int i = 0; same && i < SP::ns; ++i)                                                               \
+                same = plan.radix[i] == SP::radix (i);                                                             \
+            if (same)                                                                                              \
+                return launch_generic_inplace_tw<MODE, INV, BLOCK, true, SP> (plan, t, in, out, batch, stream);    \
+        }                                                                                                          \
+    }
+            CFFT_TRY_STATIC_INPLACE (4608, 256)
+            CFFT_TRY_STATIC_INPLACE (9216, 512)
+#undef CFFT_TRY_STATIC_INPLACE
             return launch_generic_inplace_tw<MODE, INV, BLOCK, true> (plan, t, in, out, batch, stream);
         }
     }
