@@ -28,6 +28,7 @@ struct GenericPlan
     unsigned in_stride, out_stride;   // float2 between consecutive frames in global memory (n for packed batches)
     int radix[kGenericMaxStages];     // each in {2, 3, 4, 5, 6, 8, 9, 10, 12, 15, 16}
     int tw_offset[kGenericMaxStages]; // float2 offset of the stage's table: (radix-1) * p entries, [a-1][k]
+    int pair_lds;                     // generic_kernel, real modes: the pair twiddles ride in LDS too (behind the stage twiddles)
     int lds_stages;                   // generic_inplace_kernel: the tables of stages [0, lds_stages) ride in LDS behind the image
     int lds_tw_len;                   // ... that many float2 (the tables are contiguous from tw_offset[0])
 };
@@ -416,10 +417,20 @@ __global__ __launch_bounds__ (BLOCK) void generic_kernel (const float2* __restri
     float2* bufA = smem;
     float2* bufB = smem + (size_t) F * n;
     float2* twl = smem + (size_t) 2 * F * n;
+    // real transforms: the pair-stage twiddles W_N^k, k <= n / 2, ride behind the stage twiddles where that costs no workgroup
+    // per CU (plan.pair_lds, decided by the launcher; read from L2 at their use they sit in front of the spectrum's stores, and
+    // every "load W; wait" drains the stores before it: real N = 384 0.46 -> 0.58 of 8 TB/s)
+    float2* wlds = twl + (n - 1);
+    const bool pair_lds = TWLDS && MODE != 0 && plan.pair_lds != 0;
     if constexpr (TWLDS)
     {
         for (int i = tid; i < n - 1; i += BLOCK)
             twl[i] = twtab[plan.tw_offset[0] + i];
+        if (pair_lds)
+        {
+            for (int i = tid; i < half; i += BLOCK)
+                wlds[i] = wtab[i];
+        }
         // the first barrier of the group loop orders these writes before any stage
     }
     const unsigned ngroups = (batch + F - 1) / F;
@@ -433,29 +444,35 @@ __global__ __launch_bounds__ (BLOCK) void generic_kernel (const float2* __restri
         if (MODE == 2)
         {
             // merge pairs straight from global memory (k and n-k), stored re<->im swapped for the inverse core
-            for (int idx = tid; idx < nframes * half; idx += BLOCK)
-            {
-                const int f = fast_div (idx, magic_half), k = idx - f * half;
-                const int kp = (k == 0) ? 0 : n - k;
-                const float2 A = gload (&src[f * is + k]);
-                const float2 Xp = gload (&src[f * is + kp]);
-                float2 zk, zp;
-                if (k == 0)
+            const auto merge_all = [&] (const float2* wp) { // wp: the pair twiddles, in LDS or in L2 (one instantiation each)
+                for (int idx = tid; idx < nframes * half; idx += BLOCK)
                 {
-                    zk = make_float2 (A.x + A.y, A.x - A.y); // Z[0] = (X0 + XM) + i (X0 - XM)
-                    zp = zk;
+                    const int f = fast_div (idx, magic_half), k = idx - f * half;
+                    const int kp = (k == 0) ? 0 : n - k;
+                    const float2 A = gload (&src[f * is + k]);
+                    const float2 Xp = gload (&src[f * is + kp]);
+                    float2 zk, zp;
+                    if (k == 0)
+                    {
+                        zk = make_float2 (A.x + A.y, A.x - A.y); // Z[0] = (X0 + XM) + i (X0 - XM)
+                        zp = zk;
+                    }
+                    else if (2 * k == n)
+                    {
+                        zk = make_float2 (2.f * A.x, -2.f * A.y); // Z[n/2] = 2 conj(X[n/2])
+                        zp = zk;
+                    }
+                    else
+                        real_merge_pair (A, Xp, wp[k], zk, zp);
+                    bufA[f * n + k] = make_float2 (zk.y, zk.x);
+                    if (kp != k)
+                        bufA[f * n + kp] = make_float2 (zp.y, zp.x);
                 }
-                else if (2 * k == n)
-                {
-                    zk = make_float2 (2.f * A.x, -2.f * A.y); // Z[n/2] = 2 conj(X[n/2])
-                    zp = zk;
-                }
-                else
-                    real_merge_pair (A, Xp, wtab[k], zk, zp);
-                bufA[f * n + k] = make_float2 (zk.y, zk.x);
-                if (kp != k)
-                    bufA[f * n + kp] = make_float2 (zp.y, zp.x);
-            }
+            };
+            if (pair_lds)
+                merge_all (wlds);
+            else
+                merge_all (wtab);
         }
         // MODE 0 / 1: stage 0 reads the frames straight from global memory
         if (MODE == 2)
@@ -470,29 +487,35 @@ __global__ __launch_bounds__ (BLOCK) void generic_kernel (const float2* __restri
             res = generic_core<BLOCK, IN_GLOBAL, OUT_GLOBAL, (MODE == 2) || INV> (plan, twtab, bufA, bufB, src, dst, nframes, tid, (unsigned) n);
         if (MODE == 1)
         {
-            for (int idx = tid; idx < nframes * half; idx += BLOCK)
-            {
-                const int f = fast_div (idx, magic_half), k = idx - f * half;
-                const int kp = (k == 0) ? 0 : n - k;
-                const float2 A = res[f * n + k];
-                const float2 Zp = res[f * n + kp];
-                float2 Xk, Xp;
-                if (k == 0)
+            const auto split_all = [&] (const float2* wp) {
+                for (int idx = tid; idx < nframes * half; idx += BLOCK)
                 {
-                    Xk = make_float2 (A.x + A.y, A.x - A.y); // [X0.re, X(N/2).re]
-                    Xp = Xk;
+                    const int f = fast_div (idx, magic_half), k = idx - f * half;
+                    const int kp = (k == 0) ? 0 : n - k;
+                    const float2 A = res[f * n + k];
+                    const float2 Zp = res[f * n + kp];
+                    float2 Xk, Xp;
+                    if (k == 0)
+                    {
+                        Xk = make_float2 (A.x + A.y, A.x - A.y); // [X0.re, X(N/2).re]
+                        Xp = Xk;
+                    }
+                    else if (2 * k == n)
+                    {
+                        Xk = make_float2 (A.x, -A.y); // X[n/2] = conj(Z[n/2])
+                        Xp = Xk;
+                    }
+                    else
+                        real_split_pair (A, Zp, wp[k], Xk, Xp);
+                    gstore (&dst[f * os + k], Xk);
+                    if (kp != k)
+                        gstore (&dst[f * os + kp], Xp);
                 }
-                else if (2 * k == n)
-                {
-                    Xk = make_float2 (A.x, -A.y); // X[n/2] = conj(Z[n/2])
-                    Xp = Xk;
-                }
-                else
-                    real_split_pair (A, Zp, wtab[k], Xk, Xp);
-                gstore (&dst[f * os + k], Xk);
-                if (kp != k)
-                    gstore (&dst[f * os + kp], Xp);
-            }
+            };
+            if (pair_lds)
+                split_all (wlds);
+            else
+                split_all (wtab);
         }
     }
 }

@@ -19,11 +19,14 @@ inline bool generic_tw_lds_enabled()
     return ! off;
 }
 
+// float2 of twiddles generic_kernel keeps in LDS: the n - 1 stage twiddles, and for the real modes the n / 2 + 1 pair twiddles
+inline size_t generic_table_len (int mode, int n) { return (size_t) n + (mode != 0 ? (size_t) n / 2 + 1 : 0); }
+
 template <int MODE, bool INV, int BLOCK, bool TWLDS, class SP = void>
 hipError_t launch_generic_mb_tw (const GenericPlan& plan, const DeviceTables& t, const float2* in, float2* out, size_t batch, hipStream_t stream)
 {
     auto kernel = generic_kernel<MODE, INV, BLOCK, TWLDS, SP>;
-    const size_t lds = ((size_t) 2 * plan.frames * plan.n + (TWLDS ? (size_t) plan.n : 0)) * sizeof (float2);
+    const size_t lds = ((size_t) 2 * plan.frames * plan.n + (TWLDS ? generic_table_len (plan.pair_lds ? MODE : 0, plan.n) : 0)) * sizeof (float2);
     if (lds > 64 * 1024)
     {
         const hipError_t e = hipFuncSetAttribute ((const void*) kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
@@ -40,14 +43,22 @@ hipError_t launch_generic_mb_tw (const GenericPlan& plan, const DeviceTables& t,
 
 // the stage twiddles ride in LDS wherever the n - 1 values fit behind the two images (generic_kernels.hpp: TWLDS)
 template <int MODE, bool INV, int BLOCK>
-hipError_t launch_generic_mb (const GenericPlan& plan, const DeviceTables& t, const float2* in, float2* out, size_t batch, hipStream_t stream)
+hipError_t launch_generic_mb (const GenericPlan& plan_in, const DeviceTables& t, const float2* in, float2* out, size_t batch, hipStream_t stream)
 {
+    const GenericPlan& plan = plan_in;
     DeviceInfo dev;
     if (! current_device_info (dev))
         return hipErrorNoDevice;
-    const size_t with_table = ((size_t) 2 * plan.frames * plan.n + (size_t) plan.n) * sizeof (float2);
+    const size_t with_table = ((size_t) 2 * plan.frames * plan.n + generic_table_len (0, plan.n)) * sizeof (float2);
     if (generic_tw_lds_enabled() && with_table <= dev.lds_per_cu)
     {
+        // real modes: the pair twiddles too, for the short frames (several per workgroup).  Measured on MI355X, fraction of 8 TB/s
+        // with / without: real N = 96 0.50 / 0.39, 384 0.58 / 0.46, 480 0.56 / 0.45, 1280 0.63 / 0.60 -- but 3072 0.50 / 0.56,
+        // 3840 0.31 / 0.45 (one frame per workgroup: the longer copy at kernel start and the LDS it takes cost more than the
+        // loads from L2)
+        GenericPlan plan = plan_in;
+        const size_t with_pair = ((size_t) 2 * plan.frames * plan.n + generic_table_len (MODE, plan.n)) * sizeof (float2);
+        plan.pair_lds = (MODE != 0 && plan.n <= 640 && with_pair <= dev.lds_per_cu) ? 1 : 0;
         // the reference's "other sizes" (generic_kernels.hpp: StaticPlanFor): compile-time stage list where the planner's list
         // (by which the twiddle table is laid out) is the one the template was written for
         static const bool static_off = [] {
