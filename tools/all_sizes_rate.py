@@ -11,7 +11,9 @@ from chowdsp_fft_amd import api  # noqa: E402
 
 dev = torch.device("cuda:0")
 sizes = [(1 << lg, True) for lg in range(4, 22)] + [(1 << lg, False) for lg in range(5, 22)]
-sizes += [(n, True) for n in (480, 640, 768, 1536, 5120, 9216, 19200, 20736, 46080, 245760)] + [(9216, False), (41472, False)]
+# mixed radix: the reference's "other sizes" (test/test.cpp:279-285) complex and real, then a spread of others
+sizes += [(n, True) for n in (96, 192, 384, 480, 640, 768, 9216)] + [(n, False) for n in (96, 192, 384, 480, 640, 768, 9216)]
+sizes += [(n, True) for n in (1536, 1920, 5120, 19200, 20736, 46080, 245760)] + [(n, False) for n in (1920, 3840, 18432, 41472)]
 if len(sys.argv) > 1:  # subset: "c480,c768,r9216"
     sizes = [(int(t[1:]), t[0] == "c") for t in sys.argv[1].split(",")]
 for n, cplx in sizes:
