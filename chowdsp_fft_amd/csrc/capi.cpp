@@ -262,6 +262,12 @@ FusedOptions& fused_options()
 // "split16384" / CHOWDSP_FFT_SPLIT16384: N = 16384 complex / real N = 32768 through the split-plane kernels (frame in registers,
 // exchanges one component at a time; 512 work-items) instead of the interleaved-image plan with streamed twiddles
 std::atomic<int> g_split16384 { -1 };
+// "split8192": N = 8192 complex / real N = 16384 through the split-plane kernels with 256 work-items (32 x 32 x 8) instead of
+// the 512-thread interleaved-image plan; an A/B switch, off by default
+std::atomic<int> g_split8192 { 0 };
+// "fused_conv_split": fft_convolve_frames_batch on the split-plane sizes (8192 / 16384 / 32768 complex points, real N = 16384 / 32768 / 65536)
+// as ONE launch (default) or as the three-launch composition (0), for A/B timing
+std::atomic<int> g_fused_conv_split { 1 };
 bool split16384_enabled()
 {
     int v = g_split16384.load();
@@ -519,6 +525,8 @@ int run_transform (Setup* s, const float* in, float* out, size_t batch, cf::fft_
             e = launch_c2c_split (nc, inverse, cin, cout, t->stage_twiddles, batch, stream, is2, os2);
         else if (nc == 16384 && split16384_enabled())
             e = launch_c2c_split (nc, inverse, cin, cout, t->stage_twiddles + cfft::CorePlan<16384>::type::tw_total, batch, stream, is2, os2);
+        else if (nc == 8192 && g_split8192.load() != 0)
+            e = launch_c2c_split (nc, inverse, cin, cout, t->stage_twiddles + cfft::CorePlan<8192>::type::tw_total, batch, stream, is2, os2);
         else
             e = launch_c2c (nc, inverse, cin, cout, t->stage_twiddles, batch, stream, is2, os2);
     }
@@ -529,6 +537,10 @@ int run_transform (Setup* s, const float* in, float* out, size_t batch, cf::fft_
     else if (lds_resident && nc == 16384 && split16384_enabled())
     {
         e = launch_real_split (nc, ! inverse, cin, cout, t->stage_twiddles + cfft::CorePlan<16384>::type::tw_total, t->real_twiddles, batch, stream, is2, os2);
+    }
+    else if (lds_resident && nc == 8192 && g_split8192.load() != 0)
+    {
+        e = launch_real_split (nc, ! inverse, cin, cout, t->stage_twiddles + cfft::CorePlan<8192>::type::tw_total, t->real_twiddles, batch, stream, is2, os2);
     }
     else if (lds_resident)
     {
@@ -1206,6 +1218,10 @@ int fft_gpu_set_option (const char* name, long value)
         set_wave4096 (value != 0);
     else if (std::strcmp (name, "split16384") == 0)
         g_split16384 = value != 0 ? 1 : 0;
+    else if (std::strcmp (name, "split8192") == 0)
+        g_split8192 = value != 0 ? 1 : 0;
+    else if (std::strcmp (name, "fused_conv_split") == 0)
+        g_fused_conv_split = value != 0 ? 1 : 0;
     else
     {
         set_last_error ("fft_gpu_set_option: unknown option or value out of range");
@@ -1362,6 +1378,20 @@ int fft_convolve_frames_batch (void* setup, const float* x, const float* dft_fil
     const DeviceGuard guard (s->device);
     const DeviceTables* t = s->tables;
     const int nc = complex_len (s);
+    if (g_fused_conv_split.load() != 0 && t->core_n == nc && t->gen_ns == 0 && (nc == cfft::kSplitCoreN || nc == 16384 || nc == 8192))
+    {
+        // frame in registers (split_plane_kernels.hpp): both cores and the multiplication in one launch
+        const float2* tw = (nc == 16384)  ? t->stage_twiddles + cfft::CorePlan<16384>::type::tw_total
+                           : (nc == 8192) ? t->stage_twiddles + cfft::CorePlan<8192>::type::tw_total
+                                          : t->stage_twiddles;
+        const hipError_t es = launch_conv_frames_split (nc, s->transform == FFT_REAL, (const float2*) x, (const float2*) dft_filter, (float2*) y, tw, t->real_twiddles, scaling, batch, (hipStream_t) stream);
+        if (es != hipSuccess)
+        {
+            set_last_error ("fused convolution kernel launch (split-plane)", es);
+            return FFT_GPU_ELAUNCH;
+        }
+        return FFT_GPU_OK;
+    }
     if (t->core_n != nc || nc > cfft::kMaxFusedN)
     {
         // No fused kernel for this size (two-pass, 8192-point and mixed-radix plans): the same three steps as separate

@@ -44,9 +44,31 @@ hipError_t real_split (bool forward, const float2* in, float2* out, const float2
     hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (G::T), G::lds_bytes, stream, in, out, tw, real_tw, (unsigned) batch, is, os);
     return hipGetLastError();
 }
+template <class G>
+hipError_t conv_frames_split (bool real, const float2* in, const float2* H, float2* out, const float2* tw, const float2* real_tw, float scaling, size_t batch, hipStream_t stream)
+{
+    unsigned grid = 0, is = 0, os = 0;
+    if (real)
+    {
+        auto kernel = conv_frames_real_split_kernel<G>;
+        const hipError_t e = launch_split<G> (kernel, batch, stream, 0, 0, grid, is, os);
+        if (e != hipSuccess)
+            return e;
+        hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (G::T), G::lds_bytes, stream, in, H, out, tw, real_tw, scaling, (unsigned) batch);
+    }
+    else
+    {
+        auto kernel = conv_frames_c2c_split_kernel<G>;
+        const hipError_t e = launch_split<G> (kernel, batch, stream, 0, 0, grid, is, os);
+        if (e != hipSuccess)
+            return e;
+        hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (G::T), G::lds_bytes, stream, in, H, out, tw, scaling, (unsigned) batch);
+    }
+    return hipGetLastError();
+}
 } // namespace
 
-bool split_plane_length (int n) { return n == SplitGeom<1024>::N || n == SplitGeom<512>::N; }
+bool split_plane_length (int n) { return n == SplitGeom<1024>::N || n == SplitGeom<512>::N || n == SplitGeom<256>::N; }
 
 hipError_t launch_c2c_split (int n, bool inverse, const float2* in, float2* out, const float2* tw, size_t batch, hipStream_t stream, size_t in_stride, size_t out_stride)
 {
@@ -56,6 +78,8 @@ hipError_t launch_c2c_split (int n, bool inverse, const float2* in, float2* out,
         return c2c_split<SplitGeom<1024>> (inverse, in, out, tw, batch, stream, in_stride, out_stride);
     if (n == SplitGeom<512>::N)
         return c2c_split<SplitGeom<512>> (inverse, in, out, tw, batch, stream, in_stride, out_stride);
+    if (n == SplitGeom<256>::N)
+        return c2c_split<SplitGeom<256>> (inverse, in, out, tw, batch, stream, in_stride, out_stride);
     return hipErrorInvalidValue;
 }
 
@@ -67,6 +91,21 @@ hipError_t launch_real_split (int m, bool forward, const float2* in, float2* out
         return real_split<SplitGeom<1024>> (forward, in, out, tw, real_tw, batch, stream, in_stride, out_stride);
     if (m == SplitGeom<512>::N)
         return real_split<SplitGeom<512>> (forward, in, out, tw, real_tw, batch, stream, in_stride, out_stride);
+    if (m == SplitGeom<256>::N)
+        return real_split<SplitGeom<256>> (forward, in, out, tw, real_tw, batch, stream, in_stride, out_stride);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_conv_frames_split (int n, bool real, const float2* in, const float2* H, float2* out, const float2* tw, const float2* real_tw, float scaling, size_t batch, hipStream_t stream)
+{
+    if (batch == 0)
+        return hipSuccess;
+    if (n == SplitGeom<1024>::N)
+        return conv_frames_split<SplitGeom<1024>> (real, in, H, out, tw, real_tw, scaling, batch, stream);
+    if (n == SplitGeom<512>::N)
+        return conv_frames_split<SplitGeom<512>> (real, in, H, out, tw, real_tw, scaling, batch, stream);
+    if (n == SplitGeom<256>::N)
+        return conv_frames_split<SplitGeom<256>> (real, in, H, out, tw, real_tw, scaling, batch, stream);
     return hipErrorInvalidValue;
 }
 } // namespace cfft::host

@@ -27,6 +27,9 @@ hipError_t launch_c2r (int m, const float2* in, float2* out, const float2* stage
 // (n / m = 32768 or 16384 complex points)
 bool split_plane_length (int n);
 hipError_t launch_c2c_split (int n, bool inverse, const float2* in, float2* out, const float2* tw, size_t batch, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
+// fused forward -> * H * scaling -> backward on the same kernels (n = complex core length 32768 or 16384; real: N = 2 n samples,
+// H the packed spectrum)
+hipError_t launch_conv_frames_split (int n, bool real, const float2* in, const float2* H, float2* out, const float2* tw, const float2* real_tw, float scaling, size_t batch, hipStream_t stream);
 hipError_t launch_real_split (int m, bool forward, const float2* in, float2* out, const float2* tw, const float2* real_tw, size_t batch, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
 
 // ab += a*b*scaling on `batch` frames of `cplx_per_frame` complex values; real_packed: bin 0 is (DC, Nyquist)

@@ -27,20 +27,23 @@ namespace cfft
 //   T = 1024: N = 32768 = 32 x 32 x 32                      (one workgroup per CU, 132 KiB plane)
 //   T =  512: N = 16384 = 32 x 32 x 16, the last stage as two radix-16 butterflies per work-item
 //             (two workgroups per CU, 66 KiB plane each; replaces the interleaved-image plan with streamed twiddles)
+//   T =  256: N =  8192 = 32 x 32 x 8, the last stage as four radix-8 butterflies per work-item (four workgroups per CU,
+//             33 KiB plane each); used by the fused convolution, where the interleaved-image plan has no registers left
 // Invariant: register slot c of work-item t holds element t + T c -- on input, after each exchange and on output.
 template <int T_>
 struct SplitGeom
 {
     static constexpr int T = T_;
     static constexpr int N = 32 * T_;
-    static constexpr int LAST = N / 1024;                    // radix of the last stage: 32 or 16
+    static constexpr int LAST = N / 1024;                    // radix of the last stage: 32, 16 or 8
     static constexpr int RS = T_ + T_ / 32;                  // physical distance of consecutive slots in the plane
     static constexpr int plane_floats = N + N / 32;          // one float per point, one float of padding after every 32
     static constexpr size_t lds_bytes = (size_t) plane_floats * sizeof (float);
     // twiddle table: stage 1 (p = 32): [10][32] rows a = 1..7, 8, 16, 24 of W_1024^(a k); stage 2 (p = 1024):
-    // LAST = 32: [10][1024] the same rows of W_N^(a k); LAST = 16: [6][1024] rows a = 1, 2, 3, 4, 8, 12
+    // LAST = 32: [10][1024] the same rows of W_N^(a k); LAST = 16: [6][1024] rows a = 1, 2, 3, 4, 8, 12; LAST = 8: [7][1024]
+    // rows a = 1..7
     static constexpr int tw_stage2 = 10 * 32;
-    static constexpr int tw_rows2 = LAST == 32 ? 10 : 6;
+    static constexpr int tw_rows2 = LAST == 32 ? 10 : (LAST == 16 ? 6 : 7);
     static constexpr int tw_total = tw_stage2 + tw_rows2 * 1024;
 };
 constexpr int kSplitN = SplitGeom<1024>::N;   // the longest frame of this family
@@ -265,6 +268,47 @@ __device__ __forceinline__ void sp_core (float2 (&v)[32], const float2* __restri
         CFFT_PHASE_FENCE();
         fft_reg32<true> (v, w);
     }
+    else if constexpr (G::LAST == 8)
+    {
+        // N = 8192: 1024 radix-8 butterflies, four per work-item: butterfly q works on the slots c = q + 4 a (elements
+        // t + 256 q + 1024 a) and leaves X[t + 256 q + 1024 b] in slot q + 4 b; its seven twiddles W_N^(a (t + 256 q)) are
+        // requested before the exchange, two butterflies at a time (28 VGPRs)
+        float2 w8[2][7];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < 7; ++j)
+                w8[q][j] = tw[G::tw_stage2 + j * 1024 + t + 256 * q];
+        sp_exchange<G, 32> (v, plane, t);
+        CFFT_PHASE_FENCE();
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+        {
+            if (h == 1)
+            {
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int j = 0; j < 7; ++j)
+                        w8[q][j] = tw[G::tw_stage2 + j * 1024 + t + 256 * (2 + q)];
+            }
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2)
+            {
+                const int q = 2 * h + q2;
+                float2 u[8];
+                u[0] = v[q];
+#pragma unroll
+                for (int a = 1; a < 8; ++a)
+                    u[a] = cmul (v[q + 4 * a], w8[q2][a - 1]);
+                fft_reg<8> (u);
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+                    v[q + 4 * b] = u[b];
+            }
+            CFFT_PHASE_FENCE();
+        }
+    }
     else
     {
         // N = 16384: 1024 radix-16 butterflies, two per work-item: butterfly q works on the slots c = q + 2 a (elements
@@ -482,6 +526,146 @@ __global__ __launch_bounds__ (G::T) void c2r_split_kernel (const float2* __restr
         for (int q = 0; q < 16; ++q)
             v[16 + q] = up[q];
         sp_core<G> (v, tw, sp_plane, t);
+        int ts = t0;
+        CFFT_LAUNDER_INDEX (ts);
+#pragma unroll
+        for (int b = 0; b < 32; ++b)
+            gstore (&dst[(unsigned) (ts + G::T * b)], make_float2 (v[b].y, v[b].x));
+    }
+}
+// ---- fused convolution frames: y = BACKWARD (FORWARD (x) * H) * scaling in ONE pass -----------------------------------------------
+// (the call sequence of test/test.cpp:161-166 per frame; conv_kernels.hpp holds the LDS-resident plans' form).  The frame
+// never leaves the registers between the two cores: the spectrum bins of work-item t are slots t + T b, exactly where the
+// inverse core wants its input.  The filter bins are the same for every frame but 64 VGPRs of them do not fit next to the
+// frame: they are re-read from L2 per frame, in rounds, requested before the multiplications that use them.
+template <class G>
+__global__ __launch_bounds__ (G::T) void conv_frames_c2c_split_kernel (const float2* __restrict__ in,
+                                                                        const float2* __restrict__ H,
+                                                                        float2* __restrict__ out,
+                                                                        const float2* __restrict__ tw,
+                                                                        float scaling,
+                                                                        unsigned batch)
+{
+    extern __shared__ __attribute__ ((aligned (16))) float sp_plane[];
+    const int t0 = threadIdx.x;
+    for (unsigned g = blockIdx.x; g < batch; g += gridDim.x)
+    {
+        int t = t0;
+        CFFT_LAUNDER_INDEX (t);
+        const float2* __restrict__ src = in + (size_t) g * G::N;
+        float2* __restrict__ dst = out + (size_t) g * G::N;
+        float2 v[32];
+#pragma unroll
+        for (int a = 0; a < 32; ++a)
+            v[a] = gload (&src[(unsigned) (t + G::T * a)]);
+        sp_core<G> (v, tw, sp_plane, t);
+        int tm = t0;
+        CFFT_LAUNDER_INDEX (tm);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+        {
+            float2 h[8];
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+                h[b] = H[tm + G::T * (8 * r + b)];
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+            {
+                const float2 y = cmul (v[8 * r + b], h[b]);
+                v[8 * r + b] = make_float2 (y.y * scaling, y.x * scaling); // re <-> im: the inverse DFT is swap (DFT (swap (.)))
+            }
+            CFFT_PHASE_FENCE();
+        }
+        sp_core<G> (v, tw, sp_plane, tm);
+        int ts = t0;
+        CFFT_LAUNDER_INDEX (ts);
+#pragma unroll
+        for (int b = 0; b < 32; ++b)
+            gstore (&dst[(unsigned) (ts + G::T * b)], make_float2 (v[b].y, v[b].x));
+    }
+}
+
+// REAL frames of N = 2 M samples, H a packed real spectrum (M float2, element 0 = DC / Nyquist): forward core, the pair
+// exchange of r2c_split_kernel, split -> * H -> merge on every (k, M - k) pair in registers, the pair exchange of
+// c2r_split_kernel, inverse core.
+template <class G>
+__global__ __launch_bounds__ (G::T) void conv_frames_real_split_kernel (const float2* __restrict__ in,
+                                                                         const float2* __restrict__ H,
+                                                                         float2* __restrict__ out,
+                                                                         const float2* __restrict__ tw,
+                                                                         const float2* __restrict__ wtab,
+                                                                         float scaling,
+                                                                         unsigned batch)
+{
+    extern __shared__ __attribute__ ((aligned (16))) float sp_plane[];
+    constexpr int M = G::N;
+    const int t0 = threadIdx.x;
+    for (unsigned g = blockIdx.x; g < batch; g += gridDim.x)
+    {
+        int t = t0;
+        CFFT_LAUNDER_INDEX (t);
+        const float2* __restrict__ src = in + (size_t) g * M;
+        float2* __restrict__ dst = out + (size_t) g * M;
+        float2 v[32];
+#pragma unroll
+        for (int a = 0; a < 32; ++a)
+            v[a] = gload (&src[(unsigned) (t + G::T * a)]);
+        sp_core<G> (v, tw, sp_plane, t);
+        int tm = t0;
+        CFFT_LAUNDER_INDEX (tm);
+        float2 up[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            up[q] = v[16 + q];
+        sp_pair_exchange<G, false> (up, sp_plane, tm);
+        CFFT_PHASE_FENCE();
+        // eight rounds of two pairs: pair twiddle + the two filter bins of a pair are 6 VGPRs next to the 96 of v / up
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+        {
+            float2 pw[2], hk[2], hp[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+            {
+                const int k = tm + G::T * (2 * r + j);
+                pw[j] = wtab[k];
+                hk[j] = H[k];
+                hp[j] = H[k == 0 ? M / 2 : M - k];
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+            {
+                const int q = 2 * r + j;
+                const int k = tm + G::T * q;
+                const float2 A = v[q], Zp = up[q];
+                float2 Xk, Xp;
+                real_split_pair (A, Zp, pw[j], Xk, Xp);
+                float2 Yk = cmul (Xk, hk[j]), Yp = cmul (Xp, hp[j]);
+                if (k == 0)
+                {
+                    // packed DC / Nyquist: real products (simd/chowdsp_fft_impl_sse.cpp:1640-1644); X[M/2] = conj (Z[M/2])
+                    Yk = make_float2 ((A.x + A.y) * hk[j].x, (A.x - A.y) * hk[j].y);
+                    Yp = cmul (make_float2 (Zp.x, -Zp.y), hp[j]);
+                }
+                Yk = make_float2 (Yk.x * scaling, Yk.y * scaling);
+                Yp = make_float2 (Yp.x * scaling, Yp.y * scaling);
+                float2 zk, zp;
+                real_merge_pair (Yk, Yp, pw[j], zk, zp);
+                if (k == 0)
+                {
+                    zk = make_float2 (Yk.x + Yk.y, Yk.x - Yk.y);
+                    zp = make_float2 (2.f * Yp.x, -2.f * Yp.y);
+                }
+                v[q] = make_float2 (zk.y, zk.x);
+                up[q] = make_float2 (zp.y, zp.x);
+            }
+            CFFT_PHASE_FENCE();
+        }
+        sp_pair_exchange<G, true> (up, sp_plane, tm);
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            v[16 + q] = up[q];
+        sp_core<G> (v, tw, sp_plane, tm);
         int ts = t0;
         CFFT_LAUNDER_INDEX (ts);
 #pragma unroll

@@ -23,7 +23,7 @@ float2 unit_root (long long num, long long den) // exp(-2*pi*i*num/den)
 
 // split-plane single pass (split_plane_kernels.hpp), N = 32 T: per twiddled stage rows [j][k], k < p, of W_{r p}^{a k}:
 // stage 1 (p = 32, r = 32): a = 1..7, 8, 16, 24; stage 2 (p = 1024): the same ten rows for r = 32 (N = 32768), or
-// a = 1, 2, 3, 4, 8, 12 for r = 16 (N = 16384)
+// a = 1, 2, 3, 4, 8, 12 for r = 16 (N = 16384), or a = 1..7 for r = 8 (N = 8192)
 void append_split_plane_twiddles (int n, std::vector<float2>& out)
 {
     static const int a32[10] = { 1, 2, 3, 4, 5, 6, 7, 8, 16, 24 };
@@ -32,9 +32,9 @@ void append_split_plane_twiddles (int n, std::vector<float2>& out)
         for (int k = 0; k < 32; ++k)
             out.push_back (unit_root ((long long) a32[j] * k, 1024));
     const int last = n / 1024;
-    for (int j = 0; j < (last == 32 ? 10 : 6); ++j)
+    for (int j = 0; j < (last == 32 ? 10 : (last == 16 ? 6 : 7)); ++j) // last == 8 (N = 8192): a = 1..7, the head of a32
         for (int k = 0; k < 1024; ++k)
-            out.push_back (unit_root ((long long) (last == 32 ? a32[j] : a16[j]) * k, n));
+            out.push_back (unit_root ((long long) (last == 16 ? a16[j] : a32[j]) * k, n));
 }
 
 void append_stage_twiddles (const PlanDesc& d, std::vector<float2>& out)
@@ -434,7 +434,7 @@ bool build_host_tables (int N, int transform, HostTables& out)
         if (! core_plan_desc (nc, d))
             return false;
         append_stage_twiddles (d, out.stage_twiddles);
-        if (nc == 16384) // the split-plane form of this length: its table follows the interleaved-image plan's
+        if (nc == 16384 || nc == 8192) // the split-plane form of this length: its table follows the interleaved-image plan's
             append_split_plane_twiddles (nc, out.stage_twiddles);
         if (nc == 4096)
         {

@@ -260,7 +260,9 @@ def test_convolution_golden(gpu, golden, n, tag):
 # sizes where fft_convolve_frames_batch runs the three steps as separate launches (8192-point plan, two-pass, mixed radix)
 @pytest.mark.parametrize("n,tr", [(16, COMPLEX), (1024, COMPLEX), (2048, COMPLEX), (4096, COMPLEX), (32, REAL), (1024, REAL),
                                   (2048, REAL), (4096, REAL), (8192, REAL),
-                                  (8192, COMPLEX), (65536, COMPLEX), (16384, REAL), (32768, REAL), (480, COMPLEX), (960, REAL)])
+                                  (8192, COMPLEX), (65536, COMPLEX), (16384, REAL), (32768, REAL), (480, COMPLEX), (960, REAL),
+                                  # fused on the split-plane kernels (frame in registers): one launch
+                                  (16384, COMPLEX), (32768, COMPLEX), (65536, REAL)])
 def test_batched_convolution_ops_vs_oracle(gpu, oracle, n, tr):
     """fft_convolve_unordered_batch (per-frame and shared filter), accumulate into a non-zero ab, fused kernel"""
     api, torch, dev = gpu
@@ -406,5 +408,36 @@ def test_wave_per_frame_form_of_n4096(gpu, oracle):
         assert np.all(o[:, 2 * n:] == 9.0)
     finally:
         api.set_option("wave4096", 0)
+    api.fft_destroy_setup(s)
+    oracle.destroy_setup(so)
+
+
+@pytest.mark.parametrize("tr", [COMPLEX, REAL])
+def test_split_plane_form_of_n8192(gpu, oracle, tr):
+    """option "split8192": the 8192-point core (N = 8192 complex, real N = 16384) through the 256-work-item split-plane
+    kernels (csrc/split_plane_kernels.hpp, 32 x 32 x 8) -- same results as the interleaved-image plan; the fused
+    convolution of these sizes always runs on them"""
+    api, torch, dev = gpu
+    n = 8192 if tr == COMPLEX else 16384
+    nf, batch = _frame(n, tr), 11
+    s, so = api.fft_new_setup(n, api.FFT_COMPLEX if tr == COMPLEX else api.FFT_REAL), oracle.new_setup(n, tr)
+    x = ol.uniform(batch * nf, 777 + n).reshape(batch, nf)
+    want_f = oracle.transform_batch(so, x, FORWARD)
+    want_b = oracle.transform_batch(so, want_f, BACKWARD)
+    api.set_option("split8192", 1)
+    try:
+        assert_frames_close(_gpu_transform(gpu, s, x, api.FFT_FORWARD), want_f, what="split-plane 8192 fwd")
+        assert_frames_close(_gpu_transform(gpu, s, want_f, api.FFT_BACKWARD), want_b, what="split-plane 8192 bwd")
+        stride = nf + 64
+        buf = torch.zeros((batch, stride), device=dev)
+        buf[:, :nf] = torch.from_numpy(x).to(dev)
+        out = torch.full((batch, stride), 9.0, device=dev)
+        api.fft_transform_batch_strided(s, buf, stride, out, stride, batch, api.FFT_FORWARD)
+        torch.cuda.synchronize()
+        o = out.cpu().numpy()
+        assert_frames_close(o[:, :nf], want_f, what="split-plane 8192 strided")
+        assert np.all(o[:, nf:] == 9.0)
+    finally:
+        api.set_option("split8192", 0)
     api.fft_destroy_setup(s)
     oracle.destroy_setup(so)
