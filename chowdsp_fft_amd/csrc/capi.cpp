@@ -265,6 +265,9 @@ std::atomic<int> g_split16384 { -1 };
 // "split8192": N = 8192 complex / real N = 16384 through the split-plane kernels with 256 work-items (32 x 32 x 8) instead of
 // the 512-thread interleaved-image plan; an A/B switch, off by default
 std::atomic<int> g_split8192 { 0 };
+// "conv_wave2048": fused convolution of 2048-point cores (real N = 4096, complex N = 2048) by ONE WAVEFRONT per frame on the
+// split-plane kernels (64 work-items x 32 points, no workgroup barrier) instead of the 128-thread LDS-image plan
+std::atomic<int> g_conv_wave2048 { 0 };
 // "fused_conv_split": fft_convolve_frames_batch on the split-plane sizes (8192 / 16384 / 32768 complex points, real N = 16384 / 32768 / 65536)
 // as ONE launch (default) or as the three-launch composition (0), for A/B timing
 std::atomic<int> g_fused_conv_split { 1 };
@@ -1220,6 +1223,8 @@ int fft_gpu_set_option (const char* name, long value)
         g_split16384 = value != 0 ? 1 : 0;
     else if (std::strcmp (name, "split8192") == 0)
         g_split8192 = value != 0 ? 1 : 0;
+    else if (std::strcmp (name, "conv_wave2048") == 0)
+        g_conv_wave2048 = value != 0 ? 1 : 0;
     else if (std::strcmp (name, "fused_conv_split") == 0)
         g_fused_conv_split = value != 0 ? 1 : 0;
     else
@@ -1378,11 +1383,12 @@ int fft_convolve_frames_batch (void* setup, const float* x, const float* dft_fil
     const DeviceGuard guard (s->device);
     const DeviceTables* t = s->tables;
     const int nc = complex_len (s);
-    if (g_fused_conv_split.load() != 0 && t->core_n == nc && t->gen_ns == 0 && (nc == cfft::kSplitCoreN || nc == 16384 || nc == 8192))
+    if (g_fused_conv_split.load() != 0 && t->core_n == nc && t->gen_ns == 0 && (nc == cfft::kSplitCoreN || nc == 16384 || nc == 8192 || (nc == 2048 && g_conv_wave2048.load() != 0)))
     {
         // frame in registers (split_plane_kernels.hpp): both cores and the multiplication in one launch
         const float2* tw = (nc == 16384)  ? t->stage_twiddles + cfft::CorePlan<16384>::type::tw_total
                            : (nc == 8192) ? t->stage_twiddles + cfft::CorePlan<8192>::type::tw_total
+                           : (nc == 2048) ? t->stage_twiddles + cfft::CorePlan<2048>::type::tw_total
                                           : t->stage_twiddles;
         const hipError_t es = launch_conv_frames_split (nc, s->transform == FFT_REAL, (const float2*) x, (const float2*) dft_filter, (float2*) y, tw, t->real_twiddles, scaling, batch, (hipStream_t) stream);
         if (es != hipSuccess)

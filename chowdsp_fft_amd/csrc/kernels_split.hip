@@ -106,6 +106,8 @@ hipError_t launch_conv_frames_split (int n, bool real, const float2* in, const f
         return conv_frames_split<SplitGeom<512>> (real, in, H, out, tw, real_tw, scaling, batch, stream);
     if (n == SplitGeom<256>::N)
         return conv_frames_split<SplitGeom<256>> (real, in, H, out, tw, real_tw, scaling, batch, stream);
+    if (n == SplitGeom<64>::N)
+        return conv_frames_split<SplitGeom<64>> (real, in, H, out, tw, real_tw, scaling, batch, stream);
     return hipErrorInvalidValue;
 }
 } // namespace cfft::host

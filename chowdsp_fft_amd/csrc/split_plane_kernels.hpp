@@ -29,6 +29,8 @@ namespace cfft
 //             (two workgroups per CU, 66 KiB plane each; replaces the interleaved-image plan with streamed twiddles)
 //   T =  256: N =  8192 = 32 x 32 x 8, the last stage as four radix-8 butterflies per work-item (four workgroups per CU,
 //             33 KiB plane each); used by the fused convolution, where the interleaved-image plan has no registers left
+//   T =   64: N =  2048 = 32 x 32 x 2, ONE WAVEFRONT per frame: sixteen radix-2 butterflies per work-item, an 8.25 KiB
+//             wave-private plane, no workgroup barrier that another wave takes part in (fused convolution of real N = 4096)
 // Invariant: register slot c of work-item t holds element t + T c -- on input, after each exchange and on output.
 template <int T_>
 struct SplitGeom
@@ -43,7 +45,7 @@ struct SplitGeom
     // LAST = 32: [10][1024] the same rows of W_N^(a k); LAST = 16: [6][1024] rows a = 1, 2, 3, 4, 8, 12; LAST = 8: [7][1024]
     // rows a = 1..7
     static constexpr int tw_stage2 = 10 * 32;
-    static constexpr int tw_rows2 = LAST == 32 ? 10 : (LAST == 16 ? 6 : 7);
+    static constexpr int tw_rows2 = LAST == 32 ? 10 : (LAST == 16 ? 6 : LAST - 1); // LAST = 8 / 4 / 2: rows a = 1 .. LAST - 1
     static constexpr int tw_total = tw_stage2 + tw_rows2 * 1024;
 };
 constexpr int kSplitN = SplitGeom<1024>::N;   // the longest frame of this family
@@ -267,6 +269,23 @@ __device__ __forceinline__ void sp_core (float2 (&v)[32], const float2* __restri
         sp_exchange<G, 32> (v, plane, t);
         CFFT_PHASE_FENCE();
         fft_reg32<true> (v, w);
+    }
+    else if constexpr (G::LAST == 2)
+    {
+        // N = 2048: 1024 radix-2 butterflies, sixteen per work-item: slots q and q + 16 (elements i = t + 64 q and i + 1024),
+        // twiddle W_N^i = W_N^t W_32^q on the second input: ONE table entry per work-item, the W_32^q are constants
+        const float2 w0 = tw[G::tw_stage2 + t];
+        sp_exchange<G, 32> (v, plane, t);
+        CFFT_PHASE_FENCE();
+#define CFFT_R2(Q) \
+    { \
+        const float2 a = v[Q], b = cmul (mul_w32<Q> (v[Q + 16]), w0); \
+        v[Q] = make_float2 (a.x + b.x, a.y + b.y); \
+        v[Q + 16] = make_float2 (a.x - b.x, a.y - b.y); \
+    }
+        CFFT_R2 (0) CFFT_R2 (1) CFFT_R2 (2) CFFT_R2 (3) CFFT_R2 (4) CFFT_R2 (5) CFFT_R2 (6) CFFT_R2 (7)
+        CFFT_R2 (8) CFFT_R2 (9) CFFT_R2 (10) CFFT_R2 (11) CFFT_R2 (12) CFFT_R2 (13) CFFT_R2 (14) CFFT_R2 (15)
+#undef CFFT_R2
     }
     else if constexpr (G::LAST == 8)
     {
@@ -539,7 +558,7 @@ __global__ __launch_bounds__ (G::T) void c2r_split_kernel (const float2* __restr
 // inverse core wants its input.  The filter bins are the same for every frame but 64 VGPRs of them do not fit next to the
 // frame: they are re-read from L2 per frame, in rounds, requested before the multiplications that use them.
 template <class G>
-__global__ __launch_bounds__ (G::T) void conv_frames_c2c_split_kernel (const float2* __restrict__ in,
+__global__ __launch_bounds__ (G::T, 4) void conv_frames_c2c_split_kernel (const float2* __restrict__ in,
                                                                         const float2* __restrict__ H,
                                                                         float2* __restrict__ out,
                                                                         const float2* __restrict__ tw,
@@ -589,7 +608,7 @@ __global__ __launch_bounds__ (G::T) void conv_frames_c2c_split_kernel (const flo
 // exchange of r2c_split_kernel, split -> * H -> merge on every (k, M - k) pair in registers, the pair exchange of
 // c2r_split_kernel, inverse core.
 template <class G>
-__global__ __launch_bounds__ (G::T) void conv_frames_real_split_kernel (const float2* __restrict__ in,
+__global__ __launch_bounds__ (G::T, 4) void conv_frames_real_split_kernel (const float2* __restrict__ in,
                                                                          const float2* __restrict__ H,
                                                                          float2* __restrict__ out,
                                                                          const float2* __restrict__ tw,
@@ -619,23 +638,24 @@ __global__ __launch_bounds__ (G::T) void conv_frames_real_split_kernel (const fl
             up[q] = v[16 + q];
         sp_pair_exchange<G, false> (up, sp_plane, tm);
         CFFT_PHASE_FENCE();
-        // eight rounds of two pairs: pair twiddle + the two filter bins of a pair are 6 VGPRs next to the 96 of v / up
+        constexpr int PR = (G::T == 64) ? 1 : 2;
+        // rounds of PR pairs: pair twiddle + the two filter bins of a pair are 6 VGPRs next to the 96 of v / up
 #pragma unroll
-        for (int r = 0; r < 8; ++r)
+        for (int r = 0; r < 16 / PR; ++r)
         {
-            float2 pw[2], hk[2], hp[2];
+            float2 pw[PR], hk[PR], hp[PR];
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < PR; ++j)
             {
-                const int k = tm + G::T * (2 * r + j);
+                const int k = tm + G::T * (PR * r + j);
                 pw[j] = wtab[k];
                 hk[j] = H[k];
                 hp[j] = H[k == 0 ? M / 2 : M - k];
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < PR; ++j)
             {
-                const int q = 2 * r + j;
+                const int q = PR * r + j;
                 const int k = tm + G::T * q;
                 const float2 A = v[q], Zp = up[q];
                 float2 Xk, Xp;

@@ -32,7 +32,7 @@ void append_split_plane_twiddles (int n, std::vector<float2>& out)
         for (int k = 0; k < 32; ++k)
             out.push_back (unit_root ((long long) a32[j] * k, 1024));
     const int last = n / 1024;
-    for (int j = 0; j < (last == 32 ? 10 : (last == 16 ? 6 : 7)); ++j) // last == 8 (N = 8192): a = 1..7, the head of a32
+    for (int j = 0; j < (last == 32 ? 10 : (last == 16 ? 6 : last - 1)); ++j) // last == 8 / 2 (N = 8192 / 2048): a = 1 .. last - 1, the head of a32
         for (int k = 0; k < 1024; ++k)
             out.push_back (unit_root ((long long) (last == 16 ? a16[j] : a32[j]) * k, n));
 }
@@ -434,7 +434,7 @@ bool build_host_tables (int N, int transform, HostTables& out)
         if (! core_plan_desc (nc, d))
             return false;
         append_stage_twiddles (d, out.stage_twiddles);
-        if (nc == 16384 || nc == 8192) // the split-plane form of this length: its table follows the interleaved-image plan's
+        if (nc == 16384 || nc == 8192 || nc == 2048) // the split-plane form of this length: its table follows the interleaved-image plan's
             append_split_plane_twiddles (nc, out.stage_twiddles);
         if (nc == 4096)
         {

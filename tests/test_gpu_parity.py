@@ -441,3 +441,35 @@ def test_split_plane_form_of_n8192(gpu, oracle, tr):
         api.set_option("split8192", 0)
     api.fft_destroy_setup(s)
     oracle.destroy_setup(so)
+
+
+@pytest.mark.parametrize("n,tr", [(4096, REAL), (2048, COMPLEX)])
+def test_wave_per_frame_fused_convolution(gpu, oracle, n, tr):
+    """option "conv_wave2048": fft_convolve_frames_batch of 2048-point cores by one wavefront per frame
+    (csrc/split_plane_kernels.hpp, SplitGeom<64>) -- same results as the workgroup plan and the oracle's pipeline"""
+    api, torch, dev = gpu
+    nf, batch = _frame(n, tr), 37
+    x = ol.uniform(batch * nf, 91 + n).reshape(batch, nf)
+    h = ol.uniform(nf, 92 + n).reshape(1, nf)
+    s, so = api.fft_new_setup(n, api.FFT_COMPLEX if tr == COMPLEX else api.FFT_REAL), oracle.new_setup(n, tr)
+    xd, hd = torch.from_numpy(x).to(dev), torch.from_numpy(h).to(dev)
+    H = torch.empty_like(hd)
+    api.fft_transform_unordered_batch(s, hd, H, api.FFT_FORWARD)
+    b0 = oracle.transform(so, h[0], FORWARD, False)
+    want = np.empty_like(x)
+    for f in range(batch):
+        a = oracle.transform(so, x[f], FORWARD, False)
+        want[f] = oracle.transform(so, oracle.convolve(so, a, b0, np.zeros(nf, np.float32), 1.0 / n), BACKWARD, False)
+    api.set_option("conv_wave2048", 1)
+    try:
+        y = torch.empty_like(xd)
+        api.fft_convolve_frames_batch(s, xd, H, y, 1.0 / n)
+        inplace = xd.clone()
+        api.fft_convolve_frames_batch(s, inplace, H, inplace, 1.0 / n)
+        torch.cuda.synchronize()
+        assert_frames_close(y.cpu().numpy(), want, what="wave-per-frame fused convolution")
+        assert_frames_close(inplace.cpu().numpy(), want, what="wave-per-frame fused convolution in place")
+    finally:
+        api.set_option("conv_wave2048", 0)
+    api.fft_destroy_setup(s)
+    oracle.destroy_setup(so)

@@ -11,6 +11,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from chowdsp_fft_amd import api  # noqa: E402
 
 dev = torch.device("cuda:0")
+opts = [a for a in sys.argv[1:] if "=" in a]
+sys.argv = [a for a in sys.argv if "=" not in a]
+for o in opts:
+    api.set_option(o.split("=")[0], int(o.split("=")[1]))
 sizes = sys.argv[1:] or ["c4096", "r8192", "c8192", "r16384", "c16384", "r32768", "c32768", "r65536"]
 _w = torch.rand((1 << 26,), device=dev)
 for _ in range(200):  # idle clocks: the first milliseconds run 10-25 % slow
