@@ -70,6 +70,13 @@ int fft_gpu_release_stream_resources (void* stream);
                         frames per XCD, > lag)
      "wave4096"         1: N = 4096 complex transforms run one wavefront per frame (two radix-64 stages in registers, one
                         wave-private exchange) instead of one 256-work-item workgroup per frame; same rate, default 0
+     "split16384"       0: N = 16384 complex / real N = 32768 through the round-1 plan instead of the split-plane kernels
+     "split8192"        1: N = 8192 complex / real N = 16384 through the split-plane kernels (256 work-items x 32 points)
+                        instead of the 512-work-item LDS-image plan; same rate, default 0
+     "fused_conv_split" 0: fft_convolve_frames_batch of the 8192 / 16384 / 32768-point cores as three launches instead of
+                        the one-launch split-plane form (A/B switch; default 1)
+     "conv_wave2048"    1: fft_convolve_frames_batch of 2048-point cores by one wavefront per frame; 12-14 % slower than
+                        the workgroup plan, default 0
    Returns 0, or FFT_GPU_EINVAL for an unknown name / a value out of range. */
 int fft_gpu_set_option (const char* name, long value);
 
@@ -136,9 +143,10 @@ int fft_accumulate_batch (void* setup, const float* a, const float* b, float* ab
    i.e. the reference call sequence of test/test.cpp:161-166 / :212-215       unordered layout)
        fft_transform_unordered(x, FORWARD) -> fft_convolve_unordered(X, H, 0-initialised, scaling)
        -> fft_transform_unordered(BACKWARD)
-   in ONE kernel for N <= 4096 complex / N <= 8192 real powers of two: the spectrum never leaves the CU, HBM
-   traffic is one read + one write per frame.  Every other supported size runs the same three steps as separate
-   launches with `y` holding the spectra in between (x == y allowed either way). */
+   in ONE kernel for every power of two that runs as a single pass (N <= 32768 complex / N <= 65536 real): the
+   spectrum never leaves the CU, HBM traffic is one read + one write per frame.  Every other supported size (two-pass
+   and mixed-radix plans) runs the same three steps as separate launches with `y` holding the spectra in between
+   (x == y allowed either way). */
 int fft_convolve_frames_batch (void* setup, const float* x, const float* dft_filter, float* y, float scaling, size_t batch, void* stream);
 
 /* ---- several devices in one process (SURVEY section 8 row e) ------------------------------------------------------
