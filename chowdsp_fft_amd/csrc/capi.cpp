@@ -1219,8 +1219,6 @@ int fft_gpu_set_option (const char* name, long value)
         o.slots = value;
     else if (std::strcmp (name, "wave4096") == 0)
         set_wave4096 (value != 0);
-    else if (std::strcmp (name, "fused_prefetch") == 0)
-        set_fused_prefetch (value != 0);
     else if (std::strcmp (name, "split16384") == 0)
         g_split16384 = value != 0 ? 1 : 0;
     else if (std::strcmp (name, "split8192") == 0)

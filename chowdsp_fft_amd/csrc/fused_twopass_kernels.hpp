@@ -255,8 +255,6 @@ __device__ __forceinline__ FusedItem fused_resolve (FusedState* st, FusedQueue* 
 struct Fused256Shared
 {
     FusedItem item[2];    // current / next item: written by lane 0, read by everybody a barrier later
-    unsigned slot_free;   // pass A: the slot's previous frame has been read completely (looked at one phase ahead of the stores)
-    unsigned pad[3];
     float2 tw[15 * 16];   // stage-1 twiddles of Plan256: [a - 1][k]
 };
 
@@ -311,8 +309,7 @@ __global__ __launch_bounds__ (256) void fused256_kernel (const float2* __restric
                                                         size_t out_stride,
                                                         unsigned lag,
                                                         unsigned slots,
-                                                        unsigned dbg,
-                                                        unsigned prefetch)
+                                                        unsigned dbg)
 {
     extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
     __shared__ Fused256Shared sh;
@@ -340,100 +337,49 @@ __global__ __launch_bounds__ (256) void fused256_kernel (const float2* __restric
 
     // Look-ahead pipeline of lane 0 / wave 0, one item ahead, every step asynchronous:
     //   end of item i - 1 : draw the ticket of item i + 1
-    //   start of item i   : (operands of item i requested)  ticket -> ask for its frame and, for a pass-B ticket, for the
-    //                       completion flags it depends on (slot and use count follow from the ticket alone)
-    //   first barrier     : frame -> item i + 1 known, with "ready" from that early look at its flags; parked in LDS
-    //   second barrier    : everybody knows item i + 1: ITS OPERANDS ARE REQUESTED NOW (pass A: always; pass B: if ready),
-    //                       ahead of item i's second butterfly and stores -- session r02j: the items of this kernel are not
-    //                       bounded by the store path (tools/membench4.hip) but by running load, arithmetic and store phases
-    //                       of an item one after the other at two workgroups per CU
-    //   end of item i     : a pass-B item that was not ready gets a second look; draw the ticket of item i + 2
+    //   start of item i   : (operands of item i requested)  ticket -> ask for its frame
+    //   first barrier     : frame -> item i + 1 known; ask for its dependency flags (wave 0)
+    //   end of item i     : flags -> "ready"; item i + 1 parked in LDS; draw the ticket of item i + 2
     unsigned tk = 0;             // lane 0: the next ticket
     unsigned long long fe = 0;   // lane 0: its frame_of entry
     FusedItem ni;                // lane 0: the next item
-    unsigned eflag = 0;          // wave 0: early look at one of the next (pass-B) item's 16 dependency flags
-    unsigned nflag = 0;          // wave 0: ... the second look
-    unsigned sflag = 0;          // wave 0: one of the 16 "previous frame of my slot has been read" flags of the current pass-A item
+    unsigned nflag = 0;          // wave 0: one of the next item's 16 dependency flags
     unsigned nkind = 2, nneed = 0;
-    bool early = false;          // wave 0: the next item was found ready at the first barrier
     if (tid == 0)
         tk = __hip_atomic_fetch_add (&q->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // Pass-A items whose completion flag has not been stored yet (workgroup-uniform), at most two: `pb` belongs to the item
-    // before the current one, `pa` to the one before that.  Vector-memory operations retire in issue order, so once a wave
-    // holds the operands of item j, every store it issued BEFORE requesting them has been acknowledged: the stores of item
-    // j - 1 if the operands were requested at the start of item j, those of item j - 2 if they were requested during item
-    // j - 1 (prefetched: ahead of that item's stores).  The flags go out behind the barrier that follows the operands.
-    bool pa_valid = false, pb_valid = false;
-    unsigned pa_slot = 0, pa_tile = 0, pa_val = 0, pb_slot = 0, pb_tile = 0, pb_val = 0;
-    // operands of the next item, requested during the current one
-    float2 pv[16], pbw[16];
-    bool have_pf = false;
+    // a pass-A item whose completion flag has not been stored yet (workgroup-uniform)
+    bool pend = false;
+    unsigned pend_slot = 0, pend_tile = 0, pend_val = 0;
 
-// every pending flag, the slow way: every wave waits for all of its stores, the workgroup meets, lane 0 stores the flags
+// the pending flag, the slow way: every wave waits for all of its stores, the workgroup meets, lane 0 stores the flag
 #define CFFT_FUSED_FLUSH_PENDING()                                              \
-    if (pa_valid || pb_valid)                                                   \
+    if (pend)                                                                   \
     {                                                                           \
         asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");                       \
         __syncthreads();                                                        \
         if (tid == 0)                                                           \
-        {                                                                       \
-            if (pa_valid)                                                       \
-                flag_store (&q->aflag[pa_slot][pa_tile], pa_val);               \
-            if (pb_valid)                                                       \
-                flag_store (&q->aflag[pb_slot][pb_tile], pb_val);               \
-        }                                                                       \
-        pa_valid = pb_valid = false;                                            \
+            flag_store (&q->aflag[pend_slot][pend_tile], pend_val);             \
+        pend = false;                                                           \
     }
 // ... and the fast way, right after a barrier that every wave reached AFTER its current operands had arrived
-// (WAS_PF: those operands had been requested during the previous item, i.e. before its stores)
-#define CFFT_FUSED_SIGNAL_PENDING(WAS_PF)                                       \
+#define CFFT_FUSED_SIGNAL_PENDING()                                             \
+    if (pend)                                                                   \
     {                                                                           \
-        if (pa_valid)                                                           \
-        {                                                                       \
-            if (tid == 0)                                                       \
-                flag_store (&q->aflag[pa_slot][pa_tile], pa_val);               \
-            pa_valid = false;                                                   \
-        }                                                                       \
-        if (pb_valid && ! (WAS_PF))                                             \
-        {                                                                       \
-            if (tid == 0)                                                       \
-                flag_store (&q->aflag[pb_slot][pb_tile], pb_val);               \
-            pb_valid = false;                                                   \
-        }                                                                       \
-    }
-// end of an item: the flags age by one item (`pa` has always gone out by now: every item signals or flushes it)
-#define CFFT_FUSED_PENDING_SHIFT(NEW_VALID, SLOT, TILE, VAL)                    \
-    {                                                                           \
-        pa_valid = pb_valid;                                                    \
-        pa_slot = pb_slot;                                                      \
-        pa_tile = pb_tile;                                                      \
-        pa_val = pb_val;                                                        \
-        pb_valid = (NEW_VALID);                                                 \
-        pb_slot = (SLOT);                                                       \
-        pb_tile = (TILE);                                                       \
-        pb_val = (VAL);                                                         \
-    }
-// look-ahead at the start of an item (wave 0, after the item's operands have been requested): ticket -> ask for its frame,
-// for the flags a pass-B ticket depends on, and (CUR_A) for the flags that say the current item's slot may be overwritten
-#define CFFT_FUSED_LOOKAHEAD_TICKET(CUR_A)                                      \
-    if (tid < 64 && ! (CFFT_FUSED_EXPERIMENT && (dbg & 0x100u)))                \
-    {                                                                           \
-        const unsigned tk_ = __builtin_amdgcn_readfirstlane (tk);               \
-        bool is_a_, fill_;                                                      \
-        const unsigned fs_ = fused_frame_step<TILES> (tk_, lag, is_a_, fill_);  \
         if (tid == 0)                                                           \
-        {                                                                       \
-            fused_publish_if_opening<TILES> (st, q, tk_, batch);                \
-            fe = fill_ ? 0ull : ld_relaxed64 (&q->frame_of[fs_ % kFusedRing]);  \
-        }                                                                       \
-        eflag = 0;                                                              \
-        if (! is_a_ && ! fill_)                                                 \
-            eflag = ld_relaxed (&q->aflag[fs_ % slots][tid & 15]);              \
-        if ((CUR_A) && it.need != 0)                                            \
-            sflag = ld_relaxed (&q->bflag[it.slot][tid & 15]);                  \
+            flag_store (&q->aflag[pend_slot][pend_tile], pend_val);             \
+        pend = false;                                                           \
     }
-// look-ahead after the first barrier (wave 0): frame -> the next item, ready or not, parked in LDS for everybody
-#define CFFT_FUSED_LOOKAHEAD_FRAME(CUR_A)                                                                        \
+// look-ahead at the start of an item (lane 0, after the item's operands have been requested): ticket -> ask for its frame
+#define CFFT_FUSED_LOOKAHEAD_TICKET()                                           \
+    if (tid == 0 && ! (CFFT_FUSED_EXPERIMENT && (dbg & 0x100u)))                \
+    {                                                                           \
+        fused_publish_if_opening<TILES> (st, q, tk, batch);                     \
+        bool is_a_, fill_;                                                      \
+        const unsigned fs_ = fused_frame_step<TILES> (tk, lag, is_a_, fill_);   \
+        fe = fill_ ? 0ull : ld_relaxed64 (&q->frame_of[fs_ % kFusedRing]);      \
+    }
+// look-ahead after the first barrier (wave 0): frame -> the next item; ask for its dependency flags
+#define CFFT_FUSED_LOOKAHEAD_FRAME()                                                                             \
     if (tid < 64 && ! (CFFT_FUSED_EXPERIMENT && (dbg & 0x100u)))                                                 \
     {                                                                                                            \
         if (tid == 0)                                                                                            \
@@ -445,57 +391,20 @@ __global__ __launch_bounds__ (256) void fused256_kernel (const float2* __restric
         nkind = __builtin_amdgcn_readfirstlane (ni.kind);                                                        \
         nneed = __builtin_amdgcn_readfirstlane (ni.need);                                                        \
         const unsigned nslot_ = __builtin_amdgcn_readfirstlane (ni.slot);                                        \
-        early = (nkind == 1) && (__all (eflag >= nneed) != 0);                                                   \
-        bool free_ = true;                                                                                       \
-        if ((CUR_A) && it.need != 0)                                                                             \
-            free_ = __all (sflag >= it.need) != 0;                                                               \
-        if (tid == 0)                                                                                            \
-        {                                                                                                        \
-            ni.ready = early ? 1u : 0u;                                                                          \
-            sh.item[cur ^ 1u] = ni;                                                                              \
-            sh.slot_free = free_ ? 1u : 0u;                                                                      \
-        }                                                                                                        \
-        if (nkind == 1 && ! early)                                                                               \
+        if (nkind == 1)                                                                                          \
             nflag = ld_relaxed (&q->aflag[nslot_][tid & 15]);                                                    \
     }
-// after the second barrier (everybody): request the next item's operands
-#define CFFT_FUSED_PREFETCH()                                                                                    \
-    have_pf = false;                                                                                             \
-    if (prefetch != 0 && ! (CFFT_FUSED_EXPERIMENT && dbg != 0))                                                  \
-    {                                                                                                            \
-        const unsigned xk_ = sh.item[cur ^ 1u].kind, xf_ = sh.item[cur ^ 1u].frame, xt_ = sh.item[cur ^ 1u].tile; \
-        const unsigned xs_ = sh.item[cur ^ 1u].slot, xr_ = sh.item[cur ^ 1u].ready;                              \
-        if (xk_ == 0)                                                                                            \
-        {                                                                                                        \
-            const float2* __restrict__ psrc = in + (size_t) xf_ * in_stride + xt_ * 16;                          \
-            _Pragma ("unroll") for (int s_ = 0; s_ < 16; ++s_)                                                   \
-                pv[s_] = gload (&psrc[(unsigned) (t0 + 16 * s_) * n1 + c0]);                                     \
-            const size_t pbase = (size_t) (xt_ * 16) * 256 + c1 * 16 + i1;                                       \
-            _Pragma ("unroll") for (int b_ = 0; b_ < 16; ++b_)                                                   \
-                pbw[b_] = big_tw[pbase + b_ * 256];                                                              \
-            have_pf = true;                                                                                      \
-        }                                                                                                        \
-        else if (xk_ == 1 && xr_ != 0)                                                                           \
-        {                                                                                                        \
-            const float2* __restrict__ psrc = wq + (size_t) xs_ * N + xt_ * 256 + tid;                           \
-            _Pragma ("unroll") for (int s_ = 0; s_ < 16; ++s_)                                                   \
-                pv[s_] = gload_l2 (&psrc[s_ * 16 * 256]);                                                        \
-            have_pf = true;                                                                                      \
-        }                                                                                                        \
-    }                                                                                                            \
-    CFFT_PHASE_FENCE();
-// look-ahead at the end of an item (wave 0): a second look at the flags of a pass-B item that was not ready, the ticket
-// after it drawn
+// look-ahead at the end of an item (wave 0): flags -> "ready", the next item parked in LDS, the ticket after it drawn
 #define CFFT_FUSED_LOOKAHEAD_PARK()                                                                              \
     if (tid < 64 && ! (CFFT_FUSED_EXPERIMENT && (dbg & 0x100u)))                                                 \
     {                                                                                                            \
         bool ready_ = false;                                                                                     \
-        if (nkind == 1 && ! early)                                                                               \
+        if (nkind == 1)                                                                                          \
             ready_ = __all (nflag >= nneed) != 0;                                                                \
         if (tid == 0)                                                                                            \
         {                                                                                                        \
-            if (ready_)                                                                                          \
-                sh.item[cur ^ 1u].ready = 1u;                                                                    \
+            ni.ready = ready_ ? 1u : 0u;                                                                         \
+            sh.item[cur ^ 1u] = ni;                                                                              \
             tk = __hip_atomic_fetch_add (&q->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);            \
         }                                                                                                        \
     }
@@ -543,54 +452,31 @@ __global__ __launch_bounds__ (256) void fused256_kernel (const float2* __restric
             it.ready = 1;
         }
 #endif
-        const bool was_pf = have_pf;
         float2 v[16];
         if (it.kind == 0)
         {
             // ---- pass A: columns [16 tile, 16 tile + 16) of frame it.frame; the inter-pass twiddles come along
+            const float2* __restrict__ src = in + (size_t) it.frame * in_stride + it.tile * 16;
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+            {
+                const float2 x = gload (&src[(unsigned) (t0 + 16 * s) * n1 + c0]);
+                v[s] = INV ? make_float2 (x.y, x.x) : x;
+            }
             const size_t base = (size_t) (it.tile * 16) * 256 + c1 * 16 + i1;
             float2 bw[16];
-            if (was_pf)
-            {
 #pragma unroll
-                for (int s = 0; s < 16; ++s)
-                    v[s] = INV ? make_float2 (pv[s].y, pv[s].x) : pv[s];
-#pragma unroll
-                for (int b = 0; b < 16; ++b)
-                    bw[b] = pbw[b];
-            }
-            else
-            {
-                const float2* __restrict__ src = in + (size_t) it.frame * in_stride + it.tile * 16;
-#pragma unroll
-                for (int s = 0; s < 16; ++s)
-                {
-                    const float2 x = gload (&src[(unsigned) (t0 + 16 * s) * n1 + c0]);
-                    v[s] = INV ? make_float2 (x.y, x.x) : x;
-                }
-#pragma unroll
-                for (int b = 0; b < 16; ++b)
-                    bw[b] = big_tw[base + b * 256];
-            }
-            CFFT_FUSED_LOOKAHEAD_TICKET (true)
+            for (int b = 0; b < 16; ++b)
+                bw[b] = big_tw[base + b * 256];
+            CFFT_FUSED_LOOKAHEAD_TICKET()
             fft_reg<16> (v);
-            __syncthreads(); // the previous item's stage-1 reads are finished; every wave holds this item's operands
-            CFFT_FUSED_SIGNAL_PENDING (was_pf)
-            CFFT_FUSED_LOOKAHEAD_FRAME (true)
+            __syncthreads(); // the previous item's stage-1 reads are finished; every wave's older stores are acknowledged
+            CFFT_FUSED_SIGNAL_PENDING()
+            CFFT_FUSED_LOOKAHEAD_FRAME()
 #pragma unroll
             for (int b = 0; b < 16; ++b)
                 smem[c0 * kFS256 + 17 * t0 + b] = v[b];
             __syncthreads();
-            if (it.need != 0 && sh.slot_free == 0)
-            {
-                // the slot's previous frame must have been read completely by its pass B (drawn slots - lag steps ago); it
-                // almost always has been.  Whoever is waited for may in turn wait for a flag this workgroup still owes.
-                CFFT_FUSED_FLUSH_PENDING()
-                if (tid < 64)
-                    flags_wait (&q->bflag[it.slot][0], it.need, tid, st, 4);
-                __syncthreads();
-            }
-            CFFT_FUSED_PREFETCH()
 #pragma unroll
             for (int a = 0; a < 16; ++a)
                 v[a] = smem[c1 * kFS256 + i1 + 17 * a];
@@ -601,42 +487,43 @@ __global__ __launch_bounds__ (256) void fused256_kernel (const float2* __restric
 #pragma unroll
             for (int b = 0; b < 16; ++b)
                 v[b] = cmul (v[b], bw[b]);
+            if (it.need != 0)
+            {
+                // the slot's previous frame must have been read completely by its pass B (drawn slots - lag steps ago)
+                if (tid < 64)
+                    flags_wait (&q->bflag[it.slot][0], it.need, tid, st, 4);
+                __syncthreads();
+            }
             float2* __restrict__ dst = wq + (size_t) it.slot * N + base;
 #pragma unroll
             for (int b = 0; b < 16; ++b)
                 dst[b * 256] = v[b]; // plain store: stays in this XCD's L2
             CFFT_FUSED_LOOKAHEAD_PARK()
-            CFFT_FUSED_PENDING_SHIFT (true, it.slot, it.tile, it.need + 1)
-            __syncthreads(); // the second look at the next item is visible to everybody
+            pend = true;
+            pend_slot = it.slot;
+            pend_tile = it.tile;
+            pend_val = it.need + 1;
+            __syncthreads(); // the next item is visible to everybody
         }
         else if (it.kind == 1)
         {
             // ---- pass B: rows [16 tile, 16 tile + 16) of the slot -> transposed store into frame it.frame
-            if (was_pf)
+            if (it.ready == 0)
             {
-#pragma unroll
-                for (int s = 0; s < 16; ++s)
-                    v[s] = pv[s];
+                CFFT_FUSED_FLUSH_PENDING() // what is waited for below may include this workgroup's own last tile
+                if (tid < 64)
+                    flags_wait (&q->aflag[it.slot][0], it.need, tid, st, 3);
+                __syncthreads();
             }
-            else
-            {
-                if (it.ready == 0)
-                {
-                    CFFT_FUSED_FLUSH_PENDING() // what is waited for below may include this workgroup's own last tiles
-                    if (tid < 64)
-                        flags_wait (&q->aflag[it.slot][0], it.need, tid, st, 3);
-                    __syncthreads();
-                }
-                const float2* __restrict__ src = wq + (size_t) it.slot * N + it.tile * 256 + tid;
+            const float2* __restrict__ src = wq + (size_t) it.slot * N + it.tile * 256 + tid;
 #pragma unroll
-                for (int s = 0; s < 16; ++s)
-                    v[s] = gload_l2 (&src[s * 16 * 256]); // block (a_hi = s, kb_hi = tile), element tid
-            }
-            CFFT_FUSED_LOOKAHEAD_TICKET (false)
+            for (int s = 0; s < 16; ++s)
+                v[s] = gload_l2 (&src[s * 16 * 256]); // block (a_hi = s, kb_hi = tile), element tid
+            CFFT_FUSED_LOOKAHEAD_TICKET()
             fft_reg<16> (v);
             __syncthreads();
-            CFFT_FUSED_SIGNAL_PENDING (was_pf)
-            CFFT_FUSED_LOOKAHEAD_FRAME (false)
+            CFFT_FUSED_SIGNAL_PENDING()
+            CFFT_FUSED_LOOKAHEAD_FRAME()
 #pragma unroll
             for (int b = 0; b < 16; ++b)
                 smem[kbl * kFS256 + 17 * tb + b] = v[b];
@@ -644,7 +531,6 @@ __global__ __launch_bounds__ (256) void fused256_kernel (const float2* __restric
             // every load of this workgroup has returned (the values went through the exchange): the slot may be rewritten
             if (tid == 0)
                 flag_store (&q->bflag[it.slot][it.tile], it.need);
-            CFFT_FUSED_PREFETCH()
 #pragma unroll
             for (int a = 0; a < 16; ++a)
                 v[a] = smem[kbl * kFS256 + tb + 17 * a];
@@ -657,17 +543,13 @@ __global__ __launch_bounds__ (256) void fused256_kernel (const float2* __restric
             for (int b = 0; b < 16; ++b)
                 gstore (&dst[(unsigned) (tb + 16 * b) * n2], INV ? make_float2 (v[b].y, v[b].x) : v[b]);
             CFFT_FUSED_LOOKAHEAD_PARK()
-            CFFT_FUSED_PENDING_SHIFT (false, 0u, 0u, 0u)
-            __syncthreads(); // the second look at the next item is visible to everybody
+            __syncthreads(); // the next item is visible to everybody
         }
         else
         {
-            // nothing to do for this ticket (queue filling up or running out): no operands, so no prefetch either
             CFFT_FUSED_FLUSH_PENDING()
-            CFFT_FUSED_LOOKAHEAD_TICKET (false)
-            CFFT_FUSED_LOOKAHEAD_FRAME (false)
-            have_pf = false;
-            __syncthreads();
+            CFFT_FUSED_LOOKAHEAD_TICKET()
+            CFFT_FUSED_LOOKAHEAD_FRAME()
             CFFT_FUSED_LOOKAHEAD_PARK()
             __syncthreads();
         }
@@ -675,10 +557,8 @@ __global__ __launch_bounds__ (256) void fused256_kernel (const float2* __restric
     CFFT_FUSED_FLUSH_PENDING()
 #undef CFFT_FUSED_FLUSH_PENDING
 #undef CFFT_FUSED_SIGNAL_PENDING
-#undef CFFT_FUSED_PENDING_SHIFT
 #undef CFFT_FUSED_LOOKAHEAD_FRAME
 #undef CFFT_FUSED_LOOKAHEAD_TICKET
 #undef CFFT_FUSED_LOOKAHEAD_PARK
-#undef CFFT_FUSED_PREFETCH
 }
 } // namespace cfft

@@ -1,5 +1,4 @@
 // Instantiation + launch of the two-pass (N > 4096) kernels and the stand-alone real pair stage.
-#include <atomic>
 #include "launch_util.hpp"
 #include "multipass_kernels.hpp"
 #include "fused_twopass_kernels.hpp"
@@ -352,17 +351,6 @@ size_t fused_state_bytes() { return sizeof (FusedState); }
 size_t fused_workspace_bytes (int nc, int slots) { return (size_t) kFusedMaxXcc * (size_t) slots * (size_t) nc * sizeof (float2); }
 bool fused_supported (int n1, int n2) { return n1 == 256 && n2 == 256; }
 
-// "fused_prefetch" / CHOWDSP_FFT_FUSED_PREFETCH: the one-launch form requests an item's operands during the item before it
-static std::atomic<int>& fused_prefetch_flag()
-{
-    static std::atomic<int> v { [] {
-        const char* e = std::getenv ("CHOWDSP_FFT_FUSED_PREFETCH");
-        return e != nullptr ? std::atoi (e) : 1;
-    }() };
-    return v;
-}
-void set_fused_prefetch (bool on) { fused_prefetch_flag() = on ? 1 : 0; }
-
 hipError_t launch_fused_c2c (int n1, int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, void* state, size_t batch, int lag, int slots, hipStream_t stream, size_t in_stride, size_t out_stride)
 {
     if (batch == 0)
@@ -398,7 +386,7 @@ hipError_t launch_fused_c2c (int n1, int n2, bool inverse, const float2* in, flo
         if (current_device_info (dev))
             grid = std::min (grid, (unsigned) (dev.num_cus * grid_cap));
     }
-    hipLaunchKernelGGL (k, dim3 (grid), dim3 (256), lds, stream, in, work, out, stage_tw, big_tw, (FusedState*) state, (unsigned) batch, in_stride, out_stride, (unsigned) lag, (unsigned) slots, (unsigned) dbg_mode, (unsigned) (fused_prefetch_flag().load() != 0 ? 1 : 0));
+    hipLaunchKernelGGL (k, dim3 (grid), dim3 (256), lds, stream, in, work, out, stage_tw, big_tw, (FusedState*) state, (unsigned) batch, in_stride, out_stride, (unsigned) lag, (unsigned) slots, (unsigned) dbg_mode);
     e = hipGetLastError();
     static const bool debug = std::getenv ("CHOWDSP_FFT_FUSED_DEBUG") != nullptr;
     if (debug && e == hipSuccess)

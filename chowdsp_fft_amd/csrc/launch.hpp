@@ -75,7 +75,6 @@ hipError_t launch_real4 (int r1, int r2, bool inverse, const float2* in, float2*
 // the same two passes in ONE launch with the intermediate handed over inside an XCD's L2 (fused_twopass_kernels.hpp):
 // `state` = fused_state_bytes() of device memory (zeroed by the launcher on `stream`), `work` = fused_workspace_bytes()
 bool fused_supported (int n1, int n2);
-void set_fused_prefetch (bool on); // operands of the next work item requested during the current one (default on)
 size_t fused_state_bytes();
 size_t fused_workspace_bytes (int nc, int slots);
 hipError_t launch_fused_c2c (int n1, int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, void* state, size_t batch, int lag, int slots, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
