@@ -5,6 +5,7 @@
 #include "host_common.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 
@@ -59,9 +60,28 @@ Pipe* ensure_pipe (int device, size_t floats)
     return grow_pipe (p, floats) ? &p : nullptr;
 }
 
+// Buffers this large are registered (pinned) in place for the duration of the call; smaller ones are handed to hipMemcpyAsync
+// as they are (the runtime stages them).  Two reasons: below a few tens of MiB registering costs more than it saves, and a
+// block larger than glibc's largest mmap threshold (32 MiB) is always a mapping of its own, whereas a smaller block may lie
+// inside the process heap and share its first and last page with unrelated objects -- registering and unregistering pages
+// that other code (the HIP runtime's own pageable-copy path among it) may be using at the same time is not something a
+// library should do to its host.  (Session r02j: a test run aborted twice with "Memory access fault ... on address <process
+// heap>" inside a later, unrelated pageable copy, each time right after the host-streaming tests had registered small heap
+// blocks; CHOWDSP_FFT_HOST_PIN_MIN_BYTES overrides.)
+size_t pin_min_bytes()
+{
+    static const size_t v = [] {
+        const char* e = std::getenv ("CHOWDSP_FFT_HOST_PIN_MIN_BYTES");
+        return e != nullptr ? (size_t) std::strtoull (e, nullptr, 10) : ((size_t) 32 << 20) + 4096;
+    }();
+    return v;
+}
+
 // pin a caller buffer in place; returns true if WE registered it (and must unregister)
 bool pin (const void* p, size_t bytes)
 {
+    if (bytes < pin_min_bytes())
+        return false;
     const hipError_t e = hipHostRegister (const_cast<void*> (p), bytes, hipHostRegisterDefault);
     if (e == hipSuccess)
         return true;
