@@ -74,6 +74,10 @@ __device__ __forceinline__ void real_merge_pair (float2 A, float2 Xmk, float2 w,
     Zmk = make_float2 (E.x - O.x, -(E.y - O.y));
 }
 
+#ifndef CFFT_REAL_ROTATE_LANE0
+#define CFFT_REAL_ROTATE_LANE0 1
+#endif
+
 // ---- r2c -----------------------------------------------------------------------------------------
 // P is the plan of the M = N/2 point complex core.
 // LAYOUT 0: the packed spectrum.  LAYOUT 1 / 2: the JUCE engine's interleaved layout written by the pair stage itself
@@ -139,6 +143,13 @@ __global__ __launch_bounds__ (P::T* FPB) void r2c_kernel (const float2* __restri
         team_sync<P::T>();
 
         float2 hi_k[(STAGED && LAYOUT == 2) ? P::R / 2 : 1], hi_p[(STAGED && LAYOUT == 2) ? P::R / 2 : 1]; // the conjugate half's values
+        // One-wavefront teams (T = 64): the mirrored bins M - k of one store instruction are the 64 elements ENDING at a
+        // multiple of 64 -- a 512-byte run that starts one element off a 128-byte line, five lines touched, two of them
+        // for 8 bytes.  Lane 0's element is the odd one: it belongs to the aligned block that the NEXT pair index covers.
+        // So lane 0 stores its mirrored bins one instruction late (same values, same addresses, another store instruction)
+        // and every instruction writes one aligned 512-byte block (CFFT_REAL_ROTATE_LANE0 = 0: the plain order).
+        constexpr bool ROT = CFFT_REAL_ROTATE_LANE0 && ! STAGED && LAYOUT == 0 && P::T == 64;
+        float2 xp_keep[ROT ? P::R / 2 : 1];
 #pragma unroll
         for (int q = 0; q < P::R / 2; ++q)
         {
@@ -170,7 +181,12 @@ __global__ __launch_bounds__ (P::T* FPB) void r2c_kernel (const float2* __restri
             else if (active)
             {
                 const unsigned kp = (unsigned) (k == 0 ? M / 2 : M - k);
-                if constexpr (LAYOUT == 0)
+                if constexpr (ROT)
+                {
+                    gstore (&dst[team_out + (unsigned) k], Xk);
+                    xp_keep[q] = Xp;
+                }
+                else if constexpr (LAYOUT == 0)
                 {
                     gstore (&dst[team_out + (unsigned) k], Xk);
                     gstore (&dst[team_out + kp], Xp);
@@ -191,6 +207,23 @@ __global__ __launch_bounds__ (P::T* FPB) void r2c_kernel (const float2* __restri
                     gstore (&dst[team_out + kp], Xp);
                     if constexpr (LAYOUT == 2)
                         gstore (&dst[team_out + (unsigned) (2 * M) - kp], make_float2 (Xp.x, -Xp.y));
+                }
+            }
+        }
+        if constexpr (ROT)
+        {
+            if (active)
+            {
+                constexpr int H = P::R / 2;
+#pragma unroll
+                for (int q = 0; q < H; ++q)
+                {
+                    const int qn = (q + 1) % H;                                   // lane 0: the pair index after this one
+                    const int kn = P::T * qn;                                     // ... its k (a multiple of 64; 0 for the last q)
+                    const unsigned kp0 = (unsigned) (kn == 0 ? M / 2 : M - kn);  // ... and that pair's mirrored bin
+                    const unsigned kp = (t == 0) ? kp0 : (unsigned) (M - (t + P::T * q));
+                    const float2 val = (t == 0) ? xp_keep[qn] : xp_keep[q];
+                    gstore (&dst[team_out + kp], val);
                 }
             }
         }
@@ -380,6 +413,23 @@ __global__ __launch_bounds__ (P::T* FPB) void c2r_kernel (const float2* __restri
 
         // pair stage straight from global memory (ascending k and descending M-k, both lane-contiguous)
         float2 zk[P::R / 2], zp[P::R / 2];
+        // one-wavefront teams: lane 0 loads its mirrored bins one instruction late, so that every load instruction reads one
+        // aligned 512-byte block (see r2c_kernel)
+        constexpr bool ROT = CFFT_REAL_ROTATE_LANE0 && ! STAGED && LAYOUT == 0 && P::T == 64;
+        float2 xp_l[ROT ? P::R / 2 : 1];
+        if constexpr (ROT)
+        {
+            constexpr int H = P::R / 2;
+#pragma unroll
+            for (int q = 0; q < H; ++q)
+            {
+                const int qn = (q + 1) % H;
+                const int kn = P::T * qn;
+                const unsigned kp0 = (unsigned) (kn == 0 ? M / 2 : M - kn);
+                const unsigned kp = (t == 0) ? kp0 : (unsigned) (M - (t + P::T * q));
+                xp_l[q] = active ? gload (&src[team_in + kp]) : make_float2 (0.f, 0.f);
+            }
+        }
 #pragma unroll
         for (int q = 0; q < P::R / 2; ++q)
         {
@@ -387,8 +437,12 @@ __global__ __launch_bounds__ (P::T* FPB) void c2r_kernel (const float2* __restri
             const int kq = (k == 0 ? M / 2 : M - k);
             float2 A = STAGED ? stage[team_base + (unsigned) k]
                               : (active ? gload (&src[team_in + (unsigned) k]) : make_float2 (0.f, 0.f));
-            const float2 Xp = STAGED ? stage[team_base + (unsigned) kq]
-                                     : (active ? gload (&src[team_in + (unsigned) kq]) : make_float2 (0.f, 0.f));
+            float2 Xp;
+            if constexpr (ROT)
+                Xp = (t == 0) ? xp_l[(q + P::R / 2 - 1) % (P::R / 2)] : xp_l[q]; // lane 0's bin of pair q came with the instruction before
+            else
+                Xp = STAGED ? stage[team_base + (unsigned) kq]
+                            : (active ? gload (&src[team_in + (unsigned) kq]) : make_float2 (0.f, 0.f));
             if constexpr (LAYOUT == 1)
             {
                 if (k == 0)
