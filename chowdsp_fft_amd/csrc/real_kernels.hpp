@@ -74,6 +74,9 @@ __device__ __forceinline__ void real_merge_pair (float2 A, float2 Xmk, float2 w,
     Zmk = make_float2 (E.x - O.x, -(E.y - O.y));
 }
 
+#ifndef CFFT_C2R512_WAVES5
+#define CFFT_C2R512_WAVES5 1
+#endif
 #ifndef CFFT_REAL_ROTATE_LANE0
 #define CFFT_REAL_ROTATE_LANE0 1
 #endif
@@ -370,8 +373,9 @@ __global__ __launch_bounds__ (P::T* FPB) void r2c_kernel_pf (const float2* __res
 // LAYOUT 1: the spectrum comes in the JUCE engine's interleaved layout (X0 = c[0].re, X_{N/2} = c[M].re,
 // chowdsp_fft_juce.cpp:71-73) and the signal is stored times `scale` (the adapter's 1/N, :85) -- one launch instead of a
 // repacking pass over the frames before the transform.
+// (M = 512: one VGPR over the five-waves-per-SIMD budget without the hint; measured below)
 template <class P, int FPB, bool STRIDED, int LAYOUT = 0>
-__global__ __launch_bounds__ (P::T* FPB) void c2r_kernel (const float2* __restrict__ in,
+__global__ __launch_bounds__ (P::T* FPB, (P::N == 512 && CFFT_C2R512_WAVES5) ? 5 : 1) void c2r_kernel (const float2* __restrict__ in,
                                                          float2* __restrict__ out,
                                                          const float2* __restrict__ twtab,
                                                          const float2* __restrict__ wtab,
@@ -390,8 +394,12 @@ __global__ __launch_bounds__ (P::T* FPB) void c2r_kernel (const float2* __restri
 
     TwiddleRegs<P> tw;
     load_twiddles<P> (tw, twtab, t);
+    // M = 512 sits one VGPR above the five-waves-per-SIMD budget (96): there the four pair twiddles are re-read per group
+    // (a 2 KiB table, requested together with the group's bins) instead of living in registers
+    constexpr bool STREAM_PW = (P::N == 512) && CFFT_C2R512_WAVES5;
     PairTwiddles<P> pw;
-    load_pair_twiddles<P> (pw, wtab, t);
+    if constexpr (! STREAM_PW)
+        load_pair_twiddles<P> (pw, wtab, t);
 
     const unsigned ngroups = (batch + FPB - 1) / FPB;
     const unsigned team_base = (unsigned) team * M; // inside the LDS staging area
@@ -411,6 +419,12 @@ __global__ __launch_bounds__ (P::T* FPB) void c2r_kernel (const float2* __restri
             __syncthreads();
         }
 
+        if constexpr (STREAM_PW)
+        {
+            const float2* wp = wtab;
+            asm volatile ("" : "+s"(wp)); // not hoisted out of the group loop
+            load_pair_twiddles<P> (pw, wp, t);
+        }
         // pair stage straight from global memory (ascending k and descending M-k, both lane-contiguous)
         float2 zk[P::R / 2], zp[P::R / 2];
         // one-wavefront teams: lane 0 loads its mirrored bins one instruction late, so that every load instruction reads one
