@@ -131,3 +131,39 @@ def test_config5_c2c_65536_batch_8192(gpu, oracle):
     api.fft_transform_batch(s, y, y, api.FFT_BACKWARD)  # in place
     assert float((y / n - x).abs().max()) < 3e-6
     api.fft_destroy_setup(s)
+
+
+@pytest.mark.parametrize("n,tr,batch", [(8192, COMPLEX, 2600), (16384, REAL, 2600), (16384, COMPLEX, 1300), (32768, REAL, 1300),
+                                        (32768, COMPLEX, 700), (65536, REAL, 700)])
+def test_fused_convolution_on_the_split_plane_kernels_large_batches(gpu, n, tr, batch):
+    """fft_convolve_frames_batch on the frame-in-registers kernels (one launch) with more frames than resident workgroups,
+    so that every workgroup goes round its persistent loop several times: the one-launch result equals the three-launch
+    composition (option fused_conv_split = 0) on every frame, and an all-pass filter returns the input"""
+    api, torch, dev = gpu
+    nf = 2 * n if tr == COMPLEX else n
+    s = api.fft_new_setup(n, api.FFT_COMPLEX if tr == COMPLEX else api.FFT_REAL)
+    x = _rand(torch, dev, (batch, nf), 4000 + n)
+    h = _rand(torch, dev, (1, nf), 4001 + n)
+    H = torch.empty_like(h)
+    api.fft_transform_unordered_batch(s, h, H, api.FFT_FORWARD)
+    y1 = torch.empty_like(x)
+    api.fft_convolve_frames_batch(s, x, H, y1, 1.0 / n)
+    api.set_option("fused_conv_split", 0)
+    try:
+        y3 = torch.empty_like(x)
+        api.fft_convolve_frames_batch(s, x, H, y3, 1.0 / n)
+    finally:
+        api.set_option("fused_conv_split", 1)
+    torch.cuda.synchronize()
+    rel = (y1 - y3).norm(dim=1) / y3.norm(dim=1)
+    assert float(rel.max()) < 1e-6
+    # identity filter: the spectrum of a unit impulse at sample 0 is all ones (packed real: DC and Nyquist both 1)
+    d = torch.zeros((1, nf), device=dev)
+    d[0, 0] = 1.0
+    D = torch.empty_like(d)
+    api.fft_transform_unordered_batch(s, d, D, api.FFT_FORWARD)
+    y = x.clone()
+    api.fft_convolve_frames_batch(s, y, D, y, 1.0 / n)  # in place
+    torch.cuda.synchronize()
+    assert float((y - x).abs().max()) < 3e-6
+    api.fft_destroy_setup(s)
