@@ -1,5 +1,7 @@
 #!/bin/bash
-# one-launch two-pass form with operand prefetch: parity first (short timeout: a broken queue ends by its bounded spins), then timing
+# one-launch two-pass form: parity first (short timeout: a broken queue ends by its bounded spins), then a lag / workgroup sweep.
+# Written for the operand-prefetch experiment of session r02j (commit 06d0325, reverted; CHOWDSP_FFT_FUSED_PREFETCH exists only
+# there: with the current library the prefetch=0 and prefetch=1 rows are the same kernel); profiles/r02_fused_prefetch_experiment.txt
 OUT=$PWD/gpurun_out/fused_pf
 mkdir -p "$OUT"
 export TMPDIR=/tmp
