@@ -102,7 +102,18 @@ __device__ __forceinline__ void load_twiddles_stage (TwiddleRegs<P>& tw, const f
         const int k = i & (p - 1);
 #pragma unroll
         for (int a = 1; a < r; ++a)
+        {
+#if defined(CFFT_EXPERIMENT_FEW_TWIDDLES) && CFFT_EXPERIMENT_FEW_TWIDDLES
+            // TIMING EXPERIMENT ONLY (wrong results): one twiddle stands in for the stage's fifteen, which frees ~28 VGPRs of the
+            // N = 4096 plan: what would a third workgroup per CU be worth if the registers were there?
+            if constexpr (P::N == 4096 && S == 2)
+            {
+                tw.w[S - 1][q * (r - 1) + (a - 1)] = table[P::tw_offset (S) + k];
+                continue;
+            }
+#endif
             tw.w[S - 1][q * (r - 1) + (a - 1)] = table[P::tw_offset (S) + (a - 1) * p + k];
+        }
     }
 }
 
