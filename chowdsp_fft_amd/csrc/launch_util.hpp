@@ -19,7 +19,15 @@ inline unsigned persistent_grid (K kernel, int threads, size_t lds_bytes, size_t
     return (unsigned) std::max<size_t> (1, work_items); // experiment: one workgroup per work item
 #endif
     const int per_cu = blocks_per_cu_cached ((const void*) kernel, threads, lds_bytes);
-    const size_t resident = (size_t) dev.num_cus * (size_t) per_cu;
+    size_t resident = (size_t) dev.num_cus * (size_t) per_cu;
+    // developer knob (percent of the resident grid; read once): how does a kernel respond to fewer workgroups in flight?
+    static const long grid_percent = [] {
+        const char* e = std::getenv ("CHOWDSP_FFT_GRID_PERCENT");
+        const long v = e != nullptr ? std::atol (e) : 100;
+        return (v >= 10 && v <= 100) ? v : 100L;
+    }();
+    if (grid_percent != 100)
+        resident = std::max<size_t> (1, resident * (size_t) grid_percent / 100);
     return (unsigned) std::max<size_t> (1, std::min (work_items, resident));
 }
 
