@@ -388,6 +388,27 @@ __device__ __forceinline__ float2* static_core (const float2* twl, float2* a, fl
     }
 }
 
+#ifndef CFFT_GENERIC_STAGED_MAX_N
+#define CFFT_GENERIC_STAGED_MAX_N 256
+#endif
+// Lengths whose complex transforms go through the staged-I/O path of generic_kernel (below), by measurement on MI355X
+// (profiles/r02_generic_staged_io_ab.txt, staged against direct, GB/s): 96 5419 / 4509, 144 5169 / 4304, 160 5494 / 4556 -- but
+// 48 4142 / 4189, 80 4139 / 4214 (no difference) and 192 3858 / 4442, 240 3813 / 4396 (their radix-16 last stage writes the
+// image at a pitch of 12 / 15 points: LDS conflicts cost more than the half-used lines did).
+__host__ __device__ constexpr bool generic_staged_io (int n) { return n <= CFFT_GENERIC_STAGED_MAX_N && (n == 96 || n == 144 || n == 160); }
+// ... and whose REAL transforms (N = 2 n) do: real N = 192 4677 / 4423, 288 4767 / 4407 -- but 320 3368 / 3856
+__host__ __device__ constexpr bool generic_staged_io_real (int n) { return n <= CFFT_GENERIC_STAGED_MAX_N && (n == 96 || n == 144); }
+template <class SP>
+struct SP_N_OR_ZERO
+{
+    static constexpr int value = SP::n;
+};
+template <>
+struct SP_N_OR_ZERO<void>
+{
+    static constexpr int value = 1 << 30;
+};
+
 // MODE 0: complex <-> complex (INV: backward).  MODE 1: real forward (packed spectrum out).  MODE 2: real backward.
 // For the real modes plan.n = N/2 and wtab holds W_N^k, k <= N/4 (pair stage formulas: real_kernels.hpp).
 // TWLDS: the plan's stage twiddles (n - 1 values: sum of (r - 1) p over the stages) are copied to LDS once per workgroup, behind
@@ -474,12 +495,86 @@ __global__ __launch_bounds__ (BLOCK) void generic_kernel (const float2* __restri
             else
                 merge_all (wtab);
         }
+        // Short frames (compile-time lists, complex, packed batch): with direct global I/O one first-stage load instruction
+        // fetches eight 64-byte pieces (n = 96: x[i + 8 a], eight butterflies per frame) and one last-stage store writes 96-byte
+        // runs at a 768-byte pitch -- half-used lines on both sides.  Here the workgroup's frames are ONE contiguous block:
+        // it is copied to the first image with whole-workgroup 16-byte accesses, every stage runs LDS -> LDS, and the result
+        // leaves the same way (two more LDS passes for fully used lines; the lengths that gain: generic_staged_io above;
+        // CFFT_GENERIC_STAGED_MAX_N = 0: direct I/O everywhere).
+        if constexpr (STATIC && MODE == 0)
+        {
+            if constexpr (generic_staged_io (SP_N_OR_ZERO<SP>::value))
+            {
+                if (is == (unsigned) n && os == (unsigned) n)
+                {
+                    const int quads = nframes * n / 2;
+                    const float4* __restrict__ s4 = reinterpret_cast<const float4*> (src);
+                    float4* a4 = reinterpret_cast<float4*> (bufA);
+                    for (int e = tid; e < quads; e += BLOCK)
+                    {
+                        const float4 x = gload4 (&s4[e]);
+                        a4[e] = INV ? make_float4 (x.y, x.x, x.w, x.z) : x;
+                    }
+                    __syncthreads();
+                    const float2* r2 = static_core<SP, BLOCK, false, false, false> (twl, bufA, bufB, src, dst, nframes, tid, is, os);
+                    const float4* r4 = reinterpret_cast<const float4*> (r2);
+                    float4* __restrict__ d4 = reinterpret_cast<float4*> (dst);
+                    for (int e = tid; e < quads; e += BLOCK)
+                    {
+                        const float4 x = r4[e];
+                        gstore4 (&d4[e], INV ? make_float4 (x.y, x.x, x.w, x.z) : x);
+                    }
+                    continue;
+                }
+            }
+        }
         // MODE 0 / 1: stage 0 reads the frames straight from global memory
         if (MODE == 2)
             __syncthreads();
         constexpr bool IN_GLOBAL = (MODE != 2), OUT_GLOBAL = (MODE != 1);
         const float2* res;
-        if constexpr (STATIC)
+        // real transforms of the same lengths: the forward transform's samples come in by the staged copy, the backward
+        // transform's leave by it (the pair stage keeps its own global accesses)
+        bool staged_real = false;
+        if constexpr (STATIC && MODE != 0)
+        {
+            if constexpr (generic_staged_io_real (SP_N_OR_ZERO<SP>::value))
+                staged_real = (MODE == 1) ? (is == (unsigned) n) : (os == (unsigned) n);
+        }
+        if constexpr (STATIC && MODE != 0 && generic_staged_io_real (SP_N_OR_ZERO<SP>::value))
+        {
+            if (staged_real)
+            {
+                const int quads = nframes * n / 2;
+                if constexpr (MODE == 1)
+                {
+                    const float4* __restrict__ s4 = reinterpret_cast<const float4*> (src);
+                    float4* a4 = reinterpret_cast<float4*> (bufA);
+                    for (int e = tid; e < quads; e += BLOCK)
+                        a4[e] = gload4 (&s4[e]);
+                    __syncthreads();
+                    res = static_core<SP, BLOCK, false, false, false> (twl, bufA, bufB, src, dst, nframes, tid, plan.in_stride, plan.out_stride);
+                }
+                else
+                {
+                    // the merged pairs are in bufA, re <-> im swapped; the result leaves swapped back
+                    const float2* r2 = static_core<SP, BLOCK, false, false, false> (twl, bufA, bufB, src, dst, nframes, tid, plan.in_stride, plan.out_stride);
+                    const float4* r4 = reinterpret_cast<const float4*> (r2);
+                    float4* __restrict__ d4 = reinterpret_cast<float4*> (dst);
+                    for (int e = tid; e < quads; e += BLOCK)
+                    {
+                        const float4 x = r4[e];
+                        gstore4 (&d4[e], make_float4 (x.y, x.x, x.w, x.z));
+                    }
+                    continue;
+                }
+            }
+        }
+        if (staged_real)
+        {
+            // MODE 1: res is set; fall through to the pair stage
+        }
+        else if constexpr (STATIC)
             res = static_core<SP, BLOCK, IN_GLOBAL, OUT_GLOBAL, (MODE == 2) || INV> (twl, bufA, bufB, src, dst, nframes, tid, plan.in_stride, plan.out_stride);
         else if constexpr (TWLDS)
             res = generic_core<BLOCK, IN_GLOBAL, OUT_GLOBAL, (MODE == 2) || INV> (plan, twl, bufA, bufB, src, dst, nframes, tid, (unsigned) n, plan.tw_offset[0]);

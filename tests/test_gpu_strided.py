@@ -24,8 +24,10 @@ CASES = [
     (2048, COMPLEX, 7), (4096, COMPLEX, 9), (8192, COMPLEX, 5), (16384, COMPLEX, 3), (32768, COMPLEX, 3),
     (65536, COMPLEX, 3), (480, COMPLEX, 21), (3072, COMPLEX, 5), (12288, COMPLEX, 3), (24576, COMPLEX, 3),
     (9216, COMPLEX, 4),
+    (96, COMPLEX, 45), (160, COMPLEX, 29),   # lengths whose PACKED batches take the staged-I/O path (generic_kernels.hpp): strided ones must not
     (32, REAL, 301), (64, REAL, 131), (256, REAL, 37), (1024, REAL, 21), (4096, REAL, 7), (8192, REAL, 5),
     (16384, REAL, 3), (32768, REAL, 3), (65536, REAL, 2), (131072, REAL, 2), (480, REAL, 13), (960, REAL, 9), (9216, REAL, 5), (49152, REAL, 2),
+    (192, REAL, 45), (288, REAL, 29),
 ]
 
 
