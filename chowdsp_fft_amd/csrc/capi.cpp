@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -495,6 +496,14 @@ int run_transform (Setup* s, const float* in, float* out, size_t batch, cf::fft_
 {
     if (batch == 0)
         return cf::FFT_GPU_OK;
+    // The reference casts its buffers to SIMD vectors (simd/chowdsp_fft_impl_sse.cpp:1527-1528: 16-byte alignment is part of
+    // its contract, a violation is undefined behaviour there).  Here several kernels move frames with 16-byte accesses, and a
+    // misaligned device address is a memory fault that takes the process down: refuse it instead.
+    if (((reinterpret_cast<uintptr_t> (in) | reinterpret_cast<uintptr_t> (out)) & 15u) != 0)
+    {
+        set_last_error ("transform: input and output must be 16-byte aligned (as the reference requires of its SIMD buffers)");
+        return cf::FFT_GPU_EINVAL;
+    }
     const DeviceGuard guard (s->device);
     const bool inverse = (dir == cf::FFT_BACKWARD);
     const DeviceTables* t = s->tables;
@@ -1380,6 +1389,11 @@ int fft_convolve_frames_batch (void* setup, const float* x, const float* dft_fil
     Setup* s = as_setup (setup);
     if (s == nullptr || x == nullptr || dft_filter == nullptr || y == nullptr)
         return FFT_GPU_EINVAL;
+    if (((reinterpret_cast<uintptr_t> (x) | reinterpret_cast<uintptr_t> (dft_filter) | reinterpret_cast<uintptr_t> (y)) & 15u) != 0)
+    {
+        set_last_error ("fft_convolve_frames_batch: buffers must be 16-byte aligned");
+        return FFT_GPU_EINVAL;
+    }
     const DeviceGuard guard (s->device);
     const DeviceTables* t = s->tables;
     const int nc = complex_len (s);

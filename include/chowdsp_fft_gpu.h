@@ -108,7 +108,9 @@ size_t fft_gpu_workspace_bytes (void* setup, size_t batch);
 /* ---- batched operations -------------------------------------------------------------------------- */
 
 /* `batch` x fft_transform (chowdsp_fft.h; reference chowdsp_fft.h:138,
-   simd/chowdsp_fft_impl_sse.cpp:1518-1601 with ordered = 1). */
+   simd/chowdsp_fft_impl_sse.cpp:1518-1601 with ordered = 1).  Buffers of every batched call must be 16-byte aligned
+   (the reference's own requirement for its SIMD buffers, :1527-1528); a misaligned address is refused with
+   FFT_GPU_EINVAL rather than left to fault inside a kernel. */
 int fft_transform_batch (void* setup, const float* input, float* output, size_t batch, fft_direction_t direction, void* stream);
 
 /* Strided batch: the same transform on frames embedded in larger buffers, frame b

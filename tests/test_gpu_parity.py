@@ -473,3 +473,21 @@ def test_wave_per_frame_fused_convolution(gpu, oracle, n, tr):
         api.set_option("conv_wave2048", 0)
     api.fft_destroy_setup(s)
     oracle.destroy_setup(so)
+
+
+def test_misaligned_device_buffers_are_refused(gpu):
+    """16-byte alignment is the reference's contract for its SIMD buffers (sse.cpp:1527-1528); a misaligned device address
+    would be a memory fault inside kernels that move frames with 16-byte accesses, so the batched calls return EINVAL"""
+    api, torch, dev = gpu
+    n, batch = 96, 8
+    s = api.fft_new_setup(n, api.FFT_COMPLEX)
+    buf = torch.zeros(batch * 2 * n + 8, device=dev)
+    out = torch.empty(batch * 2 * n + 8, device=dev)
+    x = buf[2:2 + batch * 2 * n]  # 8 bytes off
+    with pytest.raises(api.FFTError):
+        api.fft_transform_batch(s, x, out[:batch * 2 * n], api.FFT_FORWARD)
+    with pytest.raises(api.FFTError):
+        api.fft_transform_batch(s, buf[:batch * 2 * n], out[2:2 + batch * 2 * n], api.FFT_FORWARD)
+    api.fft_transform_batch(s, buf[4:4 + batch * 2 * n], out[:batch * 2 * n], api.FFT_FORWARD)  # 16 bytes off: fine
+    torch.cuda.synchronize()
+    api.fft_destroy_setup(s)
