@@ -579,6 +579,11 @@ int run_transform (Setup* s, const float* in, float* out, size_t batch, cf::fft_
 
 int run_convolve (Setup* s, const float* a, const float* b, float* ab, float scaling, size_t batch, bool b_is_shared, hipStream_t stream)
 {
+    if (((reinterpret_cast<uintptr_t> (a) | reinterpret_cast<uintptr_t> (b) | reinterpret_cast<uintptr_t> (ab)) & 15u) != 0)
+    {
+        set_last_error ("convolve: operands must be 16-byte aligned (as the reference requires of its SIMD buffers)");
+        return cf::FFT_GPU_EINVAL;
+    }
     const DeviceGuard guard (s->device);
     const bool real = (s->transform == cf::FFT_REAL);
     const hipError_t e = launch_conv_mac (real, a, b, ab, scaling, (size_t) complex_len (s), batch, b_is_shared, stream);
@@ -1374,6 +1379,11 @@ int fft_accumulate_batch (void* setup, const float* a, const float* b, float* ab
     Setup* s = as_setup (setup);
     if (s == nullptr || a == nullptr || b == nullptr || ab == nullptr)
         return FFT_GPU_EINVAL;
+    if (((reinterpret_cast<uintptr_t> (a) | reinterpret_cast<uintptr_t> (b) | reinterpret_cast<uintptr_t> (ab)) & 15u) != 0)
+    {
+        set_last_error ("fft_accumulate_batch: operands must be 16-byte aligned");
+        return FFT_GPU_EINVAL;
+    }
     const DeviceGuard guard (s->device);
     const hipError_t e = launch_accumulate (a, b, ab, count, (hipStream_t) stream);
     if (e != hipSuccess)
