@@ -151,7 +151,7 @@ __global__ __launch_bounds__ (P::T* FPB) void r2c_kernel (const float2* __restri
         // for 8 bytes.  Lane 0's element is the odd one: it belongs to the aligned block that the NEXT pair index covers.
         // So lane 0 stores its mirrored bins one instruction late (same values, same addresses, another store instruction)
         // and every instruction writes one aligned 512-byte block (CFFT_REAL_ROTATE_LANE0 = 0: the plain order).
-        constexpr bool ROT = CFFT_REAL_ROTATE_LANE0 && ! STAGED && LAYOUT == 0 && P::T == 64;
+        constexpr bool ROT = CFFT_REAL_ROTATE_LANE0 && ! STAGED && LAYOUT != 2 && P::T == 64; // LAYOUT 1: the same mirrored family
         float2 xp_keep[ROT ? P::R / 2 : 1];
 #pragma unroll
         for (int q = 0; q < P::R / 2; ++q)
@@ -186,7 +186,13 @@ __global__ __launch_bounds__ (P::T* FPB) void r2c_kernel (const float2* __restri
                 const unsigned kp = (unsigned) (k == 0 ? M / 2 : M - k);
                 if constexpr (ROT)
                 {
-                    gstore (&dst[team_out + (unsigned) k], Xk);
+                    if (LAYOUT == 1 && k == 0)
+                    {
+                        gstore (&dst[team_out], make_float2 (Xk.x, 0.f));
+                        gstore (&dst[team_out + (unsigned) M], make_float2 (Xk.y, 0.f));
+                    }
+                    else
+                        gstore (&dst[team_out + (unsigned) k], Xk);
                     xp_keep[q] = Xp;
                 }
                 else if constexpr (LAYOUT == 0)
@@ -429,7 +435,7 @@ __global__ __launch_bounds__ (P::T* FPB, (P::N == 512 && CFFT_C2R512_WAVES5) ? 5
         float2 zk[P::R / 2], zp[P::R / 2];
         // one-wavefront teams: lane 0 loads its mirrored bins one instruction late, so that every load instruction reads one
         // aligned 512-byte block (see r2c_kernel)
-        constexpr bool ROT = CFFT_REAL_ROTATE_LANE0 && ! STAGED && LAYOUT == 0 && P::T == 64;
+        constexpr bool ROT = CFFT_REAL_ROTATE_LANE0 && ! STAGED && P::T == 64; // the JUCE layout reads the same mirrored family
         float2 xp_l[ROT ? P::R / 2 : 1];
         if constexpr (ROT)
         {
