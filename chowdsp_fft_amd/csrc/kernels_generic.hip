@@ -194,7 +194,7 @@ template <int MODE, bool INV>
 hipError_t launch_generic_m (GenericPlan& plan, const DeviceTables& t, const float2* in, float2* out, size_t batch, hipStream_t stream)
 {
     int block = 256;
-    generic_geometry (plan.n, plan.frames, block); // tables.hpp: the stage radices were chosen for this geometry
+    generic_geometry (plan.n, plan.frames, block, MODE != 0); // tables.hpp: the stage radices were chosen for this geometry
     // CHOWDSP_FFT_GENERIC_INPLACE (experiment): 0 = two-image kernel wherever it fits (n <= 9216), 1 = in-place kernel for
     // every n > 2048; default: see use_inplace below
     static const int force = [] {

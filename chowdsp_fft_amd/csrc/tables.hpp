@@ -47,7 +47,7 @@ bool size_supported (int N, int transform);
 bool core_radices (int n, int radix[4]);
 // launch geometry of the generic mixed-radix kernel for complex length n: frames per workgroup pass and work-items
 // per workgroup (shared by the radix choice in tables.cpp and the launcher in kernels_generic.hip)
-inline void generic_geometry (int n, int& frames, int& block)
+inline void generic_geometry (int n, int& frames, int& block, bool real_transform = false)
 {
     // Long frames (n > 2048): one frame per workgroup in ONE LDS image with in-place stages (generic_inplace_kernel); the
     // workgroup grows with n so that a work-item never holds more than 20 points of a stage.
@@ -66,7 +66,23 @@ inline void generic_geometry (int n, int& frames, int& block)
 #ifndef CFFT_GENERIC_POINTS
 #define CFFT_GENERIC_POINTS 2048
 #endif
-    frames = (n <= CFFT_GENERIC_MULTI_MAX) ? (CFFT_GENERIC_POINTS / n > 1 ? CFFT_GENERIC_POINTS / n : 1) : 1;
+    // Points in flight per workgroup.  2048 is the best single value; a few lengths of the reference's list and their neighbours
+    // do measurably better with another (A/B per length, complex and real, profiles/r02_generic_points_ab.txt -- the stage
+    // list does not depend on the choice: every candidate keeps a quarter of the work-items busy at radix 16):
+    //   n = 96 (complex 96, real 192): 1536 -> +1.5 % / +8 %;  complex 48 / 80 / 192 / 768: 3072 -> +5 / +10 / +4 / +10 %
+    //   (their real counterparts lose with 3072 and keep 2048).  CFFT_GENERIC_POINTS_TUNED = 0: 2048 everywhere.
+#ifndef CFFT_GENERIC_POINTS_TUNED
+#define CFFT_GENERIC_POINTS_TUNED 1
+#endif
+    int points = CFFT_GENERIC_POINTS;
+    if (CFFT_GENERIC_POINTS_TUNED)
+    {
+        if (n == 96)
+            points = 1536;
+        else if (! real_transform && (n == 48 || n == 80 || n == 192 || n == 768))
+            points = 3072;
+    }
+    frames = (n <= CFFT_GENERIC_MULTI_MAX) ? (points / n > 1 ? points / n : 1) : 1;
 }
 inline bool generic_uses_inplace (int n) { return n > 2048; }
 
