@@ -69,17 +69,18 @@ inline void generic_geometry (int n, int& frames, int& block, bool real_transfor
     // Points in flight per workgroup.  2048 is the best single value; a few lengths of the reference's list and their neighbours
     // do measurably better with another (A/B per length, complex and real, profiles/r02_generic_points_ab.txt -- the stage
     // list does not depend on the choice: every candidate keeps a quarter of the work-items busy at radix 16):
-    //   n = 96 (complex 96, real 192): 1536 -> +1.5 % / +8 %;  complex 48 / 80 / 192 / 768: 3072 -> +5 / +10 / +4 / +10 %
-    //   (their real counterparts lose with 3072 and keep 2048).  CFFT_GENERIC_POINTS_TUNED = 0: 2048 everywhere.
+    //   n = 96 (complex 96, real 192): 1536 -> +1.5 % / +8 %;  n = 144: +11 % / +11 %;  n = 160: 0 / +16 %;
+    //   complex 48 / 80 / 192 / 432 / 576 / 768 / 800 / 960: 3072 -> +5 / +10 / +4 / +8 / +7 / +10 / +5 / +6 %
+    //   (their real counterparts lose 10-20 % with 3072 and keep 2048).  CFFT_GENERIC_POINTS_TUNED = 0: 2048 everywhere.
 #ifndef CFFT_GENERIC_POINTS_TUNED
 #define CFFT_GENERIC_POINTS_TUNED 1
 #endif
     int points = CFFT_GENERIC_POINTS;
     if (CFFT_GENERIC_POINTS_TUNED)
     {
-        if (n == 96)
+        if (n == 96 || n == 144 || n == 160)
             points = 1536;
-        else if (! real_transform && (n == 48 || n == 80 || n == 192 || n == 768))
+        else if (! real_transform && (n == 48 || n == 80 || n == 192 || n == 432 || n == 576 || n == 768 || n == 800 || n == 960))
             points = 3072;
     }
     frames = (n <= CFFT_GENERIC_MULTI_MAX) ? (points / n > 1 ? points / n : 1) : 1;
