@@ -43,6 +43,7 @@ PROTOTYPES = {
     "fft_gpu_stream_synchronize": (_i, [_vp]),
     "fft_gpu_last_error": (C.c_char_p, []),
     "fft_gpu_set_option": (_i, [C.c_char_p, C.c_long]),
+    "fft_gpu_get_option": (C.c_long, [C.c_char_p]),
     "fft_gpu_release_stream_resources": (_i, [_vp]),
     "fft_gpu_defer_begin": (_i, []),
     "fft_gpu_defer_flush": (_i, []),

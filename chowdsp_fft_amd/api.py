@@ -303,6 +303,17 @@ def set_option(name: str, value: int) -> None:
     _check(_lib.lib().fft_gpu_set_option(name.encode(), int(value)), f"fft_gpu_set_option({name})")
 
 
+def get_option(name: str) -> int:
+    """fft_gpu_get_option: current value of a run-time knob (-1: not readable)"""
+    return int(_lib.lib().fft_gpu_get_option(name.encode()))
+
+
+def stream_synchronize(stream=None) -> None:
+    """fft_gpu_stream_synchronize: waits for `stream` and reports a one-launch two-pass transform on it whose hand-offs
+    did not complete (its output is not valid) -- the point where those forms' results are validated."""
+    _check(_lib.lib().fft_gpu_stream_synchronize(_stream_handle(stream)), "fft_gpu_stream_synchronize")
+
+
 def size_supported(N: int, transform: int) -> bool:
     return bool(_lib.lib().fft_gpu_size_supported(N, transform))
 

@@ -20,6 +20,7 @@
 #include <map>
 #include <mutex>
 #include <new>
+#include <string>
 #include <utility>
 #include <vector>
 
@@ -144,7 +145,11 @@ struct Lanes
     void* fused_state = nullptr;
     float2* fused_ws = nullptr;
     size_t fused_ws_bytes = 0;
-    unsigned* fused_err_host = nullptr; // pinned: the state's error word, copied back after every launch, looked at by the next call
+    // pinned, device-visible: 0, or (launch number << 8) | code stored BY THE KERNEL whose bounded waits ran out (its output
+    // is not valid).  Sticky until the host takes it: looked at by the next one-launch call on the stream and by every
+    // library synchronisation of the stream (fft_gpu_stream_synchronize, fft_gpu_release_stream_resources, the legacy calls)
+    unsigned* fused_err_host = nullptr;
+    unsigned fused_seq = 0; // launches so far on this (device, stream)
 };
 std::mutex g_ws_mutex;
 std::map<std::pair<int, hipStream_t>, Lanes> g_lanes;
@@ -284,15 +289,37 @@ bool split16384_enabled()
     return v != 0;
 }
 bool fused_enabled() { return fused_options().enabled.load() != 0; }
+int fused_form() { return (int) fused_options().enabled.load(); } // 1 = ticket queues, 2 = static groups
 size_t fused_min_batch() { return (size_t) fused_options().min_batch.load(); }
 int fused_lag() { return (int) fused_options().lag.load(); }
 int fused_slots() { return (int) fused_options().slots.load(); }
+
+std::string fused_error_text (unsigned word)
+{
+    return "one-launch two-pass transform number " + std::to_string (word >> 8) + " on this stream did not complete its hand-offs (code "
+           + std::to_string (word & 255u) + "): its output is not valid";
+}
+// After `stream` has been synchronised: did a one-launch two-pass transform on it report that its bounded waits ran out?
+// Takes the report (the word is cleared).  0 = no.
+unsigned take_fused_error (hipStream_t stream)
+{
+    std::lock_guard<std::mutex> lock (g_ws_mutex);
+    unsigned word = 0;
+    for (auto& kv : g_lanes)
+        if (kv.first.second == stream && kv.second.fused_err_host != nullptr && *kv.second.fused_err_host != 0)
+        {
+            if (word == 0)
+                word = *kv.second.fused_err_host;
+            *kv.second.fused_err_host = 0;
+        }
+    return word;
+}
 
 // caller holds g_ws_mutex
 Lanes* get_fused (int device, hipStream_t stream, size_t ws_bytes)
 {
     Lanes& L = g_lanes[std::make_pair (device, stream)];
-    if (L.fused_state == nullptr && hipMalloc (&L.fused_state, fused_state_bytes()) != hipSuccess)
+    if (L.fused_state == nullptr && hipMalloc (&L.fused_state, std::max (fused_state_bytes(), group_state_bytes())) != hipSuccess)
     {
         L.fused_state = nullptr;
         set_last_error ("fused two-pass state allocation failed");
@@ -351,20 +378,22 @@ int big_c2c_chunked (Setup* s, int nc, bool inverse, const float2* in, float2* o
     {
         // both passes in one launch, hand-off inside an XCD's L2: no chunking, no lanes, 1.5 x instead of 2 x the traffic
         std::lock_guard<std::mutex> lock (g_ws_mutex);
+        const bool groups = fused_form() == 2;
         const int lag = fused_lag(), slots = fused_slots();
-        Lanes* L = get_fused (s->device, stream, fused_workspace_bytes (nc, slots));
+        Lanes* L = get_fused (s->device, stream, groups ? group_workspace_bytes() : fused_workspace_bytes (nc, slots));
         if (L == nullptr)
             return cf::FFT_GPU_ENOMEM;
         if (*L->fused_err_host != 0)
         {
             // a bounded wait inside an EARLIER launch on this stream ran out (its output is not valid): say so now
+            const unsigned w = *L->fused_err_host;
             *L->fused_err_host = 0;
-            set_last_error ("an earlier one-launch two-pass transform on this stream did not complete its hand-offs");
+            set_last_error (fused_error_text (w).c_str());
             return cf::FFT_GPU_ELAUNCH;
         }
-        hipError_t e = launch_fused_c2c (n1, n2, inverse, in, L->fused_ws, out, s->tables->stage_twiddles, s->tables->big_twiddles, L->fused_state, batch, lag, slots, stream, is2, os2);
-        if (e == hipSuccess) // the state's error word (offset 4) travels back behind the kernel
-            e = hipMemcpyAsync (L->fused_err_host, (const char*) L->fused_state + sizeof (unsigned), sizeof (unsigned), hipMemcpyDeviceToHost, stream);
+        const unsigned seq = ++L->fused_seq;
+        const hipError_t e = groups ? launch_group_c2c (n1, n2, inverse, in, L->fused_ws, out, s->tables->stage_twiddles, s->tables->big_twiddles, L->fused_state, L->fused_err_host, seq, batch, stream, is2, os2)
+                                    : launch_fused_c2c (n1, n2, inverse, in, L->fused_ws, out, s->tables->stage_twiddles, s->tables->big_twiddles, L->fused_state, L->fused_err_host, seq, batch, lag, slots, stream, is2, os2);
         if (e != hipSuccess)
         {
             set_last_error ("fused two-pass kernel launch", e);
@@ -604,7 +633,11 @@ int run_convolve (Setup* s, const float* a, const float* b, float* ab, float sca
 // flushes first; inputs are all read before any output is written, and outputs are written in call order.
 struct DeferredCall
 {
-    Setup* s;
+    // the plan BY VALUE: it is immutable and its device tables belong to the process-wide cache (host_common.cpp), so a
+    // recorded call stays valid after the caller's fft_destroy_setup -- or, for fft_new_setup_preallocated, after the caller
+    // has freed the memory the header lived in (the reference's new_setup -> fft_transform -> destroy sequence inside a
+    // deferred region)
+    Setup plan;
     const float* in;
     float* out;
     int dir;
@@ -612,6 +645,7 @@ struct DeferredCall
 struct DeferredQueue
 {
     bool active = false;
+    int sticky_rc = 0; // first failure of an IMPLICIT flush since fft_gpu_defer_begin(): fft_gpu_defer_flush() returns it
     std::vector<DeferredCall> calls;
     size_t floats = 0;
     float* pin = nullptr; // pinned staging: inputs, then outputs
@@ -639,15 +673,16 @@ int deferred_flush()
     calls.swap (q.calls);
     const size_t total = q.floats;
     q.floats = 0;
-    // groups of calls that share plan and direction, in order of first appearance
-    std::vector<std::pair<Setup*, int>> groups;
-    for (const DeferredCall& c : calls)
+    // groups of calls that share plan (same tables = same device, length and transform) and direction, in order of first appearance
+    const auto same_group = [] (const DeferredCall& a, const DeferredCall& b) { return a.plan.tables == b.plan.tables && a.dir == b.dir; };
+    std::vector<size_t> groups; // index of each group's first call
+    for (size_t i = 0; i < calls.size(); ++i)
     {
         bool seen = false;
-        for (const auto& g : groups)
-            seen = seen || (g.first == c.s && g.second == c.dir);
+        for (const size_t g : groups)
+            seen = seen || same_group (calls[g], calls[i]);
         if (! seen)
-            groups.emplace_back (c.s, c.dir);
+            groups.push_back (i);
     }
     if (q.pin_floats < 2 * total)
     {
@@ -667,11 +702,11 @@ int deferred_flush()
     float* pin_out = q.pin + total;
     std::vector<size_t> offset (calls.size());
     size_t pos = 0;
-    for (const auto& g : groups)
+    for (const size_t g : groups)
         for (size_t i = 0; i < calls.size(); ++i)
-            if (calls[i].s == g.first && calls[i].dir == g.second)
+            if (same_group (calls[g], calls[i]))
             {
-                const size_t nf = frame_floats (calls[i].s);
+                const size_t nf = frame_floats (&calls[i].plan);
                 std::memcpy (pin_in + pos, calls[i].in, nf * sizeof (float));
                 offset[i] = pos;
                 pos += nf;
@@ -679,13 +714,14 @@ int deferred_flush()
     // 2. one batched transform per group, device memory of the plan's device, copies and kernels on the null stream
     int rc = cf::FFT_GPU_OK;
     pos = 0;
-    for (const auto& g : groups)
+    for (const size_t g : groups)
     {
-        Setup* s = g.first;
+        Setup* s = &calls[g].plan;
+        const int gdir = calls[g].dir;
         const size_t nf = frame_floats (s);
         size_t count = 0;
         for (const DeferredCall& c : calls)
-            count += (c.s == s && c.dir == g.second) ? 1 : 0;
+            count += same_group (calls[g], c) ? 1 : 0;
         const DeviceGuard guard (s->device);
         if (q.dev_floats < 2 * count * nf || q.dev_device != s->device)
         {
@@ -706,7 +742,7 @@ int deferred_flush()
         if (hipMemcpyAsync (din, pin_in + pos, count * nf * sizeof (float), hipMemcpyHostToDevice, nullptr) != hipSuccess)
             rc = cf::FFT_GPU_ELAUNCH;
         if (rc == cf::FFT_GPU_OK)
-            rc = run_transform (s, din, dout, count, (cf::fft_direction_t) g.second, nullptr, 0, 0);
+            rc = run_transform (s, din, dout, count, (cf::fft_direction_t) gdir, nullptr, 0, 0);
         if (rc == cf::FFT_GPU_OK && hipMemcpyAsync (pin_out + pos, dout, count * nf * sizeof (float), hipMemcpyDeviceToHost, nullptr) != hipSuccess)
             rc = cf::FFT_GPU_ELAUNCH;
         if (rc == cf::FFT_GPU_OK && hipStreamSynchronize (nullptr) != hipSuccess)
@@ -720,8 +756,17 @@ int deferred_flush()
     }
     // 3. results, in call order (a later call that wrote the same buffer wins, as it would have)
     for (size_t i = 0; i < calls.size(); ++i)
-        std::memcpy (calls[i].out, pin_out + offset[i], frame_floats (calls[i].s) * sizeof (float));
+        std::memcpy (calls[i].out, pin_out + offset[i], frame_floats (&calls[i].plan) * sizeof (float));
     return cf::FFT_GPU_OK;
+}
+
+// a flush nobody asked for by name (a dependent call, a full queue, a call that cannot be recorded, a plan being destroyed):
+// its failure has no return value to travel in, so the queue remembers the first one for fft_gpu_defer_flush()
+void deferred_flush_implicit()
+{
+    const int rc = deferred_flush();
+    if (rc != cf::FFT_GPU_OK && g_deferred.sticky_rc == cf::FFT_GPU_OK)
+        g_deferred.sticky_rc = rc;
 }
 
 // true: the call was recorded (deferred mode, host pointers)
@@ -737,18 +782,18 @@ bool deferred_record (Setup* s, const float* input, float* output, cf::fft_direc
     for (const DeferredCall& c : q.calls)
     {
         const char* cb = (const char*) c.out;
-        const size_t cbytes = frame_floats (c.s) * sizeof (float);
+        const size_t cbytes = frame_floats (&c.plan) * sizeof (float);
         const bool in_hits = ib < cb + cbytes && cb < ib + bytes;
         const bool out_hits = ob < cb + cbytes && cb < ob + bytes;
         if (in_hits || (out_hits && c.out != output))
         {
-            (void) deferred_flush();
+            deferred_flush_implicit();
             break;
         }
     }
     if (q.floats + nf > kDeferredMaxFloats)
-        (void) deferred_flush();
-    q.calls.push_back (DeferredCall { s, input, output, (int) direction });
+        deferred_flush_implicit();
+    q.calls.push_back (DeferredCall { *s, input, output, (int) direction });
     q.floats += nf;
     return true;
 }
@@ -774,7 +819,7 @@ void legacy_transform (void* setup, const float* input, float* output, cf::fft_d
     {
         if (! in_dev && ! out_dev && deferred_record (s, input, output, direction))
             return; // runs at fft_gpu_defer_flush()
-        (void) deferred_flush(); // a call that cannot be recorded keeps its place in the order
+        deferred_flush_implicit(); // a call that cannot be recorded keeps its place in the order
     }
     if (in_dev && out_dev)
     {
@@ -824,7 +869,7 @@ void legacy_elementwise (Setup* s, const float* a, const float* b, float* ab, si
 {
     const DeviceGuard guard (s->device); // whole body: see legacy_transform
     if (g_deferred.active)
-        (void) deferred_flush(); // convolve / accumulate are not recorded: they keep their place in the order
+        deferred_flush_implicit(); // convolve / accumulate are not recorded: they keep their place in the order
     const bool a_dev = is_device_pointer (a), b_dev = is_device_pointer (b), ab_dev = is_device_pointer (ab);
     if (! a_dev && ! b_dev && ! ab_dev && nf * sizeof (float) <= zerocopy_max_bytes())
     {
@@ -959,6 +1004,7 @@ void fft_destroy_setup (void* setup)
     Setup* s = as_setup (setup);
     if (s == nullptr)
         return;
+    // calls recorded by fft_gpu_defer_begin() regions hold the plan by value (DeferredCall): nothing to flush here
     void* block = s->owned_block;
     s->magic = 0;
     if (block != nullptr)
@@ -1062,6 +1108,13 @@ int fft_gpu_memcpy (void* dst, const void* src, size_t nb_bytes, int kind, void*
 int fft_gpu_stream_synchronize (void* stream)
 {
     CFFT_HIP_TRY (hipStreamSynchronize ((hipStream_t) stream), FFT_GPU_ELAUNCH);
+    // the one-launch two-pass forms validate their hand-offs here: a launch whose bounded waits ran out is reported by the
+    // synchronisation that follows it, by number
+    if (const unsigned w = take_fused_error ((hipStream_t) stream))
+    {
+        set_last_error (fused_error_text (w).c_str());
+        return FFT_GPU_ELAUNCH;
+    }
     return FFT_GPU_OK;
 }
 
@@ -1160,13 +1213,26 @@ int fft_gpu_plan_describe (int N, fft_transform_t transform, int desc[8])
 
 int fft_gpu_defer_begin (void)
 {
+    if (! g_deferred.active)
+        g_deferred.sticky_rc = FFT_GPU_OK;
     g_deferred.active = true;
     return FFT_GPU_OK;
 }
 
 int fft_gpu_defer_flush (void)
 {
-    const int rc = deferred_flush();
+    int rc = deferred_flush();
+    // an implicit flush since fft_gpu_defer_begin() failed: its calls' outputs were not written, and this is the only
+    // return value that can say so
+    if (g_deferred.sticky_rc != FFT_GPU_OK)
+    {
+        if (rc == FFT_GPU_OK)
+        {
+            rc = g_deferred.sticky_rc;
+            set_last_error ("fft_gpu_defer_flush: an earlier implicit flush of this deferred region failed; its calls' outputs were not written");
+        }
+        g_deferred.sticky_rc = FFT_GPU_OK;
+    }
     g_deferred.active = false;
     return rc;
 }
@@ -1178,6 +1244,7 @@ int fft_gpu_release_stream_resources (void* stream)
     // give the memory back; the next two-pass call on the stream builds a fresh set.
     std::lock_guard<std::mutex> lock (g_ws_mutex);
     int released = 0;
+    unsigned pending_error = 0;
     for (auto it = g_lanes.begin(); it != g_lanes.end();)
     {
         if (it->first.second != (hipStream_t) stream)
@@ -1188,6 +1255,11 @@ int fft_gpu_release_stream_resources (void* stream)
         const DeviceGuard guard (it->first.first);
         Lanes& L = it->second;
         (void) hipStreamSynchronize ((hipStream_t) stream);
+        if (L.fused_err_host != nullptr && *L.fused_err_host != 0)
+        {
+            pending_error = *L.fused_err_host; // the report would be lost with the entry
+            *L.fused_err_host = 0;
+        }
         for (int k = 0; k < 2; ++k)
         {
             if (L.lane[k] != nullptr)
@@ -1211,6 +1283,11 @@ int fft_gpu_release_stream_resources (void* stream)
         it = g_lanes.erase (it);
         ++released;
     }
+    if (pending_error != 0)
+    {
+        set_last_error (fused_error_text (pending_error).c_str());
+        return FFT_GPU_ELAUNCH;
+    }
     return released;
 }
 
@@ -1219,8 +1296,8 @@ int fft_gpu_set_option (const char* name, long value)
     if (name == nullptr)
         return FFT_GPU_EINVAL;
     FusedOptions& o = fused_options();
-    if (std::strcmp (name, "fused_two_pass") == 0)
-        o.enabled = value != 0;
+    if (std::strcmp (name, "fused_two_pass") == 0 && value >= 0 && value <= 2)
+        o.enabled = value;
     else if (std::strcmp (name, "fused_min_batch") == 0 && value >= 1)
         o.min_batch = value;
     else if (std::strcmp (name, "fused_lag") == 0 && value >= 1 && value <= 6)
@@ -1231,6 +1308,10 @@ int fft_gpu_set_option (const char* name, long value)
     }
     else if (std::strcmp (name, "fused_slots") == 0 && value > o.lag.load() && value <= 8)
         o.slots = value;
+    else if (std::strcmp (name, "group_force_solo") == 0)
+        set_group_options (value != 0 ? 1 : 0, -1);
+    else if (std::strcmp (name, "group_reg_polls") == 0 && value >= 0 && value <= 1000000)
+        set_group_options (-1, (int) value);
     else if (std::strcmp (name, "wave4096") == 0)
         set_wave4096 (value != 0);
     else if (std::strcmp (name, "split16384") == 0)
@@ -1247,6 +1328,30 @@ int fft_gpu_set_option (const char* name, long value)
         return FFT_GPU_EINVAL;
     }
     return FFT_GPU_OK;
+}
+
+long fft_gpu_get_option (const char* name)
+{
+    if (name == nullptr)
+        return -1;
+    FusedOptions& o = fused_options();
+    if (std::strcmp (name, "fused_two_pass") == 0)
+        return o.enabled.load();
+    if (std::strcmp (name, "fused_min_batch") == 0)
+        return o.min_batch.load();
+    if (std::strcmp (name, "fused_lag") == 0)
+        return o.lag.load();
+    if (std::strcmp (name, "fused_slots") == 0)
+        return o.slots.load();
+    if (std::strcmp (name, "split16384") == 0)
+        return split16384_enabled() ? 1 : 0;
+    if (std::strcmp (name, "split8192") == 0)
+        return g_split8192.load();
+    if (std::strcmp (name, "conv_wave2048") == 0)
+        return g_conv_wave2048.load();
+    if (std::strcmp (name, "fused_conv_split") == 0)
+        return g_fused_conv_split.load();
+    return -1;
 }
 
 int fft_gpu_setup_size (void* setup)
@@ -1280,7 +1385,7 @@ size_t fft_gpu_workspace_bytes (void* setup, size_t batch)
     if (s->tables->mixed_n2 == 0)
         split_large (complex_len (s), n1, n2);
     if (s->transform == FFT_COMPLEX && fused_enabled() && fused_supported (n1, n2) && batch >= fused_min_batch())
-        return fused_workspace_bytes (complex_len (s), fused_slots()) + fused_state_bytes();
+        return (fused_form() == 2 ? group_workspace_bytes() : fused_workspace_bytes (complex_len (s), fused_slots())) + std::max (fused_state_bytes(), group_state_bytes());
     size_t chunk = workspace_cap() / (size_t) lane_count() / frame_bytes;
     if (s->transform == FFT_REAL && s->tables->real4_r1 == 0)
         chunk /= pair_chunk_divisor(); // the pair stage's operands share the cache with the two workspaces

@@ -304,6 +304,8 @@ __global__ __launch_bounds__ (256) void fused256_kernel (const float2* __restric
                                                         const float2* __restrict__ stage_tw,
                                                         const float2* __restrict__ big_tw,
                                                         FusedState* __restrict__ st,
+                                                        unsigned* __restrict__ host_err, // pinned, device-visible: (seq << 8) | code if a bounded wait ran out
+                                                        unsigned seq,
                                                         unsigned batch,
                                                         size_t in_stride,
                                                         size_t out_stride,
@@ -555,6 +557,14 @@ __global__ __launch_bounds__ (256) void fused256_kernel (const float2* __restric
         }
     }
     CFFT_FUSED_FLUSH_PENDING()
+    // a bounded wait that ran out anywhere in this launch (its output is not valid) is reported where the host looks
+    // after its next synchronisation; several workgroups may store the same value
+    if (tid == 0 && host_err != nullptr)
+    {
+        const unsigned err = ld_relaxed (&st->error);
+        if (err != 0)
+            __hip_atomic_store (host_err, (seq << 8) | err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 #undef CFFT_FUSED_FLUSH_PENDING
 #undef CFFT_FUSED_SIGNAL_PENDING
 #undef CFFT_FUSED_LOOKAHEAD_FRAME

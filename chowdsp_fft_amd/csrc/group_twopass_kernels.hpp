@@ -1,0 +1,291 @@
+// Two-pass (four-step) transform of N = 65536 in ONE launch, the inter-pass hand-off inside an XCD's L2, with STATIC
+// groups of workgroups instead of the ticket queues of fused_twopass_kernels.hpp.
+//
+// What the ticket form measured: its fabric traffic is 1.5 x the algorithmic bytes (the two-launch form:
+// 2 x), but it takes longer than two launches, because an item's way from its ticket to its completion flag (5-6 us) is
+// longer than the step the queue advances by (2.8 us): items wait for each other.  Here nothing is queued:
+//
+//   * At its start every workgroup reads the XCD it runs on (HW_REG_XCC_ID) and draws a rank on that XCD.  16 consecutive
+//     ranks form a GROUP; member m of a group owns tile m of both passes of every frame the group transforms -- frames
+//     g, g + G, g + 2 G ... for global group number g of G.  A member therefore needs the same 16 inter-pass twiddles per
+//     work-item for every frame (they live in VGPRs: no twiddle traffic at all), and the group's 16 tiles of one pass
+//     cover whole 2 KiB rows of the frame at about the same time.
+//   * Per frame ONE hand-off: a member stores its pass-A tile into the group's slot (plain stores: the lines stay in this
+//     XCD's L2 and are written through), waits for the stores' acknowledgements, sets its flag; when all 16 flags of the
+//     frame are up it reads its pass-B tile back from L2 (L1-bypassing loads).  Two slots per group, used alternately:
+//     a member can only see the 16 flags of frame k after every member has finished READING frame k - 1 (each sets its
+//     flag k after its own pass B of k - 1), so frame k + 1 may overwrite the slot of frame k - 1 without a second flag.
+//   * The next frame's pass-A operands are requested right behind the pass-B loads, i.e. before this frame's pass-B
+//     arithmetic and stores (vector memory operations retire in issue order: behind the pass-B loads they delay nothing).
+//
+// Placement is still NOT assumed.  Groups exist only if every workgroup of the grid is resident at the same time; that is
+// established, not presumed: every workgroup registers, and the mode of the launch is decided ONCE by a compare-and-swap
+// on one word -- GROUP by the workgroup whose registration completes the grid, SOLO by any workgroup that has waited
+// `reg_polls` polls for that to happen (a grid that is not fully resident, e.g. beside another stream's kernel).  In SOLO
+// mode every workgroup transforms whole frames by itself (16 pass-A tiles into its own slot, then 16 pass-B tiles), with
+// no dependency on any other workgroup: slower (the slots no longer fit L2), always correct, for any placement and any
+// number of resident workgroups.  Workgroups that start after the decision find it made.
+//
+// Reference: the same passes for any N, chowdsp_fft.h:131-134; cfftf1_ps simd/chowdsp_fft_impl_sse.cpp:372-432.
+#pragma once
+#include "fused_twopass_kernels.hpp"
+
+namespace cfft
+{
+constexpr int kGroupMaxXcc = 16;      // HW_REG_XCC_ID is a 4-bit field
+constexpr int kGroupMaxPerXcc = 8;    // groups per XCD that have flags and slots (more workgroups than 128 per XCD stay idle)
+constexpr unsigned kGroupMembers = 16;
+constexpr unsigned kGroupSlotsTotal = kGroupMaxXcc * kGroupMaxPerXcc * 2; // slots of N float2 the group mode addresses
+
+struct GroupState
+{
+    unsigned registered; // workgroups that have drawn their rank
+    unsigned mode;       // 0 undecided, 1 GROUP, 2 SOLO
+    unsigned next_frame; // SOLO mode: frames are claimed one by one
+    unsigned error;      // a bounded wait ran out (also stored to the host word, tagged with the launch number)
+    unsigned pad0[28];
+    struct
+    {
+        unsigned count; // ranks drawn on this XCD
+        unsigned pad[31];
+    } xcc[kGroupMaxXcc];
+    // [xcc][group][member]: number of frames whose pass-A tile the member has stored (one 64-byte poll per group)
+    unsigned aflag[kGroupMaxXcc][kGroupMaxPerXcc][32];
+};
+
+__device__ __forceinline__ void group_fail (GroupState* st, unsigned* host_err, unsigned seq, unsigned code)
+{
+    __hip_atomic_store (&st->error, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (host_err != nullptr)
+        __hip_atomic_store (host_err, (seq << 8) | code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// pass A operands of one tile: 16 rows per work-item, lanes along the tile's 16 columns (128 contiguous bytes per row)
+template <bool INV>
+__device__ __forceinline__ void g256_load_a (float (&re)[16], float (&im)[16], const float2* __restrict__ src, int t0, int c0)
+{
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+    {
+        const float2 x = gload (&src[(unsigned) (t0 + 16 * s) * 256u + c0]);
+        re[s] = INV ? x.y : x.x;
+        im[s] = INV ? x.x : x.y;
+    }
+}
+
+// fft256_two_stage (multipass_kernels.hpp) with the stage-1 twiddles read from LDS, tw[(a - 1) * 16 + k]: pass A and pass B
+// index them by different roles, and both sets in VGPRs next to the resident inter-pass twiddles do not fit 256 registers
+__device__ __forceinline__ void fft256_two_stage_lds (float2 (&v)[16], const float2* __restrict__ tw, int k, float2* __restrict__ smem,
+                                                      int c0, int t0, int c1, int i1)
+{
+    fft_reg<16> (v);
+    __syncthreads(); // the previous tile's stage-1 reads are finished
+#pragma unroll
+    for (int b = 0; b < 16; ++b)
+        smem[c0 * kFS256 + 17 * t0 + b] = v[b];
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 16; ++a)
+        v[a] = smem[c1 * kFS256 + i1 + 17 * a];
+#pragma unroll
+    for (int a = 1; a < 16; ++a)
+        v[a] = cmul (v[a], tw[(a - 1) * 16 + k]);
+    fft_reg<16> (v);
+}
+
+template <bool INV>
+__global__ __launch_bounds__ (256, 2) void group256_kernel (const float2* __restrict__ in,
+                                                        float2* __restrict__ work, // max (kGroupSlotsTotal, gridDim.x) slots of 65536 float2
+                                                        float2* __restrict__ out,
+                                                        const float2* __restrict__ stage_tw,
+                                                        const float2* __restrict__ big_tw,
+                                                        GroupState* __restrict__ st,
+                                                        unsigned* __restrict__ host_err,
+                                                        unsigned batch,
+                                                        size_t in_stride,
+                                                        size_t out_stride,
+                                                        unsigned seq,
+                                                        unsigned reg_polls,
+                                                        unsigned force_solo)
+{
+    extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
+    __shared__ unsigned info[8];
+    __shared__ float2 tw1[15 * 16]; // stage-1 twiddles of Plan256: [a - 1][k]
+    constexpr unsigned N = 65536;
+    const int tid = threadIdx.x;
+    // pass A roles (multipass_kernels.hpp): stage 0 lanes run along the tile's 16 columns, stage 1 along the butterfly index
+    const int c0 = tid & 15, t0 = tid >> 4;
+    const int i1 = tid & 15, c1 = tid >> 4;
+    // pass B roles: lanes run along the tile's 16 rows in both stages
+    const int kbl = tid & 15, tb = tid >> 4;
+
+    if (tid < 240)
+        tw1[tid] = stage_tw[Plan256::tw_offset (1) + tid];
+    if (tid == 0)
+    {
+        const unsigned xcc = hw_xcc_id();
+        const unsigned r = __hip_atomic_fetch_add (&st->xcc[xcc].count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile ("s_waitcnt vmcnt(0)" ::: "memory"); // the rank is drawn before the registration below is counted
+        const unsigned tot = __hip_atomic_fetch_add (&st->registered, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        if (tot == gridDim.x || force_solo != 0)
+        {
+            unsigned expect = 0;
+            (void) __hip_atomic_compare_exchange_strong (&st->mode, &expect, force_solo != 0 ? 2u : 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        unsigned mode, n = 0;
+        while ((mode = ld_relaxed (&st->mode)) == 0)
+        {
+            __builtin_amdgcn_s_sleep (4);
+            if (++n > reg_polls)
+            {
+                unsigned expect = 0; // not every workgroup of the grid is running: nobody may wait for another one
+                (void) __hip_atomic_compare_exchange_strong (&st->mode, &expect, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        unsigned gg = 0, total = 0, valid = 1;
+        if (mode == 1)
+        {
+            // every rank has been drawn: the XCD populations are final.  Global group number = groups of the XCDs before this one + r / 16
+            unsigned mine = 0;
+            for (unsigned x = 0; x < (unsigned) kGroupMaxXcc; ++x)
+            {
+                unsigned g = ld_relaxed (&st->xcc[x].count) / kGroupMembers;
+                g = g > (unsigned) kGroupMaxPerXcc ? (unsigned) kGroupMaxPerXcc : g;
+                if (x == xcc)
+                {
+                    gg = total + r / kGroupMembers;
+                    mine = g;
+                }
+                total += g;
+            }
+            valid = (r / kGroupMembers < mine) ? 1u : 0u; // a rank beyond the last complete group has nothing to do
+        }
+        info[0] = mode;
+        info[1] = xcc;
+        info[2] = r;
+        info[3] = gg;
+        info[4] = total;
+        info[5] = valid;
+    }
+    __syncthreads();
+    const unsigned mode = info[0];
+
+    if (mode == 1)
+    {
+        if (info[5] == 0)
+            return;
+        const unsigned xcc = info[1], r = info[2], gg = info[3], total = info[4];
+        const unsigned g = r / kGroupMembers, tile = r % kGroupMembers;
+        float2* __restrict__ slots = work + (size_t) ((xcc * kGroupMaxPerXcc + g) * 2u) * N;
+        unsigned* __restrict__ af = &st->aflag[xcc][g][0];
+        const size_t base_a = (size_t) (tile * 16) * 256 + c1 * 16 + i1; // this work-item's 16 pass-A outputs: base_a + 256 b
+        float2 bw[16];
+#pragma unroll
+        for (int b = 0; b < 16; ++b)
+            bw[b] = big_tw[base_a + b * 256];
+
+        float nre[16], nim[16];
+        unsigned f = gg;
+        if (f < batch)
+            g256_load_a<INV> (nre, nim, in + (size_t) f * in_stride + tile * 16, t0, c0);
+        for (unsigned k = 0; f < batch; f += total, ++k)
+        {
+            float2 v[16];
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                v[s] = make_float2 (nre[s], nim[s]);
+            // ---- pass A: columns [16 tile, 16 tile + 16) of frame f
+            fft256_two_stage_lds (v, tw1, i1, smem, c0, t0, c1, i1);
+            float2* __restrict__ slot = slots + (size_t) (k & 1u) * N;
+#pragma unroll
+            for (int b = 0; b < 16; ++b)
+                slot[base_a + b * 256] = cmul (v[b], bw[b]); // plain store: stays in this XCD's L2
+            asm volatile ("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's stores are in L2
+            __syncthreads();
+            if (tid == 0)
+                flag_store (&af[tile], k + 1u);
+            if (tid < 64)
+            {
+                unsigned n = 0;
+                while (! flags_reached (af, k + 1u, tid))
+                {
+                    __builtin_amdgcn_s_sleep (2);
+                    if (++n > kFusedSpinLimit)
+                    {
+                        if (tid == 0)
+                            group_fail (st, host_err, seq, 1u);
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- pass B: rows [16 tile, 16 tile + 16) of the slot -> transposed store into frame f
+            const float2* __restrict__ srcb = slot + tile * 256 + tid;
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                v[s] = gload_l2 (&srcb[s * 16 * 256]); // block (a_hi = s, kb_hi = tile), element tid
+            // the next frame's pass-A operands, behind the pass-B loads and ahead of everything else of this frame
+            const unsigned fn = f + total;
+            if (fn < batch)
+                g256_load_a<INV> (nre, nim, in + (size_t) fn * in_stride + tile * 16, t0, c0);
+            CFFT_PHASE_FENCE();
+            fft256_two_stage_lds (v, tw1, tb, smem, kbl, tb, kbl, tb);
+            float2* __restrict__ dst = out + (size_t) f * out_stride + tile * 16 + kbl;
+#pragma unroll
+            for (int b = 0; b < 16; ++b)
+                gstore (&dst[(unsigned) (tb + 16 * b) * 256u], INV ? make_float2 (v[b].y, v[b].x) : v[b]);
+        }
+        return;
+    }
+
+    // ---- SOLO mode: whole frames by one workgroup, its own slot, no dependency on anybody
+    float2* __restrict__ slot = work + (size_t) blockIdx.x * N;
+    for (;;)
+    {
+        __syncthreads(); // everybody has read info[6] of the previous round
+        if (tid == 0)
+            info[6] = __hip_atomic_fetch_add (&st->next_frame, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned f = info[6];
+        if (f >= batch)
+            break;
+#pragma unroll 1
+        for (unsigned tile = 0; tile < 16; ++tile)
+        {
+            float re[16], im[16];
+            g256_load_a<INV> (re, im, in + (size_t) f * in_stride + tile * 16, t0, c0);
+            const size_t base_a = (size_t) (tile * 16) * 256 + c1 * 16 + i1;
+            float2 bw[16];
+#pragma unroll
+            for (int b = 0; b < 16; ++b)
+                bw[b] = big_tw[base_a + b * 256];
+            float2 v[16];
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                v[s] = make_float2 (re[s], im[s]);
+            fft256_two_stage_lds (v, tw1, i1, smem, c0, t0, c1, i1);
+#pragma unroll
+            for (int b = 0; b < 16; ++b)
+                slot[base_a + b * 256] = cmul (v[b], bw[b]);
+        }
+        asm volatile ("s_waitcnt vmcnt(0)" ::: "memory"); // every wave's stores are in L2 (or beyond) ...
+        __syncthreads();                                   // ... before any wave reads the slot back, past its L1
+#pragma unroll 1
+        for (unsigned tile = 0; tile < 16; ++tile)
+        {
+            float2 v[16];
+            const float2* __restrict__ srcb = slot + tile * 256 + tid;
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                v[s] = gload_l2 (&srcb[s * 16 * 256]);
+            fft256_two_stage_lds (v, tw1, tb, smem, kbl, tb, kbl, tb);
+            float2* __restrict__ dst = out + (size_t) f * out_stride + tile * 16 + kbl;
+#pragma unroll
+            for (int b = 0; b < 16; ++b)
+                gstore (&dst[(unsigned) (tb + 16 * b) * 256u], INV ? make_float2 (v[b].y, v[b].x) : v[b]);
+        }
+        // the slot is rewritten by the next frame's pass A only after the barrier at the loop top, which every wave reaches
+        // with its pass-B loads consumed
+    }
+}
+} // namespace cfft

@@ -2,10 +2,12 @@
 #include "launch_util.hpp"
 #include "multipass_kernels.hpp"
 #include "fused_twopass_kernels.hpp"
+#include "group_twopass_kernels.hpp"
 #include "tile_fast_kernels.hpp"
 #include "generic_kernels.hpp"
 #include "tables.hpp"
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 
@@ -351,7 +353,7 @@ size_t fused_state_bytes() { return sizeof (FusedState); }
 size_t fused_workspace_bytes (int nc, int slots) { return (size_t) kFusedMaxXcc * (size_t) slots * (size_t) nc * sizeof (float2); }
 bool fused_supported (int n1, int n2) { return n1 == 256 && n2 == 256; }
 
-hipError_t launch_fused_c2c (int n1, int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, void* state, size_t batch, int lag, int slots, hipStream_t stream, size_t in_stride, size_t out_stride)
+hipError_t launch_fused_c2c (int n1, int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, void* state, unsigned* host_err, unsigned seq, size_t batch, int lag, int slots, hipStream_t stream, size_t in_stride, size_t out_stride)
 {
     if (batch == 0)
         return hipSuccess;
@@ -386,7 +388,7 @@ hipError_t launch_fused_c2c (int n1, int n2, bool inverse, const float2* in, flo
         if (current_device_info (dev))
             grid = std::min (grid, (unsigned) (dev.num_cus * grid_cap));
     }
-    hipLaunchKernelGGL (k, dim3 (grid), dim3 (256), lds, stream, in, work, out, stage_tw, big_tw, (FusedState*) state, (unsigned) batch, in_stride, out_stride, (unsigned) lag, (unsigned) slots, (unsigned) dbg_mode);
+    hipLaunchKernelGGL (k, dim3 (grid), dim3 (256), lds, stream, in, work, out, stage_tw, big_tw, (FusedState*) state, host_err, seq, (unsigned) batch, in_stride, out_stride, (unsigned) lag, (unsigned) slots, (unsigned) dbg_mode);
     e = hipGetLastError();
     static const bool debug = std::getenv ("CHOWDSP_FFT_FUSED_DEBUG") != nullptr;
     if (debug && e == hipSuccess)
@@ -400,6 +402,81 @@ hipError_t launch_fused_c2c (int n1, int n2, bool inverse, const float2* in, flo
             for (int x = 0; x < kFusedMaxXcc; ++x)
                 if (h.q[x].ticket != 0)
                     fprintf (stderr, " xcc%d=%u", x, h.q[x].ticket);
+            fprintf (stderr, "\n");
+        }
+    }
+    return e;
+}
+
+// ---- the same, by static groups of workgroups per XCD (group_twopass_kernels.hpp) ---------------------------------------
+namespace
+{
+int group_wg_per_cu()
+{
+    static const int v = [] {
+        const char* e = std::getenv ("CHOWDSP_FFT_GROUP_WG_PER_CU");
+        const int n = e != nullptr ? std::atoi (e) : 2;
+        return (n >= 1 && n <= 4) ? n : 2;
+    }();
+    return v;
+}
+constexpr size_t kGroupLds = (size_t) 16 * TileFrame<256>::stride * sizeof (float2);
+// options "group_force_solo" (tests: every launch takes the fall-back mode) and "group_reg_polls" (how long a workgroup waits
+// for the grid to be complete before it decides for the fall-back mode; one poll is about a microsecond)
+std::atomic<int> g_group_force_solo { 0 }, g_group_reg_polls { 200 };
+unsigned group_grid (bool inverse)
+{
+    auto k = inverse ? group256_kernel<true> : group256_kernel<false>;
+    DeviceInfo dev;
+    if (! current_device_info (dev))
+        return 0;
+    const int per_cu = std::min (group_wg_per_cu(), blocks_per_cu_cached ((const void*) k, 256, kGroupLds));
+    return (unsigned) (dev.num_cus * std::max (per_cu, 0));
+}
+} // namespace
+void set_group_options (int force_solo, int reg_polls)
+{
+    if (force_solo >= 0)
+        g_group_force_solo = force_solo != 0 ? 1 : 0;
+    if (reg_polls >= 0)
+        g_group_reg_polls = reg_polls;
+}
+size_t group_state_bytes() { return sizeof (GroupState); }
+size_t group_workspace_bytes()
+{
+    // GROUP mode addresses kGroupSlotsTotal slots, SOLO mode one per workgroup of the grid
+    const unsigned grid = std::max (group_grid (false), group_grid (true));
+    return (size_t) std::max<unsigned> (kGroupSlotsTotal, grid) * 65536u * sizeof (float2);
+}
+hipError_t launch_group_c2c (int n1, int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, void* state, unsigned* host_err, unsigned seq, size_t batch, hipStream_t stream, size_t in_stride, size_t out_stride)
+{
+    if (batch == 0)
+        return hipSuccess;
+    if (n1 != 256 || n2 != 256 || batch >= 0x7FFFFFFFull)
+        return hipErrorInvalidValue;
+    in_stride = in_stride ? in_stride : 65536;
+    out_stride = out_stride ? out_stride : 65536;
+    hipError_t e = hipMemsetAsync (state, 0, sizeof (GroupState), stream); // ranks, mode and flags start from zero in every launch
+    if (e != hipSuccess)
+        return e;
+    auto k = inverse ? group256_kernel<true> : group256_kernel<false>;
+    // the WHOLE resident grid, whatever the batch: groups form only when every workgroup of the grid has registered
+    const unsigned grid = group_grid (inverse);
+    if (grid == 0)
+        return hipErrorNoDevice;
+    const unsigned force_solo = (unsigned) g_group_force_solo.load(), reg_polls = (unsigned) g_group_reg_polls.load();
+    hipLaunchKernelGGL (k, dim3 (grid), dim3 (256), kGroupLds, stream, in, work, out, stage_tw, big_tw, (GroupState*) state, host_err, (unsigned) batch, in_stride, out_stride, seq, reg_polls, force_solo);
+    e = hipGetLastError();
+    static const bool debug = std::getenv ("CHOWDSP_FFT_FUSED_DEBUG") != nullptr;
+    if (debug && e == hipSuccess)
+    {
+        GroupState h;
+        if (hipStreamSynchronize (stream) == hipSuccess && hipMemcpy (&h, state, sizeof (h), hipMemcpyDeviceToHost) == hipSuccess)
+        {
+            fprintf (stderr, "[group] grid %u batch %zu registered %u mode %u error %u solo-claimed %u ranks:", grid, batch, h.registered, h.mode, h.error, h.next_frame);
+            for (int x = 0; x < kGroupMaxXcc; ++x)
+                if (h.xcc[x].count != 0)
+                    fprintf (stderr, " xcc%d=%u", x, h.xcc[x].count);
             fprintf (stderr, "\n");
         }
     }

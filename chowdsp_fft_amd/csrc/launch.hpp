@@ -77,7 +77,14 @@ hipError_t launch_real4 (int r1, int r2, bool inverse, const float2* in, float2*
 bool fused_supported (int n1, int n2);
 size_t fused_state_bytes();
 size_t fused_workspace_bytes (int nc, int slots);
-hipError_t launch_fused_c2c (int n1, int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, void* state, size_t batch, int lag, int slots, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
+// host_err: a pinned, device-visible word that a launch whose bounded waits ran out sets to (seq << 8) | code; else untouched
+hipError_t launch_fused_c2c (int n1, int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, void* state, unsigned* host_err, unsigned seq, size_t batch, int lag, int slots, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
+// ... and with static groups of 16 workgroups per XCD instead of ticket queues (group_twopass_kernels.hpp); same arguments,
+// `state` = group_state_bytes(), `work` = group_workspace_bytes()
+size_t group_state_bytes();
+void set_group_options (int force_solo, int reg_polls); // -1 = leave as it is
+size_t group_workspace_bytes();
+hipError_t launch_group_c2c (int n1, int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, void* state, unsigned* host_err, unsigned seq, size_t batch, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
 // long mixed-radix frames (t.mixed_n2 > 0): generic column pass + power-of-two row pass, in -> work -> out
 hipError_t launch_mixed_big_c2c (const DeviceTables& t, bool inverse, const float2* in, float2* work, float2* out, size_t batch, int grid_divisor, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
 hipError_t launch_real_pair (bool forward, const float2* in, float2* out, const float2* real_tw, unsigned m, size_t batch, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);

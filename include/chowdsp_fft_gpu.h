@@ -79,6 +79,9 @@ int fft_gpu_release_stream_resources (void* stream);
                         the workgroup plan, default 0
    Returns 0, or FFT_GPU_EINVAL for an unknown name / a value out of range. */
 int fft_gpu_set_option (const char* name, long value);
+/* Current value of an option ("fused_two_pass", "fused_min_batch", "fused_lag", "fused_slots", "split16384", "split8192",
+   "conv_wave2048", "fused_conv_split"), or -1 for a name that cannot be read back. */
+long fft_gpu_get_option (const char* name);
 
 /* ---- plan introspection -------------------------------------------------------------------------- */
 /* 1 if fft_new_setup would accept (N, transform) on a machine with a usable device, else 0.  Pure host logic (no GPU

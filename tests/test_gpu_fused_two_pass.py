@@ -1,5 +1,7 @@
-"""The one-launch two-pass form (csrc/fused_twopass_kernels.hpp): both passes of N = 65536 complex in ONE kernel, the
-inter-pass hand-off inside an XCD's L2, work handed out by per-XCD ticket queues.  Forced on for every batch size here
+"""The one-launch two-pass forms: both passes of N = 65536 complex in ONE kernel, the inter-pass hand-off inside an XCD's
+L2 -- work handed out by per-XCD ticket queues (csrc/fused_twopass_kernels.hpp, option value 1) or done by static groups
+of 16 workgroups per XCD (csrc/group_twopass_kernels.hpp, option value 2; with its fall-back mode in which every
+workgroup transforms whole frames alone).  Forced on for every batch size here
 (an option, off by default; when on, batches >= 2048 take it): parity with the oracle, and agreement with the two-launch form, for
 batches that fill the queue's pipeline only partly, exactly, and many times over; both directions; in place; strided.
 """
@@ -15,39 +17,54 @@ pytestmark = pytest.mark.gpu
 N = 65536
 
 
-@pytest.fixture()
-def fused_on(gpu):
+FORM = {"tickets": 1, "groups": 2}
+
+
+def _form_now(api):
+    return int(api.get_option("fused_two_pass"))
+
+
+@pytest.fixture(params=["tickets", "groups", "groups-solo"])
+def fused_on(gpu, request):
     api = gpu[0]
-    api.set_option("fused_two_pass", 1)
+    default = _form_now(api)
+    api.set_option("fused_two_pass", FORM[request.param.split("-")[0]])
+    api.set_option("group_force_solo", 1 if request.param.endswith("solo") else 0)
     api.set_option("fused_min_batch", 1)
     yield api
     api.set_option("fused_min_batch", 2048)
     api.set_option("fused_lag", 4)
-    api.set_option("fused_two_pass", 0)  # the library default
+    api.set_option("group_force_solo", 0)
+    api.set_option("fused_two_pass", default)
 
 
-def _run(gpu, s, x, direction, fused):
+def _run(gpu, s, x, direction, form):
     api, torch, dev = gpu
-    api.set_option("fused_two_pass", 1 if fused else 0)
+    api.set_option("fused_two_pass", form)
     xd = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
     yd = torch.empty_like(xd)
     api.fft_transform_batch(s, xd, yd, direction)
-    torch.cuda.synchronize()
-    api.set_option("fused_two_pass", 1)  # the state the fused_on fixture set up
+    api.stream_synchronize()  # where the one-launch forms report a hand-off that did not complete
     return yd.cpu().numpy()
+
+
 
 
 @pytest.mark.parametrize("batch", [1, 2, 7, 8, 9, 31, 64, 100])
 @pytest.mark.parametrize("lag", [1, 3, 4])
 def test_fused_vs_oracle_and_two_launch(gpu, oracle, fused_on, batch, lag):
     api = fused_on
+    if _form_now(api) == 2 and lag != 4:
+        pytest.skip("the group form has no lag")
     api.set_option("fused_lag", lag)
     s, so = api.fft_new_setup(N, api.FFT_COMPLEX), oracle.new_setup(N, COMPLEX)
     x = ol.uniform(batch * 2 * N, 900 + batch).reshape(batch, 2 * N)
     nref = min(batch, 3)
+    form = _form_now(api)
     for direction, odir in ((api.FFT_FORWARD, FORWARD), (api.FFT_BACKWARD, BACKWARD)):
-        got = _run(gpu, s, x, direction, True)
-        two = _run(gpu, s, x, direction, False)
+        got = _run(gpu, s, x, direction, form)
+        two = _run(gpu, s, x, direction, 0)
+        api.set_option("fused_two_pass", form)
         # same algorithm and tables; the compiler contracts the two kernels' multiply-adds differently
         assert_frames_close(got, two, tol=2e-7, maxabs_tol=6e-7, what="one-launch vs two-launch form")
         want = oracle.transform_batch(so, x[:nref], odir)
@@ -93,7 +110,7 @@ def test_fused_many_launches_back_to_back(gpu, fused_on):
     for _ in range(20):
         api.fft_transform_batch(s, x, y, api.FFT_FORWARD)
         api.fft_transform_batch(s, y, z, api.FFT_BACKWARD)
-    torch.cuda.synchronize()
+    api.stream_synchronize()
     assert float((z / N - x).abs().max()) < 3e-6
     api.fft_destroy_setup(s)
 
