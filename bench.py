@@ -36,9 +36,11 @@ WORKLOADS = {
     # name: (N, transform, frames per GPU, description)
     "c2c_n4096_b65536_fwd_inv": (4096, "complex", 65536, "BASELINE configs[1]: N=4096 fp32 complex fwd+inv, batch=65536 per GPU"),
     "real_n1024_b262144_fwd_inv": (1024, "real", 262144, "BASELINE configs[2]: N=1024 fp32 real r2c+c2r, batch=262144 per GPU"),
-    "c2c_n65536_b8192_fwd_inv": (65536, "complex", 8192, "BASELINE configs[4]: N=65536 fp32 complex (two-pass), batch=8192 per GPU"),
-    # the same configuration through the one-launch form (option fused_two_pass): the inter-pass hand-off stays in the XCDs' L2
-    "c2c_n65536_b8192_fwd_inv_one_launch": (65536, "complex", 8192, "BASELINE configs[4] through the one-launch, XCD-local two-pass form (fused_two_pass = 1)"),
+    "c2c_n65536_b8192_fwd_inv": (65536, "complex", 8192, "BASELINE configs[4]: N=65536 fp32 complex (two passes in one launch, hand-off in the XCDs' L2: the library default), batch=8192 per GPU"),
+    # the same configuration through the other two forms (option fused_two_pass): two launches per chunk (round 1), and the
+    # ticket-queue one-launch form (round 2)
+    "c2c_n65536_b8192_fwd_inv_two_launches": (65536, "complex", 8192, "BASELINE configs[4] as two launches per 256-frame chunk (fused_two_pass = 0)"),
+    "c2c_n65536_b8192_fwd_inv_tickets": (65536, "complex", 8192, "BASELINE configs[4] through the ticket-queue one-launch form (fused_two_pass = 1)"),
     "conv_real_n4096_b131072": (4096, "real", 131072, "BASELINE configs[3] per-GPU share: fused fwd->mul->inv frames, N=4096 real, 131072 frames per GPU"),
     # a mixed-radix size from the reference's "Other sizes" list (9216 = 2^10 * 3^2), generic kernel
     "c2c_n9216_b16384_fwd_inv": (9216, "complex", 16384, "mixed-radix N=9216 fp32 complex fwd+inv (generic kernel), batch=16384 per GPU"),
@@ -47,9 +49,55 @@ WORKLOADS = {
 }
 
 
+# kernels whose launches make up one library call of the workload (substrings of the demangled names): what the "kernel" field
+# of the roofline object names, and what tools/pmc_refresh.py sums the PMC counters over
+WORKLOAD_KERNELS = {
+    "c2c_n4096_b65536_fwd_inv": ["c2c_kernel_pf"],
+    "real_n1024_b262144_fwd_inv": ["r2c_kernel", "c2r_kernel"],
+    "conv_real_n4096_b131072": ["conv_frames_real_kernel"],
+    "c2c_n65536_b8192_fwd_inv": ["group256_kernel"],
+    "c2c_n65536_b8192_fwd_inv_two_launches": ["pass_a256_kernel", "pass_b256_kernel"],
+    "c2c_n65536_b8192_fwd_inv_tickets": ["fused256_kernel"],
+    "c2c_n9216_b16384_fwd_inv": ["generic_inplace_kernel", "generic_kernel", "static_"],
+    "ols_engine_b2048_p16_c8192": ["ols_block_kernel"],
+}
+
+
+def launches_per_step(workload: str) -> int:
+    return 1 if (workload.startswith("conv_") or workload.startswith("ols_engine")) else 2
+
+
+def committed_traffic(workload: str):
+    """HBM / fabric bytes per launch from the PMC counters: NOT measured by a bench run (rocprofv3 --pmc needs passes of its
+    own); read from profiles/pmc_traffic.json, which tools/pmc_refresh.sh writes together with a hash of the library sources
+    it profiled.  Returns (traffic or None, extra fields): a figure taken on other sources than the ones being timed is
+    withheld (`traffic` null, `traffic_stale` true) instead of being printed next to a kernel it does not describe."""
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(tpath):
+        return None, {"traffic_source": None}
+    try:
+        from chowdsp_fft_amd import _buildinfo
+
+        tj = json.load(open(tpath))
+        cur_src, cur_lib = _buildinfo.source_sha256(), _buildinfo.lib_sha256()
+        extra = {"traffic_source": tj.get("_taken_at"), "traffic_src_sha256": (tj.get("src_sha256") or "")[:16],
+                 "timed_src_sha256": cur_src[:16], "traffic_lib_sha256_matches": tj.get("lib_sha256") == cur_lib}
+        if tj.get("src_sha256") != cur_src:
+            extra["traffic_stale"] = True
+            return None, extra
+        entry = (tj.get("workloads") or {}).get(workload)
+        if entry is None:
+            return None, extra
+        extra["traffic_kernels"] = entry.get("kernels")
+        return entry.get("bytes_per_launch"), extra
+    except Exception as e:  # a broken summary must not break the bench line
+        return None, {"traffic_source": f"unreadable: {e}"}
+
+
 DEFAULT_WORKLOAD = "c2c_n4096_b65536_fwd_inv"
+MULTI_GPU_CONV_WORKLOAD = "conv_real_n4096_b131072"  # BASELINE configs[3]: 1M frames over 8 GPUs = 131072 per GPU
 # the other BASELINE.json configurations, reported under "secondary" of the default run's ONE JSON line
-SECONDARY_WORKLOADS = ("real_n1024_b262144_fwd_inv", "conv_real_n4096_b131072", "c2c_n65536_b8192_fwd_inv", "c2c_n65536_b8192_fwd_inv_one_launch")
+SECONDARY_WORKLOADS = ("real_n1024_b262144_fwd_inv", "conv_real_n4096_b131072", "c2c_n65536_b8192_fwd_inv", "c2c_n65536_b8192_fwd_inv_two_launches")
 
 
 def cpu_baseline(n: int, transform: str, seconds: float) -> dict:
@@ -108,7 +156,11 @@ def run_workload(workload, args, world, rank, dev, frames_override=0, gather=Fal
         frames = frames_override
     tr = api.FFT_COMPLEX if transform == "complex" else api.FFT_REAL
     frame_floats = 2 * n if transform == "complex" else n
-    api.set_option("fused_two_pass", 1 if workload.endswith("_one_launch") else 0)
+    default_form = api.get_option("fused_two_pass")
+    if workload.endswith("_two_launches"):
+        api.set_option("fused_two_pass", 0)
+    elif workload.endswith("_tickets"):
+        api.set_option("fused_two_pass", 1)
     setup = api.fft_new_setup(n, tr)
     if setup is None:
         sys.stderr.write("[bench] fft_new_setup returned NULL\n")
@@ -142,7 +194,7 @@ def run_workload(workload, args, world, rank, dev, frames_override=0, gather=Fal
             api.fft_transform_batch(setup, x, y, api.FFT_FORWARD)
             api.fft_transform_batch(setup, y, z, api.FFT_BACKWARD)
 
-    launches_per_step = 1 if (fused or engine is not None) else 2
+    launches_per_step_ = launches_per_step(workload)
     transforms_per_frame_step = 2  # forward + backward (fused: both inside one kernel)
 
     if args.prewarm_seconds > 0:
@@ -179,23 +231,18 @@ def run_workload(workload, args, world, rank, dev, frames_override=0, gather=Fal
             return 5
 
     gather_info = None
-    if gather and world > 1:
-        torch.cuda.synchronize()
-        dist.barrier()
-        tg = time.perf_counter()
-        full = sharding.gather_frames(z if not fused else y, frames * world)
-        torch.cuda.synchronize()
-        dist.barrier()
-        tg = sharding.max_over_ranks(time.perf_counter() - tg, device=dev)
-        gather_info = {"seconds": tg, "bytes_received_per_gpu": int(full.numel() * 4 * (world - 1) / world),
-                       "GB_s_per_gpu": full.numel() * 4 * (world - 1) / world / tg / 1e9}
-        del full
+    if gather and world > 1 and engine is None:
+        # the final collection of the result shards over RCCL / xGMI: the ONE collective of this path, timed on its own
+        # (twice: the first call also builds the communicator's channels), never part of `value`
+        first = sharding.timed_gather(z if not fused else y, frames * world, device=dev, synchronize=torch.cuda.synchronize)
+        gather_info = sharding.timed_gather(z if not fused else y, frames * world, device=dev, synchronize=torch.cuda.synchronize)
+        gather_info["first_call_seconds"] = first["seconds"]
 
     line = None
     if rank == 0:
         total_transforms = transforms_per_frame_step * frames * world * args.steps
         value = total_transforms / elapsed / 1e9
-        launches = launches_per_step * args.steps
+        launches = launches_per_step_ * args.steps
         avg_launch_s = event_ms * 1e-3 / launches
         alg_bytes_per_launch = (4 * frame_floats * 2) * frames  # read + write one frame each, per launch
         if engine is not None:
@@ -207,22 +254,13 @@ def run_workload(workload, args, world, rank, dev, frames_override=0, gather=Fal
             "c2c_n4096_b65536_fwd_inv": "cfft::c2c_kernel_pf<Plan<4096,256,16,16,16>, 1, INV, false> (forward and backward instantiations)",
             "real_n1024_b262144_fwd_inv": "cfft::r2c_kernel<Plan<512,64,8,8,8>, 4, false> and cfft::c2r_kernel<Plan<512,64,8,8,8>, 4, false>",
             "conv_real_n4096_b131072": "cfft::conv_frames_real_kernel_pf<Plan<2048,128,16,16,8>, 1, false>",
-            "c2c_n65536_b8192_fwd_inv": "cfft::pass_a256_kernel<INV> + cfft::pass_b256_kernel<INV> per 256-frame chunk (two passes over the frame)",
-            "c2c_n65536_b8192_fwd_inv_one_launch": "cfft::fused256_kernel<INV> (both passes in one launch, per-XCD ticket queues)",
+            "c2c_n65536_b8192_fwd_inv": "cfft::group256_kernel<INV> (both passes in one launch, static groups of 16 workgroups per XCD)",
+            "c2c_n65536_b8192_fwd_inv_two_launches": "cfft::pass_a256_kernel<INV> + cfft::pass_b256_kernel<INV> per 256-frame chunk (two passes over the frame)",
+            "c2c_n65536_b8192_fwd_inv_tickets": "cfft::fused256_kernel<INV> (both passes in one launch, per-XCD ticket queues)",
             "c2c_n9216_b16384_fwd_inv": "cfft::generic_kernel<0, INV, 1024>",
             "ols_engine_b2048_p16_c8192": "cfft::ols_block_kernel<Plan<2048,128,16,16,8>, 2>",
         }.get(workload, f"{workload} kernels")
-        # HBM bytes per launch from the PMC counters: NOT measured by this run (rocprofv3 --pmc needs its own passes);
-        # read from the committed summary of the last profiling session and labelled with where it was taken
-        traffic, traffic_source = None, None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                traffic = tj.get(workload)
-                traffic_source = tj.get("_taken_at")
-            except Exception:
-                traffic = None
+        traffic, traffic_extra = committed_traffic(workload)
         line = {
             "metric": "GFFT/s (batched fp32 complex, N=4096) + achieved HBM GB/s vs roofline" if workload == "c2c_n4096_b65536_fwd_inv"
                       else f"GFFT/s ({workload})",
@@ -234,14 +272,14 @@ def run_workload(workload, args, world, rank, dev, frames_override=0, gather=Fal
                        "transforms_per_frame_per_step": transforms_per_frame_step,
                        "sharding": f"contiguous batch blocks over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, **traffic_extra, "kernel": kernel,
                          "algorithmic_bytes_per_launch": alg_bytes_per_launch, "avg_launch_ms": avg_launch_s * 1e3,
                          "launches_timed": launches, "timer": "HIP events on the launch stream"},
         }
         if gather_info:
             line["gather_xgmi"] = gather_info
     api.fft_destroy_setup(setup)
-    api.set_option("fused_two_pass", 0)
+    api.set_option("fused_two_pass", default_form)
     del x, y, z, engine
     torch.cuda.empty_cache()
     return line
@@ -260,7 +298,8 @@ def main() -> int:
     ap.add_argument("--prewarm-seconds", type=float, default=0.3,
                     help="untimed: run the step for this long BEFORE the W warm-up steps so that the GPU has left its idle "
                          "clocks (measured: the first ~3 ms after idle run 10-25 %% slower); the timed region is still exactly K steps")
-    ap.add_argument("--gather", action="store_true", help="also time the final all-gather of results over xGMI (reported separately)")
+    ap.add_argument("--gather", action="store_true", help="(default when N > 1) time the final all-gather of results over xGMI, reported separately")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the final all-gather")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -314,21 +353,34 @@ def main() -> int:
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    line = run_workload(args.workload, args, world, rank, dev, frames_override=args.frames_per_gpu, gather=args.gather)
+    do_gather = world > 1 and not args.no_gather
+    line = run_workload(args.workload, args, world, rank, dev, frames_override=args.frames_per_gpu, gather=do_gather)
     if isinstance(line, int):
         return line
     # BASELINE.json's other configurations, driver-timed in the same run (each is a few ms of GPU time per step): same
     # protocol (prewarm, W warm-up steps, exactly K timed steps between barriers + synchronize, MAX over ranks)
-    secondary = []
+    secondary, multi_extra = [], {}
     if args.workload == DEFAULT_WORKLOAD and not args.no_secondary:
         for name in SECONDARY_WORKLOADS:
-            sec = run_workload(name, args, world, rank, dev)
+            # N > 1: BASELINE configs[3] (1M overlap-save frames over 8 GPUs = 131072 per GPU) gets a gather of its own
+            sec = run_workload(name, args, world, rank, dev, gather=(do_gather and name == MULTI_GPU_CONV_WORKLOAD))
             if isinstance(sec, int):
                 return sec
             if rank == 0:
                 secondary.append({"workload": name, "description": sec["config"]["description"], "value": sec["value"], "unit": sec["unit"],
                                   "ms_per_step": sec["ms_per_step"], "steps": sec["steps"], "warmup": sec["warmup"],
                                   "frames_per_gpu": sec["config"]["frames_per_gpu"], "roofline": sec["roofline"]})
+                if world > 1 and name == MULTI_GPU_CONV_WORKLOAD:
+                    multi_extra[name] = {"description": sec["config"]["description"], "value": sec["value"], "unit": sec["unit"],
+                                         "ms_per_step": sec["ms_per_step"], "global_frames": sec["config"]["global_frames"],
+                                         "roofline_frac_per_gpu": sec["roofline"]["frac"], "gather_xgmi": sec.get("gather_xgmi")}
+    if world > 1:
+        # proof of what the process group spans: every rank's device, collected over the process group itself
+        props = torch.cuda.get_device_properties(local_rank)
+        desc = f"rank {rank}: cuda:{local_rank} {props.name} {getattr(props, 'gcnArchName', '')} {props.multi_processor_count} CUs pid {os.getpid()}"
+        rank_desc = sharding.describe_ranks(desc)
+        if rank == 0:
+            line.update(sharding.multi_gpu_fields(world, rank_desc, line.pop("gather_xgmi", None), multi_extra))
     if rank == 0:
         if secondary:
             line["secondary"] = secondary

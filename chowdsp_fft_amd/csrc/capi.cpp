@@ -229,18 +229,25 @@ Lanes* get_lanes (int device, hipStream_t stream, size_t bytes_each)
     return &L;
 }
 
-// Run-time options of the one-launch two-pass form (fft_gpu_set_option; initial values from the environment):
-//   fused_two_pass   CHOWDSP_FFT_FUSED            1 = one launch where that form exists, 0 (default) = two launches per chunk.
-//                                                 Default 0 because it is the faster one by 1-5 % (same write traffic, which
-//                                                 is what bounds both); the one-launch form moves 21-25 % fewer bytes in all.
-//   fused_min_batch  CHOWDSP_FFT_FUSED_MIN_BATCH  smallest batch that takes it.  Its queue needs `lag` steps to fill and drain,
-//                                                 so short batches are faster as two launches (MI355X, N = 65536: batch 1:
-//                                                 13 vs 67 us, 64: 32 vs 54, 256: 98 vs 124, 1024: 417 vs 434, 8192: equal)
-//   fused_lag        CHOWDSP_FFT_FUSED_LAG        steps between a frame's pass A and its pass B
-//   fused_slots      CHOWDSP_FFT_FUSED_SLOTS      workspace slots (frames) per XCD queue, > lag (default lag + 2)
-// Measured (N = 65536 x 8192, profiles/r02_fused_two_pass.txt): lag 3 / 5 slots keeps every intermediate in L2 (fabric
-// traffic 1.50 x algorithmic) at 3.10 ms per transform; lag 4 / 6 slots 1.58 x at 2.90 ms (= the two-launch form's time,
-// whose traffic is 2.0 x); lag 5 / 7 slots no longer fits L2 (1.9 x).
+// Run-time options of the one-launch two-pass forms (fft_gpu_set_option; initial values from the environment):
+//   fused_two_pass   CHOWDSP_FFT_FUSED            which form runs the sizes that have a one-launch form (N = 65536 complex):
+//                                                 2 (default, round 3) = ONE launch by static groups of 16 workgroups per XCD
+//                                                 (group_twopass_kernels.hpp): 2.24-2.40 ms per 8192 frames, fabric traffic
+//                                                 1.38 x the algorithmic bytes (profiles/r03_group_two_pass.txt);
+//                                                 1 = one launch by per-XCD ticket queues (fused_twopass_kernels.hpp, round 2):
+//                                                 2.9 ms, 1.5-1.6 x;  0 = two launches per chunk (round 1): 2.63-2.76 ms, 2.0 x
+//   fused_min_batch  CHOWDSP_FFT_FUSED_MIN_BATCH  smallest batch that takes a one-launch form: its launch registers the whole
+//                                                 grid first (about 10 us), so short batches are faster as two launches
+//                                                 (group form, MI355X: batch 1: 20 vs 12 us, 64: 34 vs 30, 128: 56 vs 51,
+//                                                 256: 90 vs 93, 512: 163 vs 204, 8192: 2243 vs 2628;
+//                                                 profiles/r03_group_batch_sweep.txt)
+//   fused_lag        CHOWDSP_FFT_FUSED_LAG        ticket form: steps between a frame's pass A and its pass B
+//   fused_slots      CHOWDSP_FFT_FUSED_SLOTS      ticket form: workspace slots (frames) per XCD queue, > lag (default lag + 2)
+//   group_force_solo / group_reg_polls            group form: force its fall-back mode (tests) / how many polls (about a
+//                                                 microsecond each) a workgroup waits for the grid to be complete
+// Ticket form, measured (N = 65536 x 8192, profiles/r02_fused_two_pass.txt): lag 3 / 5 slots keeps every intermediate in L2
+// (fabric traffic 1.50 x algorithmic) at 3.10 ms per transform; lag 4 / 6 slots 1.58 x at 2.90 ms; lag 5 / 7 slots no longer
+// fits L2 (1.9 x).
 struct FusedOptions
 {
     std::atomic<long> enabled, min_batch, lag, slots;
@@ -250,8 +257,9 @@ struct FusedOptions
             const char* e = std::getenv (name);
             return e != nullptr ? std::atol (e) : dflt;
         };
-        enabled = env ("CHOWDSP_FFT_FUSED", 0);
-        min_batch = std::max (1l, env ("CHOWDSP_FFT_FUSED_MIN_BATCH", 2048));
+        const long form = env ("CHOWDSP_FFT_FUSED", 2);
+        enabled = (form >= 0 && form <= 2) ? form : 2;
+        min_batch = std::max (1l, env ("CHOWDSP_FFT_FUSED_MIN_BATCH", 256));
         long l = env ("CHOWDSP_FFT_FUSED_LAG", 4);
         l = (l >= 1 && l <= 6) ? l : 4;
         long sl = env ("CHOWDSP_FFT_FUSED_SLOTS", l + 2);

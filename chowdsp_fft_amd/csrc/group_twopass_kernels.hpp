@@ -10,11 +10,16 @@
 //     g, g + G, g + 2 G ... for global group number g of G.  A member therefore needs the same 16 inter-pass twiddles per
 //     work-item for every frame (they live in VGPRs: no twiddle traffic at all), and the group's 16 tiles of one pass
 //     cover whole 2 KiB rows of the frame at about the same time.
-//   * Per frame ONE hand-off: a member stores its pass-A tile into the group's slot (plain stores: the lines stay in this
+//   * Per frame one hand-off: a member stores its pass-A tile into the group's slot (plain stores: the lines stay in this
 //     XCD's L2 and are written through), waits for the stores' acknowledgements, sets its flag; when all 16 flags of the
-//     frame are up it reads its pass-B tile back from L2 (L1-bypassing loads).  Two slots per group, used alternately:
-//     a member can only see the 16 flags of frame k after every member has finished READING frame k - 1 (each sets its
-//     flag k after its own pass B of k - 1), so frame k + 1 may overwrite the slot of frame k - 1 without a second flag.
+//     frame are up it reads its pass-B tile back from L2 (L1-bypassing loads).  ONE slot per group: the footprint that
+//     has to survive in an XCD's 4 MiB L2 next to the streamed frames is then 512 KiB per group (2 MiB at two workgroups
+//     per CU).  With two slots used alternately no second flag would be needed (a member sees the 16 flags of frame k only
+//     after every member has finished reading frame k - 1), but the cyclic 4 MiB footprint thrashes L2: measured, three
+//     quarters of the pass-B loads then come back over the fabric (FETCH_SIZE 7.0 instead of 4 GiB per 8192 frames,
+//     profiles/r03_group_two_pass.txt; `two_slots` keeps that form for A/B runs).  So a second flag per member says "my
+//     pass-B loads of frame k have returned", and every wave looks at the group's 16 of them before it overwrites the
+//     slot with frame k + 1 -- two steps of arithmetic later, when they are normally all up.
 //   * The next frame's pass-A operands are requested right behind the pass-B loads, i.e. before this frame's pass-B
 //     arithmetic and stores (vector memory operations retire in issue order: behind the pass-B loads they delay nothing).
 //
@@ -29,6 +34,22 @@
 // Reference: the same passes for any N, chowdsp_fft.h:131-134; cfftf1_ps simd/chowdsp_fft_impl_sse.cpp:372-432.
 #pragma once
 #include "fused_twopass_kernels.hpp"
+
+// CFFT_GROUP_EXPERIMENT builds (tools/build_variants.sh; never the shipped library) read timing-only switches from bits 8.. of
+// `force_solo` -- results are WRONG with any of them set: 1 no waiting for the group, 2 no slot stores, 4 no slot loads,
+// 8 no input loads after the first frame, 16 no output stores
+#ifndef CFFT_GROUP_EXPERIMENT
+#define CFFT_GROUP_EXPERIMENT 0
+#endif
+#if CFFT_GROUP_EXPERIMENT
+#define CFFT_GROUP_DBG(BIT) ((dbg & (BIT)) != 0)
+#define CFFT_GROUP_STAMP(I)                                                                \
+    if (stamping && tid == 0 && k >= 100u && k < 108u)                                     \
+        st->stamps[k - 100u][I] = __builtin_amdgcn_s_memtime();
+#else
+#define CFFT_GROUP_DBG(BIT) false
+#define CFFT_GROUP_STAMP(I)
+#endif
 
 namespace cfft
 {
@@ -51,6 +72,11 @@ struct GroupState
     } xcc[kGroupMaxXcc];
     // [xcc][group][member]: number of frames whose pass-A tile the member has stored (one 64-byte poll per group)
     unsigned aflag[kGroupMaxXcc][kGroupMaxPerXcc][32];
+    // ... and whose pass-B tile it has loaded (lines of their own: they are written at another time than the aflags)
+    unsigned bflag[kGroupMaxXcc][kGroupMaxPerXcc][32];
+#if CFFT_GROUP_EXPERIMENT
+    unsigned long long stamps[8][16]; // s_memtime at the phase boundaries of eight iterations of group 0's member 0 (dbg & 32)
+#endif
 };
 
 __device__ __forceinline__ void group_fail (GroupState* st, unsigned* host_err, unsigned seq, unsigned code)
@@ -106,7 +132,8 @@ __global__ __launch_bounds__ (256, 2) void group256_kernel (const float2* __rest
                                                         size_t out_stride,
                                                         unsigned seq,
                                                         unsigned reg_polls,
-                                                        unsigned force_solo)
+                                                        unsigned force_solo,
+                                                        unsigned form) // bit 0: two slots per group; bit 1: early prefetch; bit 2: ... wave 0's share late
 {
     extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
     __shared__ unsigned info[8];
@@ -118,6 +145,12 @@ __global__ __launch_bounds__ (256, 2) void group256_kernel (const float2* __rest
     const int i1 = tid & 15, c1 = tid >> 4;
     // pass B roles: lanes run along the tile's 16 rows in both stages
     const int kbl = tid & 15, tb = tid >> 4;
+    const unsigned two_slots = form & 1u;
+    const bool early = (form & 2u) != 0, w0late = (form & 4u) != 0;
+#if CFFT_GROUP_EXPERIMENT
+    const unsigned dbg = force_solo >> 8;
+    force_solo &= 255u;
+#endif
 
     if (tid < 240)
         tw1[tid] = stage_tw[Plan256::tw_offset (1) + tid];
@@ -178,6 +211,7 @@ __global__ __launch_bounds__ (256, 2) void group256_kernel (const float2* __rest
         const unsigned g = r / kGroupMembers, tile = r % kGroupMembers;
         float2* __restrict__ slots = work + (size_t) ((xcc * kGroupMaxPerXcc + g) * 2u) * N;
         unsigned* __restrict__ af = &st->aflag[xcc][g][0];
+        unsigned* __restrict__ bf = &st->bflag[xcc][g][0];
         const size_t base_a = (size_t) (tile * 16) * 256 + c1 * 16 + i1; // this work-item's 16 pass-A outputs: base_a + 256 b
         float2 bw[16];
 #pragma unroll
@@ -188,23 +222,66 @@ __global__ __launch_bounds__ (256, 2) void group256_kernel (const float2* __rest
         unsigned f = gg;
         if (f < batch)
             g256_load_a<INV> (nre, nim, in + (size_t) f * in_stride + tile * 16, t0, c0);
+#if CFFT_GROUP_EXPERIMENT
+        const bool stamping = (dbg & 32u) != 0 && gg == 0 && tile == 0;
+#endif
         for (unsigned k = 0; f < batch; f += total, ++k)
         {
             float2 v[16];
+            CFFT_GROUP_STAMP (0)
+#if CFFT_GROUP_EXPERIMENT
+            if (dbg & 32u)
+                asm volatile ("s_waitcnt vmcnt(16)" ::: "memory"); // the operands are here (the previous frame's stores may be out)
+#endif
+            CFFT_GROUP_STAMP (1)
 #pragma unroll
             for (int s = 0; s < 16; ++s)
                 v[s] = make_float2 (nre[s], nim[s]);
             // ---- pass A: columns [16 tile, 16 tile + 16) of frame f
             fft256_two_stage_lds (v, tw1, i1, smem, c0, t0, c1, i1);
-            float2* __restrict__ slot = slots + (size_t) (k & 1u) * N;
+            float2* __restrict__ slot = slots + (size_t) (two_slots != 0 ? (k & 1u) : 0u) * N;
+            CFFT_GROUP_STAMP (2)
+            if (two_slots == 0 && k != 0 && ! CFFT_GROUP_DBG (1u))
+            {
+                // every member has read frame k - 1 out of the slot (each wave looks for itself: no barrier needed)
+                unsigned n = 0;
+                while (! flags_reached (bf, k, tid & 63))
+                {
+                    __builtin_amdgcn_s_sleep (1);
+                    if (++n > kFusedSpinLimit)
+                    {
+                        if ((tid & 63) == 0)
+                            group_fail (st, host_err, seq, 2u);
+                        break;
+                    }
+                }
+            }
+            if (! CFFT_GROUP_DBG (2u))
+            {
 #pragma unroll
-            for (int b = 0; b < 16; ++b)
-                slot[base_a + b * 256] = cmul (v[b], bw[b]); // plain store: stays in this XCD's L2
-            asm volatile ("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's stores are in L2
+                for (int b = 0; b < 16; ++b)
+                    slot[base_a + b * 256] = cmul (v[b], bw[b]); // plain store: stays in this XCD's L2
+            }
+            CFFT_GROUP_STAMP (3)
+            // The next frame's pass-A operands.  `early`: requested HERE, in front of the hand-off: the wait for the rest of the
+            // group then has this workgroup's share of the input stream in flight (vector memory operations retire in issue
+            // order, so wave 0's flag poll returns behind its own prefetch -- with `w0late` wave 0 therefore asks for its share
+            // behind the pass-B loads instead).  Otherwise: behind the pass-B loads.
+            const unsigned fn = f + total;
+            const bool pre_here = early && fn < batch && ! CFFT_GROUP_DBG (8u) && ! (w0late && tid < 64);
+            if (pre_here)
+            {
+                g256_load_a<INV> (nre, nim, in + (size_t) fn * in_stride + tile * 16, t0, c0);
+                asm volatile ("s_waitcnt vmcnt(16)" ::: "memory"); // all but the 16 prefetch loads: this wave's stores are in L2
+            }
+            else
+                asm volatile ("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's stores are in L2
+            CFFT_GROUP_STAMP (4)
             __syncthreads();
             if (tid == 0)
                 flag_store (&af[tile], k + 1u);
-            if (tid < 64)
+            CFFT_GROUP_STAMP (5)
+            if (tid < 64 && ! CFFT_GROUP_DBG (1u))
             {
                 unsigned n = 0;
                 while (! flags_reached (af, k + 1u, tid))
@@ -218,22 +295,60 @@ __global__ __launch_bounds__ (256, 2) void group256_kernel (const float2* __rest
                     }
                 }
             }
+            CFFT_GROUP_STAMP (6)
             __syncthreads();
+            CFFT_GROUP_STAMP (7)
             // ---- pass B: rows [16 tile, 16 tile + 16) of the slot -> transposed store into frame f
             const float2* __restrict__ srcb = slot + tile * 256 + tid;
+            if (! CFFT_GROUP_DBG (4u))
+            {
 #pragma unroll
-            for (int s = 0; s < 16; ++s)
-                v[s] = gload_l2 (&srcb[s * 16 * 256]); // block (a_hi = s, kb_hi = tile), element tid
-            // the next frame's pass-A operands, behind the pass-B loads and ahead of everything else of this frame
-            const unsigned fn = f + total;
-            if (fn < batch)
+                for (int s = 0; s < 16; ++s)
+                    v[s] = gload_l2 (&srcb[s * 16 * 256]); // block (a_hi = s, kb_hi = tile), element tid
+            }
+            // ... behind the pass-B loads and ahead of everything else of this frame
+            const bool pre_late = fn < batch && ! CFFT_GROUP_DBG (8u) && ! pre_here;
+            if (pre_late)
                 g256_load_a<INV> (nre, nim, in + (size_t) fn * in_stride + tile * 16, t0, c0);
             CFFT_PHASE_FENCE();
-            fft256_two_stage_lds (v, tw1, tb, smem, kbl, tb, kbl, tb);
-            float2* __restrict__ dst = out + (size_t) f * out_stride + tile * 16 + kbl;
+            CFFT_GROUP_STAMP (8)
+#if CFFT_GROUP_EXPERIMENT
+            if (dbg & 32u)
+            {
+                if (pre_late)
+                    asm volatile ("s_waitcnt vmcnt(16)" ::: "memory"); // the pass-B operands are here (the prefetch may be out)
+                else
+                    asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+#endif
+            CFFT_GROUP_STAMP (9)
+            // fft256_two_stage_lds, opened up for the flag
+            fft_reg<16> (v);
+            __syncthreads(); // the previous exchange's reads are finished; every wave's pass-B loads have returned
+            if (tid == 0 && two_slots == 0)
+                flag_store (&bf[tile], k + 1u);
 #pragma unroll
             for (int b = 0; b < 16; ++b)
-                gstore (&dst[(unsigned) (tb + 16 * b) * 256u], INV ? make_float2 (v[b].y, v[b].x) : v[b]);
+                smem[kbl * kFS256 + 17 * tb + b] = v[b];
+            __syncthreads();
+#pragma unroll
+            for (int a = 0; a < 16; ++a)
+                v[a] = smem[kbl * kFS256 + tb + 17 * a];
+#pragma unroll
+            for (int a = 1; a < 16; ++a)
+                v[a] = cmul (v[a], tw1[(a - 1) * 16 + tb]);
+            fft_reg<16> (v);
+            CFFT_GROUP_STAMP (10)
+            float2* __restrict__ dst = out + (size_t) f * out_stride + tile * 16 + kbl;
+            if (! CFFT_GROUP_DBG (16u))
+            {
+#pragma unroll
+                for (int b = 0; b < 16; ++b)
+                    gstore (&dst[(unsigned) (tb + 16 * b) * 256u], INV ? make_float2 (v[b].y, v[b].x) : v[b]);
+            }
+            else if (v[0].x == 12345.678f) // keeps the arithmetic alive
+                gstore (&dst[0], v[1]);
+            CFFT_GROUP_STAMP (11)
         }
         return;
     }

@@ -411,12 +411,14 @@ hipError_t launch_fused_c2c (int n1, int n2, bool inverse, const float2* in, flo
 // ---- the same, by static groups of workgroups per XCD (group_twopass_kernels.hpp) ---------------------------------------
 namespace
 {
-int group_wg_per_cu()
+// workgroups per CU in tenths (CHOWDSP_FFT_GROUP_WG_PER_CU, e.g. 2 or 2.5): 16 of them per XCD are one group, and every group
+// needs 512 KiB of that XCD's L2 for its slot
+int group_wg_per_cu_x10()
 {
     static const int v = [] {
         const char* e = std::getenv ("CHOWDSP_FFT_GROUP_WG_PER_CU");
-        const int n = e != nullptr ? std::atoi (e) : 2;
-        return (n >= 1 && n <= 4) ? n : 2;
+        const int n = e != nullptr ? (int) (std::atof (e) * 10.0 + 0.5) : 20;
+        return (n >= 5 && n <= 40) ? n : 20;
     }();
     return v;
 }
@@ -430,8 +432,8 @@ unsigned group_grid (bool inverse)
     DeviceInfo dev;
     if (! current_device_info (dev))
         return 0;
-    const int per_cu = std::min (group_wg_per_cu(), blocks_per_cu_cached ((const void*) k, 256, kGroupLds));
-    return (unsigned) (dev.num_cus * std::max (per_cu, 0));
+    const int per_cu_x10 = std::min (group_wg_per_cu_x10(), 10 * blocks_per_cu_cached ((const void*) k, 256, kGroupLds));
+    return (unsigned) (dev.num_cus * std::max (per_cu_x10, 0) / 10);
 }
 } // namespace
 void set_group_options (int force_solo, int reg_polls)
@@ -464,8 +466,22 @@ hipError_t launch_group_c2c (int n1, int n2, bool inverse, const float2* in, flo
     const unsigned grid = group_grid (inverse);
     if (grid == 0)
         return hipErrorNoDevice;
-    const unsigned force_solo = (unsigned) g_group_force_solo.load(), reg_polls = (unsigned) g_group_reg_polls.load();
-    hipLaunchKernelGGL (k, dim3 (grid), dim3 (256), kGroupLds, stream, in, work, out, stage_tw, big_tw, (GroupState*) state, host_err, (unsigned) batch, in_stride, out_stride, seq, reg_polls, force_solo);
+    // A/B switch: two slots per group used alternately (no second flag, twice the L2 footprint) instead of one
+    // ... and where the next frame's operands are requested (group_twopass_kernels.hpp): CHOWDSP_FFT_GROUP_PREFETCH = 0 behind the
+    // pass-B loads, 1 in front of the hand-off, 2 the same with wave 0's share behind the pass-B loads
+    static const unsigned two_slots = [] {
+        unsigned f = (std::getenv ("CHOWDSP_FFT_GROUP_SLOTS") != nullptr && std::atoi (std::getenv ("CHOWDSP_FFT_GROUP_SLOTS")) == 2) ? 1u : 0u;
+        const int pf = std::getenv ("CHOWDSP_FFT_GROUP_PREFETCH") != nullptr ? std::atoi (std::getenv ("CHOWDSP_FFT_GROUP_PREFETCH")) : 0;
+        f |= pf == 1 ? 2u : (pf == 2 ? 6u : 0u);
+        return f;
+    }();
+    unsigned force_solo = (unsigned) g_group_force_solo.load();
+    const unsigned reg_polls = (unsigned) g_group_reg_polls.load();
+#if CFFT_GROUP_EXPERIMENT
+    static const unsigned dbg = std::getenv ("CHOWDSP_FFT_GROUP_DBG") != nullptr ? (unsigned) std::atoi (std::getenv ("CHOWDSP_FFT_GROUP_DBG")) : 0u;
+    force_solo |= dbg << 8;
+#endif
+    hipLaunchKernelGGL (k, dim3 (grid), dim3 (256), kGroupLds, stream, in, work, out, stage_tw, big_tw, (GroupState*) state, host_err, (unsigned) batch, in_stride, out_stride, seq, reg_polls, force_solo, two_slots);
     e = hipGetLastError();
     static const bool debug = std::getenv ("CHOWDSP_FFT_FUSED_DEBUG") != nullptr;
     if (debug && e == hipSuccess)
@@ -478,6 +494,22 @@ hipError_t launch_group_c2c (int n1, int n2, bool inverse, const float2* in, flo
                 if (h.xcc[x].count != 0)
                     fprintf (stderr, " xcc%d=%u", x, h.xcc[x].count);
             fprintf (stderr, "\n");
+#if CFFT_GROUP_EXPERIMENT
+            // phase boundaries of eight iterations of group 0's member 0, in shader cycles since the iteration's start:
+            // 1 operands here, 2 pass A done, 3 slot stores issued, 4 ... acknowledged, 5 flag stored, 6 group complete (wave 0),
+            // 7 barrier, 8 pass-B loads + prefetch issued, 9 pass-B operands here, 10 pass B done, 11 output stores issued
+            for (int it = 0; it < 8; ++it)
+            {
+                if (h.stamps[it][0] == 0)
+                    continue;
+                fprintf (stderr, "[group] stamps it %d:", it);
+                for (int i = 1; i < 12; ++i)
+                    fprintf (stderr, " %lld", (long long) (h.stamps[it][i] - h.stamps[it][0]));
+                if (it > 0)
+                    fprintf (stderr, "   (iteration %lld)", (long long) (h.stamps[it][0] - h.stamps[it - 1][0]));
+                fprintf (stderr, "\n");
+            }
+#endif
         }
     }
     return e;

@@ -146,6 +146,26 @@ int fft_gather_multi_gpu (const float* const* shard_ptrs, const int* shard_devic
     int rc = FFT_GPU_OK;
     std::vector<hipStream_t> used;
     std::vector<int> used_dev;
+    // The copies run on the library's own streams, which know nothing of the streams that produced the shards or last used
+    // the destinations: wait for every device involved first (whatever the caller enqueued there -- fft_transform_batch on
+    // a stream of theirs, a fill of the destination -- is complete before the first byte moves).
+    for (int pass = 0; pass < 2; ++pass)
+    {
+        const int count = pass == 0 ? shards : ndst;
+        for (int i = 0; i < count; ++i)
+        {
+            if (pass == 0 ? shard_floats[i] == 0 : dst_ptrs[i] == nullptr)
+                continue;
+            const int dev = pass == 0 ? shard_devices[i] : dst_devices[i];
+            if (hipSetDevice (dev) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+            {
+                set_last_error ("fft_gather_multi_gpu: could not synchronise a source / destination device");
+                if (prev >= 0)
+                    (void) hipSetDevice (prev);
+                return FFT_GPU_ENODEV;
+            }
+        }
+    }
     // every (source, destination) pair gets its own stream on the source device: all copies are in flight together
     for (int s = 0; s < shards && rc == FFT_GPU_OK; ++s)
     {

@@ -64,3 +64,58 @@ def gather_frames(local, total_frames: int):
     if all(c == width for c in counts):
         return out
     return torch.cat([out[r * width:r * width + counts[r]] for r in range(world)], dim=0)
+
+
+def describe_ranks(description: str):
+    """Every rank's own description (device name, XCC count ...), in rank order, on every rank: the record of WHICH
+    devices the process group really spans."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [description]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, description)
+    return [str(d) for d in out]
+
+
+def timed_gather(local, total_frames: int, device=None, synchronize=None) -> dict:
+    """The one collective the north star names -- the final collection of the result shards (all-gather) -- timed on its
+    own, bracketed by barriers, MAX over ranks.  `synchronize`: waits for the device (torch.cuda.synchronize on GPUs,
+    nothing on CPU tensors).  Never part of the throughput `value`."""
+    import time
+
+    import torch.distributed as dist
+
+    sync = synchronize or (lambda: None)
+    world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    sync()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    full = gather_frames(local, total_frames)
+    sync()
+    if world > 1:
+        dist.barrier()
+    seconds = max_over_ranks(time.perf_counter() - t0, device=device)
+    nbytes = int(full.numel()) * int(full.element_size())
+    received = nbytes * (world - 1) // world
+    ok = int(full.shape[0]) == int(total_frames)
+    del full
+    return {"collective": "all_gather_into_tensor", "seconds": seconds, "bytes_gathered": nbytes,
+            "bytes_received_per_gpu": received, "GB_s_per_gpu": (received / seconds / 1e9) if seconds > 0 else None,
+            "frames_gathered": int(total_frames), "shape_ok": ok}
+
+
+def multi_gpu_fields(world: int, rank_descriptions, headline_gather, extra_lines=None) -> dict:
+    """What an N > 1 bench line carries besides the N = 1 fields (bench.py; driven by tests/test_sharding_gloo.py with
+    CPU tensors): how many ranks the process group has, which devices they are, the gather of the headline results
+    (`gather_xgmi`) and, under `multi_gpu`, the other sharded configurations with a gather of their own."""
+    import torch.distributed as dist
+
+    seen = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    fields = {"ranks_seen": int(seen), "ranks_expected": int(world), "rank_devices": list(rank_descriptions)}
+    if headline_gather is not None:
+        fields["gather_xgmi"] = headline_gather
+    if extra_lines:
+        fields["multi_gpu"] = extra_lines
+    return fields

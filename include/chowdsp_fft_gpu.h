@@ -62,12 +62,21 @@ const char* fft_gpu_last_error (void);
 int fft_gpu_release_stream_resources (void* stream);
 
 /* Run-time options (process-wide; initial values come from the environment variables named in INTEGRATION.md):
-     "fused_two_pass"   1 / 0 (default 0): run two-pass sizes that have a one-launch form (N = 65536 complex) in one
-                        launch with the inter-pass hand-off inside an XCD's L2 (1.5-1.6 x the algorithmic bytes on the
-                        fabric instead of 2 x, at 1-5 % more time), or as two launches per chunk
-     "fused_min_batch"  smallest batch that takes the one-launch form (default 2048)
-     "fused_lag", "fused_slots"   queue depth of the one-launch form (steps between a frame's two passes; workspace
+     "fused_two_pass"   which form runs two-pass sizes that have a one-launch form (N = 65536 complex), batches of at
+                        least "fused_min_batch" frames:  2 (default) one launch, static groups of 16 workgroups per XCD, the
+                        inter-pass hand-off inside that XCD's L2 (1.4 x the algorithmic bytes on the fabric);  1 one launch,
+                        per-XCD ticket queues (1.5-1.6 x, slower);  0 two launches per chunk (2 x).
+                        A one-launch transform whose bounded hand-off waits ran out (never observed) has written invalid
+                        output: that is reported, with the launch's number on its stream, by the next one-launch call on
+                        the stream and by fft_gpu_stream_synchronize / fft_gpu_release_stream_resources -- results of these
+                        forms are validated by a LIBRARY synchronise, not by hipStreamSynchronize alone.
+     "fused_min_batch"  smallest batch that takes a one-launch form (default 256)
+     "fused_lag", "fused_slots"   queue depth of the ticket form (steps between a frame's two passes; workspace
                         frames per XCD, > lag)
+     "group_force_solo" 1: the group form runs its fall-back mode (every workgroup transforms whole frames alone; what a
+                        launch does by itself when its grid is not completely resident); for tests, default 0
+     "group_reg_polls"  how many polls (about a microsecond each) a workgroup of the group form waits for the grid to be
+                        complete before the launch falls back (default 200)
      "wave4096"         1: N = 4096 complex transforms run one wavefront per frame (two radix-64 stages in registers, one
                         wave-private exchange) instead of one 256-work-item workgroup per frame; same rate, default 0
      "split16384"       0: N = 16384 complex / real N = 32768 through the round-1 plan instead of the split-plane kernels
@@ -166,7 +175,9 @@ int fft_transform_batch_multi_gpu (void* const* setups, int shards, const float*
 /* Collect result shards: shard s (shard_floats[s] floats on device shard_devices[s]) is copied behind the shards before
    it into EVERY non-NULL destination dst_ptrs[d] (a buffer of sum(shard_floats) floats on device dst_devices[d]) --
    an all-gather when every device is a destination, a gather-to-root when one is.  Each (source, destination) pair is
-   one direct peer copy on its own stream, all pairs in flight together.  Synchronous. */
+   one direct peer copy on its own stream, all pairs in flight together.  Synchronous on both sides: the call first
+   waits for every source and destination DEVICE (so shards produced by fft_transform_batch on a stream of the caller's, or a
+   destination the caller has just filled, are safe), and every copy is complete on return. */
 int fft_gather_multi_gpu (const float* const* shard_ptrs, const int* shard_devices, const size_t* shard_floats, int shards, float* const* dst_ptrs, const int* dst_devices, int ndst);
 
 /* ---- host-memory streaming mode ------------------------------------------------

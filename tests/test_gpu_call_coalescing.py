@@ -72,3 +72,36 @@ def test_dependent_calls_keep_their_order(gpu, oracle):
         api.aligned_free(p)
     api.fft_destroy_setup(s)
     oracle.destroy_setup(so)
+
+
+def test_plan_destroyed_before_the_flush(gpu, oracle):
+    """The reference caller's new_setup -> fft_transform -> fft_destroy_setup (test/test.cpp:30-67) inside a deferred region:
+    recorded calls hold their (immutable) plan by value, so they still run correctly after the handle has been destroyed --
+    or, for a pre-allocated plan, after the caller has overwritten and freed the memory its header lived in."""
+    api = gpu[0]
+    n = 2048
+    so = oracle.new_setup(n, COMPLEX)
+    x, xp = api.aligned_array(2 * n)
+    y, yp = api.aligned_array(2 * n)
+    x2, x2p = api.aligned_array(2 * n)
+    y2, y2p = api.aligned_array(2 * n)
+    x[:], x2[:] = ol.uniform(2 * n, 5), ol.uniform(2 * n, 6)
+    y[:], y2[:] = -1.0, -1.0
+    api.defer_begin()
+    s = api.fft_new_setup(n, api.FFT_COMPLEX)
+    api.fft_transform(s, x, y, None, api.FFT_FORWARD)
+    api.fft_destroy_setup(s)  # before the flush
+    nbytes = api.fft_bytes_required(n, api.FFT_COMPLEX)
+    block, blockp = api.aligned_array((nbytes + 3) // 4)
+    sp = api.fft_new_setup_preallocated(n, api.FFT_COMPLEX, blockp)
+    assert sp is not None
+    api.fft_transform(sp, x2, y2, None, api.FFT_BACKWARD)
+    block[:] = 12345.0  # the caller owns that memory (chowdsp_fft.h:98-118) and is done with the plan
+    api.aligned_free(blockp)
+    assert np.all(y == -1.0) and np.all(y2 == -1.0), "recorded calls have not run yet"
+    api.defer_flush()
+    assert_frames_close(y, oracle.transform(so, x, FORWARD), what="call recorded on a plan destroyed before the flush")
+    assert_frames_close(y2, oracle.transform(so, x2, BACKWARD), what="call recorded on a pre-allocated plan freed before the flush")
+    for p in (xp, yp, x2p, y2p):
+        api.aligned_free(p)
+    oracle.destroy_setup(so)

@@ -27,12 +27,12 @@ def _form_now(api):
 @pytest.fixture(params=["tickets", "groups", "groups-solo"])
 def fused_on(gpu, request):
     api = gpu[0]
-    default = _form_now(api)
+    default, default_min = _form_now(api), int(api.get_option("fused_min_batch"))
     api.set_option("fused_two_pass", FORM[request.param.split("-")[0]])
     api.set_option("group_force_solo", 1 if request.param.endswith("solo") else 0)
     api.set_option("fused_min_batch", 1)
     yield api
-    api.set_option("fused_min_batch", 2048)
+    api.set_option("fused_min_batch", default_min)
     api.set_option("fused_lag", 4)
     api.set_option("group_force_solo", 0)
     api.set_option("fused_two_pass", default)

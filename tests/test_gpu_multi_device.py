@@ -75,6 +75,45 @@ def test_sharded_transform_and_gather(gpu, oracle, n, tr, total, shards):
 
 
 @pytest.mark.gpu
+def test_two_real_devices_peer_gather(gpu, oracle):
+    """Needs TWO devices (skipped on a one-GPU lease, where the test above folds every shard onto device 0): shards produced
+    on two different devices by fft_transform_batch on streams of the CALLER's (no synchronisation before the gather: the
+    gather waits for the devices itself), collected by one-hop peer copies in both directions."""
+    api, torch, dev0 = gpu
+    from chowdsp_fft_amd import _lib
+
+    if api.device_count() < 2:
+        pytest.skip("one device: hipMemcpyPeerAsync between two real devices cannot run")
+    n, total = 4096, 64
+    x = ol.uniform(total * 2 * n, 77).reshape(total, 2 * n)
+    so = oracle.new_setup(n, COMPLEX)
+    want = oracle.transform_batch(so, x, FORWARD)
+    setups, outs, streams = [], [], []
+    for r in range(2):
+        first, count = api.shard_range(total, 2, r)
+        assert _lib.lib().fft_gpu_set_device(r) == 0
+        s = api.fft_new_setup(n, api.FFT_COMPLEX)
+        assert _lib.lib().fft_gpu_setup_device(s) == r
+        d = torch.device("cuda", r)
+        xin = torch.from_numpy(x[first:first + count].copy()).to(d)
+        y = torch.empty_like(xin)
+        st = torch.cuda.Stream(device=d)
+        torch.cuda.synchronize(r)
+        api.fft_transform_batch(s, xin, y, api.FFT_FORWARD, stream=st)  # NOT synchronised: the gather must wait for it
+        setups.append(s)
+        outs.append(y)
+        streams.append(st)
+    assert _lib.lib().fft_gpu_set_device(0) == 0
+    dsts = [torch.full((total, 2 * n), -3.0, device=torch.device("cuda", d)) for d in range(2)]
+    api.fft_gather_multi_gpu(outs, [0, 1], dsts, [0, 1])
+    for d in range(2):
+        assert_frames_close(dsts[d].cpu().numpy(), want, what=f"all-gather on real device {d}")
+    for s in setups:
+        api.fft_destroy_setup(s)
+    oracle.destroy_setup(so)
+
+
+@pytest.mark.gpu
 def test_release_stream_resources(gpu):
     api, torch, dev = gpu
     s = api.fft_new_setup(1 << 17, api.FFT_COMPLEX)  # two-pass: caches lanes + workspaces for the stream

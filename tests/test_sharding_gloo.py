@@ -19,7 +19,8 @@ for p in (ROOT, HERE):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-from chowdsp_fft_amd.sharding import gather_frames, max_over_ranks, shard_range, sum_over_ranks  # noqa: E402
+from chowdsp_fft_amd.sharding import (describe_ranks, gather_frames, max_over_ranks, multi_gpu_fields, shard_range,  # noqa: E402
+                                      sum_over_ranks, timed_gather)
 
 
 def test_shard_range_covers_batch_exactly_once():
@@ -62,6 +63,25 @@ def _worker(rank, world, port, total_frames, n, result_dir):
         want = oracle.transform_batch(s, full, ol.FORWARD)
         assert gathered.shape == want.shape
         assert np.array_equal(gathered, want)
+        # the N > 1 branch of bench.py, same functions, CPU tensors: the timed gather (on by default there), the record of
+        # which devices the process group spans, and the fields the JSON line gains
+        info = timed_gather(torch.from_numpy(local), total_frames)
+        assert info["collective"] == "all_gather_into_tensor" and info["shape_ok"] and info["seconds"] > 0
+        assert info["frames_gathered"] == total_frames
+        assert info["bytes_gathered"] == total_frames * 2 * n * 4
+        assert info["bytes_received_per_gpu"] == info["bytes_gathered"] * (world - 1) // world
+        ranks = describe_ranks(f"rank {rank}: cpu pid {os.getpid()}")
+        assert len(ranks) == world and all(ranks[r].startswith(f"rank {r}:") for r in range(world))
+        assert len({d.split("pid")[1] for d in ranks}) == world  # really `world` different processes
+        conv = {"conv_real_n4096_b131072": {"value": 1.0, "gather_xgmi": info}}
+        fields = multi_gpu_fields(world, ranks, info, conv)
+        assert fields["ranks_seen"] == world == fields["ranks_expected"]
+        assert fields["rank_devices"] == ranks
+        assert fields["gather_xgmi"]["GB_s_per_gpu"] > 0
+        assert fields["multi_gpu"]["conv_real_n4096_b131072"]["gather_xgmi"]["frames_gathered"] == total_frames
+        import json
+
+        json.dumps(fields)  # what bench.py prints must serialise
         oracle.destroy_setup(s)
         open(os.path.join(result_dir, f"ok{rank}"), "w").close()
     finally:
