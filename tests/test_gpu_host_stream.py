@@ -1,7 +1,8 @@
-"""fft_transform_host_batch -- frames in HOST memory, pinned in place, pipelined over two
-streams.  Must equal `batch` single-frame legacy calls, i.e. the oracle, frame for frame (1e-6), for batches that
-span several pipeline chunks, ragged batch counts, in-place buffers and every execution path (LDS-resident,
-two-pass, generic)."""
+"""fft_transform_host_batch -- frames in HOST memory, pipelined over two streams; large buffers
+pinned in place (only the pages that lie entirely inside them; partial head / tail pages through bounce pages), small
+ones through the library's pinned staging ring.  Must equal `batch` single-frame legacy calls, i.e. the oracle, frame
+for frame (1e-6), for batches that span several pipeline chunks, ragged batch counts, in-place buffers, unaligned views
+into larger arrays, and every execution path (LDS-resident, two-pass, generic)."""
 import numpy as np
 import pytest
 
@@ -53,3 +54,60 @@ def test_host_batch_with_library_pinned_memory(gpu, oracle):
     oracle.destroy_setup(so)
     _lib.lib().fft_gpu_host_free(p_in)
     _lib.lib().fft_gpu_host_free(p_out)
+
+
+@pytest.mark.parametrize("inplace", [False, True])
+def test_unaligned_view_of_a_larger_array(gpu, oracle, inplace):
+    """A 64 MiB+ slice starting 20 bytes into a larger array (the caller pattern `ptr + offset`): its first and last page
+    are shared with the rest of the parent, so only the pages inside the slice may be pinned; the bytes around the slice
+    must come back untouched."""
+    api = gpu[0]
+    n, batch = 4096, 2100  # 2100 x 32 KiB = 65.6 MiB
+    nf = 2 * n
+    guard = 4099  # floats before and after, not a multiple of a page
+    parent_in = np.full(batch * nf + 2 * guard, 7.0, np.float32)
+    parent_out = parent_in if inplace else np.full(batch * nf + 2 * guard, -9.0, np.float32)
+    x = parent_in[5:5 + batch * nf].reshape(batch, nf)
+    assert x.ctypes.data % 4096 != 0 and (x.ctypes.data - parent_in.ctypes.data) == 20
+    x[:] = ol.uniform(batch * nf, 321).reshape(batch, nf)
+    x0 = x.copy()
+    y = parent_out[5:5 + batch * nf].reshape(batch, nf)
+    s, so = api.fft_new_setup(n, api.FFT_COMPLEX), oracle.new_setup(n, COMPLEX)
+    api.fft_transform_host_batch(s, x, y, api.FFT_FORWARD)
+    idx = np.array([0, 1, 2, 1023, 1024, 1025, 2047, 2048, batch - 2, batch - 1])  # chunk edges, first and last page
+    assert_frames_close(y[idx], oracle.transform_batch(so, x0[idx], FORWARD), what="unaligned view")
+    fill_in, fill_out = 7.0, (7.0 if inplace else -9.0)
+    assert np.all(parent_in[:5] == fill_in) and np.all(parent_in[5 + batch * nf:] == fill_in)
+    assert np.all(parent_out[:5] == fill_out) and np.all(parent_out[5 + batch * nf:] == fill_out), "bytes outside the view were written"
+    if not inplace:
+        assert np.array_equal(x, x0), "the input view was modified"
+    api.fft_destroy_setup(s)
+    oracle.destroy_setup(so)
+
+
+def test_small_heap_blocks_next_to_pageable_copies(gpu, oracle):
+    """The sequence that faulted in round 2 (session r02j): small heap blocks -- which share their first and last page with
+    other heap objects -- streamed through the library while the runtime makes pageable copies from and to NEIGHBOURING
+    objects of the same pages, and the addresses are recycled.  Small buffers go through the staging ring now (nothing of
+    the caller's is pinned), so neighbouring pageable copies must stay valid."""
+    api, torch, dev = gpu
+    for rounds in range(3):
+        for n, batch in ((64, 7), (480, 333), (1024, 200), (4096, 23), (4096, 250)):
+            nf = 2 * n
+            s, so = api.fft_new_setup(n, api.FFT_COMPLEX), oracle.new_setup(n, COMPLEX)
+            left = np.random.rand(1000 + 37 * rounds).astype(np.float32)   # heap neighbours
+            x = ol.uniform(batch * nf, 11 * rounds + n).reshape(batch, nf)
+            right = np.random.rand(777).astype(np.float32)
+            y = np.empty_like(x)
+            dl = torch.from_numpy(left).to(dev)       # pageable H2D from a neighbour before ...
+            api.fft_transform_host_batch(s, x, y, api.FFT_FORWARD)
+            dr = torch.from_numpy(right).to(dev)      # ... and after
+            dx = torch.from_numpy(x).to(dev)          # and from the very addresses the call just used
+            torch.cuda.synchronize()
+            assert np.array_equal(dl.cpu().numpy(), left) and np.array_equal(dr.cpu().numpy(), right)
+            assert np.array_equal(dx.cpu().numpy(), x)
+            pick = np.array([0, batch // 2, batch - 1])
+            assert_frames_close(y[pick], oracle.transform_batch(so, x[pick], FORWARD), what="small heap block")
+            api.fft_destroy_setup(s)
+            oracle.destroy_setup(so)
+            del x, y, left, right, dl, dr, dx  # freed: the next round's arrays reuse the addresses
