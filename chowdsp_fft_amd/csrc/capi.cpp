@@ -285,6 +285,8 @@ std::atomic<int> g_conv_wave2048 { 0 };
 // "fused_conv_split": fft_convolve_frames_batch on the split-plane sizes (8192 / 16384 / 32768 complex points, real N = 16384 / 32768 / 65536)
 // as ONE launch (default) or as the three-launch composition (0), for A/B timing
 std::atomic<int> g_fused_conv_split { 1 };
+// "fused_conv_generic": the same switch for mixed-radix frames (one launch, generic_conv_kernels.hpp) -- A/B against the composition
+std::atomic<int> g_fused_conv_generic { 1 };
 bool split16384_enabled()
 {
     int v = g_split16384.load();
@@ -1330,6 +1332,8 @@ int fft_gpu_set_option (const char* name, long value)
         g_conv_wave2048 = value != 0 ? 1 : 0;
     else if (std::strcmp (name, "fused_conv_split") == 0)
         g_fused_conv_split = value != 0 ? 1 : 0;
+    else if (std::strcmp (name, "fused_conv_generic") == 0)
+        g_fused_conv_generic = value != 0 ? 1 : 0;
     else
     {
         set_last_error ("fft_gpu_set_option: unknown option or value out of range");
@@ -1359,6 +1363,8 @@ long fft_gpu_get_option (const char* name)
         return g_conv_wave2048.load();
     if (std::strcmp (name, "fused_conv_split") == 0)
         return g_fused_conv_split.load();
+    if (std::strcmp (name, "fused_conv_generic") == 0)
+        return g_fused_conv_generic.load();
     return -1;
 }
 
@@ -1534,6 +1540,19 @@ int fft_convolve_frames_batch (void* setup, const float* x, const float* dft_fil
             return FFT_GPU_ELAUNCH;
         }
         return FFT_GPU_OK;
+    }
+    if (t->gen_ns > 0 && t->mixed_n2 == 0 && g_fused_conv_generic.load() != 0)
+    {
+        // mixed-radix frame that stays on chip (up to 20000 complex points): forward, product and backward in one launch
+        const hipError_t eg = launch_generic_conv (s->transform == FFT_REAL, nc, *t, (const float2*) x, (const float2*) dft_filter, (float2*) y, scaling, batch, (hipStream_t) stream);
+        if (eg == hipSuccess)
+            return FFT_GPU_OK;
+        if (eg != hipErrorNotSupported)
+        {
+            set_last_error ("fused convolution kernel launch (mixed radix)", eg);
+            return FFT_GPU_ELAUNCH;
+        }
+        (void) hipGetLastError(); // no one-launch form for this plan: the composition below
     }
     if (t->core_n != nc || nc > cfft::kMaxFusedN)
     {

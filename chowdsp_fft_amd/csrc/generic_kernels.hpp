@@ -203,10 +203,13 @@ __device__ __forceinline__ int fast_div (int x, unsigned magic) { return (int) _
 // IO 2: LDS -> global memory: the last stage stores y[j + b*p] straight to the result (lane-contiguous in k).
 // IO 3: global -> global (single-stage plans).
 // STATIC: n and p are compile-time constants at the call (static_core below): everything derived from them folds.
-template <int R, int BLOCK, int IO, bool SWAP, bool STATIC = false>
+// CONV (fused convolution, generic_conv_kernels.hpp): this is the forward transform's last stage and it writes the LDS image;
+// every output is multiplied by H[its index] * scaling and stored re <-> im swapped, ready for the backward transform.
+template <int R, int BLOCK, int IO, bool SWAP, bool STATIC = false, bool CONV = false>
 __device__ __forceinline__ void generic_stage (const float2* __restrict__ src, float2* __restrict__ dst,
                                                const float2* __restrict__ tw, int n, int p, int nframes, int tid,
-                                               unsigned gs_in, unsigned gs_out, unsigned lfs)
+                                               unsigned gs_in, unsigned gs_out, unsigned lfs,
+                                               const float2* __restrict__ H = nullptr, float scaling = 1.f)
 {
     // lfs: distance between consecutive frames inside an LDS image (n, or n + 1 where lanes walk across frames)
     if constexpr (! STATIC)
@@ -243,6 +246,12 @@ __device__ __forceinline__ void generic_stage (const float2* __restrict__ src, f
         {
             if (IO & 2)
                 gstore (&d[j + b * p], SWAP ? make_float2 (u[b].y, u[b].x) : u[b]);
+            else if constexpr (CONV)
+            {
+                const float2 h = H[j + b * p];
+                const float2 y = cmul (u[b], make_float2 (h.x * scaling, h.y * scaling));
+                d[j + b * p] = make_float2 (y.y, y.x);
+            }
             else
                 d[j + b * p] = u[b];
         }
@@ -370,9 +379,11 @@ template <> struct StaticPlanFor<1920> { using type = StaticPlan<1920, 12, 10, 1
 template <> struct StaticPlanFor<2000> { using type = StaticPlan<2000, 10, 5, 5, 8>; };
 
 // all stages of a static plan; twl: the workgroup's LDS copy of the plan's twiddles.  Returns the image that holds the result.
-template <class SP, int BLOCK, bool IN_GLOBAL, bool OUT_GLOBAL, bool SWAP, int S = 0>
+// CONV: the last stage (which then writes an LDS image: OUT_GLOBAL false) multiplies by H * scaling and swaps, see generic_stage
+template <class SP, int BLOCK, bool IN_GLOBAL, bool OUT_GLOBAL, bool SWAP, int S = 0, bool CONV = false>
 __device__ __forceinline__ float2* static_core (const float2* twl, float2* a, float2* b, const float2* __restrict__ gin, float2* __restrict__ gout,
-                                                int nframes, int tid, unsigned gs_in, unsigned gs_out)
+                                                int nframes, int tid, unsigned gs_in, unsigned gs_out,
+                                                const float2* __restrict__ H = nullptr, float scaling = 1.f)
 {
     if constexpr (S == SP::ns)
         return a;
@@ -381,10 +392,11 @@ __device__ __forceinline__ float2* static_core (const float2* twl, float2* a, fl
         constexpr int R = SP::radix (S), P = SP::period (S);
         constexpr bool first = IN_GLOBAL && S == 0, last = OUT_GLOBAL && S == SP::ns - 1;
         constexpr int IO = (first ? 1 : 0) | (last ? 2 : 0);
-        generic_stage<R, BLOCK, IO, IO != 0 && SWAP, true> (first ? gin : a, last ? gout : b, twl + SP::tw_offset (S), SP::n, P, nframes, tid, gs_in, gs_out, (unsigned) SP::n);
+        constexpr bool conv_here = CONV && ! OUT_GLOBAL && S == SP::ns - 1;
+        generic_stage<R, BLOCK, IO, IO != 0 && SWAP, true, conv_here> (first ? gin : a, last ? gout : b, twl + SP::tw_offset (S), SP::n, P, nframes, tid, gs_in, gs_out, (unsigned) SP::n, H, scaling);
         if constexpr (! last)
             __syncthreads();
-        return static_core<SP, BLOCK, IN_GLOBAL, OUT_GLOBAL, SWAP, S + 1> (twl, b, a, gin, gout, nframes, tid, gs_in, gs_out);
+        return static_core<SP, BLOCK, IN_GLOBAL, OUT_GLOBAL, SWAP, S + 1, CONV> (twl, b, a, gin, gout, nframes, tid, gs_in, gs_out, H, scaling);
     }
 }
 
@@ -623,9 +635,10 @@ __global__ __launch_bounds__ (BLOCK) void generic_kernel (const float2* __restri
 // CU up to n = 10240 (their load / compute / store phases overlap), and frames of up to 20000 points fit at all.
 static constexpr int kInplaceMaxPoints = 20; // points per work-item and stage
 
-template <int R, int BLOCK, int IO, bool SWAP, bool STATIC = false>
+template <int R, int BLOCK, int IO, bool SWAP, bool STATIC = false, bool CONV = false>
 __device__ __forceinline__ void inplace_stage (const float2* __restrict__ gin, float2* __restrict__ gout, float2* __restrict__ buf,
-                                               const float2* __restrict__ tw, int n, int p, int tid)
+                                               const float2* __restrict__ tw, int n, int p, int tid,
+                                               const float2* __restrict__ H = nullptr, float scaling = 1.f)
 {
     constexpr int J = (kInplaceMaxPoints + R - 1) / R; // butterflies per work-item
     // n passes through an opaque (volatile) statement: everything below derives from it, so the loop-invariant code motion of
@@ -716,6 +729,13 @@ __device__ __forceinline__ void inplace_stage (const float2* __restrict__ gin, f
                 {
                     if (IO & 2)
                         gstore (&gout[(unsigned) (jj + b * p)], SWAP ? make_float2 (u[j][b].y, u[j][b].x) : u[j][b]);
+                    else if constexpr (CONV)
+                    {
+                        // fused convolution: the forward transform's last stage multiplies by H * scaling and swaps (generic_stage)
+                        const float2 h = H[jj + b * p];
+                        const float2 y = cmul (u[j][b], make_float2 (h.x * scaling, h.y * scaling));
+                        buf[jj + b * p] = make_float2 (y.y, y.x);
+                    }
                     else
                         buf[jj + b * p] = u[j][b];
                 }
@@ -726,31 +746,34 @@ __device__ __forceinline__ void inplace_stage (const float2* __restrict__ gin, f
     }
 }
 
-template <int BLOCK, int IO, bool SWAP>
+template <int BLOCK, int IO, bool SWAP, bool CONV = false>
 __device__ __forceinline__ void inplace_stage_dispatch (int r, const float2* __restrict__ gin, float2* __restrict__ gout, float2* __restrict__ buf,
-                                                        const float2* __restrict__ tw, int n, int p, int tid)
+                                                        const float2* __restrict__ tw, int n, int p, int tid,
+                                                        const float2* __restrict__ H = nullptr, float scaling = 1.f)
 {
     switch (r)
     {
-        case 2: inplace_stage<2, BLOCK, IO, SWAP> (gin, gout, buf, tw, n, p, tid); break;
-        case 3: inplace_stage<3, BLOCK, IO, SWAP> (gin, gout, buf, tw, n, p, tid); break;
-        case 4: inplace_stage<4, BLOCK, IO, SWAP> (gin, gout, buf, tw, n, p, tid); break;
-        case 5: inplace_stage<5, BLOCK, IO, SWAP> (gin, gout, buf, tw, n, p, tid); break;
-        case 6: inplace_stage<6, BLOCK, IO, SWAP> (gin, gout, buf, tw, n, p, tid); break;
-        case 8: inplace_stage<8, BLOCK, IO, SWAP> (gin, gout, buf, tw, n, p, tid); break;
-        case 9: inplace_stage<9, BLOCK, IO, SWAP> (gin, gout, buf, tw, n, p, tid); break;
-        case 10: inplace_stage<10, BLOCK, IO, SWAP> (gin, gout, buf, tw, n, p, tid); break;
-        case 12: inplace_stage<12, BLOCK, IO, SWAP> (gin, gout, buf, tw, n, p, tid); break;
-        case 15: inplace_stage<15, BLOCK, IO, SWAP> (gin, gout, buf, tw, n, p, tid); break;
-        default: inplace_stage<16, BLOCK, IO, SWAP> (gin, gout, buf, tw, n, p, tid); break;
+        case 2: inplace_stage<2, BLOCK, IO, SWAP, false, CONV> (gin, gout, buf, tw, n, p, tid, H, scaling); break;
+        case 3: inplace_stage<3, BLOCK, IO, SWAP, false, CONV> (gin, gout, buf, tw, n, p, tid, H, scaling); break;
+        case 4: inplace_stage<4, BLOCK, IO, SWAP, false, CONV> (gin, gout, buf, tw, n, p, tid, H, scaling); break;
+        case 5: inplace_stage<5, BLOCK, IO, SWAP, false, CONV> (gin, gout, buf, tw, n, p, tid, H, scaling); break;
+        case 6: inplace_stage<6, BLOCK, IO, SWAP, false, CONV> (gin, gout, buf, tw, n, p, tid, H, scaling); break;
+        case 8: inplace_stage<8, BLOCK, IO, SWAP, false, CONV> (gin, gout, buf, tw, n, p, tid, H, scaling); break;
+        case 9: inplace_stage<9, BLOCK, IO, SWAP, false, CONV> (gin, gout, buf, tw, n, p, tid, H, scaling); break;
+        case 10: inplace_stage<10, BLOCK, IO, SWAP, false, CONV> (gin, gout, buf, tw, n, p, tid, H, scaling); break;
+        case 12: inplace_stage<12, BLOCK, IO, SWAP, false, CONV> (gin, gout, buf, tw, n, p, tid, H, scaling); break;
+        case 15: inplace_stage<15, BLOCK, IO, SWAP, false, CONV> (gin, gout, buf, tw, n, p, tid, H, scaling); break;
+        default: inplace_stage<16, BLOCK, IO, SWAP, false, CONV> (gin, gout, buf, tw, n, p, tid, H, scaling); break;
     }
 }
 
 // TWLDS: stages [0, plan.lds_stages) take their twiddles from the workgroup's LDS copy `twl` (twl[0] = table entry
 // plan.tw_offset[0]), the rest from the table in L2.  Two call sites per kind of stage so that each keeps its address space.
-template <int BLOCK, bool IN_GLOBAL, bool OUT_GLOBAL, bool SWAP, bool TWLDS>
+// CONV: the last stage (which then writes the image: OUT_GLOBAL false) multiplies by H * scaling and swaps (inplace_stage)
+template <int BLOCK, bool IN_GLOBAL, bool OUT_GLOBAL, bool SWAP, bool TWLDS, bool CONV = false>
 __device__ __forceinline__ void inplace_core (const GenericPlan& plan, const float2* __restrict__ twtab, const float2* twl, float2* buf,
-                                              const float2* __restrict__ gin, float2* __restrict__ gout, int tid)
+                                              const float2* __restrict__ gin, float2* __restrict__ gout, int tid,
+                                              const float2* __restrict__ H = nullptr, float scaling = 1.f)
 {
     int p = 1, s0 = 0;
     if constexpr (IN_GLOBAL)
@@ -770,7 +793,9 @@ __device__ __forceinline__ void inplace_core (const GenericPlan& plan, const flo
         const int r = plan.radix[s];
         const float2* tw = twtab + plan.tw_offset[s];
         const bool last = OUT_GLOBAL && s == plan.ns - 1;
-        if (TWLDS && s < plan.lds_stages)
+        if (CONV && ! OUT_GLOBAL && s == plan.ns - 1) // (a plan's last table never rides in LDS with the earlier ones missing: take it from L2)
+            inplace_stage_dispatch<BLOCK, 0, false, CONV> (r, gin, gout, buf, tw, plan.n, p, tid, H, scaling);
+        else if (TWLDS && s < plan.lds_stages)
         {
             const float2* tl = twl + (plan.tw_offset[s] - plan.tw_offset[0]);
             if (last)
@@ -789,15 +814,17 @@ __device__ __forceinline__ void inplace_core (const GenericPlan& plan, const flo
 // The same with a compile-time stage list (StaticPlan): for the long frames of the reference's test list (9216 complex points, and
 // 4608 for the real transform of 9216) and a handful of lengths audio hosts use.  Whether a stage's twiddles come from the LDS
 // copy or from L2 stays a run-time (uniform) choice: the launcher decides how many tables fit.
-template <class SP, int BLOCK, bool IN_GLOBAL, bool OUT_GLOBAL, bool SWAP, bool TWLDS, int S = 0>
+template <class SP, int BLOCK, bool IN_GLOBAL, bool OUT_GLOBAL, bool SWAP, bool TWLDS, int S = 0, bool CONV = false>
 __device__ __forceinline__ void static_inplace_core (const GenericPlan& plan, const float2* __restrict__ twtab, const float2* twl, float2* buf,
-                                                     const float2* __restrict__ gin, float2* __restrict__ gout, int tid)
+                                                     const float2* __restrict__ gin, float2* __restrict__ gout, int tid,
+                                                     const float2* __restrict__ H = nullptr, float scaling = 1.f)
 {
     if constexpr (S < SP::ns)
     {
         constexpr int R = SP::radix (S), P = SP::period (S);
         constexpr bool first = IN_GLOBAL && S == 0, last = OUT_GLOBAL && S == SP::ns - 1;
         constexpr int IO = (first ? 1 : 0) | (last ? 2 : 0);
+        constexpr bool conv_here = CONV && ! OUT_GLOBAL && S == SP::ns - 1;
         if constexpr (first)
             inplace_stage<R, BLOCK, IO, SWAP, true> (gin, gout, buf, twtab, SP::n, 1, tid); // p == 1: no twiddles
         else
@@ -806,11 +833,11 @@ __device__ __forceinline__ void static_inplace_core (const GenericPlan& plan, co
             if constexpr (TWLDS)
                 from_lds = S < plan.lds_stages;
             if (from_lds)
-                inplace_stage<R, BLOCK, IO, IO != 0 && SWAP, true> (gin, gout, buf, twl + SP::tw_offset (S), SP::n, P, tid);
+                inplace_stage<R, BLOCK, IO, IO != 0 && SWAP, true, conv_here> (gin, gout, buf, twl + SP::tw_offset (S), SP::n, P, tid, H, scaling);
             else
-                inplace_stage<R, BLOCK, IO, IO != 0 && SWAP, true> (gin, gout, buf, twtab + plan.tw_offset[0] + SP::tw_offset (S), SP::n, P, tid);
+                inplace_stage<R, BLOCK, IO, IO != 0 && SWAP, true, conv_here> (gin, gout, buf, twtab + plan.tw_offset[0] + SP::tw_offset (S), SP::n, P, tid, H, scaling);
         }
-        static_inplace_core<SP, BLOCK, IN_GLOBAL, OUT_GLOBAL, SWAP, TWLDS, S + 1> (plan, twtab, twl, buf, gin, gout, tid);
+        static_inplace_core<SP, BLOCK, IN_GLOBAL, OUT_GLOBAL, SWAP, TWLDS, S + 1, CONV> (plan, twtab, twl, buf, gin, gout, tid, H, scaling);
     }
 }
 template <int N_> struct StaticInplacePlanFor { using type = void; };

@@ -92,6 +92,10 @@ hipError_t launch_real_pair (bool forward, const float2* in, float2* out, const 
 // mixed-radix (non power of two) frames: mode 0 c2c, 1 real forward, 2 real backward; nc = complex length
 hipError_t launch_generic (int mode, bool inverse, int nc, const DeviceTables& t, const float2* in, float2* out, size_t batch, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
 
+// fused forward -> * H * scaling -> backward for mixed-radix frames up to 20000 complex points (generic_conv_kernels.hpp);
+// hipErrorNotSupported where no one-launch form exists (the caller then composes the three launches)
+hipError_t launch_generic_conv (bool real, int nc, const DeviceTables& t, const float2* in, const float2* H, float2* out, float scaling, size_t batch, hipStream_t stream);
+
 // column pass of the 2-D transform (row f4): rows-point FFTs along the columns of `batch` row-major [rows][cols] complex arrays,
 // in place; `t` = acquire_column_tables (device, rows)
 hipError_t launch_column_fft (bool inverse, int rows, int cols, const DeviceTables& t, float2* data, size_t batch, hipStream_t stream);

@@ -84,12 +84,14 @@ int fft_gpu_release_stream_resources (void* stream);
                         instead of the 512-work-item LDS-image plan; same rate, default 0
      "fused_conv_split" 0: fft_convolve_frames_batch of the 8192 / 16384 / 32768-point cores as three launches instead of
                         the one-launch split-plane form (A/B switch; default 1)
+     "fused_conv_generic" 0: fft_convolve_frames_batch of mixed-radix frames (up to 20000 complex points) as three launches
+                        instead of the one-launch form (A/B switch; default 1)
      "conv_wave2048"    1: fft_convolve_frames_batch of 2048-point cores by one wavefront per frame; 12-14 % slower than
                         the workgroup plan, default 0
    Returns 0, or FFT_GPU_EINVAL for an unknown name / a value out of range. */
 int fft_gpu_set_option (const char* name, long value);
 /* Current value of an option ("fused_two_pass", "fused_min_batch", "fused_lag", "fused_slots", "split16384", "split8192",
-   "conv_wave2048", "fused_conv_split"), or -1 for a name that cannot be read back. */
+   "conv_wave2048", "fused_conv_split", "fused_conv_generic"), or -1 for a name that cannot be read back. */
 long fft_gpu_get_option (const char* name);
 
 /* ---- plan introspection -------------------------------------------------------------------------- */

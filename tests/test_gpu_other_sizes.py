@@ -190,3 +190,42 @@ def test_other_size_convolution_ops(gpu, oracle):
     assert_frames_close(y2.cpu().numpy(), want, what="N=480 one-call convolution")
     api.fft_destroy_setup(s)
     oracle.destroy_setup(so)
+
+
+# The reference's "other sizes" (test/test.cpp:279-285) and longer mixed-radix frames: fft_convolve_frames_batch as ONE launch
+# (generic_conv_kernels.hpp: two-image kernel with a compile-time stage list up to 2048 complex points, in-place kernel above,
+# compile-time list for 4608 / 9216) == the three-launch composition == the oracle's call sequence (test/test.cpp:161-166, 212-218).
+@pytest.mark.parametrize("n,tr", [(96, COMPLEX), (192, COMPLEX), (384, COMPLEX), (480, COMPLEX), (640, COMPLEX), (768, COMPLEX),
+                                  (96, REAL), (192, REAL), (384, REAL), (480, REAL), (640, REAL), (768, REAL),
+                                  (1536, COMPLEX), (1920, REAL), (2000, COMPLEX), (3072, REAL),
+                                  (9216, COMPLEX), (9216, REAL), (18432, REAL), (5120, COMPLEX), (12288, COMPLEX), (19200, COMPLEX)])
+def test_fused_convolution_mixed_radix(gpu, oracle, n, tr):
+    api, torch, dev = gpu
+    nf = 2 * n if tr == COMPLEX else n
+    nc = n if tr == COMPLEX else n // 2
+    frames_per_group = max(1, 2048 // nc)
+    batch = 3 * frames_per_group + 1 if nc <= 1024 else 5  # a ragged last group for the short frames
+    s, so = api.fft_new_setup(n, tr), oracle.new_setup(n, tr)
+    x = ol.uniform(batch * nf, 61 + n).reshape(batch, nf)
+    h = ol.uniform(nf, 62 + n).reshape(1, nf)
+    xd, hd = torch.from_numpy(x).to(dev), torch.from_numpy(h).to(dev)
+    H = torch.empty_like(hd)
+    api.fft_transform_unordered_batch(s, hd, H, api.FFT_FORWARD)
+    assert api.get_option("fused_conv_generic") == 1
+    one = torch.full_like(xd, -3.0)
+    api.fft_convolve_frames_batch(s, xd, H, one, 1.0 / n)
+    api.set_option("fused_conv_generic", 0)
+    three = torch.full_like(xd, -5.0)
+    api.fft_convolve_frames_batch(s, xd, H, three, 1.0 / n)
+    api.set_option("fused_conv_generic", 1)
+    inplace = xd.clone()
+    api.fft_convolve_frames_batch(s, inplace, H, inplace, 1.0 / n)
+    torch.cuda.synchronize()
+    assert_frames_close(one.cpu().numpy(), three.cpu().numpy(), tol=3e-7, maxabs_tol=1e-6, what=f"N={n} one launch vs three launches")
+    assert np.array_equal(inplace.cpu().numpy(), one.cpu().numpy()), "in place == out of place"
+    hb = oracle.transform(so, h[0], FORWARD, False)
+    pick = sorted({0, 1, batch // 2, batch - 1})
+    want = np.stack([oracle.transform(so, oracle.convolve(so, oracle.transform(so, x[i], FORWARD, False), hb, np.zeros(nf, np.float32), 1.0 / n), BACKWARD, False) for i in pick])
+    assert_frames_close(one.cpu().numpy()[pick], want, maxabs_tol=MIXED_RADIX_MAXABS_TOL, what=f"N={n} fused convolution vs the oracle's call sequence")
+    api.fft_destroy_setup(s)
+    oracle.destroy_setup(so)

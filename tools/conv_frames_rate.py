@@ -20,8 +20,9 @@ _w = torch.rand((1 << 26,), device=dev)
 for _ in range(200):  # idle clocks: the first milliseconds run 10-25 % slow
     _w.mul_(1.0001)
 torch.cuda.synchronize()
-for form, opt in (("one launch where fused", 1), ("three launches (fused_conv_split=0)", 0)):
+for form, opt in (("one launch where fused", 1), ("three launches (fused_conv_split = fused_conv_generic = 0)", 0)):
     api.set_option("fused_conv_split", opt)
+    api.set_option("fused_conv_generic", opt)
     print(f"# {form}")
     for sz in sizes:
         real, n = sz[0] == "r", int(sz[1:])
