@@ -303,6 +303,11 @@ def set_option(name: str, value: int) -> None:
     _check(_lib.lib().fft_gpu_set_option(name.encode(), int(value)), f"fft_gpu_set_option({name})")
 
 
+def workspace_bytes(setup, batch: int) -> int:
+    """fft_gpu_workspace_bytes: device memory a two-pass plan caches per stream for a call of `batch` frames (0: none)"""
+    return int(_lib.lib().fft_gpu_workspace_bytes(setup, batch))
+
+
 def get_option(name: str) -> int:
     """fft_gpu_get_option: current value of a run-time knob (-1: not readable)"""
     return int(_lib.lib().fft_gpu_get_option(name.encode()))

@@ -374,6 +374,21 @@ Lanes* get_fused (int device, hipStream_t stream, size_t ws_bytes)
 // complex length the plan's core transforms
 int complex_len (const Setup* s) { return s->transform == cf::FFT_COMPLEX ? s->N : s->N / 2; }
 
+// bytes of ONE frame in a two-pass workspace: what big_c2c_chunked / big_real4_chunked allocate per frame of a chunk and what
+// fft_gpu_workspace_bytes reports (one helper, so that the two cannot drift apart: a ragged last column tile of the
+// generic-column plans pads the frame, the real four-step keeps r2 / 2 + 1 or + 16 rows)
+size_t workspace_frame_bytes (const DeviceTables* t, int nc)
+{
+    if (t->real4_r1 > 0)
+        return (t->real4_fast ? real4_fast_workspace_frame_len (t->real4_r1, t->real4_r2) : real4_workspace_frame_len (t->real4_r1, t->real4_r2)) * sizeof (float2);
+    if (t->mixed_n2 > 0)
+    {
+        const size_t ca = (size_t) t->mixed_ca, m1 = (size_t) t->mixed_n1, m2 = (size_t) t->mixed_n2;
+        return ((m1 + ca - 1) / ca) * ca * m2 * sizeof (float2);
+    }
+    return (size_t) nc * sizeof (float2);
+}
+
 // pair: 0 = complex transform; +1 = REAL FORWARD: the pair (split) stage runs on each chunk's output right after its
 // pass B, in place; -1 = REAL BACKWARD: the pair (merge) stage in -> out runs on each chunk right before its pass A,
 // which then works in place on `out`.  Doing it per chunk (and with smaller chunks) lets the stage find its operands in
@@ -411,12 +426,7 @@ int big_c2c_chunked (Setup* s, int nc, bool inverse, const float2* in, float2* o
         }
         return cf::FFT_GPU_OK;
     }
-    size_t frame_bytes = (size_t) nc * sizeof (float2);
-    if (mixed) // a ragged last column tile pads the workspace frame
-    {
-        const size_t ca = (size_t) s->tables->mixed_ca, m1 = (size_t) s->tables->mixed_n1, m2 = (size_t) s->tables->mixed_n2;
-        frame_bytes = ((m1 + ca - 1) / ca) * ca * m2 * sizeof (float2);
-    }
+    const size_t frame_bytes = workspace_frame_bytes (s->tables, nc);
     const int want_lanes = lane_count();
     // the cap covers BOTH workspaces, so that they fit the Infinity Cache together
     size_t chunk = workspace_cap() / (size_t) want_lanes / frame_bytes;
@@ -485,7 +495,7 @@ int big_real4_chunked (Setup* s, bool inverse, const float2* in, float2* out, si
 {
     const DeviceTables* t = s->tables;
     const int r1 = t->real4_r1, r2 = t->real4_r2;
-    const size_t frame_bytes = (t->real4_fast ? real4_fast_workspace_frame_len (r1, r2) : real4_workspace_frame_len (r1, r2)) * sizeof (float2);
+    const size_t frame_bytes = workspace_frame_bytes (t, complex_len (s));
     const int want_lanes = lane_count();
     size_t chunk = workspace_cap() / (size_t) want_lanes / frame_bytes;
     if (chunk < 1)
@@ -1391,10 +1401,7 @@ size_t fft_gpu_workspace_bytes (void* setup, size_t batch)
     Setup* s = as_setup (setup);
     if (s == nullptr || s->tables->core_n == complex_len (s) || (s->tables->gen_ns > 0 && s->tables->mixed_n2 == 0))
         return 0;
-    size_t frame_bytes = (size_t) complex_len (s) * sizeof (float2);
-    if (s->tables->real4_r1 > 0)
-        frame_bytes = (s->tables->real4_fast ? real4_fast_workspace_frame_len (s->tables->real4_r1, s->tables->real4_r2)
-                                             : real4_workspace_frame_len (s->tables->real4_r1, s->tables->real4_r2)) * sizeof (float2);
+    const size_t frame_bytes = workspace_frame_bytes (s->tables, complex_len (s));
     int n1 = 0, n2 = 0;
     if (s->tables->mixed_n2 == 0)
         split_large (complex_len (s), n1, n2);

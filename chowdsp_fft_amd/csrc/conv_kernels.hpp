@@ -171,6 +171,32 @@ __global__ __launch_bounds__ (256) void ols_extract_kernel (const float4* __rest
     }
 }
 
+// The cores of the fused kernels.  CFFT_CONV_STREAM_TW = 1 (an A/B switch of the translation unit): plans of 1024 points and
+// more fetch each stage's twiddles from the L2-resident table while the previous stage's outputs travel through LDS
+// (fft_core_streamed, stockham.hpp) instead of keeping them in ~60 VGPRs -- the registers that the packed-arithmetic form
+// (CFFT_PACKED, butterflies.hpp) needs to stay at two waves per SIMD.  These kernels are VALU-issue bound: 1427 vector
+// instructions per work-item and frame at N = 4096 real, the two resident waves of a SIMD each 50 % VALU-active
+// (profiles/r03_sq_counters_conv.txt).
+#ifndef CFFT_CONV_STREAM_TW
+#define CFFT_CONV_STREAM_TW 0
+#endif
+// minimum waves per SIMD asked of the compiler for the software-pipelined fused kernels (1 = no constraint beyond the workgroup)
+#ifndef CFFT_CONV_PF_MIN_WAVES
+#define CFFT_CONV_PF_MIN_WAVES 1
+#endif
+template <class P>
+__device__ __forceinline__ void conv_core (float2 (&v)[P::R], const TwiddleRegs<P>& tw, const float2* __restrict__ twtab, float2* __restrict__ lds, int t)
+{
+#if CFFT_CONV_STREAM_TW
+    if constexpr (P::N >= 1024)
+    {
+        fft_core_streamed<P> (v, twtab, lds, t);
+        return;
+    }
+#endif
+    fft_core<P> (v, tw, lds, t);
+}
+
 // ---- fused: y = BACKWARD( FORWARD(x) * H ) * scaling, one kernel, spectrum never leaves the CU -----
 // COMPLEX plan: P is the N point plan, H has N complex bins in canonical order.
 // The bins a work-item multiplies (its output_index positions) are the same for every frame: kept in VGPRs.
@@ -183,10 +209,11 @@ __device__ __forceinline__ void conv_c2c_finish (float2 (&v)[P::R],
                                                  unsigned team_base,
                                                  int t,
                                                  float scaling,
-                                                 bool active)
+                                                 bool active,
+                                                 const float2* __restrict__ twtab)
 {
     team_sync<P::T>();
-    fft_core<P> (v, tw, lds, t);
+    conv_core<P> (v, tw, twtab, lds, t);
     // multiply by the filter spectrum, scale, swap re/im for the inverse
     float2 w[P::R];
 #pragma unroll
@@ -202,7 +229,7 @@ __device__ __forceinline__ void conv_c2c_finish (float2 (&v)[P::R],
     float2 u[P::R]; // fresh arrays: reusing the caller's `v` through the reference leaves it in scratch memory
     lds_load_input_order<P> (u, lds, t);
     team_sync<P::T>();
-    fft_core<P> (u, tw, lds, t);
+    conv_core<P> (u, tw, twtab, lds, t);
     if (! PREDICATED || active)
     {
 #pragma unroll
@@ -242,14 +269,14 @@ __global__ __launch_bounds__ (P::T* FPB) void conv_frames_c2c_kernel (const floa
 #pragma unroll
         for (int s = 0; s < P::R; ++s)
             v[s] = active ? gload (&src[team_base + (unsigned) input_index<P> (t, s)]) : make_float2 (0.f, 0.f);
-        conv_c2c_finish<P, true> (v, tw, h, lds, out + (size_t) g * (FPB * P::N), team_base, t, scaling, active);
+        conv_c2c_finish<P, true> (v, tw, h, lds, out + (size_t) g * (FPB * P::N), team_base, t, scaling, active, twtab);
     }
 }
 
 // software-pipelined variant: the next group's loads are in flight while this group's two FFT cores run; full
 // groups store unconditionally, a ragged last group is handled once by the workgroup whose turn it would be
 template <class P, int FPB>
-__global__ __launch_bounds__ (P::T* FPB) void conv_frames_c2c_kernel_pf (const float2* __restrict__ in,
+__global__ __launch_bounds__ (P::T* FPB, CFFT_CONV_PF_MIN_WAVES) void conv_frames_c2c_kernel_pf (const float2* __restrict__ in,
                                                                         const float2* __restrict__ H,
                                                                         float2* __restrict__ out,
                                                                         const float2* __restrict__ twtab,
@@ -293,7 +320,7 @@ __global__ __launch_bounds__ (P::T* FPB) void conv_frames_c2c_kernel_pf (const f
                     nim[s] = x.y;
                 }
             }
-            conv_c2c_finish<P, false> (v, tw, h, lds, out + (size_t) g * (FPB * P::N), team_base, t, scaling, true);
+            conv_c2c_finish<P, false> (v, tw, h, lds, out + (size_t) g * (FPB * P::N), team_base, t, scaling, true, twtab);
         }
         for (g += gridDim.x; g < nfull; g += gridDim.x)
         {
@@ -313,7 +340,7 @@ __global__ __launch_bounds__ (P::T* FPB) void conv_frames_c2c_kernel_pf (const f
                     nim[s] = x.y;
                 }
             }
-            conv_c2c_finish<P, false> (v, tw, h, lds, out + (size_t) g * (FPB * P::N), team_base, t, scaling, true);
+            conv_c2c_finish<P, false> (v, tw, h, lds, out + (size_t) g * (FPB * P::N), team_base, t, scaling, true, twtab);
         }
     }
     if (FPB > 1 && nfull * FPB < batch && blockIdx.x == nfull % gridDim.x)
@@ -324,7 +351,7 @@ __global__ __launch_bounds__ (P::T* FPB) void conv_frames_c2c_kernel_pf (const f
 #pragma unroll
         for (int s = 0; s < P::R; ++s)
             v[s] = active ? gload (&src[team_base + (unsigned) input_index<P> (t, s)]) : make_float2 (0.f, 0.f);
-        conv_c2c_finish<P, true> (v, tw, h, lds, out + (size_t) nfull * (FPB * P::N), team_base, t, scaling, active);
+        conv_c2c_finish<P, true> (v, tw, h, lds, out + (size_t) nfull * (FPB * P::N), team_base, t, scaling, active, twtab);
     }
 }
 
@@ -368,11 +395,12 @@ __device__ __forceinline__ void conv_real_finish (float2 (&v)[P::R],
                                                   unsigned team_base,
                                                   int t,
                                                   float scaling,
-                                                  bool active)
+                                                  bool active,
+                                                  const float2* __restrict__ twtab)
 {
     constexpr int M = P::N;
     team_sync<P::T>();
-    fft_core<P> (v, tw, lds, t);
+    conv_core<P> (v, tw, twtab, lds, t);
     if constexpr (P::NS > 1)
         team_sync<P::T>();
     lds_store_output_order<P> (v, lds, t);
@@ -418,7 +446,7 @@ __device__ __forceinline__ void conv_real_finish (float2 (&v)[P::R],
     float2 u[P::R]; // a fresh array: reusing the caller's `v` through the reference leaves it in scratch memory
     lds_load_input_order<P> (u, lds, t);
     team_sync<P::T>();
-    fft_core<P> (u, tw, lds, t);
+    conv_core<P> (u, tw, twtab, lds, t);
     if (!PREDICATED || active)
     {
 #pragma unroll
@@ -460,14 +488,14 @@ __global__ __launch_bounds__ (P::T* FPB) void conv_frames_real_kernel (const flo
 #pragma unroll
         for (int s = 0; s < P::R; ++s)
             v[s] = active ? gload (&src[team_base + (unsigned) input_index<P> (t, s)]) : make_float2 (0.f, 0.f);
-        conv_real_finish<P, true, HREGS> (v, tw, pw, h, lds, out + (size_t) g * (FPB * M), team_base, t, scaling, active);
+        conv_real_finish<P, true, HREGS> (v, tw, pw, h, lds, out + (size_t) g * (FPB * M), team_base, t, scaling, active, twtab);
     }
 }
 
 // software-pipelined variant (same scheme as r2c_kernel_pf): the next group's loads are in flight while this
 // group's two FFT cores run; full groups store unconditionally, the ragged last group is handled separately
 template <class P, int FPB, bool HREGS>
-__global__ __launch_bounds__ (P::T* FPB) void conv_frames_real_kernel_pf (const float2* __restrict__ in,
+__global__ __launch_bounds__ (P::T* FPB, CFFT_CONV_PF_MIN_WAVES) void conv_frames_real_kernel_pf (const float2* __restrict__ in,
                                                                          const float2* __restrict__ H,
                                                                          float2* __restrict__ out,
                                                                          const float2* __restrict__ twtab,
@@ -513,7 +541,7 @@ __global__ __launch_bounds__ (P::T* FPB) void conv_frames_real_kernel_pf (const 
                     nim[s] = x.y;
                 }
             }
-            conv_real_finish<P, false, HREGS> (v, tw, pw, h, lds, out + (size_t) g * (FPB * M), team_base, t, scaling, true);
+            conv_real_finish<P, false, HREGS> (v, tw, pw, h, lds, out + (size_t) g * (FPB * M), team_base, t, scaling, true, twtab);
         }
         for (g += gridDim.x; g < nfull; g += gridDim.x)
         {
@@ -533,7 +561,7 @@ __global__ __launch_bounds__ (P::T* FPB) void conv_frames_real_kernel_pf (const 
                     nim[s] = x.y;
                 }
             }
-            conv_real_finish<P, false, HREGS> (v, tw, pw, h, lds, out + (size_t) g * (FPB * M), team_base, t, scaling, true);
+            conv_real_finish<P, false, HREGS> (v, tw, pw, h, lds, out + (size_t) g * (FPB * M), team_base, t, scaling, true, twtab);
         }
     }
     if (FPB > 1 && nfull * FPB < batch && blockIdx.x == nfull % gridDim.x)
@@ -544,7 +572,7 @@ __global__ __launch_bounds__ (P::T* FPB) void conv_frames_real_kernel_pf (const 
 #pragma unroll
         for (int s = 0; s < P::R; ++s)
             v[s] = active ? gload (&src[team_base + (unsigned) input_index<P> (t, s)]) : make_float2 (0.f, 0.f);
-        conv_real_finish<P, true, HREGS> (v, tw, pw, h, lds, out + (size_t) nfull * (FPB * M), team_base, t, scaling, active);
+        conv_real_finish<P, true, HREGS> (v, tw, pw, h, lds, out + (size_t) nfull * (FPB * M), team_base, t, scaling, active, twtab);
     }
 }
 

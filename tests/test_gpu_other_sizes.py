@@ -229,3 +229,37 @@ def test_fused_convolution_mixed_radix(gpu, oracle, n, tr):
     assert_frames_close(one.cpu().numpy()[pick], want, maxabs_tol=MIXED_RADIX_MAXABS_TOL, what=f"N={n} fused convolution vs the oracle's call sequence")
     api.fft_destroy_setup(s)
     oracle.destroy_setup(so)
+
+
+def test_workspace_bytes_reports_what_is_allocated(gpu):
+    """fft_gpu_workspace_bytes and the allocation share one helper (capi.cpp workspace_frame_bytes).  Known answers: the
+    ragged generic-column plan 34992 = 216 x 162 pads its 216 columns to 14 tiles of 16 (224 x 162 x 8 bytes per frame, not
+    34992 x 8); N = 2^17 keeps the plain frame; single-pass plans cache nothing; and the device's free memory drops by
+    about that much on the first call."""
+    api, torch, dev = gpu
+    s = api.fft_new_setup(34992, api.FFT_COMPLEX)
+    desc = api.plan_describe(34992, api.FFT_COMPLEX)
+    assert desc["passes"] == 2 and sorted((desc["n1"], desc["n2"])) == [162, 216]
+    batch = 64
+    frame = 224 * 162 * 8
+    want = 2 * batch * frame  # two lanes, the whole batch in one chunk per lane at most
+    got = api.workspace_bytes(s, batch)
+    assert got in (want, batch * frame * 2), (got, want)
+    assert got > 2 * batch * 34992 * 8  # the padding is included
+    st = torch.cuda.Stream()
+    x = torch.rand((batch, 2 * 34992), device=dev)
+    y = torch.empty_like(x)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    api.fft_transform_batch(s, x, y, api.FFT_FORWARD, stream=st)
+    st.synchronize()
+    used = free0 - torch.cuda.mem_get_info()[0]
+    assert got <= used + (1 << 20) and used <= got + (16 << 20), (used, got)
+    assert api.release_stream_resources(st) == 1
+    api.fft_destroy_setup(s)
+    s2 = api.fft_new_setup(1 << 17, api.FFT_COMPLEX)
+    assert api.workspace_bytes(s2, 8) == 2 * 8 * (8 << 17)
+    api.fft_destroy_setup(s2)
+    s3 = api.fft_new_setup(4096, api.FFT_COMPLEX)
+    assert api.workspace_bytes(s3, 1000) == 0
+    api.fft_destroy_setup(s3)
