@@ -287,6 +287,8 @@ std::atomic<int> g_conv_wave2048 { 0 };
 std::atomic<int> g_fused_conv_split { 1 };
 // "fused_conv_generic": the same switch for mixed-radix frames (one launch, generic_conv_kernels.hpp) -- A/B against the composition
 std::atomic<int> g_fused_conv_generic { 1 };
+// "fused_conv_group": ... and for N = 65536 complex (one launch on the static groups of the one-launch transform)
+std::atomic<int> g_fused_conv_group { 1 };
 bool split16384_enabled()
 {
     int v = g_split16384.load();
@@ -1344,6 +1346,8 @@ int fft_gpu_set_option (const char* name, long value)
         g_fused_conv_split = value != 0 ? 1 : 0;
     else if (std::strcmp (name, "fused_conv_generic") == 0)
         g_fused_conv_generic = value != 0 ? 1 : 0;
+    else if (std::strcmp (name, "fused_conv_group") == 0)
+        g_fused_conv_group = value != 0 ? 1 : 0;
     else
     {
         set_last_error ("fft_gpu_set_option: unknown option or value out of range");
@@ -1375,6 +1379,8 @@ long fft_gpu_get_option (const char* name)
         return g_fused_conv_split.load();
     if (std::strcmp (name, "fused_conv_generic") == 0)
         return g_fused_conv_generic.load();
+    if (std::strcmp (name, "fused_conv_group") == 0)
+        return g_fused_conv_group.load();
     return -1;
 }
 
@@ -1544,6 +1550,29 @@ int fft_convolve_frames_batch (void* setup, const float* x, const float* dft_fil
         if (es != hipSuccess)
         {
             set_last_error ("fused convolution kernel launch (split-plane)", es);
+            return FFT_GPU_ELAUNCH;
+        }
+        return FFT_GPU_OK;
+    }
+    if (s->transform == FFT_COMPLEX && nc == 65536 && t->fast_n1 == 0 && t->mixed_n2 == 0 && fused_form() == 2 && batch >= fused_min_batch() && g_fused_conv_group.load() != 0)
+    {
+        // N = 65536 complex: both transforms and the product in ONE launch on the static groups (group_twopass_kernels.hpp)
+        std::lock_guard<std::mutex> lock (g_ws_mutex);
+        Lanes* L = get_fused (s->device, (hipStream_t) stream, group_workspace_bytes());
+        if (L == nullptr)
+            return FFT_GPU_ENOMEM;
+        if (*L->fused_err_host != 0)
+        {
+            const unsigned w = *L->fused_err_host;
+            *L->fused_err_host = 0;
+            set_last_error (fused_error_text (w).c_str());
+            return FFT_GPU_ELAUNCH;
+        }
+        const unsigned seq = ++L->fused_seq;
+        const hipError_t eg = launch_group_conv ((const float2*) x, (const float2*) dft_filter, L->fused_ws, (float2*) y, t->stage_twiddles, t->big_twiddles, L->fused_state, L->fused_err_host, seq, scaling, batch, (hipStream_t) stream);
+        if (eg != hipSuccess)
+        {
+            set_last_error ("fused convolution kernel launch (N = 65536, static groups)", eg);
             return FFT_GPU_ELAUNCH;
         }
         return FFT_GPU_OK;

@@ -99,6 +99,73 @@ __device__ __forceinline__ void g256_load_a (float (&re)[16], float (&im)[16], c
     }
 }
 
+// Lane 0 of every workgroup, first thing: draw a rank on this XCD, register, learn (or make) the launch's mode.
+// info[0] = mode (1 GROUP, 2 SOLO), [1] = XCD, [2] = rank on it, [3] = global group number, [4] = groups in all, [5] = 0 for a
+// rank beyond its XCD's last complete group (nothing to do in GROUP mode).
+__device__ __forceinline__ void group_register (GroupState* __restrict__ st, unsigned* info, unsigned reg_polls, unsigned force_solo)
+{
+    const unsigned xcc = hw_xcc_id();
+    const unsigned r = __hip_atomic_fetch_add (&st->xcc[xcc].count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile ("s_waitcnt vmcnt(0)" ::: "memory"); // the rank is drawn before the registration below is counted
+    const unsigned tot = __hip_atomic_fetch_add (&st->registered, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    if (tot == gridDim.x || force_solo != 0)
+    {
+        unsigned expect = 0;
+        (void) __hip_atomic_compare_exchange_strong (&st->mode, &expect, force_solo != 0 ? 2u : 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    unsigned mode, n = 0;
+    while ((mode = ld_relaxed (&st->mode)) == 0)
+    {
+        __builtin_amdgcn_s_sleep (4);
+        if (++n > reg_polls)
+        {
+            unsigned expect = 0; // not every workgroup of the grid is running: nobody may wait for another one
+            (void) __hip_atomic_compare_exchange_strong (&st->mode, &expect, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    unsigned gg = 0, total = 0, valid = 1;
+    if (mode == 1)
+    {
+        // every rank has been drawn: the XCD populations are final.  Global group number = groups of the XCDs before this one + r / 16
+        unsigned mine = 0;
+        for (unsigned x = 0; x < (unsigned) kGroupMaxXcc; ++x)
+        {
+            unsigned g = ld_relaxed (&st->xcc[x].count) / kGroupMembers;
+            g = g > (unsigned) kGroupMaxPerXcc ? (unsigned) kGroupMaxPerXcc : g;
+            if (x == xcc)
+            {
+                gg = total + r / kGroupMembers;
+                mine = g;
+            }
+            total += g;
+        }
+        valid = (r / kGroupMembers < mine) ? 1u : 0u; // a rank beyond the last complete group has nothing to do
+    }
+    info[0] = mode;
+    info[1] = xcc;
+    info[2] = r;
+    info[3] = gg;
+    info[4] = total;
+    info[5] = valid;
+}
+
+// one wave: wait until the group's 16 flags at `flags` have reached `need` (bounded; uniform)
+template <int SLEEP>
+__device__ __forceinline__ void group_wait (const unsigned* flags, unsigned need, int lane, GroupState* st, unsigned* host_err, unsigned seq, unsigned code)
+{
+    unsigned n = 0;
+    while (! flags_reached (flags, need, lane))
+    {
+        __builtin_amdgcn_s_sleep (SLEEP);
+        if (++n > kFusedSpinLimit)
+        {
+            if (lane == 0)
+                group_fail (st, host_err, seq, code);
+            break;
+        }
+    }
+}
+
 // fft256_two_stage (multipass_kernels.hpp) with the stage-1 twiddles read from LDS, tw[(a - 1) * 16 + k]: pass A and pass B
 // index them by different roles, and both sets in VGPRs next to the resident inter-pass twiddles do not fit 256 registers
 __device__ __forceinline__ void fft256_two_stage_lds (float2 (&v)[16], const float2* __restrict__ tw, int k, float2* __restrict__ smem,
@@ -155,51 +222,7 @@ __global__ __launch_bounds__ (256, 2) void group256_kernel (const float2* __rest
     if (tid < 240)
         tw1[tid] = stage_tw[Plan256::tw_offset (1) + tid];
     if (tid == 0)
-    {
-        const unsigned xcc = hw_xcc_id();
-        const unsigned r = __hip_atomic_fetch_add (&st->xcc[xcc].count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile ("s_waitcnt vmcnt(0)" ::: "memory"); // the rank is drawn before the registration below is counted
-        const unsigned tot = __hip_atomic_fetch_add (&st->registered, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-        if (tot == gridDim.x || force_solo != 0)
-        {
-            unsigned expect = 0;
-            (void) __hip_atomic_compare_exchange_strong (&st->mode, &expect, force_solo != 0 ? 2u : 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        unsigned mode, n = 0;
-        while ((mode = ld_relaxed (&st->mode)) == 0)
-        {
-            __builtin_amdgcn_s_sleep (4);
-            if (++n > reg_polls)
-            {
-                unsigned expect = 0; // not every workgroup of the grid is running: nobody may wait for another one
-                (void) __hip_atomic_compare_exchange_strong (&st->mode, &expect, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        unsigned gg = 0, total = 0, valid = 1;
-        if (mode == 1)
-        {
-            // every rank has been drawn: the XCD populations are final.  Global group number = groups of the XCDs before this one + r / 16
-            unsigned mine = 0;
-            for (unsigned x = 0; x < (unsigned) kGroupMaxXcc; ++x)
-            {
-                unsigned g = ld_relaxed (&st->xcc[x].count) / kGroupMembers;
-                g = g > (unsigned) kGroupMaxPerXcc ? (unsigned) kGroupMaxPerXcc : g;
-                if (x == xcc)
-                {
-                    gg = total + r / kGroupMembers;
-                    mine = g;
-                }
-                total += g;
-            }
-            valid = (r / kGroupMembers < mine) ? 1u : 0u; // a rank beyond the last complete group has nothing to do
-        }
-        info[0] = mode;
-        info[1] = xcc;
-        info[2] = r;
-        info[3] = gg;
-        info[4] = total;
-        info[5] = valid;
-    }
+        group_register (st, info, reg_polls, force_solo);
     __syncthreads();
     const unsigned mode = info[0];
 
@@ -402,5 +425,289 @@ __global__ __launch_bounds__ (256, 2) void group256_kernel (const float2* __rest
         // the slot is rewritten by the next frame's pass A only after the barrier at the loop top, which every wave reaches
         // with its pass-B loads consumed
     }
+}
+// =====================================================================================================
+// Fused convolution of N = 65536 complex frames in ONE launch on the same groups:
+//     y = BACKWARD (FORWARD (x) * H * scaling)          (the call sequence of reference test/test.cpp:161-166)
+// The backward transform is the four-step algorithm run the other way round, which lets it start where the forward one
+// ends: with n = a + 256 b and k = 256 ka + kb,
+//     y[a + 256 b] = sum_kb W_256^(-b kb) [ W_N^(-a kb) sum_ka Y[256 ka + kb] W_256^(-a ka) ]
+// and a pass-B work-item that has just produced X[256 ka + kb] for ka = tb + 16 b' of its row kb holds exactly the operands
+// -- in exactly the order -- that the inner sum over ka needs from it.  So per frame and member (tile T of every phase):
+//     A   columns of x -> slot (block T)                        hand-off 1 (as in group256_kernel)
+//     B   rows of the slot -> X;  * H * scaling;  inverse 256-point transform over ka in the same registers;
+//         * conj W_N^(a kb)  -> slot (block T again: a member only ever writes its own block)    hand-off 2
+//     A'  rows kb of the slot for 16 columns a -> inverse 256-point transform over kb -> y
+// The frame is read once and written once; the two intermediates stay in the XCD's L2 (written through, read back from L2).
+// H, both sets of inter-pass twiddles and the filter bins a work-item multiplies are the same for every frame: VGPRs.
+// Flags per frame: hand-off 1 stored / read, hand-off 2 stored / read (each member's counters; a block is rewritten only
+// after every member has read the previous contents out of it).  SOLO mode (fall-back, see above): two slots per workgroup.
+template <bool UNUSED = false>
+__global__ __launch_bounds__ (256, 2) void group256_conv_kernel (const float2* __restrict__ in,
+                                                                 float2* __restrict__ work, // max (kGroupSlotsTotal, 2 * gridDim.x) slots of 65536 float2
+                                                                 float2* __restrict__ out,
+                                                                 const float2* __restrict__ H,
+                                                                 const float2* __restrict__ stage_tw,
+                                                                 const float2* __restrict__ big_tw,
+                                                                 GroupState* __restrict__ st,
+                                                                 unsigned* __restrict__ host_err,
+                                                                 unsigned batch,
+                                                                 float scaling,
+                                                                 unsigned seq,
+                                                                 unsigned reg_polls,
+                                                                 unsigned force_solo)
+{
+    extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
+    __shared__ unsigned info[8];
+    __shared__ float2 tw1[15 * 16];
+    constexpr unsigned N = 65536;
+    const int tid = threadIdx.x;
+    const int lo = tid & 15, hi = tid >> 4;
+    if (tid < 240)
+        tw1[tid] = stage_tw[Plan256::tw_offset (1) + tid];
+    if (tid == 0)
+        group_register (st, info, reg_polls, force_solo);
+    __syncthreads();
+    const unsigned mode = info[0];
+
+// one tile of each phase, shared by both modes.  v in / out as described at the call sites.
+#define CFFT_GCONV_PASS_A(V, TILE, SLOT, BWA)                                                       \
+    {                                                                                               \
+        fft256_two_stage_lds (V, tw1, lo, smem, lo, hi, hi, lo);                                    \
+        _Pragma ("unroll") for (int b = 0; b < 16; ++b)                                             \
+            (SLOT)[(size_t) (TILE) * 4096u + b * 256 + tid] = cmul (V[b], BWA[b]);                  \
+    }
+// rows of the slot -> X -> * H -> inverse over ka -> * conj W: V[b'] = J'[kb = 16 TILE + lo][a = hi + 16 b'].  (SOLO mode only: the
+// filter bins and twiddles are fetched where they are used, behind a laundered index -- no early requests, no register cost)
+#define CFFT_GCONV_PASS_B(V, TILE)                                                                  \
+    {                                                                                               \
+        fft256_two_stage_lds (V, tw1, hi, smem, lo, hi, lo, hi);                                    \
+        int tq_ = tid;                                                                              \
+        CFFT_LAUNDER_INDEX (tq_);                                                                   \
+        _Pragma ("unroll") for (int b = 0; b < 16; ++b)                                             \
+        {                                                                                           \
+            const float2 h_ = H[(unsigned) ((tq_ >> 4) + 16 * b) * 256u + (TILE) * 16 + (tq_ & 15)]; \
+            const float2 y_ = cmul (V[b], make_float2 (h_.x * scaling, h_.y * scaling));            \
+            V[b] = make_float2 (y_.y, y_.x); /* swapped: operand of the inverse transform */        \
+        }                                                                                           \
+        fft256_two_stage_lds (V, tw1, hi, smem, lo, hi, lo, hi);                                    \
+        int tr_ = tid;                                                                              \
+        CFFT_LAUNDER_INDEX (tr_);                                                                   \
+        _Pragma ("unroll") for (int b = 0; b < 16; ++b)                                             \
+            V[b] = cmulc (make_float2 (V[b].y, V[b].x), big_tw[(size_t) b * 4096u + (TILE) * 256 + tr_]); \
+    }
+// rows kb of the slot for the tile's 16 columns (V[s] = J'[kb = lo + 16 s][a = 16 TILE + hi]) -> y[b = hi + 16 b'][a = 16 TILE + lo]
+#define CFFT_GCONV_PASS_A_INV(V, TILE, DST)                                                         \
+    {                                                                                               \
+        _Pragma ("unroll") for (int s = 0; s < 16; ++s)                                             \
+            V[s] = make_float2 (V[s].y, V[s].x);                                                    \
+        fft256_two_stage_lds (V, tw1, hi, smem, hi, lo, lo, hi);                                    \
+        _Pragma ("unroll") for (int b = 0; b < 16; ++b)                                             \
+            gstore (&(DST)[(unsigned) (hi + 16 * b) * 256u + (TILE) * 16 + lo], make_float2 (V[b].y, V[b].x)); \
+    }
+
+    if (mode == 1)
+    {
+        if (info[5] == 0)
+            return;
+        const unsigned xcc = info[1], r = info[2], gg = info[3], total = info[4];
+        const unsigned g = r / kGroupMembers, tile = r % kGroupMembers;
+        float2* __restrict__ slot = work + (size_t) ((xcc * kGroupMaxPerXcc + g) * 2u) * N;
+        unsigned* __restrict__ af = &st->aflag[xcc][g][0]; // stored: 2 k + 1 after hand-off 1, 2 k + 2 after hand-off 2 of frame k
+        unsigned* __restrict__ bf = &st->bflag[xcc][g][0]; // read:   the same counts
+        float2 bwa[16];
+#pragma unroll
+        for (int b = 0; b < 16; ++b)
+            bwa[b] = big_tw[(size_t) tile * 4096u + b * 256 + tid];        // W_N^(a kb), a = 16 tile + hi, kb = lo + 16 b
+        float nre[16], nim[16];
+        unsigned f = gg;
+        if (f < batch)
+            g256_load_a<false> (nre, nim, in + (size_t) f * N + tile * 16, hi, lo);
+        const int tid_outer = tid;
+        for (unsigned k = 0; f < batch; f += total, ++k)
+        {
+            // the work-item index is laundered per frame: otherwise the ~100 loop-invariant LDS / slot offsets of the three
+            // phases are lifted out of the frame loop and held (then spilled) for good (stockham.hpp, CFFT_LAUNDER_INDEX)
+            int tid = tid_outer;
+            CFFT_LAUNDER_INDEX (tid);
+            const int lo = tid & 15, hi = tid >> 4;
+            float2 v[16];
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                v[s] = make_float2 (nre[s], nim[s]);
+            // ---- A: columns [16 tile, 16 tile + 16) of frame f -> block `tile` of the slot
+            fft256_two_stage_lds (v, tw1, lo, smem, lo, hi, hi, lo);
+            if (k != 0)
+                group_wait<1> (bf, 2u * k, tid & 63, st, host_err, seq, 2u); // every member has read frame k - 1's second intermediate
+#pragma unroll
+            for (int b = 0; b < 16; ++b)
+                slot[(size_t) tile * 4096u + b * 256 + tid] = cmul (v[b], bwa[b]);
+            asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0)
+                flag_store (&af[tile], 2u * k + 1u);
+            if (tid < 64)
+                group_wait<2> (af, 2u * k + 1u, tid, st, host_err, seq, 1u);
+            __syncthreads();
+            // ---- B: rows [16 tile, 16 tile + 16)
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                v[s] = gload_l2 (&slot[(size_t) s * 4096u + tile * 256 + tid]);
+            CFFT_PHASE_FENCE();
+            fft_reg<16> (v);
+            __syncthreads(); // every wave's loads of the first intermediate have returned
+            if (tid == 0)
+                flag_store (&bf[tile], 2u * k + 1u);
+#pragma unroll
+            for (int b = 0; b < 16; ++b)
+                smem[lo * kFS256 + 17 * hi + b] = v[b];
+            __syncthreads();
+            // The member's filter bins (16 per work-item, the same for every frame) and its twiddles of the backward direction
+            // do not fit the registers next to the forward twiddles and the prefetched operands: they come from L2 per frame,
+            // requested HALF A TRANSFORM ahead of their use.  Their addresses hang on an index laundered at this point, so that
+            // the requests cannot be moved further up (with the requests at the phase's start the kernel spilled 94 registers).
+            int tq = tid;
+            CFFT_LAUNDER_INDEX (tq);
+            float2 hr[16];
+#pragma unroll
+            for (int b = 0; b < 16; ++b)
+                hr[b] = H[(unsigned) ((tq >> 4) + 16 * b) * 256u + tile * 16 + (tq & 15)]; // bin 256 ka + kb, ka = hi + 16 b, kb = 16 tile + lo
+#pragma unroll
+            for (int a = 0; a < 16; ++a)
+                v[a] = smem[lo * kFS256 + hi + 17 * a];
+#pragma unroll
+            for (int a = 1; a < 16; ++a)
+                v[a] = cmul (v[a], tw1[(a - 1) * 16 + hi]);
+            fft_reg<16> (v);
+#pragma unroll
+            for (int b = 0; b < 16; ++b)
+            {
+                const float2 y = cmul (v[b], make_float2 (hr[b].x * scaling, hr[b].y * scaling));
+                v[b] = make_float2 (y.y, y.x); // swapped: operand of the inverse transform over ka
+            }
+            // the inverse 256-point transform over ka, in the same roles (fft256_two_stage_lds opened up for the requests)
+            fft_reg<16> (v);
+            __syncthreads();
+#pragma unroll
+            for (int b = 0; b < 16; ++b)
+                smem[lo * kFS256 + 17 * hi + b] = v[b];
+            __syncthreads();
+            int tr = tid;
+            CFFT_LAUNDER_INDEX (tr);
+            float2 bwb[16];
+#pragma unroll
+            for (int b = 0; b < 16; ++b)
+                bwb[b] = big_tw[(size_t) b * 4096u + tile * 256 + tr]; // W_N^(a kb), a = hi + 16 b, kb = 16 tile + lo
+#pragma unroll
+            for (int a = 0; a < 16; ++a)
+                v[a] = smem[lo * kFS256 + hi + 17 * a];
+#pragma unroll
+            for (int a = 1; a < 16; ++a)
+                v[a] = cmul (v[a], tw1[(a - 1) * 16 + hi]);
+            fft_reg<16> (v);
+            group_wait<1> (bf, 2u * k + 1u, tid & 63, st, host_err, seq, 3u); // every member has read the first intermediate
+#pragma unroll
+            for (int b = 0; b < 16; ++b)
+                slot[(size_t) tile * 4096u + b * 256 + tid] = cmulc (make_float2 (v[b].y, v[b].x), bwb[b]);
+            asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0)
+                flag_store (&af[tile], 2u * k + 2u);
+            if (tid < 64)
+                group_wait<2> (af, 2u * k + 2u, tid, st, host_err, seq, 4u);
+            __syncthreads();
+            // ---- A': rows kb of the second intermediate for columns [16 tile, 16 tile + 16) -> y
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+            {
+                const float2 x = gload_l2 (&slot[(size_t) s * 4096u + tile * 256 + tid]);
+                v[s] = make_float2 (x.y, x.x);
+            }
+            // the next frame's pass-A operands, behind these loads and ahead of this phase's arithmetic and stores (the filter
+            // bins and these operands do not fit the registers together: hence here and not behind the pass-B loads)
+            const unsigned fn = f + total;
+            if (fn < batch)
+                g256_load_a<false> (nre, nim, in + (size_t) fn * N + tile * 16, hi, lo);
+            CFFT_PHASE_FENCE();
+            fft_reg<16> (v);
+            __syncthreads(); // every wave's loads of the second intermediate have returned
+            if (tid == 0)
+                flag_store (&bf[tile], 2u * k + 2u);
+#pragma unroll
+            for (int b = 0; b < 16; ++b)
+                smem[hi * kFS256 + 17 * lo + b] = v[b];
+            __syncthreads();
+#pragma unroll
+            for (int a = 0; a < 16; ++a)
+                v[a] = smem[lo * kFS256 + hi + 17 * a];
+#pragma unroll
+            for (int a = 1; a < 16; ++a)
+                v[a] = cmul (v[a], tw1[(a - 1) * 16 + hi]);
+            fft_reg<16> (v);
+            float2* __restrict__ dst = out + (size_t) f * N;
+#pragma unroll
+            for (int b = 0; b < 16; ++b)
+                gstore (&dst[(unsigned) (hi + 16 * b) * 256u + tile * 16 + lo], make_float2 (v[b].y, v[b].x));
+        }
+        return;
+    }
+
+    // ---- SOLO mode: whole frames by one workgroup, two slots of its own (first and second intermediate)
+    float2* __restrict__ s1 = work + (size_t) (2u * blockIdx.x) * N;
+    float2* __restrict__ s2 = s1 + N;
+    for (;;)
+    {
+        __syncthreads();
+        if (tid == 0)
+            info[6] = __hip_atomic_fetch_add (&st->next_frame, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned f = info[6];
+        if (f >= batch)
+            break;
+#pragma unroll 1
+        for (unsigned tile = 0; tile < 16; ++tile)
+        {
+            float re[16], im[16];
+            g256_load_a<false> (re, im, in + (size_t) f * N + tile * 16, hi, lo);
+            float2 bwa[16];
+#pragma unroll
+            for (int b = 0; b < 16; ++b)
+                bwa[b] = big_tw[(size_t) tile * 4096u + b * 256 + tid];
+            float2 v[16];
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                v[s] = make_float2 (re[s], im[s]);
+            CFFT_GCONV_PASS_A (v, tile, s1, bwa)
+        }
+        asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll 1
+        for (unsigned tile = 0; tile < 16; ++tile)
+        {
+            float2 v[16];
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                v[s] = gload_l2 (&s1[(size_t) s * 4096u + tile * 256 + tid]);
+            CFFT_GCONV_PASS_B (v, tile)
+#pragma unroll
+            for (int b = 0; b < 16; ++b)
+                s2[(size_t) tile * 4096u + b * 256 + tid] = v[b];
+        }
+        asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll 1
+        for (unsigned tile = 0; tile < 16; ++tile)
+        {
+            float2 v[16];
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                v[s] = gload_l2 (&s2[(size_t) s * 4096u + tile * 256 + tid]);
+            float2* __restrict__ dst = out + (size_t) f * N;
+            CFFT_GCONV_PASS_A_INV (v, tile, dst)
+        }
+    }
+#undef CFFT_GCONV_PASS_A
+#undef CFFT_GCONV_PASS_B
+#undef CFFT_GCONV_PASS_A_INV
 }
 } // namespace cfft

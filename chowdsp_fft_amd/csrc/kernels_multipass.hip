@@ -443,11 +443,17 @@ void set_group_options (int force_solo, int reg_polls)
     if (reg_polls >= 0)
         g_group_reg_polls = reg_polls;
 }
+void get_group_options (int& force_solo, int& reg_polls)
+{
+    force_solo = g_group_force_solo.load();
+    reg_polls = g_group_reg_polls.load();
+}
+int group_wg_per_cu_tenths() { return group_wg_per_cu_x10(); }
 size_t group_state_bytes() { return sizeof (GroupState); }
 size_t group_workspace_bytes()
 {
-    // GROUP mode addresses kGroupSlotsTotal slots, SOLO mode one per workgroup of the grid
-    const unsigned grid = std::max (group_grid (false), group_grid (true));
+    // GROUP mode addresses kGroupSlotsTotal slots; SOLO mode one per workgroup of the grid (the fused convolution: two)
+    const unsigned grid = std::max (std::max (group_grid (false), group_grid (true)), 2u * group_conv_grid());
     return (size_t) std::max<unsigned> (kGroupSlotsTotal, grid) * 65536u * sizeof (float2);
 }
 hipError_t launch_group_c2c (int n1, int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, void* state, unsigned* host_err, unsigned seq, size_t batch, hipStream_t stream, size_t in_stride, size_t out_stride)

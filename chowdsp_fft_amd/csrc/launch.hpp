@@ -84,6 +84,10 @@ hipError_t launch_fused_c2c (int n1, int n2, bool inverse, const float2* in, flo
 size_t group_state_bytes();
 void set_group_options (int force_solo, int reg_polls); // -1 = leave as it is
 size_t group_workspace_bytes();
+void get_group_options (int& force_solo, int& reg_polls);
+int group_wg_per_cu_tenths();
+unsigned group_conv_grid(); // workgroups of the fused-convolution form's launch (kernels_group_conv.hip)
+hipError_t launch_group_conv (const float2* in, const float2* H, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, void* state, unsigned* host_err, unsigned seq, float scaling, size_t batch, hipStream_t stream);
 hipError_t launch_group_c2c (int n1, int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, void* state, unsigned* host_err, unsigned seq, size_t batch, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
 // long mixed-radix frames (t.mixed_n2 > 0): generic column pass + power-of-two row pass, in -> work -> out
 hipError_t launch_mixed_big_c2c (const DeviceTables& t, bool inverse, const float2* in, float2* work, float2* out, size_t batch, int grid_divisor, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);

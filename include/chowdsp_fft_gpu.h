@@ -86,12 +86,14 @@ int fft_gpu_release_stream_resources (void* stream);
                         the one-launch split-plane form (A/B switch; default 1)
      "fused_conv_generic" 0: fft_convolve_frames_batch of mixed-radix frames (up to 20000 complex points) as three launches
                         instead of the one-launch form (A/B switch; default 1)
+     "fused_conv_group" 0: fft_convolve_frames_batch of N = 65536 complex frames (batches of at least "fused_min_batch") as three
+                        launches instead of one launch on the static groups of "fused_two_pass" = 2 (A/B switch; default 1)
      "conv_wave2048"    1: fft_convolve_frames_batch of 2048-point cores by one wavefront per frame; 12-14 % slower than
                         the workgroup plan, default 0
    Returns 0, or FFT_GPU_EINVAL for an unknown name / a value out of range. */
 int fft_gpu_set_option (const char* name, long value);
 /* Current value of an option ("fused_two_pass", "fused_min_batch", "fused_lag", "fused_slots", "split16384", "split8192",
-   "conv_wave2048", "fused_conv_split", "fused_conv_generic"), or -1 for a name that cannot be read back. */
+   "conv_wave2048", "fused_conv_split", "fused_conv_generic", "fused_conv_group"), or -1 for a name that cannot be read back. */
 long fft_gpu_get_option (const char* name);
 
 /* ---- plan introspection -------------------------------------------------------------------------- */

@@ -121,3 +121,45 @@ def test_set_option_rejects_nonsense(gpu):
         api.set_option("no_such_option", 1)
     with pytest.raises(api.FFTError):
         api.set_option("fused_lag", 99)
+
+
+@pytest.mark.parametrize("solo", [0, 1])
+@pytest.mark.parametrize("batch", [1, 2, 31, 70])
+def test_group_convolution_n65536(gpu, oracle, batch, solo):
+    """fft_convolve_frames_batch of N = 65536 complex frames in ONE launch on the static groups (forward passes A and B, the
+    product, the backward transform started in pass B's registers, its second pass), in GROUP mode and in the fall-back mode,
+    == the three-launch composition == the oracle's call sequence (reference test/test.cpp:161-166)."""
+    api, torch, dev = gpu
+    default_min = int(api.get_option("fused_min_batch"))
+    assert api.get_option("fused_two_pass") == 2 and api.get_option("fused_conv_group") == 1
+    api.set_option("fused_min_batch", 1)
+    api.set_option("group_force_solo", solo)
+    try:
+        s, so = api.fft_new_setup(N, api.FFT_COMPLEX), oracle.new_setup(N, COMPLEX)
+        x = ol.uniform(batch * 2 * N, 1300 + batch).reshape(batch, 2 * N)
+        h = ol.uniform(2 * N, 77).reshape(1, 2 * N)
+        xd, hd = torch.from_numpy(x).to(dev), torch.from_numpy(h).to(dev)
+        H = torch.empty_like(hd)
+        api.fft_transform_unordered_batch(s, hd, H, api.FFT_FORWARD)
+        one = torch.full_like(xd, -3.0)
+        api.fft_convolve_frames_batch(s, xd, H, one, 1.0 / N)
+        api.stream_synchronize()
+        api.set_option("fused_conv_group", 0)
+        three = torch.full_like(xd, -5.0)
+        api.fft_convolve_frames_batch(s, xd, H, three, 1.0 / N)
+        api.set_option("fused_conv_group", 1)
+        inplace = xd.clone()
+        api.fft_convolve_frames_batch(s, inplace, H, inplace, 1.0 / N)  # a member reads its columns of a frame before anybody writes it
+        api.stream_synchronize()
+        assert_frames_close(one.cpu().numpy(), three.cpu().numpy(), tol=3e-7, maxabs_tol=1e-6, what="one launch vs three launches")
+        assert np.array_equal(inplace.cpu().numpy(), one.cpu().numpy()), "in place == out of place"
+        hb = oracle.transform(so, h[0], FORWARD, False)
+        pick = sorted({0, batch // 2, batch - 1})
+        want = np.stack([oracle.transform(so, oracle.convolve(so, oracle.transform(so, x[i], FORWARD, False), hb, np.zeros(2 * N, np.float32), 1.0 / N), BACKWARD, False) for i in pick])
+        assert_frames_close(one.cpu().numpy()[pick], want, what="fused convolution vs the oracle's call sequence")
+        api.fft_destroy_setup(s)
+        oracle.destroy_setup(so)
+    finally:
+        api.set_option("group_force_solo", 0)
+        api.set_option("fused_min_batch", default_min)
+        api.set_option("fused_conv_group", 1)

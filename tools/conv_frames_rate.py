@@ -20,14 +20,15 @@ _w = torch.rand((1 << 26,), device=dev)
 for _ in range(200):  # idle clocks: the first milliseconds run 10-25 % slow
     _w.mul_(1.0001)
 torch.cuda.synchronize()
-for form, opt in (("one launch where fused", 1), ("three launches (fused_conv_split = fused_conv_generic = 0)", 0)):
+for form, opt in (("one launch where fused", 1), ("three launches (fused_conv_split = fused_conv_generic = fused_conv_group = 0)", 0)):
     api.set_option("fused_conv_split", opt)
     api.set_option("fused_conv_generic", opt)
+    api.set_option("fused_conv_group", opt)
     print(f"# {form}")
     for sz in sizes:
         real, n = sz[0] == "r", int(sz[1:])
         nf = n if real else 2 * n
-        batch = max(1, (1 << 28) // nf)  # 1 GiB in + 1 GiB out
+        batch = max(1, (1 << (30 if n >= 65536 else 28)) // nf)  # 1 GiB in + 1 GiB out (4 GiB each for the two-pass sizes)
         s = api.fft_new_setup(n, api.FFT_REAL if real else api.FFT_COMPLEX)
         x = torch.rand((batch, nf), device=dev) * 2 - 1
         h = torch.rand((1, nf), device=dev) * 2 - 1
