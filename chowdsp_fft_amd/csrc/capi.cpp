@@ -150,8 +150,11 @@ struct Lanes
     // library synchronisation of the stream (fft_gpu_stream_synchronize, fft_gpu_release_stream_resources, the legacy calls)
     unsigned* fused_err_host = nullptr;
     unsigned fused_seq = 0; // launches so far on this (device, stream)
+    // frames beyond 2^21 complex points: one frame of workspace for the transposes
+    float2* huge_ws = nullptr;
+    size_t huge_ws_bytes = 0;
 };
-std::mutex g_ws_mutex;
+std::recursive_mutex g_ws_mutex; // (recursive: a frame beyond 2^21 points runs its factors' two-pass plans while it holds the lock)
 std::map<std::pair<int, hipStream_t>, Lanes> g_lanes;
 
 // CHOWDSP_FFT_PAIR_CHUNK_DIV: how much smaller the chunks of long REAL transforms are than those of complex ones.
@@ -315,7 +318,7 @@ std::string fused_error_text (unsigned word)
 // Takes the report (the word is cleared).  0 = no.
 unsigned take_fused_error (hipStream_t stream)
 {
-    std::lock_guard<std::mutex> lock (g_ws_mutex);
+    std::lock_guard<std::recursive_mutex> lock (g_ws_mutex);
     unsigned word = 0;
     for (auto& kv : g_lanes)
         if (kv.first.second == stream && kv.second.fused_err_host != nullptr && *kv.second.fused_err_host != 0)
@@ -404,7 +407,7 @@ int big_c2c_chunked (Setup* s, int nc, bool inverse, const float2* in, float2* o
     if (! mixed && pair == 0 && fused_enabled() && fused_supported (n1, n2) && batch >= fused_min_batch())
     {
         // both passes in one launch, hand-off inside an XCD's L2: no chunking, no lanes, 1.5 x instead of 2 x the traffic
-        std::lock_guard<std::mutex> lock (g_ws_mutex);
+        std::lock_guard<std::recursive_mutex> lock (g_ws_mutex);
         const bool groups = fused_form() == 2;
         const int lag = fused_lag(), slots = fused_slots();
         Lanes* L = get_fused (s->device, stream, groups ? group_workspace_bytes() : fused_workspace_bytes (nc, slots));
@@ -441,7 +444,7 @@ int big_c2c_chunked (Setup* s, int nc, bool inverse, const float2* in, float2* o
     // One enqueue sequence at a time per process: concurrent host threads sharing a stream (e.g. legacy calls on the
     // default stream) must not interleave "pass A -> workspace -> pass B" of different calls on the same workspace.
     // Only the (microseconds of) enqueueing is serialised; execution order then follows from stream order.
-    std::lock_guard<std::mutex> lock (g_ws_mutex);
+    std::lock_guard<std::recursive_mutex> lock (g_ws_mutex);
     Lanes* L = get_lanes (s->device, stream, chunk * frame_bytes);
     if (L == nullptr)
         return cf::FFT_GPU_ENOMEM;
@@ -504,7 +507,7 @@ int big_real4_chunked (Setup* s, bool inverse, const float2* in, float2* out, si
         chunk = 1;
     if (chunk > batch)
         chunk = batch;
-    std::lock_guard<std::mutex> lock (g_ws_mutex);
+    std::lock_guard<std::recursive_mutex> lock (g_ws_mutex);
     Lanes* L = get_lanes (s->device, stream, chunk * frame_bytes);
     if (L == nullptr)
         return cf::FFT_GPU_ENOMEM;
@@ -542,6 +545,100 @@ int big_real4_chunked (Setup* s, bool inverse, const float2* in, float2* out, si
     return cf::FFT_GPU_OK;
 }
 
+int run_transform (Setup* s, const float* in, float* out, size_t batch, cf::fft_direction_t dir, hipStream_t stream, size_t in_stride, size_t out_stride);
+
+// Frames beyond 2^21 complex points (tables.hpp split_huge; the reference has no upper bound, simd/chowdsp_fft_impl_common.hpp:168-177):
+// N = R x C, the frame as an [R][C] matrix (n = r C + c, k = kr + R kc):
+//     X[kr + R kc] = sum_c W_C^(c kc) [ W_N^(c kr) sum_r x[r C + c] W_R^(r kr) ]
+// as  transpose -> C batched R-point transforms (the factor's own plan, whatever form it takes) -> transpose with the twiddle ->
+// R batched C-point transforms -> transpose.  Five sweeps over a frame of at least 32 MiB: completeness, not speed (0.05-0.08 of
+// the HBM roofline).  One frame of workspace per (device, stream); real frames add the stand-alone pair stage.
+int huge_transform (Setup* s, bool inverse, const float2* in, float2* out, size_t batch, hipStream_t stream, size_t is2, size_t os2)
+{
+    const DeviceTables* t = s->tables;
+    const unsigned R = (unsigned) t->huge_r, C = (unsigned) t->huge_c;
+    const size_t nc = (size_t) R * C;
+    const bool real = s->transform == cf::FFT_REAL;
+    Setup plan_r { kMagic, (int) R, (int) cf::FFT_COMPLEX, s->device, nullptr, t->huge_plan_r };
+    Setup plan_c { kMagic, (int) C, (int) cf::FFT_COMPLEX, s->device, nullptr, t->huge_plan_c };
+    const cf::fft_direction_t dir = inverse ? cf::FFT_BACKWARD : cf::FFT_FORWARD;
+    std::lock_guard<std::recursive_mutex> lock (g_ws_mutex);
+    Lanes& L = g_lanes[std::make_pair (s->device, stream)];
+    if (L.huge_ws_bytes < nc * sizeof (float2))
+    {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing (stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+        {
+            set_last_error ("workspace would have to be allocated during stream capture: run the same call once outside the capture first");
+            return cf::FFT_GPU_ENOMEM;
+        }
+        if (L.huge_ws != nullptr)
+        {
+            (void) hipStreamSynchronize (stream);
+            (void) hipFree (L.huge_ws);
+        }
+        L.huge_ws = nullptr;
+        L.huge_ws_bytes = 0;
+        if (hipMalloc ((void**) &L.huge_ws, nc * sizeof (float2)) != hipSuccess)
+        {
+            L.huge_ws = nullptr;
+            set_last_error ("workspace allocation failed");
+            return cf::FFT_GPU_ENOMEM;
+        }
+        L.huge_ws_bytes = nc * sizeof (float2);
+    }
+    float2* W = L.huge_ws;
+    for (size_t f = 0; f < batch; ++f)
+    {
+        const float2* x = in + f * is2;
+        float2* y = out + f * os2;
+        hipError_t e = hipSuccess;
+        if (real && inverse)
+        {
+            // packed spectrum -> Z (pair stage), then the complex backward transform of Z in place
+            e = launch_real_pair (false, x, y, t->real_twiddles, (unsigned) nc, 1, stream, is2, os2);
+            x = y;
+        }
+        float2* A = (x != y) ? y : W; // first intermediate; the second one is the other buffer
+        float2* B = (A == y) ? W : y;
+        if (e == hipSuccess)
+            e = launch_transpose (x, A, R, C, 0, nullptr, nullptr, 0, stream);
+        if (e != hipSuccess)
+        {
+            set_last_error ("kernel launch (frame beyond 2^21 points)", e);
+            return cf::FFT_GPU_ELAUNCH;
+        }
+        int rc = run_transform (&plan_r, (const float*) A, (float*) A, C, dir, stream, 0, 0);
+        if (rc != cf::FFT_GPU_OK)
+            return rc;
+        e = launch_transpose (A, B, C, R, inverse ? -1 : +1, t->huge_tw_lo, t->huge_tw_hi, (unsigned) t->huge_shift, stream);
+        if (e != hipSuccess)
+        {
+            set_last_error ("kernel launch (frame beyond 2^21 points)", e);
+            return cf::FFT_GPU_ELAUNCH;
+        }
+        rc = run_transform (&plan_c, (const float*) B, (float*) B, R, dir, stream, 0, 0);
+        if (rc != cf::FFT_GPU_OK)
+            return rc;
+        if (B == W)
+            e = launch_transpose (B, y, R, C, 0, nullptr, nullptr, 0, stream);
+        else
+        {
+            e = launch_transpose (B, W, R, C, 0, nullptr, nullptr, 0, stream);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync (y, W, nc * sizeof (float2), hipMemcpyDeviceToDevice, stream);
+        }
+        if (e == hipSuccess && real && ! inverse)
+            e = launch_real_pair (true, y, y, t->real_twiddles, (unsigned) nc, 1, stream, os2, os2);
+        if (e != hipSuccess)
+        {
+            set_last_error ("kernel launch (frame beyond 2^21 points)", e);
+            return cf::FFT_GPU_ELAUNCH;
+        }
+    }
+    return cf::FFT_GPU_OK;
+}
+
 // in_stride / out_stride: floats between consecutive frames (0 = packed); validated by the caller
 int run_transform (Setup* s, const float* in, float* out, size_t batch, cf::fft_direction_t dir, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0)
 {
@@ -565,6 +662,8 @@ int run_transform (Setup* s, const float* in, float* out, size_t batch, cf::fft_
     // strides in float2, always explicit from here on
     const size_t is2 = in_stride ? in_stride / 2 : (size_t) nc, os2 = out_stride ? out_stride / 2 : (size_t) nc;
     hipError_t e = hipSuccess;
+    if (t->huge_r > 0)
+        return huge_transform (s, inverse, cin, cout, batch, stream, is2, os2);
     if (t->real4_r1 > 0)
         return big_real4_chunked (s, inverse, cin, cout, batch, stream, is2, os2);
     if (t->mixed_n2 > 0)
@@ -1150,6 +1249,18 @@ int fft_gpu_plan_describe (int N, fft_transform_t transform, int desc[8])
         return FFT_GPU_EINVAL;
     const int nc = (transform == FFT_COMPLEX) ? N : N / 2;
     int q1 = 0, q2 = 0;
+    if (nc > cfft::host::kMaxComplexLen)
+    {
+        // beyond 2^21 complex points: the plans of two factors + three transposes ("3": more than two passes through device memory)
+        if (! split_huge (nc, q1, q2))
+            return FFT_GPU_EINVAL;
+        desc[0] = nc;
+        desc[1] = 3;
+        desc[2] = q1;
+        desc[3] = q2;
+        desc[4] = desc[5] = desc[6] = desc[7] = 0;
+        return FFT_GPU_OK;
+    }
     if (transform == FFT_REAL && split_real4 (N, q1, q2))
     {
         // long real frame: the four-step algorithm on the N real samples themselves, N = q1 x q2 (rows x columns)
@@ -1264,7 +1375,7 @@ int fft_gpu_release_stream_resources (void* stream)
     // what the two-pass plans cached for (any device, this stream): two helper streams, three events, the workspaces, the
     // one-launch form's queue state.  Call it before destroying a stream (a re-used handle would inherit the entry) or to
     // give the memory back; the next two-pass call on the stream builds a fresh set.
-    std::lock_guard<std::mutex> lock (g_ws_mutex);
+    std::lock_guard<std::recursive_mutex> lock (g_ws_mutex);
     int released = 0;
     unsigned pending_error = 0;
     for (auto it = g_lanes.begin(); it != g_lanes.end();)
@@ -1302,6 +1413,8 @@ int fft_gpu_release_stream_resources (void* stream)
             (void) hipFree (L.fused_state);
         if (L.fused_err_host != nullptr)
             (void) hipHostFree (L.fused_err_host);
+        if (L.huge_ws != nullptr)
+            (void) hipFree (L.huge_ws);
         it = g_lanes.erase (it);
         ++released;
     }
@@ -1407,6 +1520,13 @@ size_t fft_gpu_workspace_bytes (void* setup, size_t batch)
     Setup* s = as_setup (setup);
     if (s == nullptr || s->tables->core_n == complex_len (s) || (s->tables->gen_ns > 0 && s->tables->mixed_n2 == 0))
         return 0;
+    if (s->tables->huge_r > 0)
+    {
+        // one frame for the transposes + what the two factors' plans cache for their batches of huge_c / huge_r frames
+        Setup plan_r { kMagic, s->tables->huge_r, (int) FFT_COMPLEX, s->device, nullptr, s->tables->huge_plan_r };
+        Setup plan_c { kMagic, s->tables->huge_c, (int) FFT_COMPLEX, s->device, nullptr, s->tables->huge_plan_c };
+        return (size_t) complex_len (s) * sizeof (float2) + std::max (fft_gpu_workspace_bytes (&plan_r, (size_t) s->tables->huge_c), fft_gpu_workspace_bytes (&plan_c, (size_t) s->tables->huge_r));
+    }
     const size_t frame_bytes = workspace_frame_bytes (s->tables, complex_len (s));
     int n1 = 0, n2 = 0;
     if (s->tables->mixed_n2 == 0)
@@ -1557,7 +1677,7 @@ int fft_convolve_frames_batch (void* setup, const float* x, const float* dft_fil
     if (s->transform == FFT_COMPLEX && nc == 65536 && t->fast_n1 == 0 && t->mixed_n2 == 0 && fused_form() == 2 && batch >= fused_min_batch() && g_fused_conv_group.load() != 0)
     {
         // N = 65536 complex: both transforms and the product in ONE launch on the static groups (group_twopass_kernels.hpp)
-        std::lock_guard<std::mutex> lock (g_ws_mutex);
+        std::lock_guard<std::recursive_mutex> lock (g_ws_mutex);
         Lanes* L = get_fused (s->device, (hipStream_t) stream, group_workspace_bytes());
         if (L == nullptr)
             return FFT_GPU_ENOMEM;

@@ -125,6 +125,20 @@ const DeviceTables* acquire_column_tables (int device, int rows)
 
 const DeviceTables* acquire_tables (int device, int N, int transform)
 {
+    // a frame beyond 2^21 complex points is transformed through the plans of its two factors: acquired first (the cache lock is
+    // not recursive), complex plans both
+    const DeviceTables *sub_r = nullptr, *sub_c = nullptr;
+    {
+        const int nc = (transform == 0) ? N / 2 : N;
+        int hr = 0, hc = 0;
+        if (nc > kMaxComplexLen && size_supported (N, transform) && split_huge (nc, hr, hc))
+        {
+            sub_r = acquire_tables (device, hr, 1);
+            sub_c = acquire_tables (device, hc, 1);
+            if (sub_r == nullptr || sub_c == nullptr)
+                return nullptr;
+        }
+    }
     std::lock_guard<std::mutex> lock (g_cache_mutex);
     const auto key = std::make_tuple (device, N, transform);
     auto it = g_tables.find (key);
@@ -161,10 +175,18 @@ const DeviceTables* acquire_tables (int device, int N, int transform)
         t->gen2_radix[i] = h.generic2_radix[(size_t) i];
         t->gen2_tw_offset[i] = h.generic2_tw_offset[(size_t) i];
     }
+    t->huge_r = h.huge_r;
+    t->huge_c = h.huge_c;
+    t->huge_shift = h.huge_shift;
+    t->huge_plan_r = sub_r;
+    t->huge_plan_c = sub_c;
+    t->huge_tw_lo = upload (h.huge_tw_lo);
+    t->huge_tw_hi = upload (h.huge_tw_hi);
     t->stage_twiddles = upload (h.stage_twiddles);
     t->real_twiddles = upload (h.real_twiddles);
     t->big_twiddles = upload (h.big_twiddles);
     if ((! h.stage_twiddles.empty() && t->stage_twiddles == nullptr)
+        || (! h.huge_tw_lo.empty() && (t->huge_tw_lo == nullptr || t->huge_tw_hi == nullptr))
         || (! h.real_twiddles.empty() && t->real_twiddles == nullptr)
         || (! h.big_twiddles.empty() && t->big_twiddles == nullptr))
     {
@@ -172,6 +194,8 @@ const DeviceTables* acquire_tables (int device, int N, int transform)
         (void) hipFree (t->stage_twiddles);
         (void) hipFree (t->real_twiddles);
         (void) hipFree (t->big_twiddles);
+        (void) hipFree (t->huge_tw_lo);
+        (void) hipFree (t->huge_tw_hi);
         delete t;
         return nullptr;
     }

@@ -60,6 +60,13 @@ struct DeviceTables
     int gen2_ns = 0;
     int gen2_radix[10] = { 0 };
     int gen2_tw_offset[10] = { 0 };
+    // frames beyond 2^21 complex points: huge_r x huge_c (tables.hpp split_huge); the two factors' own plans, and the two-level
+    // table of W_N^j = huge_tw_hi[j >> huge_shift] * huge_tw_lo[j & mask]
+    int huge_r = 0, huge_c = 0, huge_shift = 0;
+    const DeviceTables* huge_plan_r = nullptr;
+    const DeviceTables* huge_plan_c = nullptr;
+    float2* huge_tw_lo = nullptr;
+    float2* huge_tw_hi = nullptr;
 };
 
 // The plan header.  Lives either in a block we allocated (fft_new_setup) or in caller memory

@@ -6,6 +6,7 @@
 // same conversions run on a whole batch of 2N-float device buffers.
 #include "butterflies.hpp"
 #include "launch.hpp"
+#include "launch_util.hpp"
 
 #include <algorithm>
 
@@ -114,6 +115,68 @@ hipError_t launch_scale (float* data, size_t count, float scale, hipStream_t str
     if (grid == 0)
         return hipErrorNoDevice;
     hipLaunchKernelGGL (scale_kernel, dim3 (grid), dim3 (256), 0, stream, (float4*) data, count / 4, scale);
+    return hipGetLastError();
+}
+
+// ---- frames beyond 2^21 complex points (capi.cpp: huge_transform): tiled transposes of one [rows][cols] complex matrix --------
+// out[c][r] = in[r][c] (* W_N^(r c) or its conjugate for the twiddled form).  32 x 32 tiles through LDS, both sides move 256
+// contiguous bytes per 32 lanes; rows and cols are multiples of 16 (accepted frame lengths), edges are masked.
+// W_N^j = hi[j >> shift] * lo[j & mask]: two tables of about sqrt(N) entries instead of N (tables.cpp).
+namespace
+{
+template <int TW> // 0 plain, 1 times W_N^(r c), 2 times its conjugate
+__global__ __launch_bounds__ (256) void transpose_kernel (const float2* __restrict__ in, float2* __restrict__ out, unsigned rows, unsigned cols,
+                                                         const float2* __restrict__ lo, const float2* __restrict__ hi, unsigned shift)
+{
+    __shared__ float2 tile[32][33];
+    const unsigned tx = threadIdx.x & 31u, ty = threadIdx.x >> 5; // 32 x 8
+    const unsigned tiles_c = (cols + 31u) / 32u;
+    const size_t ntiles = (size_t) tiles_c * ((rows + 31u) / 32u);
+    for (size_t t = blockIdx.x; t < ntiles; t += gridDim.x)
+    {
+        const unsigned r0 = (unsigned) (t / tiles_c) * 32u, c0 = (unsigned) (t % tiles_c) * 32u;
+        __syncthreads();
+#pragma unroll
+        for (unsigned j = 0; j < 32u; j += 8u)
+        {
+            const unsigned r = r0 + ty + j, c = c0 + tx;
+            if (r < rows && c < cols)
+            {
+                float2 x = in[(size_t) r * cols + c];
+                if (TW != 0)
+                {
+                    const unsigned long long jj = (unsigned long long) r * c; // < N <= 2^27
+                    const float2 wl = lo[jj & ((1ull << shift) - 1ull)], wh = hi[jj >> shift];
+                    const float2 w = make_float2 (wl.x * wh.x - wl.y * wh.y, wl.x * wh.y + wl.y * wh.x);
+                    x = (TW == 1) ? make_float2 (x.x * w.x - x.y * w.y, x.x * w.y + x.y * w.x)
+                                  : make_float2 (x.x * w.x + x.y * w.y, x.y * w.x - x.x * w.y);
+                }
+                tile[ty + j][tx] = x;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (unsigned j = 0; j < 32u; j += 8u)
+        {
+            const unsigned c = c0 + ty + j, r = r0 + tx;
+            if (r < rows && c < cols)
+                out[(size_t) c * rows + r] = tile[tx][ty + j];
+        }
+    }
+}
+} // namespace
+
+// out[c][r] = in[r][c] for ONE [rows][cols] matrix; twiddle 0 none, +1 times W_N^(r c), -1 times its conjugate (N = rows * cols)
+hipError_t launch_transpose (const float2* in, float2* out, unsigned rows, unsigned cols, int twiddle, const float2* tw_lo, const float2* tw_hi, unsigned shift, hipStream_t stream)
+{
+    if (rows == 0 || cols == 0 || in == out)
+        return hipErrorInvalidValue;
+    const size_t ntiles = (size_t) ((cols + 31u) / 32u) * ((rows + 31u) / 32u);
+    auto k = twiddle == 0 ? transpose_kernel<0> : (twiddle > 0 ? transpose_kernel<1> : transpose_kernel<2>);
+    const unsigned grid = persistent_grid (k, 256, 0, ntiles);
+    if (grid == 0)
+        return hipErrorNoDevice;
+    hipLaunchKernelGGL (k, dim3 (grid), dim3 (256), 0, stream, in, out, rows, cols, tw_lo, tw_hi, shift);
     return hipGetLastError();
 }
 } // namespace cfft::host

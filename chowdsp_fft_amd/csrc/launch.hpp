@@ -111,6 +111,9 @@ hipError_t launch_real_juce (int m, bool forward, float2* inout, const float2* s
 hipError_t launch_juce_unpack (float2* data, unsigned m, size_t batch, bool mirror, hipStream_t stream);
 hipError_t launch_juce_pack_scale (float2* data, unsigned m, size_t batch, float scale, hipStream_t stream);
 hipError_t launch_scale (float* data, size_t count, float scale, hipStream_t stream); // count % 4 == 0
+// out[c][r] = in[r][c] for one [rows][cols] complex matrix (frames beyond 2^21 points); twiddle 0 none, +1 times W_N^(r c),
+// -1 times its conjugate, N = rows * cols, W_N^j = tw_hi[j >> shift] * tw_lo[j & ((1 << shift) - 1)]; in != out
+hipError_t launch_transpose (const float2* in, float2* out, unsigned rows, unsigned cols, int twiddle, const float2* tw_lo, const float2* tw_hi, unsigned shift, hipStream_t stream);
 
 // shared by the kernels_*.hip files
 int blocks_per_cu_cached (const void* kernel, int threads, size_t lds_bytes);

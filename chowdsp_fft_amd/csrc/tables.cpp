@@ -144,6 +144,28 @@ static bool is_235_smooth (int n)
 
 static constexpr int kGenericMaxComplexLen = 20000; // = cfft::kGenericMaxN (one LDS image per workgroup, in-place stages)
 
+bool split_huge (int n_complex, int& r, int& c)
+{
+    r = c = 0;
+    if (n_complex <= kMaxComplexLen || n_complex > kMaxHugeComplexLen)
+        return false;
+    // the divisor pair closest to sqrt(n) whose members are both accepted complex lengths (multiples of 16, at most 2^21)
+    for (long long d = (long long) std::sqrt ((double) n_complex) + 1; d >= 16; --d)
+    {
+        if (n_complex % d != 0)
+            continue;
+        const long long e = n_complex / d;
+        if (d % 16 != 0 || e % 16 != 0 || e > kMaxComplexLen || d > kMaxComplexLen)
+            continue;
+        if (! size_supported ((int) d, 1) || ! size_supported ((int) e, 1))
+            continue;
+        c = (int) std::min (d, e);
+        r = (int) std::max (d, e);
+        return true;
+    }
+    return false;
+}
+
 bool size_supported (int N, int transform)
 {
     // the reference needs N % 16 == 0 (complex) / N % 32 == 0 (real) on its SSE path
@@ -152,8 +174,15 @@ bool size_supported (int N, int transform)
     if (N <= 0 || N % (real ? 32 : 16) != 0)
         return false;
     const int nc = real ? N / 2 : N;
-    if (! is_235_smooth (N) || nc > kMaxComplexLen)
+    if (! is_235_smooth (N))
         return false;
+    if (nc > kMaxComplexLen)
+    {
+        int hr = 0, hc = 0;
+        if (real && nc > (1 << 24))
+            return false; // (the pair stage's table has N / 4 + 1 entries: 64 MiB at real N = 2^25)
+        return split_huge (nc, hr, hc); // frames beyond 2^21 complex points: two plans + transposes
+    }
     if (is_pow2 (N))
         return true; // single pass up to 32768 complex points, two passes beyond
     // mixed-radix sizes run LDS-resident in the generic kernel: bounded by what the frame image needs
@@ -281,6 +310,24 @@ bool build_host_tables (int N, int transform, HostTables& out)
             out.real_twiddles.push_back (unit_root (k, N));
     }
 
+    if (nc > kMaxComplexLen)
+    {
+        if (! split_huge (nc, out.huge_r, out.huge_c))
+            return false;
+        out.core_n = 0;
+        int shift = 0;
+        while ((1ll << (2 * shift)) < (long long) nc)
+            ++shift;
+        out.huge_shift = shift;
+        const long long lo_len = 1ll << shift, hi_len = ((long long) nc + lo_len - 1) / lo_len;
+        out.huge_tw_lo.reserve ((size_t) lo_len);
+        out.huge_tw_hi.reserve ((size_t) hi_len);
+        for (long long i = 0; i < lo_len; ++i)
+            out.huge_tw_lo.push_back (unit_root (i, nc));
+        for (long long i = 0; i < hi_len; ++i)
+            out.huge_tw_hi.push_back (unit_root (i * lo_len, nc));
+        return true;
+    }
     int gs1 = 0, gs2 = 0;
     if ((! is_pow2 (nc) && nc > kGenericMaxComplexLen && ! split_mixed (nc, gs1, gs2)) || (is_pow2 (nc) && nc > (1 << 20)))
     {

@@ -29,6 +29,10 @@ struct HostTables
     int fast_n1 = 0, fast_n2 = 0;   // complex 2^17 .. 2^20: register-direct passes (tile_fast_kernels.hpp)
     int real4_r1 = 0, real4_r2 = 0; // long real frames: real four-step N = r1 * r2 (multipass_kernels.hpp)
     int real4_fast = 0;             // ... on the register-direct tiles (tile_fast_kernels.hpp)
+    // frames beyond 2^21 complex points (split_huge): huge_r x huge_c, both factors transformed by plans of their own;
+    // W_N^j = huge_tw_hi[j >> huge_shift] * huge_tw_lo[j & ((1 << huge_shift) - 1)]
+    int huge_r = 0, huge_c = 0, huge_shift = 0;
+    std::vector<float2> huge_tw_lo, huge_tw_hi;
 };
 
 // Validates (N, transform) and fills the tables.  false = unsupported size.
@@ -101,6 +105,13 @@ bool split_mixed (int n_complex, int& n1, int& n2);
 bool split_general (int n_complex, int& n1, int& n2);
 static constexpr int kGeneralMaxFactor = 2559; // two LDS images of 4 frames of n + 1 points
 static constexpr int kMaxComplexLen = 1 << 21;
+// Frames longer than that (the reference has no upper bound, simd/chowdsp_fft_impl_common.hpp:168-177; its header advises a heap
+// `work` buffer for large N, chowdsp_fft.h:131-134): n = r * c with BOTH factors accepted complex lengths of at most
+// kMaxComplexLen, as close to each other as the divisors allow; the frame is transformed as c batched r-point transforms, a
+// twiddle, r batched c-point transforms and three transposes (capi.cpp: huge_transform).  Up to 2^27 complex points (1 GiB per
+// frame).  false if no such pair of factors exists (then the size is not supported).
+static constexpr int kMaxHugeComplexLen = 1 << 27;
+bool split_huge (int n_complex, int& r, int& c);
 // tile width (columns or rows) for a frame length n of the generic passes: as wide as two padded LDS images allow
 inline int general_tile_width (int n) { return n <= 639 ? 16 : (n <= 1279 ? 8 : 4); }
 // columns per pass-A tile of the mixed two-pass plans: 16 (128-byte rows) while two LDS images of 16 padded columns,

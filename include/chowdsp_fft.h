@@ -21,7 +21,9 @@
       AVX paths already differ); here it is the canonical ordered layout.
     * accepted sizes: the reference's rule -- N % 16 == 0 (complex) / N % 32 == 0 (real), N = 2^a 3^b 5^c
       (simd/chowdsp_fft_impl_common.hpp:168-177, 216-225), for every such N up to a complex length of 2^21
-      (complex N <= 2097152, real N <= 4194304; the reference has no upper bound).  fft_gpu_size_supported()
+      (complex N <= 2097152, real N <= 4194304), and beyond that -- the reference has no upper bound -- for every N
+      that is the product of two accepted complex lengths of at most 2^21 each, up to 2^27 complex points
+      (real: N <= 2^25); those frames run through the plans of the two factors.  fft_gpu_size_supported()
       (chowdsp_fft_gpu.h) is the GPU-free test; sizes it rejects return NULL from setup creation, exactly like an
       unsupported size does in the reference (which returns the tagged pointer 0x1 there,
       chowdsp_fft.cpp:271-273 -- a defect this backend does not imitate).

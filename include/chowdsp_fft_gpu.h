@@ -100,7 +100,9 @@ long fft_gpu_get_option (const char* name);
 /* 1 if fft_new_setup would accept (N, transform) on a machine with a usable device, else 0.  Pure host logic (no GPU
    needed).  The rule is the reference's SSE size rule -- N % 16 == 0 (complex) / N % 32 == 0 (real), N = 2^a 3^b 5^c
    (reference simd/chowdsp_fft_impl_common.hpp:168-177, 216-225) -- for every such N up to a complex length of 2^21
-   (complex N <= 2097152, real N <= 4194304); the reference itself has no upper bound, longer frames return NULL here.
+   (complex N <= 2097152, real N <= 4194304).  The reference itself has no upper bound; beyond 2^21 complex points a size is
+   accepted when it is the product of two accepted complex lengths of at most 2^21 each (every power of two, and every
+   2^a 3^b 5^c with a >= 8), up to 2^27 complex points = 1 GiB per frame (real: N <= 2^25); longer frames return NULL.
    How a size runs: fft_gpu_plan_describe. */
 int fft_gpu_size_supported (int N, fft_transform_t transform);
 /* How (N, transform) is executed.  Fills desc[0..7] = { complex length transformed, number of passes through device
@@ -112,6 +114,9 @@ int fft_gpu_size_supported (int N, fft_transform_t transform);
                 other lengths: generic columns x power-of-two rows where N = (odd * 2^j <= 1280, j >= 4) x (2^6..2^10)
                 exists (24576 = 48 x 512), else generic columns x generic rows, both factors near sqrt(N)
                 (20736 = 144 x 144, 2^21 = 2048 x 1024)
+     "3"      : beyond 2^21 complex points: n1 x n2 with both factors accepted lengths, n2 batched n1-point transforms and
+                n1 batched n2-point transforms by those lengths' own plans, a twiddle and three transposes in between
+                (2^22 = 2048 x 2048, 3 x 2^21 = 3072 x 2048): five or more sweeps over the frame -- completeness, not speed
    Returns 0, or FFT_GPU_EINVAL for an unsupported size.  Pure host logic. */
 int fft_gpu_plan_describe (int N, fft_transform_t transform, int desc[8]);
 int fft_gpu_setup_size (void* setup);              /* N, or negative error */

@@ -84,8 +84,16 @@ def test_size_rule_host_logic():
     for n in range(1, 2000):
         assert api.size_supported(n, api.FFT_COMPLEX) == (n % 16 == 0 and _smooth(n)), n
         assert api.size_supported(n, api.FFT_REAL) == (n % 32 == 0 and _smooth(n)), n
-    for n in (0, -16, 24, 112, 176, 7 << 18, 1 << 22, 3 << 21):
+    for n in (0, -16, 24, 112, 176, 7 << 18, 1 << 28, 3 << 27):
         assert not api.size_supported(n, api.FFT_COMPLEX)
+    # beyond 2^21 complex points: N = R x C with both factors accepted lengths (two plans + transposes), up to 2^27 complex
+    # points (real: N <= 2^25)
+    for n in (1 << 22, 3 << 21, 5 << 21, 1 << 24, 1 << 27, 15 << 20):
+        assert api.size_supported(n, api.FFT_COMPLEX), n
+        d = api.plan_describe(n, api.FFT_COMPLEX)
+        assert d["passes"] == 3 and d["n1"] * d["n2"] == n and max(d["n1"], d["n2"]) <= 1 << 21 and d["n1"] % 16 == 0 and d["n2"] % 16 == 0, (n, d)
+    assert api.size_supported(1 << 25, api.FFT_REAL) and not api.size_supported(1 << 26, api.FFT_REAL)
+    assert api.plan_describe(1 << 22, api.FFT_COMPLEX)["n1"] == 2048
     # the reference's "Other sizes" test list (test/test.cpp:279-285)
     for n in (96, 192, 384, 480, 640, 768, 9216):
         assert api.size_supported(n, api.FFT_COMPLEX) and api.size_supported(n, api.FFT_REAL)

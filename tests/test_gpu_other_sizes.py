@@ -150,7 +150,7 @@ def test_reference_other_sizes_sequence_host_pointers(gpu, oracle, n, tr, preall
 
 def test_every_long_size_the_reference_plans_gets_a_plan(gpu, oracle):
     """the reference plans any 2^a 3^b 5^c length (simd/chowdsp_fft_impl_common.hpp:51-82, 216-225); so does this backend,
-    up to a complex length of 2^21 (beyond that: NULL, documented in include/chowdsp_fft.h)"""
+    up to a complex length of 2^27 (beyond 2^21 through the plans of two factors, test_frames_beyond_2_21 below)"""
     api = gpu[0]
     for n in (20736, 41472, 62208, 1 << 21):
         so = oracle.new_setup(n, COMPLEX)
@@ -162,7 +162,7 @@ def test_every_long_size_the_reference_plans_gets_a_plan(gpu, oracle):
         s = api.fft_new_setup(2 * n, api.FFT_REAL)
         assert s is not None
         api.fft_destroy_setup(s)
-    assert api.fft_new_setup(1 << 22, api.FFT_COMPLEX) is None
+    assert api.fft_new_setup(1 << 28, api.FFT_COMPLEX) is None
 
 
 def test_other_size_convolution_ops(gpu, oracle):
@@ -263,3 +263,37 @@ def test_workspace_bytes_reports_what_is_allocated(gpu):
     s3 = api.fft_new_setup(4096, api.FFT_COMPLEX)
     assert api.workspace_bytes(s3, 1000) == 0
     api.fft_destroy_setup(s3)
+
+
+# Frames beyond 2^21 complex points (the reference has no upper bound, simd/chowdsp_fft_impl_common.hpp:168-177, and advises a heap
+# work buffer for large N, chowdsp_fft.h:131-134): N = R x C, both factors transformed by plans of their own -- single-pass
+# (2^22 = 2048 x 2048), two-pass (2^25 = 8192 x 4096 ... ) and mixed-radix ones (3 x 2^21 = 3072 x 2048) -- plus three transposes.
+@pytest.mark.parametrize("n,tr", [(1 << 22, COMPLEX), (3 << 21, COMPLEX), (1 << 23, REAL), (5 << 20, REAL), (1 << 24, COMPLEX)])
+def test_frames_beyond_2_21(gpu, oracle, n, tr):
+    api, torch, dev = gpu
+    nf = 2 * n if tr == COMPLEX else n
+    batch = 2 if n <= (1 << 23) else 1
+    s, so = api.fft_new_setup(n, tr), oracle.new_setup(n, tr)
+    assert s is not None and so is not None
+    x = ol.uniform(batch * nf, 17 + (n % 1000)).reshape(batch, nf)
+    xd = torch.from_numpy(x).to(dev)
+    y = torch.full_like(xd, -3.0)
+    api.fft_transform_batch(s, xd, y, api.FFT_FORWARD)
+    torch.cuda.synchronize()
+    want = oracle.transform_batch(so, x, FORWARD)
+    mixed = (n & (n - 1)) != 0
+    assert_frames_close(y.cpu().numpy(), want, maxabs_tol=MIXED_RADIX_MAXABS_TOL if mixed else 1e-6, what=f"N={n} forward")
+    z = y.clone()
+    api.fft_transform_batch(s, z, z, api.FFT_BACKWARD)  # in place
+    torch.cuda.synchronize()
+    assert float((z / n - xd).abs().max()) < 4e-6, "round trip"
+    # backward of the SAME spectrum in both implementations (the oracle's), in place.  Element-wise bound 2e-6 at these lengths:
+    # the error of either implementation grows with log N, and the reference's float-angle twiddles (common.hpp:90-113) put
+    # it about 1e-6 from the exact transform by itself; the relative-L2 bound stays 1e-6
+    w = torch.from_numpy(want[:1].copy()).to(dev)
+    api.fft_transform_batch(s, w, w, api.FFT_BACKWARD)
+    torch.cuda.synchronize()
+    back = oracle.transform_batch(so, want[:1], BACKWARD)
+    assert_frames_close(w.cpu().numpy(), back, maxabs_tol=2e-6, what=f"N={n} backward in place")
+    api.fft_destroy_setup(s)
+    oracle.destroy_setup(so)

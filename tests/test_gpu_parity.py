@@ -342,7 +342,7 @@ def test_edge_cases(gpu):
     api, torch, dev = gpu
     # sizes the reference rejects, or that are too long for this backend -> NULL, no crash
     for n, tr in ((0, COMPLEX), (-64, COMPLEX), (8, COMPLEX), (16, REAL), (24, COMPLEX), (112, COMPLEX), (48, REAL),
-                  (1 << 22, COMPLEX), (3 << 21, COMPLEX), (1 << 23, REAL)):
+                  (1 << 28, COMPLEX), (3 << 27, COMPLEX), (1 << 26, REAL), ((1 << 22) + 16, COMPLEX)):
         assert api.fft_new_setup(n, tr) is None
     s = api.fft_new_setup(256, api.FFT_COMPLEX)
     x = torch.zeros(512, device=dev)
