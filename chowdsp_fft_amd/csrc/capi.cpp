@@ -945,7 +945,13 @@ void legacy_transform (void* setup, const float* input, float* output, cf::fft_d
     if (in_dev && out_dev)
     {
         if (run_transform (s, input, output, 1, direction, nullptr) == cf::FFT_GPU_OK)
+        {
             CFFT_HIP_TRY (hipStreamSynchronize (nullptr), (void) 0);
+            // (a one-launch two-pass transform validates its hand-offs at a library synchronisation: this is one)
+            if (fused_enabled())
+                if (const unsigned w = take_fused_error (nullptr))
+                    set_last_error (fused_error_text (w).c_str());
+        }
         return;
     }
     if (! in_dev && ! out_dev && nf * sizeof (float) <= zerocopy_max_bytes())

@@ -6,6 +6,7 @@
 
 #include "host_common.hpp"
 #include "launch.hpp"
+#include "plans.hpp"
 #include "tables.hpp"
 
 #include <cstdlib>
@@ -21,9 +22,8 @@ int fail (const char* what, hipError_t e)
     return cf::FFT_GPU_ELAUNCH;
 }
 
-// One launch: the layout conversion is the pair stage's own load / store pattern (real_kernels.hpp: LAYOUT) for every
-// power-of-two N whose half-length core is a plain LDS-resident plan (N <= 16384: every block size an audio host asks a
-// JUCE engine for).  Returns FFT_GPU_OK, an error, or +1 = "no fused form for this setup" (longer / mixed-radix frames: the
+// One launch: the layout conversion is the pair stage's own load / store pattern (real_kernels.hpp / split_plane_kernels.hpp:
+// LAYOUT) for every power-of-two N that runs in one pass (N <= 65536; round 3 added 32768 and 65536 on the split-plane kernels).  Returns FFT_GPU_OK, an error, or +1 = "no fused form for this setup" (longer / mixed-radix frames: the
 // caller converts in a second launch).
 int fused_real (void* setup, float* inout, size_t batch, bool forward, bool mirror, hipStream_t stream, const char* what)
 {
@@ -36,10 +36,17 @@ int fused_real (void* setup, float* inout, size_t batch, bool forward, bool mirr
         return 1;
     const DeviceTables* t = s->tables;
     const int m = s->N / 2;
-    if (t->gen_ns > 0 || t->real4_r1 > 0 || t->mixed_n2 > 0 || t->core_n != m || m > 8192 || (m & (m - 1)) != 0)
+    if (t->gen_ns > 0 || t->real4_r1 > 0 || t->mixed_n2 > 0 || t->huge_r > 0 || t->core_n != m || (m & (m - 1)) != 0)
         return 1;
     const DeviceGuard guard (s->device);
-    const hipError_t e = launch_real_juce (m, forward, (float2*) inout, t->stage_twiddles, t->real_twiddles, batch, stream, mirror, 1.0f / (float) s->N);
+    hipError_t e = hipErrorNotSupported;
+    if (m == 32768)
+        e = launch_real_split_juce (m, forward, (float2*) inout, t->stage_twiddles, t->real_twiddles, batch, stream, mirror, 1.0f / (float) s->N);
+    else if (m == 16384 && cf::fft_gpu_get_option ("split16384") == 1)
+        // (the split-plane table of this length follows the LDS-image plan's in the same allocation, as in capi.cpp run_transform)
+        e = launch_real_split_juce (m, forward, (float2*) inout, t->stage_twiddles + cfft::CorePlan<16384>::type::tw_total, t->real_twiddles, batch, stream, mirror, 1.0f / (float) s->N);
+    else if (m <= 8192)
+        e = launch_real_juce (m, forward, (float2*) inout, t->stage_twiddles, t->real_twiddles, batch, stream, mirror, 1.0f / (float) s->N);
     if (e == hipErrorNotSupported)
     {
         (void) hipGetLastError();

@@ -36,12 +36,47 @@ hipError_t c2c_split (bool inverse, const float2* in, float2* out, const float2*
 template <class G>
 hipError_t real_split (bool forward, const float2* in, float2* out, const float2* tw, const float2* real_tw, size_t batch, hipStream_t stream, size_t in_stride, size_t out_stride)
 {
-    auto kernel = forward ? r2c_split_kernel<G> : c2r_split_kernel<G>;
     unsigned grid = 0, is = 0, os = 0;
-    const hipError_t e = launch_split<G> (kernel, batch, stream, in_stride, out_stride, grid, is, os);
-    if (e != hipSuccess)
-        return e;
-    hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (G::T), G::lds_bytes, stream, in, out, tw, real_tw, (unsigned) batch, is, os);
+    if (forward)
+    {
+        auto kernel = r2c_split_kernel<G, 0>;
+        const hipError_t e = launch_split<G> (kernel, batch, stream, in_stride, out_stride, grid, is, os);
+        if (e != hipSuccess)
+            return e;
+        hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (G::T), G::lds_bytes, stream, in, out, tw, real_tw, (unsigned) batch, is, os);
+    }
+    else
+    {
+        auto kernel = c2r_split_kernel<G, 0>;
+        const hipError_t e = launch_split<G> (kernel, batch, stream, in_stride, out_stride, grid, is, os);
+        if (e != hipSuccess)
+            return e;
+        hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (G::T), G::lds_bytes, stream, in, out, tw, real_tw, (unsigned) batch, is, os, 1.f);
+    }
+    return hipGetLastError();
+}
+// the JUCE engine's layouts by the pair stage itself, in place on frames of 2 G::N float2 (split_plane_kernels.hpp: LAYOUT)
+template <class G>
+hipError_t real_split_juce (bool forward, float2* inout, const float2* tw, const float2* real_tw, size_t batch, hipStream_t stream, bool mirror, float scale)
+{
+    unsigned grid = 0, is = 0, os = 0;
+    const size_t stride = 2 * (size_t) G::N;
+    if (forward)
+    {
+        auto kernel = mirror ? r2c_split_kernel<G, 2> : r2c_split_kernel<G, 1>;
+        const hipError_t e = launch_split<G> (kernel, batch, stream, stride, stride, grid, is, os);
+        if (e != hipSuccess)
+            return e;
+        hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (G::T), G::lds_bytes, stream, (const float2*) inout, inout, tw, real_tw, (unsigned) batch, is, os);
+    }
+    else
+    {
+        auto kernel = c2r_split_kernel<G, 1>;
+        const hipError_t e = launch_split<G> (kernel, batch, stream, stride, stride, grid, is, os);
+        if (e != hipSuccess)
+            return e;
+        hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (G::T), G::lds_bytes, stream, (const float2*) inout, inout, tw, real_tw, (unsigned) batch, is, os, scale);
+    }
     return hipGetLastError();
 }
 template <class G>
@@ -94,6 +129,17 @@ hipError_t launch_real_split (int m, bool forward, const float2* in, float2* out
     if (m == SplitGeom<256>::N)
         return real_split<SplitGeom<256>> (forward, in, out, tw, real_tw, batch, stream, in_stride, out_stride);
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_real_split_juce (int m, bool forward, float2* inout, const float2* tw, const float2* real_tw, size_t batch, hipStream_t stream, bool mirror, float scale)
+{
+    if (batch == 0)
+        return hipSuccess;
+    if (m == SplitGeom<1024>::N)
+        return real_split_juce<SplitGeom<1024>> (forward, inout, tw, real_tw, batch, stream, mirror, scale);
+    if (m == SplitGeom<512>::N)
+        return real_split_juce<SplitGeom<512>> (forward, inout, tw, real_tw, batch, stream, mirror, scale);
+    return hipErrorNotSupported;
 }
 
 hipError_t launch_conv_frames_split (int n, bool real, const float2* in, const float2* H, float2* out, const float2* tw, const float2* real_tw, float scaling, size_t batch, hipStream_t stream)

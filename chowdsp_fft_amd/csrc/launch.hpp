@@ -108,6 +108,8 @@ hipError_t launch_column_fft (bool inverse, int rows, int cols, const DeviceTabl
 // real transform with the JUCE engine's layout fused into the pair stage, in place on frames of 4 m floats; hipErrorNotSupported
 // for core lengths without a fused form (the caller then converts in a second launch)
 hipError_t launch_real_juce (int m, bool forward, float2* inout, const float2* stage_tw, const float2* real_tw, size_t batch, hipStream_t stream, bool mirror, float scale);
+// ... and for m = 16384 / 32768 (real N = 32768 / 65536) on the split-plane kernels; `tw` = the split-plane table of that length
+hipError_t launch_real_split_juce (int m, bool forward, float2* inout, const float2* tw, const float2* real_tw, size_t batch, hipStream_t stream, bool mirror, float scale);
 hipError_t launch_juce_unpack (float2* data, unsigned m, size_t batch, bool mirror, hipStream_t stream);
 hipError_t launch_juce_pack_scale (float2* data, unsigned m, size_t batch, float scale, hipStream_t stream);
 hipError_t launch_scale (float* data, size_t count, float scale, hipStream_t stream); // count % 4 == 0

@@ -430,7 +430,11 @@ __device__ __forceinline__ void sp_pair_exchange (float2 (&up)[16], float* __res
 }
 
 // forward: N real samples (as M complex points z[n] = x[2n] + i x[2n+1]) -> packed spectrum (real_kernels.hpp)
-template <class G>
+// LAYOUT 0: the packed spectrum.  LAYOUT 1 / 2 (round 3): the JUCE engine's interleaved layout written by the pair stage itself
+// (reference chowdsp_fft_juce/chowdsp_fft_juce.cpp:57-66), as r2c_kernel<..., LAYOUT> does for the shorter frames: frames of 2 M
+// complex slots, c[0] = (X0, 0), c[k] = X_k, c[M] = (X_{N/2}, 0), and for LAYOUT 2 also c[2 M - k] = conj X_k.  In place on the
+// 2 N-float buffers: the whole frame is in registers before the first store.
+template <class G, int LAYOUT = 0>
 __global__ __launch_bounds__ (G::T) void r2c_split_kernel (const float2* __restrict__ in,
                                                             float2* __restrict__ out,
                                                             const float2* __restrict__ tw,
@@ -482,23 +486,42 @@ __global__ __launch_bounds__ (G::T) void r2c_split_kernel (const float2* __restr
                     Xk = make_float2 (A.x + A.y, A.x - A.y); // [X0.re, X(N/2).re]
                     Xp = make_float2 (Zp.x, -Zp.y);          // X[M/2] = conj(Z[M/2])
                 }
-                gstore (&dst[(unsigned) k], Xk);
-                gstore (&dst[(unsigned) (k == 0 ? M / 2 : M - k)], Xp);
+                const unsigned kp = (unsigned) (k == 0 ? M / 2 : M - k);
+                if constexpr (LAYOUT == 0)
+                {
+                    gstore (&dst[(unsigned) k], Xk);
+                    gstore (&dst[kp], Xp);
+                }
+                else
+                {
+                    gstore (&dst[(unsigned) k], k == 0 ? make_float2 (Xk.x, 0.f) : Xk);
+                    gstore (&dst[kp], Xp);
+                    if (k == 0)
+                        gstore (&dst[(unsigned) M], make_float2 (Xk.y, 0.f));
+                    if constexpr (LAYOUT == 2)
+                    {
+                        if (k != 0)
+                            gstore (&dst[(unsigned) (2 * M - k)], make_float2 (Xk.x, -Xk.y));
+                        gstore (&dst[(unsigned) (2 * M) - kp], make_float2 (Xp.x, -Xp.y));
+                    }
+                }
             }
             CFFT_PHASE_FENCE();
         }
     }
 }
 
-// backward: packed spectrum -> N real samples (unscaled)
-template <class G>
+// backward: packed spectrum -> N real samples (unscaled).  LAYOUT 1 (round 3): the JUCE engine's layout in (X0 = c[0].re,
+// X_{N/2} = c[M].re, reference chowdsp_fft_juce.cpp:74), the signal times `scale` out, in place on the 2 N-float buffers
+template <class G, int LAYOUT = 0>
 __global__ __launch_bounds__ (G::T) void c2r_split_kernel (const float2* __restrict__ in,
                                                             float2* __restrict__ out,
                                                             const float2* __restrict__ tw,
                                                             const float2* __restrict__ wtab,
                                                             unsigned batch,
                                                             unsigned in_stride,
-                                                            unsigned out_stride)
+                                                            unsigned out_stride,
+                                                            float scale = 1.f)
 {
     extern __shared__ __attribute__ ((aligned (16))) float sp_plane[];
     constexpr int M = G::N;
@@ -522,6 +545,11 @@ __global__ __launch_bounds__ (G::T) void c2r_split_kernel (const float2* __restr
                 a[q8] = gload (&src[(unsigned) k]);
                 xp[q8] = gload (&src[(unsigned) (k == 0 ? M / 2 : M - k)]);
                 pw[q8] = wtab[k];
+                if constexpr (LAYOUT != 0)
+                {
+                    if (k == 0)
+                        a[q8].y = gload (&src[(unsigned) M]).x; // packed slot 0 = (X0.re, X_{N/2}.re)
+                }
             }
 #pragma unroll
             for (int q8 = 0; q8 < 8; ++q8)
@@ -549,7 +577,7 @@ __global__ __launch_bounds__ (G::T) void c2r_split_kernel (const float2* __restr
         CFFT_LAUNDER_INDEX (ts);
 #pragma unroll
         for (int b = 0; b < 32; ++b)
-            gstore (&dst[(unsigned) (ts + G::T * b)], make_float2 (v[b].y, v[b].x));
+            gstore (&dst[(unsigned) (ts + G::T * b)], LAYOUT != 0 ? make_float2 (v[b].y * scale, v[b].x * scale) : make_float2 (v[b].y, v[b].x));
     }
 }
 // ---- fused convolution frames: y = BACKWARD (FORWARD (x) * H) * scaling in ONE pass -----------------------------------------------

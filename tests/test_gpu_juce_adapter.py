@@ -13,7 +13,7 @@ from oracle_lib import BACKWARD, COMPLEX, FORWARD, REAL
 
 pytestmark = pytest.mark.gpu
 
-ORDERS = [5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15]  # N = 32 .. 32768: staged, register-direct, pipelined plans (fused layouts, N <= 16384) and the two-launch form above
+ORDERS = [5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17]  # N = 32 .. 131072: staged, register-direct, pipelined and split-plane plans (fused layouts, N <= 65536) and the two-launch form above
 
 
 def ref_real_forward(oracle, so_real, buf, n, ignore_negative_freqs):
