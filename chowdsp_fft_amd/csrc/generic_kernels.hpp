@@ -651,7 +651,10 @@ __device__ __forceinline__ void inplace_stage (const float2* __restrict__ gin, f
     {
         // the stage that reads global memory is always the first one (p == 1: no twiddles, output index i * R + b) and
         // overwrites nothing it reads: U butterflies at a time, all their loads issued before the first butterfly
-        constexpr int U = R <= 4 ? 4 : (R <= 8 ? 2 : 1);
+#ifndef CFFT_INPLACE_FIRST_U_BIG
+#define CFFT_INPLACE_FIRST_U_BIG 1 // (2: no change for the compile-time lists, 24-32 more VGPRs for the run-time ones)
+#endif
+        constexpr int U = R <= 4 ? 4 : (R <= 8 ? 2 : CFFT_INPLACE_FIRST_U_BIG);
 #pragma unroll 1
         for (int i0 = tid; i0 < m; i0 += U * BLOCK)
         {

@@ -86,6 +86,19 @@ __device__ __forceinline__ void group_fail (GroupState* st, unsigned* host_err, 
         __hip_atomic_store (host_err, (seq << 8) | code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// ... rows [4 G, 4 G + 4) only (the operands requested a quarter at a time, between the steps of the transform before)
+template <bool INV, int G>
+__device__ __forceinline__ void g256_load_a_part (float (&re)[16], float (&im)[16], const float2* __restrict__ src, int t0, int c0)
+{
+#pragma unroll
+    for (int s = 4 * G; s < 4 * G + 4; ++s)
+    {
+        const float2 x = gload (&src[(unsigned) (t0 + 16 * s) * 256u + c0]);
+        re[s] = INV ? x.y : x.x;
+        im[s] = INV ? x.x : x.y;
+    }
+}
+
 // pass A operands of one tile: 16 rows per work-item, lanes along the tile's 16 columns (128 contiguous bytes per row)
 template <bool INV>
 __device__ __forceinline__ void g256_load_a (float (&re)[16], float (&im)[16], const float2* __restrict__ src, int t0, int c0)
@@ -200,7 +213,7 @@ __global__ __launch_bounds__ (256, 2) void group256_kernel (const float2* __rest
                                                         unsigned seq,
                                                         unsigned reg_polls,
                                                         unsigned force_solo,
-                                                        unsigned form) // bit 0: two slots per group; bit 1: early prefetch; bit 2: ... wave 0's share late
+                                                        unsigned form) // bit 0: two slots per group; bit 1: early prefetch; bit 2: ... wave 0's share late; bit 3: prefetch spread over pass B
 {
     extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
     __shared__ unsigned info[8];
@@ -213,7 +226,7 @@ __global__ __launch_bounds__ (256, 2) void group256_kernel (const float2* __rest
     // pass B roles: lanes run along the tile's 16 rows in both stages
     const int kbl = tid & 15, tb = tid >> 4;
     const unsigned two_slots = form & 1u;
-    const bool early = (form & 2u) != 0, w0late = (form & 4u) != 0;
+    const bool early = (form & 2u) != 0, w0late = (form & 4u) != 0, spread = (form & 8u) != 0;
 #if CFFT_GROUP_EXPERIMENT
     const unsigned dbg = force_solo >> 8;
     force_solo &= 255u;
@@ -331,14 +344,21 @@ __global__ __launch_bounds__ (256, 2) void group256_kernel (const float2* __rest
             }
             // ... behind the pass-B loads and ahead of everything else of this frame
             const bool pre_late = fn < batch && ! CFFT_GROUP_DBG (8u) && ! pre_here;
-            if (pre_late)
-                g256_load_a<INV> (nre, nim, in + (size_t) fn * in_stride + tile * 16, t0, c0);
+            const float2* __restrict__ nsrc = in + (size_t) fn * in_stride + tile * 16;
+            // `spread`: a quarter of them here, the others between the steps of the pass-B transform (its arithmetic and LDS
+            // traffic then run while the memory pipeline drains, instead of behind one burst of 32 loads)
+            if (pre_late && ! spread)
+                g256_load_a<INV> (nre, nim, nsrc, t0, c0);
+            if (pre_late && spread)
+                g256_load_a_part<INV, 0> (nre, nim, nsrc, t0, c0);
             CFFT_PHASE_FENCE();
             CFFT_GROUP_STAMP (8)
 #if CFFT_GROUP_EXPERIMENT
             if (dbg & 32u)
             {
-                if (pre_late)
+                if (pre_late && spread)
+                    asm volatile ("s_waitcnt vmcnt(4)" ::: "memory");
+                else if (pre_late)
                     asm volatile ("s_waitcnt vmcnt(16)" ::: "memory"); // the pass-B operands are here (the prefetch may be out)
                 else
                     asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
@@ -347,16 +367,28 @@ __global__ __launch_bounds__ (256, 2) void group256_kernel (const float2* __rest
             CFFT_GROUP_STAMP (9)
             // fft256_two_stage_lds, opened up for the flag
             fft_reg<16> (v);
+            CFFT_PHASE_FENCE();
+            if (pre_late && spread)
+                g256_load_a_part<INV, 1> (nre, nim, nsrc, t0, c0);
+            CFFT_PHASE_FENCE();
             __syncthreads(); // the previous exchange's reads are finished; every wave's pass-B loads have returned
             if (tid == 0 && two_slots == 0)
                 flag_store (&bf[tile], k + 1u);
 #pragma unroll
             for (int b = 0; b < 16; ++b)
                 smem[kbl * kFS256 + 17 * tb + b] = v[b];
+            CFFT_PHASE_FENCE();
+            if (pre_late && spread)
+                g256_load_a_part<INV, 2> (nre, nim, nsrc, t0, c0);
+            CFFT_PHASE_FENCE();
             __syncthreads();
 #pragma unroll
             for (int a = 0; a < 16; ++a)
                 v[a] = smem[kbl * kFS256 + tb + 17 * a];
+            CFFT_PHASE_FENCE();
+            if (pre_late && spread)
+                g256_load_a_part<INV, 3> (nre, nim, nsrc, t0, c0);
+            CFFT_PHASE_FENCE();
 #pragma unroll
             for (int a = 1; a < 16; ++a)
                 v[a] = cmul (v[a], tw1[(a - 1) * 16 + tb]);

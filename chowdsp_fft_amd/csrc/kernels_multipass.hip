@@ -474,13 +474,13 @@ hipError_t launch_group_c2c (int n1, int n2, bool inverse, const float2* in, flo
         return hipErrorNoDevice;
     // A/B switch: two slots per group used alternately (no second flag, twice the L2 footprint) instead of one
     // ... and where the next frame's operands are requested (group_twopass_kernels.hpp): CHOWDSP_FFT_GROUP_PREFETCH = 0 behind the
-    // pass-B loads, 1 in front of the hand-off, 2 the same with wave 0's share behind the pass-B loads
-    static const unsigned two_slots = [] {
-        unsigned f = (std::getenv ("CHOWDSP_FFT_GROUP_SLOTS") != nullptr && std::atoi (std::getenv ("CHOWDSP_FFT_GROUP_SLOTS")) == 2) ? 1u : 0u;
-        const int pf = std::getenv ("CHOWDSP_FFT_GROUP_PREFETCH") != nullptr ? std::atoi (std::getenv ("CHOWDSP_FFT_GROUP_PREFETCH")) : 0;
-        f |= pf == 1 ? 2u : (pf == 2 ? 6u : 0u);
-        return f;
-    }();
+    // pass-B loads, 1 in front of the hand-off, 2 the same with wave 0's share behind the pass-B loads, 3 a quarter at a time
+    // between the steps of pass B.  Unset: 3 for the forward transform (2.25 against 2.31 ms per 8192 frames), 0 for the
+    // backward one (whose re <-> im swaps schedule differently: 2.46 against 2.69 ms with 3; profiles/r03_group_two_pass.txt)
+    static const int pf_env = std::getenv ("CHOWDSP_FFT_GROUP_PREFETCH") != nullptr ? std::atoi (std::getenv ("CHOWDSP_FFT_GROUP_PREFETCH")) : -1;
+    static const unsigned slots_flag = (std::getenv ("CHOWDSP_FFT_GROUP_SLOTS") != nullptr && std::atoi (std::getenv ("CHOWDSP_FFT_GROUP_SLOTS")) == 2) ? 1u : 0u;
+    const int pf = pf_env >= 0 ? pf_env : (inverse ? 0 : 3);
+    const unsigned two_slots = slots_flag | (pf == 1 ? 2u : (pf == 2 ? 6u : (pf == 3 ? 8u : 0u)));
     unsigned force_solo = (unsigned) g_group_force_solo.load();
     const unsigned reg_polls = (unsigned) g_group_reg_polls.load();
 #if CFFT_GROUP_EXPERIMENT
