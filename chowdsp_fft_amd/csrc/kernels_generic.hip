@@ -183,6 +183,9 @@ hipError_t launch_generic_inplace (GenericPlan plan, const DeviceTables& t, cons
     }
             CFFT_TRY_STATIC_INPLACE (4608, 256)
             CFFT_TRY_STATIC_INPLACE (9216, 512)
+            CFFT_TRY_STATIC_INPLACE (5120, 256)
+            CFFT_TRY_STATIC_INPLACE (12288, 1024)
+            CFFT_TRY_STATIC_INPLACE (19200, 1024)
 #undef CFFT_TRY_STATIC_INPLACE
             return launch_generic_inplace_tw<MODE, INV, BLOCK, true> (plan, t, in, out, batch, stream);
         }

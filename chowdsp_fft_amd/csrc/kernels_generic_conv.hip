@@ -94,6 +94,9 @@ hipError_t launch_conv_inplace (GenericPlan plan, const DeviceTables& t, const f
     }
         CFFT_TRY_STATIC_INPLACE_CONV (4608, 256)
         CFFT_TRY_STATIC_INPLACE_CONV (9216, 512)
+        CFFT_TRY_STATIC_INPLACE_CONV (5120, 256)
+        CFFT_TRY_STATIC_INPLACE_CONV (12288, 1024)
+        CFFT_TRY_STATIC_INPLACE_CONV (19200, 1024)
 #undef CFFT_TRY_STATIC_INPLACE_CONV
         return launch_conv_inplace_tw<REAL, BLOCK, true> (plan, t, in, H, out, scaling, batch, stream);
     }
