@@ -51,6 +51,14 @@
 #define CFFT_GROUP_STAMP(I)
 #endif
 
+// The backward transform as conj (DFT (conj x)) (1) instead of swap (DFT (swap x)) (0, default).  An A/B switch kept from the
+// search for why the backward instantiation runs 5 % behind the forward one (2.43 against 2.27 ms per 8192 frames): with the
+// packed arithmetic a swap is two register moves per value where a conjugation rides on operand modifiers -- measured equal
+// (2.428 ms both ways), so the moves are not it.
+#ifndef CFFT_GROUP_INV_CONJ
+#define CFFT_GROUP_INV_CONJ 0
+#endif
+
 namespace cfft
 {
 constexpr int kGroupMaxXcc = 16;      // HW_REG_XCC_ID is a 4-bit field
@@ -94,8 +102,8 @@ __device__ __forceinline__ void g256_load_a_part (float (&re)[16], float (&im)[1
     for (int s = 4 * G; s < 4 * G + 4; ++s)
     {
         const float2 x = gload (&src[(unsigned) (t0 + 16 * s) * 256u + c0]);
-        re[s] = INV ? x.y : x.x;
-        im[s] = INV ? x.x : x.y;
+        re[s] = (INV && ! CFFT_GROUP_INV_CONJ) ? x.y : x.x;
+        im[s] = INV ? (CFFT_GROUP_INV_CONJ ? -x.y : x.x) : x.y;
     }
 }
 
@@ -107,8 +115,8 @@ __device__ __forceinline__ void g256_load_a (float (&re)[16], float (&im)[16], c
     for (int s = 0; s < 16; ++s)
     {
         const float2 x = gload (&src[(unsigned) (t0 + 16 * s) * 256u + c0]);
-        re[s] = INV ? x.y : x.x;
-        im[s] = INV ? x.x : x.y;
+        re[s] = (INV && ! CFFT_GROUP_INV_CONJ) ? x.y : x.x;
+        im[s] = INV ? (CFFT_GROUP_INV_CONJ ? -x.y : x.x) : x.y;
     }
 }
 
@@ -399,7 +407,7 @@ __global__ __launch_bounds__ (256, 2) void group256_kernel (const float2* __rest
             {
 #pragma unroll
                 for (int b = 0; b < 16; ++b)
-                    gstore (&dst[(unsigned) (tb + 16 * b) * 256u], INV ? make_float2 (v[b].y, v[b].x) : v[b]);
+                    gstore (&dst[(unsigned) (tb + 16 * b) * 256u], INV ? (CFFT_GROUP_INV_CONJ ? make_float2 (v[b].x, -v[b].y) : make_float2 (v[b].y, v[b].x)) : v[b]);
             }
             else if (v[0].x == 12345.678f) // keeps the arithmetic alive
                 gstore (&dst[0], v[1]);
@@ -452,7 +460,7 @@ __global__ __launch_bounds__ (256, 2) void group256_kernel (const float2* __rest
             float2* __restrict__ dst = out + (size_t) f * out_stride + tile * 16 + kbl;
 #pragma unroll
             for (int b = 0; b < 16; ++b)
-                gstore (&dst[(unsigned) (tb + 16 * b) * 256u], INV ? make_float2 (v[b].y, v[b].x) : v[b]);
+                gstore (&dst[(unsigned) (tb + 16 * b) * 256u], INV ? (CFFT_GROUP_INV_CONJ ? make_float2 (v[b].x, -v[b].y) : make_float2 (v[b].y, v[b].x)) : v[b]);
         }
         // the slot is rewritten by the next frame's pass A only after the barrier at the loop top, which every wave reaches
         // with its pass-B loads consumed
