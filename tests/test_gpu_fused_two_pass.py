@@ -163,3 +163,49 @@ def test_group_convolution_n65536(gpu, oracle, batch, solo):
         api.set_option("group_force_solo", 0)
         api.set_option("fused_min_batch", default_min)
         api.set_option("fused_conv_group", 1)
+
+
+@pytest.mark.parametrize("polls", [0, 1, 3])
+def test_group_mode_decision_race(gpu, polls):
+    """group_reg_polls = 0 / 1 / 3: a workgroup gives up waiting for the grid to be complete almost at once, so the launch's mode
+    (GROUP by the workgroup whose registration completes the grid, SOLO by whoever loses patience first -- one compare-and-swap)
+    is decided in a RACE, differently from launch to launch.  Whatever it comes out as, every workgroup must follow the same
+    decision and the result must be the transform: 30 launches (plain and fused convolution) against the two-launch form."""
+    api, torch, dev = gpu
+    default_min = int(api.get_option("fused_min_batch"))
+    api.set_option("fused_min_batch", 1)
+    api.set_option("group_reg_polls", polls)
+    try:
+        s = api.fft_new_setup(N, api.FFT_COMPLEX)
+        g = torch.Generator(device=dev)
+        g.manual_seed(11 + polls)
+        x = torch.rand((40, 2 * N), device=dev, generator=g) * 2 - 1
+        h = torch.rand((1, 2 * N), device=dev, generator=g) * 2 - 1
+        H = torch.empty_like(h)
+        api.fft_transform_unordered_batch(s, h, H, api.FFT_FORWARD)
+        api.set_option("fused_two_pass", 0)
+        api.set_option("fused_conv_group", 0)
+        want, want_inv, want_conv = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        api.fft_transform_batch(s, x, want, api.FFT_FORWARD)
+        api.fft_transform_batch(s, x, want_inv, api.FFT_BACKWARD)
+        api.fft_convolve_frames_batch(s, x, H, want_conv, 1.0 / N)
+        api.set_option("fused_two_pass", 2)
+        api.set_option("fused_conv_group", 1)
+        y = torch.empty_like(x)
+        for rep in range(10):
+            for direction, ref in ((api.FFT_FORWARD, want), (api.FFT_BACKWARD, want_inv)):
+                y.fill_(-1.0)
+                api.fft_transform_batch(s, x, y, direction)
+                api.stream_synchronize()
+                assert torch.equal(y, ref), f"launch {rep}, direction {direction}, polls {polls}"
+            y.fill_(-1.0)
+            api.fft_convolve_frames_batch(s, x, H, y, 1.0 / N)
+            api.stream_synchronize()
+            err = float(((y - want_conv).norm(dim=1) / want_conv.norm(dim=1)).max())
+            assert err < 3e-7, f"fused convolution, launch {rep}: {err}"
+        api.fft_destroy_setup(s)
+    finally:
+        api.set_option("group_reg_polls", 200)
+        api.set_option("fused_min_batch", default_min)
+        api.set_option("fused_two_pass", 2)
+        api.set_option("fused_conv_group", 1)
