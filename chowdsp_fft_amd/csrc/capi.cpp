@@ -398,7 +398,8 @@ size_t workspace_frame_bytes (const DeviceTables* t, int nc)
 // pass B, in place; -1 = REAL BACKWARD: the pair (merge) stage in -> out runs on each chunk right before its pass A,
 // which then works in place on `out`.  Doing it per chunk (and with smaller chunks) lets the stage find its operands in
 // the Infinity Cache instead of re-reading the whole batch from HBM afterwards.
-int big_c2c_chunked (Setup* s, int nc, bool inverse, const float2* in, float2* out, size_t batch, hipStream_t stream, size_t is2, size_t os2, int pair = 0)
+// mul_h (register-direct tile plans, forward only): every output bin times mul_h[bin] * mul_scale (fft_convolve_frames_batch)
+int big_c2c_chunked (Setup* s, int nc, bool inverse, const float2* in, float2* out, size_t batch, hipStream_t stream, size_t is2, size_t os2, int pair = 0, const float2* mul_h = nullptr, float mul_scale = 1.f)
 {
     const bool mixed = s->tables->mixed_n2 > 0; // long mixed-radix frame: generic column pass + power-of-two row pass
     int n1 = 0, n2 = 0;
@@ -474,7 +475,7 @@ int big_c2c_chunked (Setup* s, int nc, bool inverse, const float2* in, float2* o
         if (e == hipSuccess)
             e = mixed ? launch_mixed_big_c2c (*s->tables, inverse, cin, L->ws[k], out + f0 * os2, nb, lanes, st, cis, os2)
                 : s->tables->fast_n1 > 0
-                    ? launch_fast_c2c (n1, n2, inverse, cin, L->ws[k], out + f0 * os2, s->tables->stage_twiddles, s->tables->big_twiddles, nb, lanes, st, cis, os2)
+                    ? launch_fast_c2c (n1, n2, inverse, cin, L->ws[k], out + f0 * os2, s->tables->stage_twiddles, s->tables->big_twiddles, nb, lanes, st, cis, os2, mul_h, mul_scale)
                     : launch_big_c2c (n1, n2, inverse, cin, L->ws[k], out + f0 * os2, s->tables->stage_twiddles, s->tables->big_twiddles, nb, lanes, st, cis, os2);
         if (e == hipSuccess && pair > 0)
             e = launch_real_pair (true, out + f0 * os2, out + f0 * os2, s->tables->real_twiddles, (unsigned) nc, nb, st, os2, os2);
@@ -1702,6 +1703,15 @@ int fft_convolve_frames_batch (void* setup, const float* x, const float* dft_fil
             return FFT_GPU_ELAUNCH;
         }
         return FFT_GPU_OK;
+    }
+    if (s->transform == FFT_COMPLEX && t->fast_n1 > 0 && t->mixed_n2 == 0 && g_fused_conv_group.load() != 0)
+    {
+        // N = 2^17 ... 2^20 complex (register-direct two-pass tiles): the product rides on the forward transform's pass-B
+        // stores, the backward transform follows in place -- four sweeps over the batch instead of five
+        const int rc = big_c2c_chunked (s, nc, false, (const float2*) x, (float2*) y, batch, (hipStream_t) stream, (size_t) nc, (size_t) nc, 0, (const float2*) dft_filter, scaling);
+        if (rc != FFT_GPU_OK)
+            return rc;
+        return run_transform (s, y, y, batch, FFT_BACKWARD, (hipStream_t) stream);
     }
     if (t->gen_ns > 0 && t->mixed_n2 == 0 && g_fused_conv_generic.load() != 0)
     {

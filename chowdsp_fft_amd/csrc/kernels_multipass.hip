@@ -149,15 +149,16 @@ hipError_t fast_pass_a (int n1, const float2* in, float2* work, const float2* tw
     return hipGetLastError();
 }
 template <int N1, bool INV>
-hipError_t fast_pass_b (int n2, const float2* work, float2* out, const float2* tw1, size_t batch, int div, hipStream_t stream, size_t out_stride)
+hipError_t fast_pass_b (int n2, const float2* work, float2* out, const float2* tw1, size_t batch, int div, hipStream_t stream, size_t out_stride, const float2* mul_h = nullptr, float mul_scale = 1.f)
 {
     using FT = FastTile<N1>;
-    auto kernel = pass_b_fast_kernel<N1, INV>;
+    // (the product with a filter spectrum rides on the FORWARD transform's stores only: fft_convolve_frames_batch)
+    auto kernel = (mul_h != nullptr && ! INV) ? pass_b_fast_kernel<N1, false, true> : pass_b_fast_kernel<N1, INV, false>;
     unsigned grid = persistent_grid (kernel, FT::threads, FT::lds_bytes, batch * (size_t) (n2 / 16));
     if (grid == 0)
         return hipErrorNoDevice;
     grid = std::max (1u, grid / (unsigned) div);
-    hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (FT::threads), FT::lds_bytes, stream, work, out, tw1, (unsigned) n2, (unsigned) batch, out_stride);
+    hipLaunchKernelGGL (kernel, dim3 (grid), dim3 (FT::threads), FT::lds_bytes, stream, work, out, tw1, (unsigned) n2, (unsigned) batch, out_stride, mul_h, mul_scale);
     return hipGetLastError();
 }
 #define CFFT_DISPATCH_FAST(n, CALL)                          \
@@ -221,8 +222,10 @@ hipError_t launch_real4_fast (int r1, int r2, bool inverse, const float2* in, fl
     return e;
 }
 
-hipError_t launch_fast_c2c (int n1, int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, size_t batch, int grid_divisor, hipStream_t stream, size_t in_stride, size_t out_stride)
+hipError_t launch_fast_c2c (int n1, int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, size_t batch, int grid_divisor, hipStream_t stream, size_t in_stride, size_t out_stride, const float2* mul_h, float mul_scale)
 {
+    if (mul_h != nullptr && inverse)
+        return hipErrorInvalidValue;
     if (batch == 0)
         return hipSuccess;
     if (batch > 0x7FFFFFFFull || fast_tile_table_rows (n1) == 0 || fast_tile_table_rows (n2) == 0)
@@ -245,7 +248,7 @@ hipError_t launch_fast_c2c (int n1, int n2, bool inverse, const float2* in, floa
         CFFT_DISPATCH_FAST (n2, e = (fast_pass_a<N_, false> (n1, in, work, tw2, big_tw, batch, grid_divisor, stream, in_stride)));
         if (e != hipSuccess)
             return e;
-        CFFT_DISPATCH_FAST (n1, e = (fast_pass_b<N_, false> (n2, work, out, tw1, batch, grid_divisor, stream, out_stride)));
+        CFFT_DISPATCH_FAST (n1, e = (fast_pass_b<N_, false> (n2, work, out, tw1, batch, grid_divisor, stream, out_stride, mul_h, mul_scale)));
     }
     return e;
 }

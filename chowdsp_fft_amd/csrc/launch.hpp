@@ -62,7 +62,8 @@ hipError_t launch_big_c2c (int n1, int n2, bool inverse, const float2* in, float
 // factorised stage-1 rows of the n2 core, then of the n1 core (fast_tile_table_rows (n) x 32 entries each); big_tw and the
 // workspace in plain [a][kb] order
 int fast_tile_table_rows (int n);
-hipError_t launch_fast_c2c (int n1, int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, size_t batch, int grid_divisor, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
+// mul_h != nullptr (forward only): every output bin times mul_h[bin] * mul_scale (fft_convolve_frames_batch of these sizes)
+hipError_t launch_fast_c2c (int n1, int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, size_t batch, int grid_divisor, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0, const float2* mul_h = nullptr, float mul_scale = 1.f);
 // ... and long REAL frames on the same tiles (real four-step; big_tw = forward table [a][kb < r2/2 + 16] followed by the
 // backward table [kb <= r2/2][a]; work: real4_fast_workspace_frame_len() float2 per frame)
 size_t real4_fast_workspace_frame_len (int r1, int r2);

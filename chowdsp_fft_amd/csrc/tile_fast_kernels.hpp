@@ -222,13 +222,18 @@ __global__ __launch_bounds__ (FastTile<N2>::threads, FastTile<N2>::min_waves) vo
 }
 
 // ---- pass B: n1-point row FFTs of 16 adjacent rows kb, transposed store X[n2 ka + kb] ----------------------------------
-template <int N1, bool SWAP_OUT>
+// MULH (round 3, fft_convolve_frames_batch of these sizes): every bin is multiplied by H[bin] * scaling on its way out, so
+// that forward transform + product are one sweep pair instead of two (the stand-alone conv_mac pass reads and writes the
+// whole batch once more); the backward transform follows as usual.
+template <int N1, bool SWAP_OUT, bool MULH = false>
 __global__ __launch_bounds__ (FastTile<N1>::threads, FastTile<N1>::min_waves) void pass_b_fast_kernel (const float2* __restrict__ work,
                                                                            float2* __restrict__ out,
                                                                            const float2* __restrict__ stage_tw, // [rows][32] of the n1 core
                                                                            unsigned n2,
                                                                            unsigned batch,
-                                                                           size_t out_stride)
+                                                                           size_t out_stride,
+                                                                           const float2* __restrict__ H = nullptr,
+                                                                           float scaling = 1.f)
 {
     using FT = FastTile<N1>;
     extern __shared__ __attribute__ ((aligned (16))) float ft_plane[];
@@ -268,7 +273,12 @@ __global__ __launch_bounds__ (FastTile<N1>::threads, FastTile<N1>::min_waves) vo
 #pragma unroll
             for (int b = 0; b < FT::R1; ++b)
             {
-                const float2 y = v[q * FT::R1 + b];
+                float2 y = v[q * FT::R1 + b];
+                if constexpr (MULH)
+                {
+                    const float2 h = H[(size_t) (ms + FT::Tn * q + 32 * b) * n2 + kb0 + ((unsigned) ts & 15u)];
+                    y = cmul (y, make_float2 (h.x * scaling, h.y * scaling));
+                }
                 gstore (&dst[(size_t) (ms + FT::Tn * q + 32 * b) * n2], SWAP_OUT ? make_float2 (y.y, y.x) : y);
             }
     }
