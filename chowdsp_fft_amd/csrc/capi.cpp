@@ -497,7 +497,7 @@ int big_c2c_chunked (Setup* s, int nc, bool inverse, const float2* in, float2* o
 }
 
 // long real frames by the real four-step: the same chunked two-lane pipeline as big_c2c_chunked, two launches per chunk
-int big_real4_chunked (Setup* s, bool inverse, const float2* in, float2* out, size_t batch, hipStream_t stream, size_t is2, size_t os2)
+int big_real4_chunked (Setup* s, bool inverse, const float2* in, float2* out, size_t batch, hipStream_t stream, size_t is2, size_t os2, const float2* mul_h = nullptr, float mul_scale = 1.f)
 {
     const DeviceTables* t = s->tables;
     const int r1 = t->real4_r1, r2 = t->real4_r2;
@@ -527,7 +527,7 @@ int big_real4_chunked (Setup* s, bool inverse, const float2* in, float2* out, si
         const int k = (lanes == 2) ? (int) (i & 1) : 0;
         const hipStream_t st = (lanes == 2) ? L->lane[k] : stream;
         const hipError_t e = t->real4_fast
-                                 ? launch_real4_fast (r1, r2, inverse, in + f0 * is2, L->ws[k], out + f0 * os2, t->stage_twiddles, t->big_twiddles, nb, lanes, st, is2, os2)
+                                 ? launch_real4_fast (r1, r2, inverse, in + f0 * is2, L->ws[k], out + f0 * os2, t->stage_twiddles, t->big_twiddles, nb, lanes, st, is2, os2, mul_h, mul_scale)
                                  : launch_real4 (r1, r2, inverse, in + f0 * is2, L->ws[k], out + f0 * os2, t->stage_twiddles, t->big_twiddles, nb, lanes, st, is2, os2);
         if (e != hipSuccess)
         {
@@ -1709,6 +1709,14 @@ int fft_convolve_frames_batch (void* setup, const float* x, const float* dft_fil
         // N = 2^17 ... 2^20 complex (register-direct two-pass tiles): the product rides on the forward transform's pass-B
         // stores, the backward transform follows in place -- four sweeps over the batch instead of five
         const int rc = big_c2c_chunked (s, nc, false, (const float2*) x, (float2*) y, batch, (hipStream_t) stream, (size_t) nc, (size_t) nc, 0, (const float2*) dft_filter, scaling);
+        if (rc != FFT_GPU_OK)
+            return rc;
+        return run_transform (s, y, y, batch, FFT_BACKWARD, (hipStream_t) stream);
+    }
+    if (s->transform == FFT_REAL && t->real4_r1 > 0 && t->real4_fast != 0 && g_fused_conv_group.load() != 0)
+    {
+        // real N = 2^17 ... 2^20 (real four-step on the same tiles): the same, with the packed spectrum's bin 0 as two real products
+        const int rc = big_real4_chunked (s, false, (const float2*) x, (float2*) y, batch, (hipStream_t) stream, (size_t) nc, (size_t) nc, (const float2*) dft_filter, scaling);
         if (rc != FFT_GPU_OK)
             return rc;
         return run_transform (s, y, y, batch, FFT_BACKWARD, (hipStream_t) stream);

@@ -175,9 +175,17 @@ int fast_tile_table_rows (int n) { return n == 1024 ? 10 : (n == 512 ? 6 : (n ==
 
 size_t real4_fast_workspace_frame_len (int r1, int r2) { return (size_t) r1 * (size_t) (r2 / 2 + 16); }
 
+// (CFFT_REAL4_FAST_LAUNCH names its kernels as templates of the tile length alone)
+template <int N_>
+constexpr auto pass_b_real_fast_plain = pass_b_real_fast_kernel<N_, false>;
+template <int N_>
+constexpr auto pass_b_real_fast_mulh = pass_b_real_fast_kernel<N_, true>;
+
 // long REAL frames on the register-direct tiles: N = r1 x r2 samples, r1, r2 in {256, 512, 1024}
-hipError_t launch_real4_fast (int r1, int r2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, size_t batch, int grid_divisor, hipStream_t stream, size_t in_stride, size_t out_stride)
+hipError_t launch_real4_fast (int r1, int r2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, size_t batch, int grid_divisor, hipStream_t stream, size_t in_stride, size_t out_stride, const float2* mul_h, float mul_scale)
 {
+    if (mul_h != nullptr && inverse)
+        return hipErrorInvalidValue;
     if (batch == 0)
         return hipSuccess;
     if (batch > 0x7FFFFFFFull || fast_tile_table_rows (r1) == 0 || fast_tile_table_rows (r2) == 0)
@@ -209,7 +217,14 @@ hipError_t launch_real4_fast (int r1, int r2, bool inverse, const float2* in, fl
         CFFT_DISPATCH_FAST (r2, CFFT_REAL4_FAST_LAUNCH (pass_a_real_fast_kernel, N_, tiles_a, in, work, tw2, big_fwd, (unsigned) n1c, (unsigned) batch, in_stride));
         if (e != hipSuccess)
             return e;
-        CFFT_DISPATCH_FAST (r1, CFFT_REAL4_FAST_LAUNCH (pass_b_real_fast_kernel, N_, tiles_b, (const float2*) work, out, tw1, (unsigned) r2, (unsigned) batch, out_stride));
+        if (mul_h != nullptr) // the product with a packed filter spectrum rides on the stores (fft_convolve_frames_batch)
+        {
+            CFFT_DISPATCH_FAST (r1, CFFT_REAL4_FAST_LAUNCH (pass_b_real_fast_mulh, N_, tiles_b, (const float2*) work, out, tw1, (unsigned) r2, (unsigned) batch, out_stride, mul_h, mul_scale));
+        }
+        else
+        {
+            CFFT_DISPATCH_FAST (r1, CFFT_REAL4_FAST_LAUNCH (pass_b_real_fast_plain, N_, tiles_b, (const float2*) work, out, tw1, (unsigned) r2, (unsigned) batch, out_stride, (const float2*) nullptr, 1.f));
+        }
     }
     else
     {

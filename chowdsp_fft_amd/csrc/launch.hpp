@@ -67,7 +67,7 @@ hipError_t launch_fast_c2c (int n1, int n2, bool inverse, const float2* in, floa
 // ... and long REAL frames on the same tiles (real four-step; big_tw = forward table [a][kb < r2/2 + 16] followed by the
 // backward table [kb <= r2/2][a]; work: real4_fast_workspace_frame_len() float2 per frame)
 size_t real4_fast_workspace_frame_len (int r1, int r2);
-hipError_t launch_real4_fast (int r1, int r2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, size_t batch, int grid_divisor, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
+hipError_t launch_real4_fast (int r1, int r2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, size_t batch, int grid_divisor, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0, const float2* mul_h = nullptr, float mul_scale = 1.f);
 // long REAL frames (N = r1 * r2 samples, both powers of two in 256..1024): the four-step algorithm on the real data, two
 // sweeps (real columns as pairs -> rows -> packed spectrum; backward the other way round).  in / out: the real frame and the
 // packed spectrum, both as N/2 float2; work: real4_workspace_frame_len() float2 per frame.

@@ -398,13 +398,17 @@ __global__ __launch_bounds__ (FastTile<N2>::threads, FastTile<N2>::min_waves) vo
     }
 }
 
-template <int R1_>
+// MULH: every packed bin times H[bin] * scaling on its way out (bin 0 = DC / Nyquist: two real products, reference
+// simd/chowdsp_fft_impl_sse.cpp:1640-1644) -- fft_convolve_frames_batch of these sizes, as pass_b_fast_kernel<..., MULH>
+template <int R1_, bool MULH = false>
 __global__ __launch_bounds__ (FastTile<R1_>::threads, FastTile<R1_>::min_waves) void pass_b_real_fast_kernel (const float2* __restrict__ work, // Wf[a][kb]
                                                                                                          float2* __restrict__ out, // packed spectrum
                                                                                                          const float2* __restrict__ stage_tw,
                                                                                                          unsigned n2, // R2
                                                                                                          unsigned batch,
-                                                                                                         size_t out_stride)
+                                                                                                         size_t out_stride,
+                                                                                                         const float2* __restrict__ H = nullptr,
+                                                                                                         float scaling = 1.f)
 {
     using FT = FastTile<R1_>;
     extern __shared__ __attribute__ ((aligned (16))) float ft_plane[];
@@ -458,12 +462,29 @@ __global__ __launch_bounds__ (FastTile<R1_>::threads, FastTile<R1_>::min_waves) 
                     if (32 * b + FT::Tn * q < R1_ / 2) // ka < R1 / 2 for every member (Tn q + 32 b is a multiple of Tn; ms < Tn)
                     {
                         if (q == 0 && b == 0 && kb == 0 && ms == 0)
-                            gstore (&dst[0], make_float2 (y.x, v[FT::R1 / 2].x)); // (X0, X_{N/2}): Y_0[0] and Y_0[R1/2], both real, both here
+                        {
+                            float2 p0 = make_float2 (y.x, v[FT::R1 / 2].x); // (X0, X_{N/2}): Y_0[0] and Y_0[R1/2], both real, both here
+                            if constexpr (MULH)
+                                p0 = make_float2 (p0.x * H[0].x * scaling, p0.y * H[0].y * scaling);
+                            gstore (&dst[0], p0);
+                        }
                         else
-                            gstore (&dst[(size_t) ka * n2 + kb], y);
+                        {
+                            const size_t k = (size_t) ka * n2 + kb;
+                            if constexpr (MULH)
+                                gstore (&dst[k], cmul (y, make_float2 (H[k].x * scaling, H[k].y * scaling)));
+                            else
+                                gstore (&dst[k], y);
+                        }
                     }
                     else if (inner)
-                        gstore (&dst[(size_t) (R1_ - 1 - ka) * n2 + (n2 - kb)], make_float2 (y.x, -y.y));
+                    {
+                        const size_t k = (size_t) (R1_ - 1 - ka) * n2 + (n2 - kb);
+                        if constexpr (MULH)
+                            gstore (&dst[k], cmul (make_float2 (y.x, -y.y), make_float2 (H[k].x * scaling, H[k].y * scaling)));
+                        else
+                            gstore (&dst[k], make_float2 (y.x, -y.y));
+                    }
                 }
         }
     }

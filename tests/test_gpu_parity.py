@@ -264,7 +264,7 @@ def test_convolution_golden(gpu, golden, n, tag):
                                   # fused on the split-plane kernels (frame in registers): one launch
                                   (16384, COMPLEX), (32768, COMPLEX), (65536, REAL),
                                   # two-pass register-direct tiles: the product rides on the forward transform's pass-B stores
-                                  (131072, COMPLEX), (262144, COMPLEX)])
+                                  (131072, COMPLEX), (262144, COMPLEX), (131072, REAL), (524288, REAL)])
 def test_batched_convolution_ops_vs_oracle(gpu, oracle, n, tr):
     """fft_convolve_unordered_batch (per-frame and shared filter), accumulate into a non-zero ab, fused kernel"""
     api, torch, dev = gpu
