@@ -209,3 +209,50 @@ def test_group_mode_decision_race(gpu, polls):
         api.set_option("fused_min_batch", default_min)
         api.set_option("fused_two_pass", 2)
         api.set_option("fused_conv_group", 1)
+
+
+def test_group_form_beside_another_streams_kernels(gpu):
+    """The group form's grid is the whole chip; beside another stream's kernels it may not be completely resident.  Then its
+    workgroups register late or not at all within `group_reg_polls`, the launch falls back to its SOLO mode by itself (or
+    not, depending on timing) -- and must be correct either way.  Here: long-running kernels of a second stream (torch
+    element-wise passes and our own N = 4096 transforms, which fill every CU) run while group-form transforms and fused
+    convolutions are launched on the first, with short and with normal patience."""
+    api, torch, dev = gpu
+    default_min = int(api.get_option("fused_min_batch"))
+    api.set_option("fused_min_batch", 1)
+    try:
+        s = api.fft_new_setup(N, api.FFT_COMPLEX)
+        s4 = api.fft_new_setup(4096, api.FFT_COMPLEX)
+        g = torch.Generator(device=dev)
+        g.manual_seed(99)
+        x = torch.rand((96, 2 * N), device=dev, generator=g) * 2 - 1
+        api.set_option("fused_two_pass", 0)
+        want = torch.empty_like(x)
+        api.fft_transform_batch(s, x, want, api.FFT_FORWARD)
+        torch.cuda.synchronize()
+        api.set_option("fused_two_pass", 2)
+        side = torch.cuda.Stream()
+        main = torch.cuda.Stream()
+        noise = torch.rand((1 << 28,), device=dev)            # 1 GiB
+        frames = torch.rand((16384, 8192), device=dev)       # 512 MiB of N = 4096 frames
+        scratch = torch.empty_like(frames)
+        y = torch.empty_like(x)
+        for polls in (2, 200):
+            api.set_option("group_reg_polls", polls)
+            for rep in range(6):
+                with torch.cuda.stream(side):
+                    for _ in range(4):
+                        noise.mul_(1.0000001)
+                        api.fft_transform_batch(s4, frames, scratch, api.FFT_FORWARD, stream=side)
+                y.fill_(-1.0)
+                main.wait_stream(torch.cuda.current_stream())
+                api.fft_transform_batch(s, x, y, api.FFT_FORWARD, stream=main)
+                api.stream_synchronize(main)
+                side.synchronize()
+                assert torch.equal(y, want), f"polls {polls}, launch {rep}"
+        api.fft_destroy_setup(s)
+        api.fft_destroy_setup(s4)
+    finally:
+        api.set_option("group_reg_polls", 200)
+        api.set_option("fused_min_batch", default_min)
+        api.set_option("fused_two_pass", 2)
