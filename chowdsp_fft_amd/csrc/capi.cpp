@@ -292,6 +292,8 @@ std::atomic<int> g_fused_conv_split { 1 };
 std::atomic<int> g_fused_conv_generic { 1 };
 // "fused_conv_group": ... and for N = 65536 complex (one launch on the static groups of the one-launch transform)
 std::atomic<int> g_fused_conv_group { 1 };
+// "group_fast": N = 2^17 / 2^18 complex through the one-launch group form on the register-direct tiles (A/B against two launches)
+std::atomic<int> g_group_fast { 1 };
 bool split16384_enabled()
 {
     int v = g_split16384.load();
@@ -428,6 +430,30 @@ int big_c2c_chunked (Setup* s, int nc, bool inverse, const float2* in, float2* o
         if (e != hipSuccess)
         {
             set_last_error ("fused two-pass kernel launch", e);
+            return cf::FFT_GPU_ELAUNCH;
+        }
+        return cf::FFT_GPU_OK;
+    }
+    if (! mixed && pair == 0 && mul_h == nullptr && fused_form() == 2 && s->tables->fast_n1 > 0 && groupfast_supported (n1, n2) && g_group_fast.load() != 0
+        && batch >= std::max<size_t> (1, fused_min_batch() / 4))
+    {
+        // N = 2^17 / 2^18 on the register-direct tiles: one launch, static groups, one workgroup per CU (group_fast_kernels.hpp)
+        std::lock_guard<std::recursive_mutex> lock (g_ws_mutex);
+        Lanes* L = get_fused (s->device, stream, groupfast_workspace_bytes (n1, n2));
+        if (L == nullptr)
+            return cf::FFT_GPU_ENOMEM;
+        if (*L->fused_err_host != 0)
+        {
+            const unsigned w = *L->fused_err_host;
+            *L->fused_err_host = 0;
+            set_last_error (fused_error_text (w).c_str());
+            return cf::FFT_GPU_ELAUNCH;
+        }
+        const unsigned seq = ++L->fused_seq;
+        const hipError_t e = launch_groupfast_c2c (n1, n2, inverse, in, L->fused_ws, out, s->tables->stage_twiddles, s->tables->big_twiddles, L->fused_state, L->fused_err_host, seq, batch, stream, is2, os2);
+        if (e != hipSuccess)
+        {
+            set_last_error ("fused two-pass kernel launch (register-direct tiles)", e);
             return cf::FFT_GPU_ELAUNCH;
         }
         return cf::FFT_GPU_OK;
@@ -1468,6 +1494,8 @@ int fft_gpu_set_option (const char* name, long value)
         g_fused_conv_generic = value != 0 ? 1 : 0;
     else if (std::strcmp (name, "fused_conv_group") == 0)
         g_fused_conv_group = value != 0 ? 1 : 0;
+    else if (std::strcmp (name, "group_fast") == 0)
+        g_group_fast = value != 0 ? 1 : 0;
     else
     {
         set_last_error ("fft_gpu_set_option: unknown option or value out of range");
@@ -1501,6 +1529,8 @@ long fft_gpu_get_option (const char* name)
         return g_fused_conv_generic.load();
     if (std::strcmp (name, "fused_conv_group") == 0)
         return g_fused_conv_group.load();
+    if (std::strcmp (name, "group_fast") == 0)
+        return g_group_fast.load();
     return -1;
 }
 

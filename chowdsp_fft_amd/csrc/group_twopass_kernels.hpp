@@ -123,7 +123,7 @@ __device__ __forceinline__ void g256_load_a (float (&re)[16], float (&im)[16], c
 // Lane 0 of every workgroup, first thing: draw a rank on this XCD, register, learn (or make) the launch's mode.
 // info[0] = mode (1 GROUP, 2 SOLO), [1] = XCD, [2] = rank on it, [3] = global group number, [4] = groups in all, [5] = 0 for a
 // rank beyond its XCD's last complete group (nothing to do in GROUP mode).
-__device__ __forceinline__ void group_register (GroupState* __restrict__ st, unsigned* info, unsigned reg_polls, unsigned force_solo)
+__device__ __forceinline__ void group_register (GroupState* __restrict__ st, unsigned* info, unsigned reg_polls, unsigned force_solo, unsigned members = kGroupMembers)
 {
     const unsigned xcc = hw_xcc_id();
     const unsigned r = __hip_atomic_fetch_add (&st->xcc[xcc].count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -151,16 +151,16 @@ __device__ __forceinline__ void group_register (GroupState* __restrict__ st, uns
         unsigned mine = 0;
         for (unsigned x = 0; x < (unsigned) kGroupMaxXcc; ++x)
         {
-            unsigned g = ld_relaxed (&st->xcc[x].count) / kGroupMembers;
+            unsigned g = ld_relaxed (&st->xcc[x].count) / members;
             g = g > (unsigned) kGroupMaxPerXcc ? (unsigned) kGroupMaxPerXcc : g;
             if (x == xcc)
             {
-                gg = total + r / kGroupMembers;
+                gg = total + r / members;
                 mine = g;
             }
             total += g;
         }
-        valid = (r / kGroupMembers < mine) ? 1u : 0u; // a rank beyond the last complete group has nothing to do
+        valid = (r / members < mine) ? 1u : 0u; // a rank beyond the last complete group has nothing to do
     }
     info[0] = mode;
     info[1] = xcc;

@@ -3,6 +3,7 @@
 #include "multipass_kernels.hpp"
 #include "fused_twopass_kernels.hpp"
 #include "group_twopass_kernels.hpp"
+#include "group_fast_kernels.hpp"
 #include "tile_fast_kernels.hpp"
 #include "generic_kernels.hpp"
 #include "tables.hpp"
@@ -537,6 +538,52 @@ hipError_t launch_group_c2c (int n1, int n2, bool inverse, const float2* in, flo
         }
     }
     return e;
+}
+
+// ---- ... and for the register-direct tiles: N = 512 x 256 (2^17) and 512 x 512 (2^18), group_fast_kernels.hpp ----------------
+bool groupfast_supported (int n1, int n2) { return n1 == 512 && (n2 == 256 || n2 == 512); }
+namespace
+{
+template <int N1, int N2>
+hipError_t groupfast_launch (bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, void* state, unsigned* host_err, unsigned seq, size_t batch, hipStream_t stream, size_t in_stride, size_t out_stride)
+{
+    using GF = GroupFast<N1, N2>;
+    DeviceInfo dev;
+    if (! current_device_info (dev))
+        return hipErrorNoDevice;
+    auto k = inverse ? groupfast_kernel<N1, N2, true> : groupfast_kernel<N1, N2, false>;
+    if (blocks_per_cu_cached ((const void*) k, 256, GF::lds_bytes) < 1)
+        return hipErrorNoDevice;
+    const unsigned grid = (unsigned) dev.num_cus; // ONE workgroup per CU: 32 per XCD = two groups of 16 / one of 32, whose slots fit that XCD's L2
+    const float2* tw_a = stage_tw;                                  // n2 core (columns)
+    const float2* tw_b = stage_tw + fast_tile_table_rows (N2) * 32; // n1 core (rows)
+    int force_solo = 0, reg_polls = 200;
+    get_group_options (force_solo, reg_polls);
+    hipLaunchKernelGGL (k, dim3 (grid), dim3 (256), GF::lds_bytes, stream, in, work, out, tw_a, tw_b, big_tw, (GroupState*) state, host_err, (unsigned) batch, in_stride, out_stride, seq, (unsigned) reg_polls, (unsigned) force_solo);
+    return hipGetLastError();
+}
+} // namespace
+size_t groupfast_workspace_bytes (int n1, int n2)
+{
+    DeviceInfo dev;
+    const unsigned grid = current_device_info (dev) ? (unsigned) dev.num_cus : 256u;
+    // GROUP mode: one slot per group, addressed [xcc][group]; SOLO mode: one per workgroup
+    return (size_t) std::max<unsigned> ((unsigned) (kGroupMaxXcc * kGroupMaxPerXcc), grid) * (size_t) n1 * (size_t) n2 * sizeof (float2);
+}
+hipError_t launch_groupfast_c2c (int n1, int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, void* state, unsigned* host_err, unsigned seq, size_t batch, hipStream_t stream, size_t in_stride, size_t out_stride)
+{
+    if (batch == 0)
+        return hipSuccess;
+    if (! groupfast_supported (n1, n2) || batch >= 0x7FFFFFFFull)
+        return hipErrorInvalidValue;
+    const size_t frame_len = (size_t) n1 * (size_t) n2;
+    in_stride = in_stride ? in_stride : frame_len;
+    out_stride = out_stride ? out_stride : frame_len;
+    const hipError_t e = hipMemsetAsync (state, 0, sizeof (GroupState), stream);
+    if (e != hipSuccess)
+        return e;
+    return n2 == 256 ? groupfast_launch<512, 256> (inverse, in, work, out, stage_tw, big_tw, state, host_err, seq, batch, stream, in_stride, out_stride)
+                     : groupfast_launch<512, 512> (inverse, in, work, out, stage_tw, big_tw, state, host_err, seq, batch, stream, in_stride, out_stride);
 }
 
 // long mixed-radix frames: generic n2-point column pass (generic_kernels.hpp), then the ordinary n1-point row pass

@@ -85,6 +85,10 @@ hipError_t launch_fused_c2c (int n1, int n2, bool inverse, const float2* in, flo
 size_t group_state_bytes();
 void set_group_options (int force_solo, int reg_polls); // -1 = leave as it is
 size_t group_workspace_bytes();
+// ... and for N = 512 x 256 / 512 x 512 on the register-direct tiles (group_fast_kernels.hpp): one workgroup per CU
+bool groupfast_supported (int n1, int n2);
+size_t groupfast_workspace_bytes (int n1, int n2);
+hipError_t launch_groupfast_c2c (int n1, int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, void* state, unsigned* host_err, unsigned seq, size_t batch, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
 void get_group_options (int& force_solo, int& reg_polls);
 int group_wg_per_cu_tenths();
 unsigned group_conv_grid(); // workgroups of the fused-convolution form's launch (kernels_group_conv.hip)

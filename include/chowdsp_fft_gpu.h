@@ -62,7 +62,7 @@ const char* fft_gpu_last_error (void);
 int fft_gpu_release_stream_resources (void* stream);
 
 /* Run-time options (process-wide; initial values come from the environment variables named in INTEGRATION.md):
-     "fused_two_pass"   which form runs two-pass sizes that have a one-launch form (N = 65536 complex), batches of at
+     "fused_two_pass"   which form runs two-pass sizes that have a one-launch form (N = 65536, 2^17, 2^18 complex), batches of at
                         least "fused_min_batch" frames:  2 (default) one launch, static groups of 16 workgroups per XCD, the
                         inter-pass hand-off inside that XCD's L2 (1.4 x the algorithmic bytes on the fabric);  1 one launch,
                         per-XCD ticket queues (1.5-1.6 x, slower);  0 two launches per chunk (2 x).
@@ -86,6 +86,9 @@ int fft_gpu_release_stream_resources (void* stream);
                         the one-launch split-plane form (A/B switch; default 1)
      "fused_conv_generic" 0: fft_convolve_frames_batch of mixed-radix frames (up to 20000 complex points) as three launches
                         instead of the one-launch form (A/B switch; default 1)
+     "group_fast"       0: N = 2^17 / 2^18 complex as two launches per chunk instead of the one-launch group form on the
+                        register-direct tiles (one workgroup per CU; 0.35 -> 0.38 of 8 TB/s; batches of at least
+                        "fused_min_batch" / 4 frames; A/B switch, default 1)
      "fused_conv_group" 0: fft_convolve_frames_batch of N = 65536 complex frames (batches of at least "fused_min_batch") as three
                         launches instead of one launch on the static groups of "fused_two_pass" = 2 (A/B switch; default 1)
      "conv_wave2048"    1: fft_convolve_frames_batch of 2048-point cores by one wavefront per frame; 12-14 % slower than
@@ -93,7 +96,7 @@ int fft_gpu_release_stream_resources (void* stream);
    Returns 0, or FFT_GPU_EINVAL for an unknown name / a value out of range. */
 int fft_gpu_set_option (const char* name, long value);
 /* Current value of an option ("fused_two_pass", "fused_min_batch", "fused_lag", "fused_slots", "split16384", "split8192",
-   "conv_wave2048", "fused_conv_split", "fused_conv_generic", "fused_conv_group"), or -1 for a name that cannot be read back. */
+   "conv_wave2048", "fused_conv_split", "fused_conv_generic", "fused_conv_group", "group_fast"), or -1 for a name that cannot be read back. */
 long fft_gpu_get_option (const char* name);
 
 /* ---- plan introspection -------------------------------------------------------------------------- */

@@ -256,3 +256,54 @@ def test_group_form_beside_another_streams_kernels(gpu):
         api.set_option("group_reg_polls", 200)
         api.set_option("fused_min_batch", default_min)
         api.set_option("fused_two_pass", 2)
+
+
+@pytest.mark.parametrize("solo", [0, 1])
+@pytest.mark.parametrize("n,batch", [(1 << 17, 1), (1 << 17, 37), (1 << 18, 3), (1 << 18, 21)])
+def test_group_form_on_the_register_direct_tiles(gpu, oracle, n, batch, solo):
+    """N = 2^17 (512 x 256: two groups of 16 workgroups per XCD) and 2^18 (512 x 512: one group of 32) in ONE launch
+    (group_fast_kernels.hpp), GROUP and fall-back mode, both directions, in place and strided == the two-launch form == the oracle."""
+    api, torch, dev = gpu
+    default_min = int(api.get_option("fused_min_batch"))
+    assert api.get_option("fused_two_pass") == 2 and api.get_option("group_fast") == 1
+    api.set_option("fused_min_batch", 1)
+    api.set_option("group_force_solo", solo)
+    try:
+        s, so = api.fft_new_setup(n, api.FFT_COMPLEX), oracle.new_setup(n, COMPLEX)
+        x = ol.uniform(batch * 2 * n, 4000 + batch).reshape(batch, 2 * n)
+        xd = torch.from_numpy(x).to(dev)
+        for direction, odir in ((api.FFT_FORWARD, FORWARD), (api.FFT_BACKWARD, BACKWARD)):
+            one = torch.full_like(xd, -3.0)
+            api.fft_transform_batch(s, xd, one, direction)
+            api.stream_synchronize()
+            api.set_option("group_fast", 0)
+            two = torch.full_like(xd, -5.0)
+            api.fft_transform_batch(s, xd, two, direction)
+            torch.cuda.synchronize()
+            api.set_option("group_fast", 1)
+            assert_frames_close(one.cpu().numpy(), two.cpu().numpy(), tol=2e-7, maxabs_tol=6e-7, what=f"N={n} one launch vs two launches")
+            pick = sorted({0, batch - 1})
+            want = oracle.transform_batch(so, x[pick], odir)
+            assert_frames_close(one.cpu().numpy()[pick], want, what=f"N={n} batch={batch} dir={direction} solo={solo}")
+        inplace = xd.clone()
+        api.fft_transform_batch(s, inplace, inplace, api.FFT_FORWARD)
+        stride = 2 * n + 64
+        buf = torch.full((batch, stride), 123.0, device=dev)
+        buf[:, :2 * n] = xd
+        outb = torch.full((batch, stride), -7.0, device=dev)
+        api.fft_transform_batch_strided(s, buf, stride, outb, stride, batch, api.FFT_FORWARD)
+        api.stream_synchronize()
+        ref = torch.empty_like(xd)
+        api.set_option("group_fast", 0)
+        api.fft_transform_batch(s, xd, ref, api.FFT_FORWARD)
+        torch.cuda.synchronize()
+        api.set_option("group_fast", 1)
+        assert torch.equal(inplace, outb[:, :2 * n].contiguous()), "in place == strided"
+        assert_frames_close(inplace.cpu().numpy(), ref.cpu().numpy(), tol=2e-7, maxabs_tol=6e-7, what="in place vs two launches")
+        assert bool((outb[:, 2 * n:] == -7.0).all()), "padding between output frames untouched"
+        api.fft_destroy_setup(s)
+        oracle.destroy_setup(so)
+    finally:
+        api.set_option("group_force_solo", 0)
+        api.set_option("fused_min_batch", default_min)
+        api.set_option("group_fast", 1)
