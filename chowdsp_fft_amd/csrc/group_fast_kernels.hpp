@@ -68,7 +68,8 @@ __global__ __launch_bounds__ (256, 1) void groupfast_kernel (const float2* __res
                                                             size_t out_stride,
                                                             unsigned seq,
                                                             unsigned reg_polls,
-                                                            unsigned force_solo)
+                                                            unsigned force_solo,
+                                                            unsigned form) // where the next frame's operands are requested: 0 behind the pass-B loads; 1 in front of the hand-off (waves 1-3; wave 0, which polls, behind the pass-B loads); 2 in front of it, every wave
 {
     using GF = GroupFast<N1, N2>;
     using FA = typename GF::FA;
@@ -174,7 +175,18 @@ __global__ __launch_bounds__ (256, 1) void groupfast_kernel (const float2* __res
             if (k != 0)
                 group_wait_m<GF::M, 1> (bf, k, tid0 & 63, st, host_err, seq, 2u); // every member has read frame k - 1 out of the slot
             CFFT_GF_PASS_A_STORE (v, a0, slot, bw, ta)
-            asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+            // With one workgroup per CU the wait for the group is idle time for the whole CU: the next frame's operands can be in
+            // flight during it.  Vector memory operations retire in issue order, so the polling wave's flag loads would come back
+            // behind its own prefetch: form 1 leaves wave 0's share behind the pass-B loads.
+            const unsigned fn = f + total;
+            const bool pre_here = fn < batch && (form == 2u || (form == 1u && tid0 >= 64));
+            if (pre_here)
+            {
+                CFFT_GF_LOAD_A (nv, in + (size_t) fn * in_stride + a0, ta)
+                asm volatile ("s_waitcnt vmcnt(32)" ::: "memory"); // all but the 32 prefetch loads: this wave's stores are in L2
+            }
+            else
+                asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid0 == 0)
                 flag_store (&af[member], k + 1u);
@@ -189,8 +201,7 @@ __global__ __launch_bounds__ (256, 1) void groupfast_kernel (const float2* __res
                 for (int a = 0; a < 32; ++a)
                     v[a] = gload_l2 (&src[(size_t) (mb + FB::Tn * a) * N2]);
             }
-            const unsigned fn = f + total;
-            if (fn < batch)
+            if (fn < batch && ! pre_here)
                 CFFT_GF_LOAD_A (nv, in + (size_t) fn * in_stride + a0, ta)
             CFFT_PHASE_FENCE();
             fft_reg32<false> (v, wb[0]);

@@ -559,7 +559,8 @@ hipError_t groupfast_launch (bool inverse, const float2* in, float2* work, float
     const float2* tw_b = stage_tw + fast_tile_table_rows (N2) * 32; // n1 core (rows)
     int force_solo = 0, reg_polls = 200;
     get_group_options (force_solo, reg_polls);
-    hipLaunchKernelGGL (k, dim3 (grid), dim3 (256), GF::lds_bytes, stream, in, work, out, tw_a, tw_b, big_tw, (GroupState*) state, host_err, (unsigned) batch, in_stride, out_stride, seq, (unsigned) reg_polls, (unsigned) force_solo);
+    static const unsigned form = std::getenv ("CHOWDSP_FFT_GROUPFAST_PREFETCH") != nullptr ? (unsigned) std::atoi (std::getenv ("CHOWDSP_FFT_GROUPFAST_PREFETCH")) : 0u;
+    hipLaunchKernelGGL (k, dim3 (grid), dim3 (256), GF::lds_bytes, stream, in, work, out, tw_a, tw_b, big_tw, (GroupState*) state, host_err, (unsigned) batch, in_stride, out_stride, seq, (unsigned) reg_polls, (unsigned) force_solo, form);
     return hipGetLastError();
 }
 } // namespace
