@@ -186,6 +186,11 @@ hipError_t launch_generic_inplace (GenericPlan plan, const DeviceTables& t, cons
             CFFT_TRY_STATIC_INPLACE (5120, 256)
             CFFT_TRY_STATIC_INPLACE (12288, 1024)
             CFFT_TRY_STATIC_INPLACE (19200, 1024)
+            CFFT_TRY_STATIC_INPLACE (6144, 512)
+            CFFT_TRY_STATIC_INPLACE (7680, 512)
+            CFFT_TRY_STATIC_INPLACE (10240, 512)
+            CFFT_TRY_STATIC_INPLACE (15360, 1024)
+            CFFT_TRY_STATIC_INPLACE (18432, 1024)
 #undef CFFT_TRY_STATIC_INPLACE
             return launch_generic_inplace_tw<MODE, INV, BLOCK, true> (plan, t, in, out, batch, stream);
         }

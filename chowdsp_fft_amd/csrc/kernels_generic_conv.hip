@@ -97,6 +97,11 @@ hipError_t launch_conv_inplace (GenericPlan plan, const DeviceTables& t, const f
         CFFT_TRY_STATIC_INPLACE_CONV (5120, 256)
         CFFT_TRY_STATIC_INPLACE_CONV (12288, 1024)
         CFFT_TRY_STATIC_INPLACE_CONV (19200, 1024)
+        CFFT_TRY_STATIC_INPLACE_CONV (6144, 512)
+        CFFT_TRY_STATIC_INPLACE_CONV (7680, 512)
+        CFFT_TRY_STATIC_INPLACE_CONV (10240, 512)
+        CFFT_TRY_STATIC_INPLACE_CONV (15360, 1024)
+        CFFT_TRY_STATIC_INPLACE_CONV (18432, 1024)
 #undef CFFT_TRY_STATIC_INPLACE_CONV
         return launch_conv_inplace_tw<REAL, BLOCK, true> (plan, t, in, H, out, scaling, batch, stream);
     }

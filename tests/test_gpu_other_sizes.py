@@ -17,7 +17,7 @@ REFERENCE_OTHER_SIZES = [96, 192, 384, 480, 640, 768, 9216]
 # generic_kernels.hpp: StaticPlanFor; as real frames of N the complex length N / 2 is exercised too), then a spread of longer ones
 STATIC_PLAN_SIZES = [48, 80, 144, 160, 240, 288, 320, 400, 432, 576, 720, 800, 864, 960, 1152, 1200, 1280, 1296, 1440, 1536, 1600, 1728,
                      1920, 2000]
-MORE_SIZES = STATIC_PLAN_SIZES + [2304, 2400, 2880, 3072, 3200, 3456, 3840, 4000, 5120, 6400, 7680, 8640, 10240, 10368, 11520, 13824, 17280, 19200]
+MORE_SIZES = STATIC_PLAN_SIZES + [2304, 2400, 2880, 3072, 3200, 3456, 3840, 4000, 5120, 6144, 6400, 7680, 8640, 10240, 10368, 11520, 13824, 17280, 19200]
 # complex length > 20000 (and some below, as real frames of twice the length): two passes (generic n2-point column FFTs x power-of-two n1-point row FFTs) where such a split
 # exists; sizes without one (test_long_mixed_sizes_without_a_split) come back NULL although the reference accepts them
 # 655360 = 640 x 1024 and 1310720 = 1280 x 1024: the column lengths at the edge of the CU's 160 KiB LDS (two padded
@@ -198,7 +198,8 @@ def test_other_size_convolution_ops(gpu, oracle):
 @pytest.mark.parametrize("n,tr", [(96, COMPLEX), (192, COMPLEX), (384, COMPLEX), (480, COMPLEX), (640, COMPLEX), (768, COMPLEX),
                                   (96, REAL), (192, REAL), (384, REAL), (480, REAL), (640, REAL), (768, REAL),
                                   (1536, COMPLEX), (1920, REAL), (2000, COMPLEX), (3072, REAL),
-                                  (9216, COMPLEX), (9216, REAL), (18432, REAL), (5120, COMPLEX), (12288, COMPLEX), (19200, COMPLEX)])
+                                  (9216, COMPLEX), (9216, REAL), (18432, REAL), (5120, COMPLEX), (12288, COMPLEX), (19200, COMPLEX),
+                                  (6144, COMPLEX), (15360, COMPLEX), (36864, REAL)])
 def test_fused_convolution_mixed_radix(gpu, oracle, n, tr):
     api, torch, dev = gpu
     nf = 2 * n if tr == COMPLEX else n
