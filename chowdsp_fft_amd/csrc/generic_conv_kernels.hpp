@@ -89,6 +89,16 @@ __global__ __launch_bounds__ (BLOCK) void generic_conv_kernel (const float2* __r
             wlds[i] = wtab[i];
     }
     const unsigned ngroups = (batch + F - 1) / F;
+    // software pipeline (generic_kernels.hpp: generic_first_prefetch): the next group's first-stage operands are requested while
+    // this group's remaining forward stages, the product and the whole backward transform run
+    constexpr int R0 = SP::radix (0);
+    constexpr bool PIPE = CFFT_GENERIC_CONV_PIPE != 0;
+    float2 pre[R0];
+    if constexpr (PIPE)
+    {
+        if (blockIdx.x < ngroups)
+            generic_first_prefetch<R0, BLOCK, false> (pre, in + (size_t) blockIdx.x * F * n, n, (int) min ((unsigned) F, batch - blockIdx.x * F), tid, (unsigned) n);
+    }
     for (unsigned g = blockIdx.x; g < ngroups; g += gridDim.x)
     {
         const int nframes = (int) min ((unsigned) F, batch - g * F);
@@ -97,7 +107,18 @@ __global__ __launch_bounds__ (BLOCK) void generic_conv_kernel (const float2* __r
         __syncthreads(); // previous group's reads of the images are finished (and, first time round, the tables are written)
         // complex frames: the product rides on the forward transform's last stage (its outputs are multiplied as they are
         // written to the image); real frames need both bins of a pair and get a sweep of their own
-        float2* res = static_core<SP, BLOCK, true, false, false, 0, ! REAL> (twl, bufA, bufB, src, dst, nframes, tid, (unsigned) n, (unsigned) n, H, scaling);
+        float2* res;
+        if constexpr (PIPE)
+        {
+            generic_first_stage_pre<R0, BLOCK, false> (pre, src, bufB, n, nframes, tid, (unsigned) n, (unsigned) n);
+            __syncthreads();
+            const unsigned gn = g + gridDim.x;
+            if (gn < ngroups)
+                generic_first_prefetch<R0, BLOCK, false> (pre, in + (size_t) gn * F * n, n, (int) min ((unsigned) F, batch - gn * F), tid, (unsigned) n);
+            res = static_core<SP, BLOCK, true, false, false, 1, ! REAL> (twl, bufB, bufA, src, dst, nframes, tid, (unsigned) n, (unsigned) n, H, scaling);
+        }
+        else
+            res = static_core<SP, BLOCK, true, false, false, 0, ! REAL> (twl, bufA, bufB, src, dst, nframes, tid, (unsigned) n, (unsigned) n, H, scaling);
         float2* other = (res == bufA) ? bufB : bufA;
         if constexpr (REAL)
         {

@@ -379,6 +379,62 @@ template <> struct StaticPlanFor<1920> { using type = StaticPlan<1920, 12, 10, 1
 template <> struct StaticPlanFor<2000> { using type = StaticPlan<2000, 10, 5, 5, 8>; };
 
 // all stages of a static plan; twl: the workgroup's LDS copy of the plan's twiddles.  Returns the image that holds the result.
+// ---- software pipeline of the compile-time lists (round 3): the first stage's operands of the NEXT group of frames are
+// requested while this group's other stages run.  A first stage reads global memory, has no twiddles (p = 1) and writes
+// output i R + b; its butterfly number tid (the only one a work-item has for every length but the shortest) takes its
+// operands from `pre`, requested by generic_first_prefetch one group earlier; further butterflies (idx >= BLOCK) load as before.
+template <int R, int BLOCK, bool SWAP>
+__device__ __forceinline__ void generic_first_prefetch (float2 (&pre)[R], const float2* __restrict__ src, int n, int nframes, int tid, unsigned gs_in)
+{
+    const int m = n / R;
+    if (tid < nframes * m)
+    {
+        const int f = (nframes == 1) ? 0 : (m == 1 ? tid : fast_div (tid, div_magic ((unsigned) (m > 1 ? m : 2))));
+        const int i = tid - f * m;
+        const float2* s = src + (size_t) f * gs_in;
+#pragma unroll
+        for (int a = 0; a < R; ++a)
+        {
+            const float2 x = gload (&s[i + a * m]);
+            pre[a] = SWAP ? make_float2 (x.y, x.x) : x;
+        }
+    }
+}
+template <int R, int BLOCK, bool SWAP>
+__device__ __forceinline__ void generic_first_stage_pre (const float2 (&pre)[R], const float2* __restrict__ src, float2* __restrict__ dst, int n, int nframes, int tid,
+                                                         unsigned gs_in, unsigned lfs)
+{
+    const int m = n / R;
+    const unsigned magic_m = m > 1 ? div_magic ((unsigned) m) : 0u;
+    for (int idx = tid; idx < nframes * m; idx += BLOCK)
+    {
+        const int f = (nframes == 1) ? 0 : (m == 1 ? idx : fast_div (idx, magic_m));
+        const int i = idx - f * m;
+        float2 u[R];
+        if (idx == tid)
+        {
+#pragma unroll
+            for (int a = 0; a < R; ++a)
+                u[a] = pre[a];
+        }
+        else
+        {
+            const float2* s = src + (size_t) f * gs_in;
+#pragma unroll
+            for (int a = 0; a < R; ++a)
+            {
+                const float2 x = gload (&s[i + a * m]);
+                u[a] = SWAP ? make_float2 (x.y, x.x) : x;
+            }
+        }
+        fft_reg<R> (u);
+        float2* d = dst + (size_t) f * lfs + i * R;
+#pragma unroll
+        for (int b = 0; b < R; ++b)
+            d[b] = u[b];
+    }
+}
+
 // CONV: the last stage (which then writes an LDS image: OUT_GLOBAL false) multiplies by H * scaling and swaps, see generic_stage
 template <class SP, int BLOCK, bool IN_GLOBAL, bool OUT_GLOBAL, bool SWAP, int S = 0, bool CONV = false>
 __device__ __forceinline__ float2* static_core (const float2* twl, float2* a, float2* b, const float2* __restrict__ gin, float2* __restrict__ gout,
@@ -414,12 +470,25 @@ template <class SP>
 struct SP_N_OR_ZERO
 {
     static constexpr int value = SP::n;
+    static constexpr int r0 = SP::radix (0); // radix of the first stage
 };
 template <>
 struct SP_N_OR_ZERO<void>
 {
     static constexpr int value = 1 << 30;
+    static constexpr int r0 = 1;
 };
+// CFFT_GENERIC_PIPE / CFFT_GENERIC_CONV_PIPE (A/B switches): compile-time lists request the next group's first-stage operands one
+// group ahead (generic_first_prefetch above).  Measured on MI355X, pipelined against not, same process order: the plain
+// transforms LOSE more than they gain (c768 0.76 -> 0.69, c1920 0.75 -> 0.68, c2000 0.67 -> 0.63, c480 0.60 -> 0.58; c192, c640,
+// r768, r1920 + 1-3 %): off.  The fused convolutions, with two transforms between a group's loads and stores, gain 1-4.5 %
+// (c480 0.497 -> 0.511, c768 0.456 -> 0.477, c1536 0.516 -> 0.528): on.
+#ifndef CFFT_GENERIC_PIPE
+#define CFFT_GENERIC_PIPE 0
+#endif
+#ifndef CFFT_GENERIC_CONV_PIPE
+#define CFFT_GENERIC_CONV_PIPE 1
+#endif
 
 // MODE 0: complex <-> complex (INV: backward).  MODE 1: real forward (packed spectrum out).  MODE 2: real backward.
 // For the real modes plan.n = N/2 and wtab holds W_N^k, k <= N/4 (pair stage formulas: real_kernels.hpp).
@@ -467,6 +536,14 @@ __global__ __launch_bounds__ (BLOCK) void generic_kernel (const float2* __restri
         // the first barrier of the group loop orders these writes before any stage
     }
     const unsigned ngroups = (batch + F - 1) / F;
+    constexpr int R0 = SP_N_OR_ZERO<SP>::r0;
+    constexpr bool PIPE = STATIC && MODE != 2 && CFFT_GENERIC_PIPE != 0;
+    float2 pre[R0];
+    if constexpr (PIPE)
+    {
+        if (blockIdx.x < ngroups)
+            generic_first_prefetch<R0, BLOCK, INV> (pre, in + (size_t) blockIdx.x * F * plan.in_stride, n, (int) min ((unsigned) F, batch - blockIdx.x * F), tid, plan.in_stride);
+    }
     for (unsigned g = blockIdx.x; g < ngroups; g += gridDim.x)
     {
         const int nframes = (int) min ((unsigned) F, batch - g * F);
@@ -585,6 +662,17 @@ __global__ __launch_bounds__ (BLOCK) void generic_kernel (const float2* __restri
         if (staged_real)
         {
             // MODE 1: res is set; fall through to the pair stage
+        }
+        else if constexpr (PIPE)
+        {
+            // first stage from the operands requested one group ago; the next group's are requested now and stay in flight
+            // while the other stages of this group run
+            generic_first_stage_pre<R0, BLOCK, INV> (pre, src, bufB, n, nframes, tid, is, (unsigned) n);
+            __syncthreads();
+            const unsigned gn = g + gridDim.x;
+            if (gn < ngroups)
+                generic_first_prefetch<R0, BLOCK, INV> (pre, in + (size_t) gn * F * is, n, (int) min ((unsigned) F, batch - gn * F), tid, is);
+            res = static_core<SP, BLOCK, IN_GLOBAL, OUT_GLOBAL, INV, 1> (twl, bufB, bufA, src, dst, nframes, tid, is, os);
         }
         else if constexpr (STATIC)
             res = static_core<SP, BLOCK, IN_GLOBAL, OUT_GLOBAL, (MODE == 2) || INV> (twl, bufA, bufB, src, dst, nframes, tid, plan.in_stride, plan.out_stride);
