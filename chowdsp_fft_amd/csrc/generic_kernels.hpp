@@ -436,7 +436,8 @@ __device__ __forceinline__ void generic_first_stage_pre (const float2 (&pre)[R],
 }
 
 // CONV: the last stage (which then writes an LDS image: OUT_GLOBAL false) multiplies by H * scaling and swaps, see generic_stage
-template <class SP, int BLOCK, bool IN_GLOBAL, bool OUT_GLOBAL, bool SWAP, int S = 0, bool CONV = false>
+// LFS: distance of consecutive frames inside an LDS image where it is not n (the tile kernels pad every frame by one point)
+template <class SP, int BLOCK, bool IN_GLOBAL, bool OUT_GLOBAL, bool SWAP, int S = 0, bool CONV = false, int LFS = 0>
 __device__ __forceinline__ float2* static_core (const float2* twl, float2* a, float2* b, const float2* __restrict__ gin, float2* __restrict__ gout,
                                                 int nframes, int tid, unsigned gs_in, unsigned gs_out,
                                                 const float2* __restrict__ H = nullptr, float scaling = 1.f)
@@ -449,10 +450,10 @@ __device__ __forceinline__ float2* static_core (const float2* twl, float2* a, fl
         constexpr bool first = IN_GLOBAL && S == 0, last = OUT_GLOBAL && S == SP::ns - 1;
         constexpr int IO = (first ? 1 : 0) | (last ? 2 : 0);
         constexpr bool conv_here = CONV && ! OUT_GLOBAL && S == SP::ns - 1;
-        generic_stage<R, BLOCK, IO, IO != 0 && SWAP, true, conv_here> (first ? gin : a, last ? gout : b, twl + SP::tw_offset (S), SP::n, P, nframes, tid, gs_in, gs_out, (unsigned) SP::n, H, scaling);
+        generic_stage<R, BLOCK, IO, IO != 0 && SWAP, true, conv_here> (first ? gin : a, last ? gout : b, twl + SP::tw_offset (S), SP::n, P, nframes, tid, gs_in, gs_out, (unsigned) (LFS != 0 ? LFS : SP::n), H, scaling);
         if constexpr (! last)
             __syncthreads();
-        return static_core<SP, BLOCK, IN_GLOBAL, OUT_GLOBAL, SWAP, S + 1, CONV> (twl, b, a, gin, gout, nframes, tid, gs_in, gs_out, H, scaling);
+        return static_core<SP, BLOCK, IN_GLOBAL, OUT_GLOBAL, SWAP, S + 1, CONV, LFS> (twl, b, a, gin, gout, nframes, tid, gs_in, gs_out, H, scaling);
     }
 }
 
@@ -1039,6 +1040,45 @@ __global__ __launch_bounds__ (BLOCK, BLOCK == 512 ? 4 : 1) void generic_inplace_
     }
 }
 
+// Loads of a tile, kTileLoadsInFlight per work-item at a time: the plain `for (e = tid; e < total; e += BLOCK)` loop compiles to
+// one global_load followed by s_waitcnt vmcnt(0) per iteration (run-time trip count, LDS store behind every load), i.e. 9 full
+// round trips per work-item for a 16 x 144 tile and 80 % of the wave cycles parked (profiles/r03_general_two_pass.txt).
+// Every address is clamped into the tile so that the loads are unconditional (loads inside divergent branches get serialised
+// the same way); what does not exist is replaced by zero afterwards.
+#ifndef CFFT_TILE_LOADS_IN_FLIGHT
+#define CFFT_TILE_LOADS_IN_FLIGHT 8
+#endif
+static constexpr int kTileLoadsInFlight = CFFT_TILE_LOADS_IN_FLIGHT;
+#ifndef CFFT_TILE_PREFETCH_B
+#define CFFT_TILE_PREFETCH_B 4
+#endif
+static constexpr int kTilePrefetchB = CFFT_TILE_PREFETCH_B;
+#ifndef CFFT_TILE_PREFETCH_A
+#define CFFT_TILE_PREFETCH_A 10
+#endif
+static constexpr int kTilePrefetchA = CFFT_TILE_PREFETCH_A;
+static constexpr int kTileStoreBatch = 10;
+
+// SP (tile kernels): compile-time stage list of the tile's frame length (the lists of StaticPlanFor, checked against the
+// planner's by the launcher): the radix switch, the stage loop and every division fold away, and the tile is requested with
+// exactly as many loads per work-item as it has.  SP = void: the run-time list of GenericPlan.
+template <class SP>
+__device__ __forceinline__ int tile_frame_len (const GenericPlan& plan)
+{
+    if constexpr (std::is_void<SP>::value)
+        return plan.n;
+    else
+        return SP::n;
+}
+template <class SP, int C, int BLOCK>
+constexpr int tile_slots (int dynamic)
+{
+    if constexpr (std::is_void<SP>::value)
+        return dynamic;
+    else
+        return (C * SP::n + BLOCK - 1) / BLOCK;
+}
+
 // ---- long mixed-radix frames (complex length > 20000): pass A of the two-pass plan -----------------------------------
 // N = n1 * n2 as in multipass_kernels.hpp, with n2 = (odd part) * 2^j a mixed-radix length and n1 a power of two:
 // this kernel does the n2-point COLUMN FFTs of a tile of CA (16, or 8 for n2 > 640) adjacent columns with the run-time stage list above and
@@ -1046,8 +1086,13 @@ __global__ __launch_bounds__ (BLOCK, BLOCK == 512 ? 4 : 1) void generic_inplace_
 // power-of-two pass_b_kernel.  LDS: two images of 16 frames of n2 + 1 points (the + 1 keeps the 16 lanes that walk
 // across frames while the tile is loaded / stored off each other's banks).
 // BLOCK: 256 work-items, or 1024 where the two images leave room for only one workgroup per CU (4 waves would be all a CU has)
-template <bool SWAP_IN, int CA, int BLOCK>
-__global__ __launch_bounds__ (BLOCK) void pass_a_generic_kernel (const float2* __restrict__ in,
+// PIPE: the first kTileLoadsInFlight operands per work-item of the NEXT tile are requested as soon as this tile's have been
+// committed to the image, and stay in registers across the stages and the stores (the tile kernels were parked on memory for
+// 65-80 % of their wave cycles: a workgroup had loads in flight only during its own load phase).  vmcnt is one in-order
+// counter, so nothing between the request and the end of the stages may wait on a younger load: the stage twiddles are then
+// read from an LDS copy behind the images (plan.n - 1 entries; the launcher grants PIPE where that costs no workgroup per CU).
+template <bool SWAP_IN, int CA, int BLOCK, bool PIPE = false, class SP = void>
+__global__ __launch_bounds__ (BLOCK, PIPE ? 4 : 1) void pass_a_generic_kernel (const float2* __restrict__ in,
                                                               float2* __restrict__ work,
                                                               const float2* __restrict__ twtab,
                                                               const float2* __restrict__ big_tw,
@@ -1060,11 +1105,45 @@ __global__ __launch_bounds__ (BLOCK) void pass_a_generic_kernel (const float2* _
 {
     extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
     const int tid = threadIdx.x;
-    const int n2 = plan.n;
+    constexpr bool STATIC = ! std::is_void<SP>::value;
+    static_assert (! STATIC || PIPE, "compile-time lists come with the pipelined form only");
+    const int n2 = tile_frame_len<SP> (plan);
+    if constexpr (STATIC)
+        lfs = SP::n + 1;
     float2* bufA = smem;
     float2* bufB = smem + (size_t) CA * lfs;
+    float2* twl = smem + (size_t) 2 * CA * lfs;
+    if constexpr (PIPE)
+    {
+        for (int i = tid; i < n2 - 1; i += BLOCK)
+            twl[i] = twtab[plan.tw_offset[0] + i]; // ordered before the stages by the tile loop's barriers
+    }
     const unsigned tiles = (n1 + CA - 1) / CA;
     const size_t nwork = (size_t) batch * tiles;
+    const int total = CA * n2;
+    // Every tile shape the launchers choose has at most 10 operands per work-item (16 x 160 / 256, 16 x 639 / 1024, 8 x 1280 /
+    // 1024, 4 x 2559 / 1024), so the whole tile is requested ahead.  Slots beyond the tile re-read its last element: a
+    // test around a load -- even a workgroup-uniform one -- makes the compiler wait for every load before the next.
+    constexpr int PF = tile_slots<SP, CA, BLOCK> (kTilePrefetchA);
+    constexpr int SB = tile_slots<SP, CA, BLOCK> (CA == 16 ? kTileStoreBatch : 8); // (run-time list: 10 spills a few bytes in the narrow-tile variants)
+    float2 pre[PF];
+    const auto request = [&] (size_t w) {
+        const unsigned f = (unsigned) (w / tiles), tile = (unsigned) (w % tiles);
+        const int valid = (int) min ((unsigned) CA, n1 - tile * CA);
+        const float2* __restrict__ src = in + (size_t) f * in_stride + (size_t) tile * CA;
+#pragma unroll
+        for (int u = 0; u < PF; ++u)
+        {
+            const int e = min (tid + u * BLOCK, total - 1);
+            const int c = min (e % CA, valid - 1), j = e / CA;
+            pre[u] = gload (&src[(size_t) j * n1 + c]);
+        }
+    };
+    if constexpr (PIPE)
+    {
+        if (blockIdx.x < nwork)
+            request (blockIdx.x);
+    }
     for (size_t w = blockIdx.x; w < nwork; w += gridDim.x)
     {
         const unsigned f = (unsigned) (w / tiles);
@@ -1074,18 +1153,67 @@ __global__ __launch_bounds__ (BLOCK) void pass_a_generic_kernel (const float2* _
         float2* __restrict__ dst = work + (size_t) f * ws_frame_len + (size_t) tile * ((size_t) n2 * CA);
         const float2* __restrict__ twp = big_tw + (size_t) tile * ((size_t) n2 * CA);
         __syncthreads(); // previous tile fully stored
-        for (int e = tid; e < CA * n2; e += BLOCK)
+        if constexpr (PIPE)
         {
-            const int c = e % CA, j = e / CA;
-            const float2 x = c < valid ? gload (&src[(size_t) j * n1 + c]) : make_float2 (0.f, 0.f);
-            bufA[c * lfs + j] = SWAP_IN ? make_float2 (x.y, x.x) : x;
+#pragma unroll
+            for (int u = 0; u < PF; ++u)
+            {
+                const int e = tid + u * BLOCK;
+                const int c = e % CA, j = e / CA;
+                if (e < total)
+                    bufA[c * lfs + j] = c < valid ? (SWAP_IN ? make_float2 (pre[u].y, pre[u].x) : pre[u]) : make_float2 (0.f, 0.f);
+            }
+        }
+        for (int e0 = tid + (PIPE ? PF * BLOCK : 0); e0 < total; e0 += BLOCK * kTileLoadsInFlight)
+        {
+            float2 x[kTileLoadsInFlight];
+#pragma unroll
+            for (int u = 0; u < kTileLoadsInFlight; ++u)
+            {
+                const int e = min (e0 + u * BLOCK, total - 1);
+                const int c = min (e % CA, valid - 1), j = e / CA;
+                x[u] = gload (&src[(size_t) j * n1 + c]);
+            }
+#pragma unroll
+            for (int u = 0; u < kTileLoadsInFlight; ++u)
+            {
+                const int e = e0 + u * BLOCK;
+                const int c = e % CA, j = e / CA;
+                if (e < total)
+                    bufA[c * lfs + j] = c < valid ? (SWAP_IN ? make_float2 (x[u].y, x[u].x) : x[u]) : make_float2 (0.f, 0.f);
+            }
         }
         __syncthreads();
-        const float2* res = generic_core<BLOCK, false, false, false> (plan, twtab, bufA, bufB, nullptr, nullptr, CA, tid, lfs);
-        for (int e = tid; e < CA * n2; e += BLOCK)
+        const float2* res;
+        if constexpr (PIPE)
         {
-            const int c = e % CA, k = e / CA;
-            dst[e] = cmul (res[c * lfs + k], twp[e]); // plain store: the workspace should stay cached (padding columns: zeros)
+            if (w + gridDim.x < nwork)
+                request (w + gridDim.x);
+            if constexpr (STATIC)
+                res = static_core<SP, BLOCK, false, false, false, 0, false, SP_N_OR_ZERO<SP>::value + 1> (twl, bufA, bufB, nullptr, nullptr, CA, tid, 0u, 0u);
+            else
+                res = generic_core<BLOCK, false, false, false> (plan, twl, bufA, bufB, nullptr, nullptr, CA, tid, lfs, plan.tw_offset[0]);
+        }
+        else
+            res = generic_core<BLOCK, false, false, false> (plan, twtab, bufA, bufB, nullptr, nullptr, CA, tid, lfs);
+        // the inter-pass twiddles of the whole tile first, then the stores: a twiddle load behind stores would wait for them
+        // too (one in-order counter) -- a store drain per tile
+        for (int e0 = tid; e0 < total; e0 += BLOCK * SB)
+        {
+            float2 tw[SB];
+#pragma unroll
+            for (int u = 0; u < SB; ++u)
+            {
+                tw[u] = twp[min (e0 + u * BLOCK, total - 1)];
+            }
+#pragma unroll
+            for (int u = 0; u < SB; ++u)
+            {
+                const int e = e0 + u * BLOCK;
+                const int c = e % CA, k = e / CA;
+                if (e < total)
+                    dst[e] = cmul (res[c * lfs + k], tw[u]); // plain store: the workspace should stay cached (padding columns: zeros)
+            }
         }
     }
 }
@@ -1093,7 +1221,7 @@ __global__ __launch_bounds__ (BLOCK) void pass_a_generic_kernel (const float2* _
 // Row pass of the same plans when the row length n1 is not a power of two either (and for powers of two beyond the
 // compile-time cores): n1-point FFTs of CB adjacent rows kb with the run-time stage list, read from pass A's tile-major
 // workspace [tile tA][kb][c] (CA columns per tile), stored transposed to X[n2 ka + kb].  n2 need not be a multiple of CB.
-template <bool SWAP_OUT, int CB, int BLOCK>
+template <bool SWAP_OUT, int CB, int BLOCK, bool PIPE = false, class SP = void>
 __global__ __launch_bounds__ (BLOCK) void pass_b_generic_kernel (const float2* __restrict__ work,
                                                               float2* __restrict__ out,
                                                               const float2* __restrict__ twtab,
@@ -1107,12 +1235,44 @@ __global__ __launch_bounds__ (BLOCK) void pass_b_generic_kernel (const float2* _
 {
     extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
     const int tid = threadIdx.x;
-    const int n1 = plan.n;
+    constexpr bool STATIC = ! std::is_void<SP>::value;
+    static_assert (! STATIC || PIPE, "compile-time lists come with the pipelined form only");
+    const int n1 = tile_frame_len<SP> (plan);
+    if constexpr (STATIC)
+        lfs = SP::n + 1;
     float2* bufA = smem;
     float2* bufB = smem + (size_t) CB * lfs;
+    float2* twl = smem + (size_t) 2 * CB * lfs; // PIPE (see pass_a_generic_kernel): the stage twiddles' LDS copy
+    if constexpr (PIPE)
+    {
+        for (int i = tid; i < n1 - 1; i += BLOCK)
+            twl[i] = twtab[plan.tw_offset[0] + i];
+    }
     const unsigned tiles = (n2 + CB - 1) / CB;
     const unsigned magic_n1 = div_magic ((unsigned) n1), magic_ca = ca > 1 ? div_magic (ca) : 0u;
     const size_t nwork = (size_t) batch * tiles;
+    const int total = CB * n1;
+    constexpr int PF = tile_slots<SP, CB, BLOCK> (kTilePrefetchB); // (run-time list: 8 costs pass B a workgroup per CU with 256 work-items and spills with 1024)
+    float2 pre[PF];
+    // element (row kbl, column a): c = a % ca fastest (contiguous in the workspace), then the row, then pass A's tile
+    const auto element = [&] (const float2* __restrict__ src, unsigned kb0, int valid, int e) {
+        const unsigned kbl = (unsigned) fast_div (e, magic_n1), a = (unsigned) e - kbl * (unsigned) n1;
+        const unsigned tA = (unsigned) fast_div ((int) a, magic_ca), c = a - tA * ca;
+        return src[((size_t) tA * n2 + kb0 + min (kbl, (unsigned) (valid - 1))) * ca + c];
+    };
+    const auto request = [&] (size_t w) {
+        const unsigned f = (unsigned) (w / tiles), kb0 = (unsigned) (w % tiles) * CB;
+        const int valid = (int) min ((unsigned) CB, n2 - kb0);
+        const float2* __restrict__ src = work + (size_t) f * ws_frame_len;
+#pragma unroll
+        for (int u = 0; u < PF; ++u)
+            pre[u] = element (src, kb0, valid, min (tid + u * BLOCK, total - 1));
+    };
+    if constexpr (PIPE)
+    {
+        if (blockIdx.x < nwork)
+            request (blockIdx.x);
+    }
     for (size_t w = blockIdx.x; w < nwork; w += gridDim.x)
     {
         const unsigned f = (unsigned) (w / tiles);
@@ -1122,16 +1282,45 @@ __global__ __launch_bounds__ (BLOCK) void pass_b_generic_kernel (const float2* _
         const float2* __restrict__ src = work + (size_t) f * ws_frame_len;
         float2* __restrict__ dst = out + (size_t) f * out_stride + kb0;
         __syncthreads();
-        // element (row kbl, column a): c = a % ca fastest (contiguous in the workspace), then the row, then pass A's tile
-        for (int e = tid; e < CB * n1; e += BLOCK)
+        if constexpr (PIPE)
         {
-            const unsigned kbl = (unsigned) fast_div (e, magic_n1), a = (unsigned) e - kbl * (unsigned) n1;
-            const unsigned tA = (unsigned) fast_div ((int) a, magic_ca), c = a - tA * ca;
-            const float2 x = (int) kbl < valid ? src[((size_t) tA * n2 + kb0 + kbl) * ca + c] : make_float2 (0.f, 0.f);
-            bufA[kbl * lfs + a] = x;
+#pragma unroll
+            for (int u = 0; u < PF; ++u)
+            {
+                const int e = tid + u * BLOCK;
+                const unsigned kbl = (unsigned) fast_div (e, magic_n1), a = (unsigned) e - kbl * (unsigned) n1;
+                if (e < total)
+                    bufA[kbl * lfs + a] = (int) kbl < valid ? pre[u] : make_float2 (0.f, 0.f);
+            }
+        }
+        for (int e0 = tid + (PIPE ? PF * BLOCK : 0); e0 < total; e0 += BLOCK * kTileLoadsInFlight)
+        {
+            float2 x[kTileLoadsInFlight];
+#pragma unroll
+            for (int u = 0; u < kTileLoadsInFlight; ++u)
+                x[u] = element (src, kb0, valid, min (e0 + u * BLOCK, total - 1));
+#pragma unroll
+            for (int u = 0; u < kTileLoadsInFlight; ++u)
+            {
+                const int e = e0 + u * BLOCK;
+                const unsigned kbl = (unsigned) fast_div (e, magic_n1), a = (unsigned) e - kbl * (unsigned) n1;
+                if (e < total)
+                    bufA[kbl * lfs + a] = (int) kbl < valid ? x[u] : make_float2 (0.f, 0.f);
+            }
         }
         __syncthreads();
-        const float2* res = generic_core<BLOCK, false, false, false> (plan, twtab, bufA, bufB, nullptr, nullptr, CB, tid, lfs);
+        const float2* res;
+        if constexpr (PIPE)
+        {
+            if (w + gridDim.x < nwork)
+                request (w + gridDim.x);
+            if constexpr (STATIC)
+                res = static_core<SP, BLOCK, false, false, false, 0, false, SP_N_OR_ZERO<SP>::value + 1> (twl, bufA, bufB, nullptr, nullptr, CB, tid, 0u, 0u);
+            else
+                res = generic_core<BLOCK, false, false, false> (plan, twl, bufA, bufB, nullptr, nullptr, CB, tid, lfs, plan.tw_offset[0]);
+        }
+        else
+            res = generic_core<BLOCK, false, false, false> (plan, twtab, bufA, bufB, nullptr, nullptr, CB, tid, lfs);
         for (int e = tid; e < CB * n1; e += BLOCK)
         {
             const int c = e % CB, k = e / CB;
@@ -1172,11 +1361,25 @@ __global__ __launch_bounds__ (BLOCK) void column_fft_kernel (float2* __restrict_
         const int valid = (int) min ((unsigned) C, cols - tile * C);
         float2* __restrict__ base = data + (size_t) f * array_stride + (size_t) tile * C;
         __syncthreads(); // previous tile fully stored
-        for (int e = tid; e < C * rows; e += BLOCK)
+        const int total = C * rows;
+        for (int e0 = tid; e0 < total; e0 += BLOCK * kTileLoadsInFlight)
         {
-            const int c = e % C, j = e / C;
-            const float2 x = c < valid ? gload (&base[(size_t) j * cols + c]) : make_float2 (0.f, 0.f);
-            bufA[c * lfs + j] = SWAP ? make_float2 (x.y, x.x) : x;
+            float2 x[kTileLoadsInFlight];
+#pragma unroll
+            for (int u = 0; u < kTileLoadsInFlight; ++u)
+            {
+                const int e = min (e0 + u * BLOCK, total - 1);
+                const int c = min (e % C, valid - 1), j = e / C;
+                x[u] = gload (&base[(size_t) j * cols + c]);
+            }
+#pragma unroll
+            for (int u = 0; u < kTileLoadsInFlight; ++u)
+            {
+                const int e = e0 + u * BLOCK;
+                const int c = e % C, j = e / C;
+                if (e < total)
+                    bufA[c * lfs + j] = c < valid ? (SWAP ? make_float2 (x[u].y, x[u].x) : x[u]) : make_float2 (0.f, 0.f);
+            }
         }
         __syncthreads();
         const float2* res = generic_core<BLOCK, false, false, false> (plan, twtab, bufA, bufB, nullptr, nullptr, C, tid, lfs);

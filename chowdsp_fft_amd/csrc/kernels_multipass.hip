@@ -7,6 +7,7 @@
 #include "tile_fast_kernels.hpp"
 #include "generic_kernels.hpp"
 #include "tables.hpp"
+#include "tile_static.hpp"
 
 #include <atomic>
 #include <cstdio>
@@ -588,6 +589,49 @@ hipError_t launch_groupfast_c2c (int n1, int n2, bool inverse, const float2* in,
 }
 
 // long mixed-radix frames: generic n2-point column pass (generic_kernels.hpp), then the ordinary n1-point row pass
+namespace
+{
+// PIPE variants of the generic tile kernels (generic_kernels.hpp: the next tile's operands requested across the stages) need an
+// LDS copy of the n - 1 stage twiddles behind the two images: granted where that leaves the workgroups per CU as they are.
+// CHOWDSP_FFT_TILE_PIPE (experiments): bit 0 = pass A / the 2-D column pass, bit 1 = pass B; a set bit grants it wherever the
+// copy fits at all, a clear one withholds it.
+bool tile_pipe_fits (size_t images_bytes, size_t n, size_t lds_per_cu, int which)
+{
+    static const int forced = [] {
+        const char* e = std::getenv ("CHOWDSP_FFT_TILE_PIPE");
+        return e != nullptr ? std::atoi (e) : -1;
+    }();
+    const size_t with_tw = images_bytes + (n - 1) * sizeof (float2);
+    if ((forced >= 0 && (forced & which) == 0) || with_tw > lds_per_cu)
+        return false;
+    return forced >= 0 || lds_per_cu / with_tw == lds_per_cu / images_bytes;
+}
+template <int C, int BLOCK>
+PassAGenericFn pick_pass_a_cb (bool inverse, bool pipe)
+{
+    return inverse ? (pipe ? pass_a_generic_kernel<true, C, BLOCK, true> : pass_a_generic_kernel<true, C, BLOCK, false>)
+                   : (pipe ? pass_a_generic_kernel<false, C, BLOCK, true> : pass_a_generic_kernel<false, C, BLOCK, false>);
+}
+template <int C, int BLOCK>
+PassBGenericFn pick_pass_b_cb (bool inverse, bool pipe)
+{
+    return inverse ? (pipe ? pass_b_generic_kernel<true, C, BLOCK, true> : pass_b_generic_kernel<true, C, BLOCK, false>)
+                   : (pipe ? pass_b_generic_kernel<false, C, BLOCK, true> : pass_b_generic_kernel<false, C, BLOCK, false>);
+}
+PassAGenericFn pick_pass_a (int c, int block, bool inverse, bool pipe)
+{
+    if (block == 1024)
+        return c == 16 ? pick_pass_a_cb<16, 1024> (inverse, pipe) : (c == 8 ? pick_pass_a_cb<8, 1024> (inverse, pipe) : pick_pass_a_cb<4, 1024> (inverse, pipe));
+    return c == 16 ? pick_pass_a_cb<16, 256> (inverse, pipe) : (c == 8 ? pick_pass_a_cb<8, 256> (inverse, pipe) : pick_pass_a_cb<4, 256> (inverse, pipe));
+}
+PassBGenericFn pick_pass_b (int c, int block, bool inverse, bool pipe)
+{
+    if (block == 1024)
+        return c == 16 ? pick_pass_b_cb<16, 1024> (inverse, pipe) : (c == 8 ? pick_pass_b_cb<8, 1024> (inverse, pipe) : pick_pass_b_cb<4, 1024> (inverse, pipe));
+    return c == 16 ? pick_pass_b_cb<16, 256> (inverse, pipe) : (c == 8 ? pick_pass_b_cb<8, 256> (inverse, pipe) : pick_pass_b_cb<4, 256> (inverse, pipe));
+}
+} // namespace
+
 hipError_t launch_mixed_big_c2c (const DeviceTables& t, bool inverse, const float2* in, float2* work, float2* out, size_t batch, int grid_divisor, hipStream_t stream, size_t in_stride, size_t out_stride)
 {
     if (batch == 0)
@@ -619,18 +663,20 @@ hipError_t launch_mixed_big_c2c (const DeviceTables& t, bool inverse, const floa
     unsigned lfs = (unsigned) n2 + 1u;
     if ((size_t) 2 * ca * lfs * sizeof (float2) > dev.lds_per_cu)
         lfs = (unsigned) n2;
-    const size_t lds = (size_t) 2 * ca * lfs * sizeof (float2);
+    size_t lds = (size_t) 2 * ca * lfs * sizeof (float2);
     if (lds > dev.lds_per_cu)
         return hipErrorInvalidValue;
     const size_t ws_frame_len = (size_t) ((n1 + ca - 1) / ca) * (size_t) ca * (size_t) n2; // = n1 * n2 unless the last tile is ragged
     const int block_a = generic_tile_block (lds, dev.lds_per_cu);
-    auto ka256 = ca == 16 ? (inverse ? pass_a_generic_kernel<true, 16, 256> : pass_a_generic_kernel<false, 16, 256>)
-                 : ca == 8 ? (inverse ? pass_a_generic_kernel<true, 8, 256> : pass_a_generic_kernel<false, 8, 256>)
-                           : (inverse ? pass_a_generic_kernel<true, 4, 256> : pass_a_generic_kernel<false, 4, 256>);
-    auto ka1024 = ca == 16 ? (inverse ? pass_a_generic_kernel<true, 16, 1024> : pass_a_generic_kernel<false, 16, 1024>)
-                  : ca == 8 ? (inverse ? pass_a_generic_kernel<true, 8, 1024> : pass_a_generic_kernel<false, 8, 1024>)
-                            : (inverse ? pass_a_generic_kernel<true, 4, 1024> : pass_a_generic_kernel<false, 4, 1024>);
-    auto ka = block_a == 1024 ? ka1024 : ka256;
+    const bool pipe_a = tile_pipe_fits (lds, (size_t) n2, dev.lds_per_cu, 1);
+    if (pipe_a)
+        lds += (size_t) (n2 - 1) * sizeof (float2);
+    auto ka = pick_pass_a (ca, block_a, inverse, pipe_a);
+    if (pipe_a)
+    {
+        if (auto ks = pick_static_pass_a (plan, ca, block_a, lfs, inverse))
+            ka = ks;
+    }
     unsigned grid = persistent_grid (ka, block_a, lds, batch * (size_t) ((n1 + ca - 1) / ca));
     if (grid == 0)
         return hipErrorNoDevice;
@@ -658,17 +704,19 @@ hipError_t launch_mixed_big_c2c (const DeviceTables& t, bool inverse, const floa
         unsigned lfsb = (unsigned) n1 + 1u;
         if ((size_t) 2 * cb * lfsb * sizeof (float2) > dev.lds_per_cu)
             lfsb = (unsigned) n1;
-        const size_t ldsb = (size_t) 2 * cb * lfsb * sizeof (float2);
+        size_t ldsb = (size_t) 2 * cb * lfsb * sizeof (float2);
         if (ldsb > dev.lds_per_cu)
             return hipErrorInvalidValue;
         const int block_b = generic_tile_block (ldsb, dev.lds_per_cu);
-        auto kb256 = cb == 16 ? (inverse ? pass_b_generic_kernel<true, 16, 256> : pass_b_generic_kernel<false, 16, 256>)
-                     : cb == 8 ? (inverse ? pass_b_generic_kernel<true, 8, 256> : pass_b_generic_kernel<false, 8, 256>)
-                               : (inverse ? pass_b_generic_kernel<true, 4, 256> : pass_b_generic_kernel<false, 4, 256>);
-        auto kb1024 = cb == 16 ? (inverse ? pass_b_generic_kernel<true, 16, 1024> : pass_b_generic_kernel<false, 16, 1024>)
-                      : cb == 8 ? (inverse ? pass_b_generic_kernel<true, 8, 1024> : pass_b_generic_kernel<false, 8, 1024>)
-                                : (inverse ? pass_b_generic_kernel<true, 4, 1024> : pass_b_generic_kernel<false, 4, 1024>);
-        auto kb = block_b == 1024 ? kb1024 : kb256;
+        const bool pipe_b = tile_pipe_fits (ldsb, (size_t) n1, dev.lds_per_cu, 2);
+        if (pipe_b)
+            ldsb += (size_t) (n1 - 1) * sizeof (float2);
+        auto kb = pick_pass_b (cb, block_b, inverse, pipe_b);
+        if (pipe_b)
+        {
+            if (auto ks = pick_static_pass_b (pb, cb, block_b, lfsb, inverse))
+                kb = ks;
+        }
         unsigned gridb = persistent_grid (kb, block_b, ldsb, batch * (size_t) ((n2 + cb - 1) / cb));
         if (gridb == 0)
             return hipErrorNoDevice;
