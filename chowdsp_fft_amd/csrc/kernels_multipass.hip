@@ -595,7 +595,7 @@ namespace
 // LDS copy of the n - 1 stage twiddles behind the two images: granted where that leaves the workgroups per CU as they are.
 // CHOWDSP_FFT_TILE_PIPE (experiments): bit 0 = pass A / the 2-D column pass, bit 1 = pass B; a set bit grants it wherever the
 // copy fits at all, a clear one withholds it.
-bool tile_pipe_fits (size_t images_bytes, size_t n, size_t lds_per_cu, int which)
+bool tile_pipe_fits (size_t images_bytes, size_t n, size_t lds_per_cu, int which, int block)
 {
     static const int forced = [] {
         const char* e = std::getenv ("CHOWDSP_FFT_TILE_PIPE");
@@ -604,7 +604,8 @@ bool tile_pipe_fits (size_t images_bytes, size_t n, size_t lds_per_cu, int which
     const size_t with_tw = images_bytes + (n - 1) * sizeof (float2);
     if ((forced >= 0 && (forced & which) == 0) || with_tw > lds_per_cu)
         return false;
-    return forced >= 0 || lds_per_cu / with_tw == lds_per_cu / images_bytes;
+    const size_t by_waves = (size_t) 2048 / (size_t) block; // 32 waves per CU
+    return forced >= 0 || std::min (by_waves, lds_per_cu / with_tw) == std::min (by_waves, lds_per_cu / images_bytes);
 }
 template <int C, int BLOCK>
 PassAGenericFn pick_pass_a_cb (bool inverse, bool pipe)
@@ -667,8 +668,8 @@ hipError_t launch_mixed_big_c2c (const DeviceTables& t, bool inverse, const floa
     if (lds > dev.lds_per_cu)
         return hipErrorInvalidValue;
     const size_t ws_frame_len = (size_t) ((n1 + ca - 1) / ca) * (size_t) ca * (size_t) n2; // = n1 * n2 unless the last tile is ragged
-    const int block_a = generic_tile_block (lds, dev.lds_per_cu);
-    const bool pipe_a = tile_pipe_fits (lds, (size_t) n2, dev.lds_per_cu, 1);
+    int block_a = generic_tile_block (lds, dev.lds_per_cu);
+    const bool pipe_a = tile_pipe_fits (lds, (size_t) n2, dev.lds_per_cu, 1, block_a);
     if (pipe_a)
         lds += (size_t) (n2 - 1) * sizeof (float2);
     auto ka = pick_pass_a (ca, block_a, inverse, pipe_a);
@@ -707,8 +708,8 @@ hipError_t launch_mixed_big_c2c (const DeviceTables& t, bool inverse, const floa
         size_t ldsb = (size_t) 2 * cb * lfsb * sizeof (float2);
         if (ldsb > dev.lds_per_cu)
             return hipErrorInvalidValue;
-        const int block_b = generic_tile_block (ldsb, dev.lds_per_cu);
-        const bool pipe_b = tile_pipe_fits (ldsb, (size_t) n1, dev.lds_per_cu, 2);
+        int block_b = generic_tile_block (ldsb, dev.lds_per_cu);
+        const bool pipe_b = tile_pipe_fits (ldsb, (size_t) n1, dev.lds_per_cu, 2, block_b);
         if (pipe_b)
             ldsb += (size_t) (n1 - 1) * sizeof (float2);
         auto kb = pick_pass_b (cb, block_b, inverse, pipe_b);

@@ -1,6 +1,7 @@
 // Instantiation of the tile kernels with compile-time stage lists (tile_static.hpp).
 #include "tile_static.hpp"
 #include "launch_util.hpp"
+#include "tables.hpp"
 
 #include <cstdlib>
 
@@ -16,44 +17,48 @@ struct StaticTile
 {
     static constexpr int c = N_ <= 639 ? 16 : 8;
     static constexpr size_t lds = (size_t) 2 * c * (N_ + 1) * sizeof (float2);
-    static constexpr int block = 4 * lds > 160 * 1024 ? 1024 : 256;
+    // work-items per workgroup: 256 where four workgroups fit a CU, 1024 where only one does, and 512 between (n = 160 .. 288:
+    // two or three workgroups of 8 waves each work through their phases independently; measured against 1024 / 256 on MI355X,
+    // fraction of 8 TB/s: c23040 0.355 / 0.305 / 0.353, c57600 0.336 / 0.305 / 0.284, c82944 0.317 / 0.287 / 0.220,
+    // c61440 0.321 / 0.298 / 0.283, c245760 0.285 / 0.276 / 0.257)
+#ifndef CFFT_STATIC_TILE_MID_BLOCK
+#define CFFT_STATIC_TILE_MID_BLOCK 512
+#endif
+    static constexpr int block = 4 * lds <= 160 * 1024 ? 256 : (2 * (lds + N_ * sizeof (float2)) <= 160 * 1024 ? CFFT_STATIC_TILE_MID_BLOCK : 1024);
 };
 template <int N_>
-bool static_tile_matches (const GenericPlan& plan, int c, int block, unsigned lfs)
+bool static_tile_matches (const GenericPlan& plan, int c, unsigned lfs)
 {
     using SP = typename StaticPlanFor<N_>::type;
-    bool same = plan.n == N_ && plan.ns == SP::ns && c == StaticTile<N_>::c && block == StaticTile<N_>::block && lfs == (unsigned) N_ + 1u;
+    bool same = plan.n == N_ && plan.ns == SP::ns && c == StaticTile<N_>::c && lfs == (unsigned) N_ + 1u;
     for (int i = 0; same && i < SP::ns; ++i)
         same = plan.radix[i] == SP::radix (i);
     return same;
 }
-// every length of StaticPlanFor whose padded images fit the CU's LDS (n = 1280 runs unpadded: run-time list)
-#define CFFT_STATIC_TILE_SIZES(X) \
-    X (48) X (80) X (96) X (144) X (160) X (192) X (240) X (288) X (320) X (384) X (400) X (432) X (480) X (576) X (640) X (720) \
-    X (768) X (800) X (864) X (960) X (1152) X (1200)
+// (the lengths: CFFT_STATIC_TILE_SIZES in tables.hpp -- every length of StaticPlanFor up to 1200; n = 1280 runs unpadded: run-time list)
 } // namespace
 
-PassAGenericFn pick_static_pass_a (const GenericPlan& plan, int c, int block, unsigned lfs, bool inverse)
+PassAGenericFn pick_static_pass_a (const GenericPlan& plan, int c, int& block, unsigned lfs, bool inverse)
 {
     static const bool off = [] { const char* e = std::getenv ("CHOWDSP_FFT_TILE_STATIC"); return e != nullptr && std::atoi (e) == 0; }();
     if (off)
         return nullptr;
 #define CFFT_TRY(N_)                                                                                                                  \
-    if (static_tile_matches<N_> (plan, c, block, lfs))                                                                                \
-        return inverse ? pass_a_generic_kernel<true, StaticTile<N_>::c, StaticTile<N_>::block, true, typename StaticPlanFor<N_>::type> \
+    if (static_tile_matches<N_> (plan, c, lfs))                                                                                       \
+        return block = StaticTile<N_>::block, inverse ? pass_a_generic_kernel<true, StaticTile<N_>::c, StaticTile<N_>::block, true, typename StaticPlanFor<N_>::type> \
                        : pass_a_generic_kernel<false, StaticTile<N_>::c, StaticTile<N_>::block, true, typename StaticPlanFor<N_>::type>;
     CFFT_STATIC_TILE_SIZES (CFFT_TRY)
 #undef CFFT_TRY
     return nullptr;
 }
-PassBGenericFn pick_static_pass_b (const GenericPlan& plan, int c, int block, unsigned lfs, bool inverse)
+PassBGenericFn pick_static_pass_b (const GenericPlan& plan, int c, int& block, unsigned lfs, bool inverse)
 {
     static const bool off = [] { const char* e = std::getenv ("CHOWDSP_FFT_TILE_STATIC"); return e != nullptr && std::atoi (e) == 0; }();
     if (off)
         return nullptr;
 #define CFFT_TRY(N_)                                                                                                                  \
-    if (static_tile_matches<N_> (plan, c, block, lfs))                                                                                \
-        return inverse ? pass_b_generic_kernel<true, StaticTile<N_>::c, StaticTile<N_>::block, true, typename StaticPlanFor<N_>::type> \
+    if (static_tile_matches<N_> (plan, c, lfs))                                                                                       \
+        return block = StaticTile<N_>::block, inverse ? pass_b_generic_kernel<true, StaticTile<N_>::c, StaticTile<N_>::block, true, typename StaticPlanFor<N_>::type> \
                        : pass_b_generic_kernel<false, StaticTile<N_>::c, StaticTile<N_>::block, true, typename StaticPlanFor<N_>::type>;
     CFFT_STATIC_TILE_SIZES (CFFT_TRY)
 #undef CFFT_TRY

@@ -77,6 +77,26 @@ void split_large (int n_complex, int& n1, int& n2)
     n1 = 1 << (lg - l2);
 }
 
+bool has_static_tile (int n)
+{
+#define CFFT_IS(N_) if (n == N_) return true;
+    CFFT_STATIC_TILE_SIZES (CFFT_IS)
+#undef CFFT_IS
+    return false;
+}
+
+bool split_static_pair (int n_complex, int max_factor, int& n1, int& n2)
+{
+    n1 = n2 = 0;
+    for (int d = 1; (long long) d * d <= (long long) n_complex; ++d)
+        if (n_complex % d == 0 && n_complex / d <= max_factor && has_static_tile (d) && has_static_tile (n_complex / d))
+        {
+            n2 = d; // the largest such d wins: closest to sqrt(n)
+            n1 = n_complex / d;
+        }
+    return n2 != 0;
+}
+
 bool split_mixed (int n_complex, int& n1, int& n2)
 {
     n1 = n2 = 0;
@@ -93,6 +113,12 @@ bool split_mixed (int n_complex, int& n1, int& n2)
         // pass B works on tiles of tile_width_for (n1) adjacent rows (32 for n1 = 64): n2 must be a whole number of them
         if (r1 >= 64 && r1 <= 1024 && c2 % tile_width_for (r1) == 0)
         {
+            // columns longer than 639 points run in tiles of 8 (64-byte pieces of the caller's rows): where the length is also
+            // the product of two static tile lengths of at most 639 points, the general form (16-column tiles, compile-time
+            // lists on both sides) is faster -- 46080 = 64 x 720: 0.26 of 8 TB/s, = 240 x 192: see profiles/r03_general_two_pass.txt
+            int s1 = 0, s2 = 0;
+            if (c2 > kMixedMaxN2Wide && split_static_pair (n_complex, kMixedMaxN2Wide, s1, s2))
+                return false;
             n1 = r1;
             n2 = (int) c2;
             return true;
@@ -119,7 +145,10 @@ bool split_general (int n_complex, int& n1, int& n2)
     n1 = n2 = 0;
     if (n_complex <= 0)
         return false;
-    // the divisor closest to sqrt(n) from below becomes the column length n2, the cofactor the row length n1
+    // two static tile lengths where the length has such a factorisation (38400 = 240 x 160 rather than 200 x 192) ...
+    if (split_static_pair (n_complex, 1200, n1, n2))
+        return true;
+    // ... else the divisor closest to sqrt(n) from below becomes the column length n2, the cofactor the row length n1
     int best = 0;
     for (int d = 1; (long long) d * d <= (long long) n_complex; ++d)
         if (n_complex % d == 0)

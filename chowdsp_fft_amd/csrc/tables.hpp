@@ -103,6 +103,14 @@ bool split_mixed (int n_complex, int& n1, int& n2);
 // included): n = n1 * n2 with both factors 2-3-5-smooth and as close to sqrt(n) as possible; columns AND rows run the
 // generic kernel.  false only if a factor would exceed kGeneralMaxFactor (never below 2^21).
 bool split_general (int n_complex, int& n1, int& n2);
+// Column / row lengths for which the tile kernels have a compile-time stage list (kernels_tile_static.hip instantiates exactly
+// these; generic_kernels.hpp: StaticPlanFor holds the lists).  The splits below prefer them: such a pass runs 1.4-1.7x faster.
+#define CFFT_STATIC_TILE_SIZES(X) \
+    X (48) X (80) X (96) X (144) X (160) X (192) X (240) X (288) X (320) X (384) X (400) X (432) X (480) X (576) X (640) X (720) \
+    X (768) X (800) X (864) X (960) X (1152) X (1200)
+bool has_static_tile (int n);
+// n = n1 * n2 with both factors static tile lengths of at most max_factor, n2 <= n1, as close to each other as possible
+bool split_static_pair (int n_complex, int max_factor, int& n1, int& n2);
 static constexpr int kGeneralMaxFactor = 2559; // two LDS images of 4 frames of n + 1 points
 static constexpr int kMaxComplexLen = 1 << 21;
 // Frames longer than that (the reference has no upper bound, simd/chowdsp_fft_impl_common.hpp:168-177; its header advises a heap

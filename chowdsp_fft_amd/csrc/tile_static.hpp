@@ -8,7 +8,8 @@ namespace cfft::host
 {
 using PassAGenericFn = void (*) (const float2*, float2*, const float2*, const float2*, GenericPlan, unsigned, unsigned, size_t, unsigned, size_t);
 using PassBGenericFn = void (*) (const float2*, float2*, const float2*, GenericPlan, unsigned, unsigned, unsigned, size_t, unsigned, size_t);
-// nullptr: no compile-time list for this (plan, tile width, workgroup size, frame pitch) -- run the run-time list
-PassAGenericFn pick_static_pass_a (const GenericPlan& plan, int c, int block, unsigned lfs, bool inverse);
-PassBGenericFn pick_static_pass_b (const GenericPlan& plan, int c, int block, unsigned lfs, bool inverse);
+// nullptr: no compile-time list for this (plan, tile width, frame pitch) -- run the run-time list.  Otherwise `block` becomes
+// the workgroup size the kernel was instantiated for.
+PassAGenericFn pick_static_pass_a (const GenericPlan& plan, int c, int& block, unsigned lfs, bool inverse);
+PassBGenericFn pick_static_pass_b (const GenericPlan& plan, int c, int& block, unsigned lfs, bool inverse);
 } // namespace cfft::host
