@@ -377,6 +377,47 @@ template <> struct StaticPlanFor<1600> { using type = StaticPlan<1600, 10, 10, 1
 template <> struct StaticPlanFor<1728> { using type = StaticPlan<1728, 12, 12, 12>; };
 template <> struct StaticPlanFor<1920> { using type = StaticPlan<1920, 12, 10, 16>; };
 template <> struct StaticPlanFor<2000> { using type = StaticPlan<2000, 10, 5, 5, 8>; };
+// lengths that only occur as the column / row length of a long plan's tile kernels (kernels_tile_static*.hip): every other
+// 2-3-5-smooth length from 100 to 1125, same planner rule (tables.cpp: generic_radices; the launcher checks the list)
+template <> struct StaticPlanFor<100> { using type = StaticPlan<100, 10, 10>; };
+template <> struct StaticPlanFor<108> { using type = StaticPlan<108, 12, 9>; };
+template <> struct StaticPlanFor<120> { using type = StaticPlan<120, 12, 10>; };
+template <> struct StaticPlanFor<125> { using type = StaticPlan<125, 5, 5, 5>; };
+template <> struct StaticPlanFor<128> { using type = StaticPlan<128, 16, 8>; };
+template <> struct StaticPlanFor<135> { using type = StaticPlan<135, 15, 9>; };
+template <> struct StaticPlanFor<150> { using type = StaticPlan<150, 15, 10>; };
+template <> struct StaticPlanFor<162> { using type = StaticPlan<162, 9, 6, 3>; };
+template <> struct StaticPlanFor<180> { using type = StaticPlan<180, 15, 12>; };
+template <> struct StaticPlanFor<200> { using type = StaticPlan<200, 5, 5, 8>; };
+template <> struct StaticPlanFor<216> { using type = StaticPlan<216, 6, 6, 6>; };
+template <> struct StaticPlanFor<225> { using type = StaticPlan<225, 15, 15>; };
+template <> struct StaticPlanFor<243> { using type = StaticPlan<243, 9, 9, 3>; };
+template <> struct StaticPlanFor<250> { using type = StaticPlan<250, 10, 5, 5>; };
+template <> struct StaticPlanFor<256> { using type = StaticPlan<256, 16, 16>; };
+template <> struct StaticPlanFor<270> { using type = StaticPlan<270, 9, 6, 5>; };
+template <> struct StaticPlanFor<300> { using type = StaticPlan<300, 10, 6, 5>; };
+template <> struct StaticPlanFor<324> { using type = StaticPlan<324, 9, 6, 6>; };
+template <> struct StaticPlanFor<360> { using type = StaticPlan<360, 10, 6, 6>; };
+template <> struct StaticPlanFor<375> { using type = StaticPlan<375, 15, 5, 5>; };
+template <> struct StaticPlanFor<405> { using type = StaticPlan<405, 9, 9, 5>; };
+template <> struct StaticPlanFor<450> { using type = StaticPlan<450, 10, 9, 5>; };
+template <> struct StaticPlanFor<486> { using type = StaticPlan<486, 9, 9, 6>; };
+template <> struct StaticPlanFor<500> { using type = StaticPlan<500, 10, 10, 5>; };
+template <> struct StaticPlanFor<512> { using type = StaticPlan<512, 8, 8, 8>; };
+template <> struct StaticPlanFor<540> { using type = StaticPlan<540, 10, 9, 6>; };
+template <> struct StaticPlanFor<600> { using type = StaticPlan<600, 10, 10, 6>; };
+template <> struct StaticPlanFor<625> { using type = StaticPlan<625, 5, 5, 5, 5>; };
+template <> struct StaticPlanFor<648> { using type = StaticPlan<648, 9, 9, 8>; };
+template <> struct StaticPlanFor<675> { using type = StaticPlan<675, 15, 9, 5>; };
+template <> struct StaticPlanFor<729> { using type = StaticPlan<729, 9, 9, 9>; };
+template <> struct StaticPlanFor<750> { using type = StaticPlan<750, 15, 10, 5>; };
+template <> struct StaticPlanFor<810> { using type = StaticPlan<810, 10, 9, 9>; };
+template <> struct StaticPlanFor<900> { using type = StaticPlan<900, 10, 10, 9>; };
+template <> struct StaticPlanFor<972> { using type = StaticPlan<972, 12, 9, 9>; };
+template <> struct StaticPlanFor<1000> { using type = StaticPlan<1000, 10, 10, 10>; };
+template <> struct StaticPlanFor<1024> { using type = StaticPlan<1024, 16, 8, 8>; };
+template <> struct StaticPlanFor<1080> { using type = StaticPlan<1080, 12, 10, 9>; };
+template <> struct StaticPlanFor<1125> { using type = StaticPlan<1125, 15, 15, 5>; };
 
 // all stages of a static plan; twl: the workgroup's LDS copy of the plan's twiddles.  Returns the image that holds the result.
 // ---- software pipeline of the compile-time lists (round 3): the first stage's operands of the NEXT group of frames are
@@ -1131,12 +1172,24 @@ __global__ __launch_bounds__ (BLOCK, PIPE ? 4 : 1) void pass_a_generic_kernel (c
         const unsigned f = (unsigned) (w / tiles), tile = (unsigned) (w % tiles);
         const int valid = (int) min ((unsigned) CA, n1 - tile * CA);
         const float2* __restrict__ src = in + (size_t) f * in_stride + (size_t) tile * CA;
-#pragma unroll
-        for (int u = 0; u < PF; ++u)
-        {
+        const auto slot = [&] (int u) {
             const int e = min (tid + u * BLOCK, total - 1);
             const int c = min (e % CA, valid - 1), j = e / CA;
             pre[u] = gload (&src[(size_t) j * n1 + c]);
+        };
+        // run-time list: short tiles on 1024 work-items have 2-4 operands each -- one branch around the whole group of loads
+        // (not one per load) keeps the other six from re-reading the tile's last element
+        if (! STATIC && PF > 4 && total <= 4 * BLOCK)
+        {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                slot (u);
+        }
+        else
+        {
+#pragma unroll
+            for (int u = 0; u < PF; ++u)
+                slot (u);
         }
     };
     if constexpr (PIPE)
@@ -1198,23 +1251,28 @@ __global__ __launch_bounds__ (BLOCK, PIPE ? 4 : 1) void pass_a_generic_kernel (c
             res = generic_core<BLOCK, false, false, false> (plan, twtab, bufA, bufB, nullptr, nullptr, CA, tid, lfs);
         // the inter-pass twiddles of the whole tile first, then the stores: a twiddle load behind stores would wait for them
         // too (one in-order counter) -- a store drain per tile
-        for (int e0 = tid; e0 < total; e0 += BLOCK * SB)
-        {
-            float2 tw[SB];
-#pragma unroll
-            for (int u = 0; u < SB; ++u)
+        const auto store_tile = [&] (auto batch) {
+            constexpr int NB = decltype (batch)::value;
+            for (int e0 = tid; e0 < total; e0 += BLOCK * NB)
             {
-                tw[u] = twp[min (e0 + u * BLOCK, total - 1)];
-            }
+                float2 tw[NB];
 #pragma unroll
-            for (int u = 0; u < SB; ++u)
-            {
-                const int e = e0 + u * BLOCK;
-                const int c = e % CA, k = e / CA;
-                if (e < total)
-                    dst[e] = cmul (res[c * lfs + k], tw[u]); // plain store: the workspace should stay cached (padding columns: zeros)
+                for (int u = 0; u < NB; ++u)
+                    tw[u] = twp[min (e0 + u * BLOCK, total - 1)];
+#pragma unroll
+                for (int u = 0; u < NB; ++u)
+                {
+                    const int e = e0 + u * BLOCK;
+                    const int c = e % CA, k = e / CA;
+                    if (e < total)
+                        dst[e] = cmul (res[c * lfs + k], tw[u]); // plain store: the workspace should stay cached (padding columns: zeros)
+                }
             }
-        }
+        };
+        if (! STATIC && CA == 16 && total <= 4 * BLOCK) // (the narrow-tile variants spill with the second form)
+            store_tile (std::integral_constant<int, 4> {});
+        else
+            store_tile (std::integral_constant<int, SB> {});
     }
 }
 

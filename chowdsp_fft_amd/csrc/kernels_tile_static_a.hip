@@ -1,0 +1,5 @@
+// Tile kernels with compile-time stage lists, group A of tables.hpp's lengths (tile_static_impl.hpp).
+#define CFFT_TILE_GROUP CFFT_STATIC_TILE_SIZES_A
+#define CFFT_TILE_PICK_A pick_static_pass_a_a
+#define CFFT_TILE_PICK_B pick_static_pass_b_a
+#include "tile_static_impl.hpp"

@@ -1,17 +1,16 @@
-// Instantiation of the tile kernels with compile-time stage lists (tile_static.hpp).
+// Body of kernels_tile_static_{a,b,c}.hip: the tile kernels with compile-time stage lists for ONE group of lengths.
+// The including file defines CFFT_TILE_GROUP (the list macro of tables.hpp) and CFFT_TILE_PICK_A / CFFT_TILE_PICK_B (the names
+// of the two functions it provides; tile_static.hpp declares them).
 #include "tile_static.hpp"
 #include "launch_util.hpp"
 #include "tables.hpp"
-
-#include <cstdlib>
 
 namespace cfft::host
 {
 namespace
 {
-// compile-time stage lists for the tile kernels (generic_kernels.hpp: SP): one (tile width, workgroup size) per length, the pair
-// the launchers below choose on MI355X; anything else (another LDS size, a forced block, a planner list that differs from the
-// template's) runs the run-time list
+// one (tile width, workgroup size) per length: the pair the launchers choose on MI355X; anything else (another LDS size, a planner
+// list that differs from the template's) runs the run-time list
 template <int N_>
 struct StaticTile
 {
@@ -38,29 +37,23 @@ bool static_tile_matches (const GenericPlan& plan, int c, unsigned lfs)
 // (the lengths: CFFT_STATIC_TILE_SIZES in tables.hpp -- every length of StaticPlanFor up to 1200; n = 1280 runs unpadded: run-time list)
 } // namespace
 
-PassAGenericFn pick_static_pass_a (const GenericPlan& plan, int c, int& block, unsigned lfs, bool inverse)
+PassAGenericFn CFFT_TILE_PICK_A (const GenericPlan& plan, int c, int& block, unsigned lfs, bool inverse)
 {
-    static const bool off = [] { const char* e = std::getenv ("CHOWDSP_FFT_TILE_STATIC"); return e != nullptr && std::atoi (e) == 0; }();
-    if (off)
-        return nullptr;
 #define CFFT_TRY(N_)                                                                                                                  \
     if (static_tile_matches<N_> (plan, c, lfs))                                                                                       \
         return block = StaticTile<N_>::block, inverse ? pass_a_generic_kernel<true, StaticTile<N_>::c, StaticTile<N_>::block, true, typename StaticPlanFor<N_>::type> \
                        : pass_a_generic_kernel<false, StaticTile<N_>::c, StaticTile<N_>::block, true, typename StaticPlanFor<N_>::type>;
-    CFFT_STATIC_TILE_SIZES (CFFT_TRY)
+    CFFT_TILE_GROUP (CFFT_TRY)
 #undef CFFT_TRY
     return nullptr;
 }
-PassBGenericFn pick_static_pass_b (const GenericPlan& plan, int c, int& block, unsigned lfs, bool inverse)
+PassBGenericFn CFFT_TILE_PICK_B (const GenericPlan& plan, int c, int& block, unsigned lfs, bool inverse)
 {
-    static const bool off = [] { const char* e = std::getenv ("CHOWDSP_FFT_TILE_STATIC"); return e != nullptr && std::atoi (e) == 0; }();
-    if (off)
-        return nullptr;
 #define CFFT_TRY(N_)                                                                                                                  \
     if (static_tile_matches<N_> (plan, c, lfs))                                                                                       \
         return block = StaticTile<N_>::block, inverse ? pass_b_generic_kernel<true, StaticTile<N_>::c, StaticTile<N_>::block, true, typename StaticPlanFor<N_>::type> \
                        : pass_b_generic_kernel<false, StaticTile<N_>::c, StaticTile<N_>::block, true, typename StaticPlanFor<N_>::type>;
-    CFFT_STATIC_TILE_SIZES (CFFT_TRY)
+    CFFT_TILE_GROUP (CFFT_TRY)
 #undef CFFT_TRY
     return nullptr;
 }

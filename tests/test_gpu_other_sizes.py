@@ -300,14 +300,18 @@ def test_frames_beyond_2_21(gpu, oracle, n, tr):
     oracle.destroy_setup(so)
 
 
-# The tile kernels of the long plans with a compile-time stage list (kernels_tile_static.hip): one length per column pass
-# (n2 = 48 ... 1152, 1200) and per row pass (n1 = 144 ... 1200).  The workgroups are persistent and request their NEXT tile while
-# the current one is in the stages, so the batch is made large enough that every workgroup walks through several tiles (a
+# The tile kernels of the long plans with a compile-time stage list (kernels_tile_static_{a,b,c}.hip): for every static length the
+# shortest frame that runs it as the column pass and the shortest that runs it as the row pass (generated from
+# fft_gpu_plan_describe over the products of two static lengths).  The workgroups are persistent and request their NEXT tile
+# while the current one is in the stages, so the batch is made large enough that every workgroup walks through several tiles (a
 # batch of a few frames would end after the first); the frames repeat five distinct ones, each checked against the oracle.
-STATIC_TILE_SIZES = sorted({20480, 20736, 24576, 25600, 27648, 30720, 32000, 38400, 46080, 76800, 82944, 98304, 103680, 165888, 230400,
-                            331776, 414720, 622080, 640000, 746496, 921600, 1179648,
-                            23040, 34560, 57600, 96000, 124416, 128000, 192000, 288000, 384000, 460800, 497664, 512000, 663552, 768000,
-                            1327104, 1382400, 256000, 307200, 552960})
+STATIC_TILE_SIZES = [20480, 20736, 21600, 23040, 23328, 24000, 24576, 25600, 25920, 27648, 28800, 30000, 30720, 31104, 32400, 34992, 38400, 40000,
+                     46080, 46656, 50000, 54000, 58320, 62208, 64000, 64800, 69120, 69984, 76800, 77760, 80000, 82944, 90000, 93312, 98304, 100000,
+                     103680, 104976, 108000, 120000, 124416, 129600, 139968, 144000, 153600, 155520, 174960, 180000, 184320, 200000, 209952, 216000,
+                     230400, 248832, 250000, 259200, 276480, 279936, 291600, 300000, 314928, 320000, 331776, 360000, 368640, 384000, 400000, 414720,
+                     419904, 432000, 450000, 480000, 486000, 497664, 500000, 524880, 559872, 576000, 614400, 622080, 629856, 640000, 699840, 720000,
+                     746496, 750000, 768000, 810000, 839808, 921600, 944784, 995328, 1000000, 1036800, 1105920, 1119744, 1152000, 1166400, 1179648,
+                     1200000, 1296000]
 
 
 @pytest.mark.parametrize("n", STATIC_TILE_SIZES)
