@@ -1396,8 +1396,9 @@ __global__ __launch_bounds__ (BLOCK) void pass_b_generic_kernel (const float2* _
 // column, in place.  Same tile scheme as the two-pass column pass above -- C adjacent columns staged through LDS so that
 // every global access touches C * 8 contiguous bytes, the FFTs by the run-time stage list -- without the inter-pass
 // twiddle, and stored back where it came from.  cols need not be a multiple of C.
-template <bool SWAP, int C, int BLOCK>
-__global__ __launch_bounds__ (BLOCK) void column_fft_kernel (float2* __restrict__ data,
+// PIPE / SP: as in pass_a_generic_kernel (the next tile requested across the stages, stage twiddles in LDS; compile-time list).
+template <bool SWAP, int C, int BLOCK, bool PIPE = false, class SP = void>
+__global__ __launch_bounds__ (BLOCK, PIPE ? 4 : 1) void column_fft_kernel (float2* __restrict__ data,
                                                           const float2* __restrict__ twtab,
                                                           GenericPlan plan, // n = rows, frames = C
                                                           unsigned cols,
@@ -1407,11 +1408,51 @@ __global__ __launch_bounds__ (BLOCK) void column_fft_kernel (float2* __restrict_
 {
     extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
     const int tid = threadIdx.x;
-    const int rows = plan.n;
+    constexpr bool STATIC = ! std::is_void<SP>::value;
+    static_assert (! STATIC || PIPE, "compile-time lists come with the pipelined form only");
+    const int rows = tile_frame_len<SP> (plan);
+    if constexpr (STATIC)
+        lfs = SP::n + 1;
     float2* bufA = smem;
     float2* bufB = smem + (size_t) C * lfs;
+    float2* twl = smem + (size_t) 2 * C * lfs;
+    if constexpr (PIPE)
+    {
+        for (int i = tid; i < rows - 1; i += BLOCK)
+            twl[i] = twtab[plan.tw_offset[0] + i];
+    }
     const unsigned tiles = (cols + C - 1) / C;
     const size_t nwork = (size_t) batch * tiles;
+    const int total = C * rows;
+    constexpr int PF = tile_slots<SP, C, BLOCK> (kTilePrefetchA);
+    float2 pre[PF];
+    const auto request = [&] (size_t w) {
+        const unsigned f = (unsigned) (w / tiles), tile = (unsigned) (w % tiles);
+        const int valid = (int) min ((unsigned) C, cols - tile * C);
+        const float2* __restrict__ src = data + (size_t) f * array_stride + (size_t) tile * C;
+        const auto slot = [&] (int u) {
+            const int e = min (tid + u * BLOCK, total - 1);
+            const int c = min (e % C, valid - 1), j = e / C;
+            pre[u] = gload (&src[(size_t) j * cols + c]);
+        };
+        if (! STATIC && PF > 4 && total <= 4 * BLOCK) // (one branch around the group of loads, see pass_a_generic_kernel)
+        {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                slot (u);
+        }
+        else
+        {
+#pragma unroll
+            for (int u = 0; u < PF; ++u)
+                slot (u);
+        }
+    };
+    if constexpr (PIPE)
+    {
+        if (blockIdx.x < nwork)
+            request (blockIdx.x);
+    }
     for (size_t w = blockIdx.x; w < nwork; w += gridDim.x)
     {
         const unsigned f = (unsigned) (w / tiles);
@@ -1419,8 +1460,18 @@ __global__ __launch_bounds__ (BLOCK) void column_fft_kernel (float2* __restrict_
         const int valid = (int) min ((unsigned) C, cols - tile * C);
         float2* __restrict__ base = data + (size_t) f * array_stride + (size_t) tile * C;
         __syncthreads(); // previous tile fully stored
-        const int total = C * rows;
-        for (int e0 = tid; e0 < total; e0 += BLOCK * kTileLoadsInFlight)
+        if constexpr (PIPE)
+        {
+#pragma unroll
+            for (int u = 0; u < PF; ++u)
+            {
+                const int e = tid + u * BLOCK;
+                const int c = e % C, j = e / C;
+                if (e < total)
+                    bufA[c * lfs + j] = c < valid ? (SWAP ? make_float2 (pre[u].y, pre[u].x) : pre[u]) : make_float2 (0.f, 0.f);
+            }
+        }
+        for (int e0 = tid + (PIPE ? PF * BLOCK : 0); e0 < total; e0 += BLOCK * kTileLoadsInFlight)
         {
             float2 x[kTileLoadsInFlight];
 #pragma unroll
@@ -1440,8 +1491,19 @@ __global__ __launch_bounds__ (BLOCK) void column_fft_kernel (float2* __restrict_
             }
         }
         __syncthreads();
-        const float2* res = generic_core<BLOCK, false, false, false> (plan, twtab, bufA, bufB, nullptr, nullptr, C, tid, lfs);
-        for (int e = tid; e < C * rows; e += BLOCK)
+        const float2* res;
+        if constexpr (PIPE)
+        {
+            if (w + gridDim.x < nwork)
+                request (w + gridDim.x); // another tile: never the lines this one is about to store
+            if constexpr (STATIC)
+                res = static_core<SP, BLOCK, false, false, false, 0, false, SP_N_OR_ZERO<SP>::value + 1> (twl, bufA, bufB, nullptr, nullptr, C, tid, 0u, 0u);
+            else
+                res = generic_core<BLOCK, false, false, false> (plan, twl, bufA, bufB, nullptr, nullptr, C, tid, lfs, plan.tw_offset[0]);
+        }
+        else
+            res = generic_core<BLOCK, false, false, false> (plan, twtab, bufA, bufB, nullptr, nullptr, C, tid, lfs);
+        for (int e = tid; e < total; e += BLOCK)
         {
             const int c = e % C, k = e / C;
             if (c < valid)

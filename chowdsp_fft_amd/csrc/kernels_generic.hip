@@ -2,6 +2,7 @@
 #include "generic_kernels.hpp"
 #include "launch_util.hpp"
 #include "tables.hpp"
+#include "tile_static.hpp"
 
 #include <cstdlib>
 
@@ -268,6 +269,22 @@ hipError_t launch_generic (int mode, bool inverse, int nc, const DeviceTables& t
 }
 
 // column pass of the 2-D transform: rows-point FFTs along the columns of `batch` [rows][cols] arrays, in place
+namespace
+{
+template <int C, int BLOCK>
+ColumnFftFn pick_column_cb (bool inverse, bool pipe)
+{
+    return inverse ? (pipe ? column_fft_kernel<true, C, BLOCK, true> : column_fft_kernel<true, C, BLOCK, false>)
+                   : (pipe ? column_fft_kernel<false, C, BLOCK, true> : column_fft_kernel<false, C, BLOCK, false>);
+}
+ColumnFftFn pick_column (int c, int block, bool inverse, bool pipe)
+{
+    if (block == 1024)
+        return c == 16 ? pick_column_cb<16, 1024> (inverse, pipe) : (c == 8 ? pick_column_cb<8, 1024> (inverse, pipe) : pick_column_cb<4, 1024> (inverse, pipe));
+    return c == 16 ? pick_column_cb<16, 256> (inverse, pipe) : (c == 8 ? pick_column_cb<8, 256> (inverse, pipe) : pick_column_cb<4, 256> (inverse, pipe));
+}
+} // namespace
+
 hipError_t launch_column_fft (bool inverse, int rows, int cols, const DeviceTables& t, float2* data, size_t batch, hipStream_t stream)
 {
     if (batch == 0)
@@ -291,17 +308,19 @@ hipError_t launch_column_fft (bool inverse, int rows, int cols, const DeviceTabl
     unsigned lfs = (unsigned) rows + 1u;
     if ((size_t) 2 * c * lfs * sizeof (float2) > dev.lds_per_cu)
         lfs = (unsigned) rows;
-    const size_t lds = (size_t) 2 * c * lfs * sizeof (float2);
+    size_t lds = (size_t) 2 * c * lfs * sizeof (float2);
     if (lds > dev.lds_per_cu)
         return hipErrorInvalidValue;
-    const int block = generic_tile_block (lds, dev.lds_per_cu);
-    auto k256 = c == 16 ? (inverse ? column_fft_kernel<true, 16, 256> : column_fft_kernel<false, 16, 256>)
-                : c == 8 ? (inverse ? column_fft_kernel<true, 8, 256> : column_fft_kernel<false, 8, 256>)
-                         : (inverse ? column_fft_kernel<true, 4, 256> : column_fft_kernel<false, 4, 256>);
-    auto k1024 = c == 16 ? (inverse ? column_fft_kernel<true, 16, 1024> : column_fft_kernel<false, 16, 1024>)
-                 : c == 8 ? (inverse ? column_fft_kernel<true, 8, 1024> : column_fft_kernel<false, 8, 1024>)
-                          : (inverse ? column_fft_kernel<true, 4, 1024> : column_fft_kernel<false, 4, 1024>);
-    auto k = block == 1024 ? k1024 : k256;
+    int block = generic_tile_block (lds, dev.lds_per_cu);
+    const bool pipe = tile_pipe_fits (lds, (size_t) rows, dev.lds_per_cu, 1, block);
+    if (pipe)
+        lds += (size_t) (rows - 1) * sizeof (float2);
+    ColumnFftFn k = pick_column (c, block, inverse, pipe);
+    if (pipe)
+    {
+        if (auto ks = pick_static_column (plan, c, block, lfs, inverse))
+            k = ks;
+    }
     const unsigned grid = persistent_grid (k, block, lds, batch * (size_t) ((cols + c - 1) / c));
     if (grid == 0)
         return hipErrorNoDevice;

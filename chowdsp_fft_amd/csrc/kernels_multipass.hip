@@ -591,22 +591,6 @@ hipError_t launch_groupfast_c2c (int n1, int n2, bool inverse, const float2* in,
 // long mixed-radix frames: generic n2-point column pass (generic_kernels.hpp), then the ordinary n1-point row pass
 namespace
 {
-// PIPE variants of the generic tile kernels (generic_kernels.hpp: the next tile's operands requested across the stages) need an
-// LDS copy of the n - 1 stage twiddles behind the two images: granted where that leaves the workgroups per CU as they are.
-// CHOWDSP_FFT_TILE_PIPE (experiments): bit 0 = pass A / the 2-D column pass, bit 1 = pass B; a set bit grants it wherever the
-// copy fits at all, a clear one withholds it.
-bool tile_pipe_fits (size_t images_bytes, size_t n, size_t lds_per_cu, int which, int block)
-{
-    static const int forced = [] {
-        const char* e = std::getenv ("CHOWDSP_FFT_TILE_PIPE");
-        return e != nullptr ? std::atoi (e) : -1;
-    }();
-    const size_t with_tw = images_bytes + (n - 1) * sizeof (float2);
-    if ((forced >= 0 && (forced & which) == 0) || with_tw > lds_per_cu)
-        return false;
-    const size_t by_waves = (size_t) 2048 / (size_t) block; // 32 waves per CU
-    return forced >= 0 || std::min (by_waves, lds_per_cu / with_tw) == std::min (by_waves, lds_per_cu / images_bytes);
-}
 template <int C, int BLOCK>
 PassAGenericFn pick_pass_a_cb (bool inverse, bool pipe)
 {

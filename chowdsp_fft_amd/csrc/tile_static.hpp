@@ -10,6 +10,7 @@ namespace cfft::host
 {
 using PassAGenericFn = void (*) (const float2*, float2*, const float2*, const float2*, GenericPlan, unsigned, unsigned, size_t, unsigned, size_t);
 using PassBGenericFn = void (*) (const float2*, float2*, const float2*, GenericPlan, unsigned, unsigned, unsigned, size_t, unsigned, size_t);
+using ColumnFftFn = void (*) (float2*, const float2*, GenericPlan, unsigned, unsigned, size_t, unsigned); // the 2-D transforms' column pass
 // nullptr: no compile-time list for this (plan, tile width, frame pitch) in the group.  Otherwise `block` becomes the workgroup
 // size the kernel was instantiated for.
 PassAGenericFn pick_static_pass_a_a (const GenericPlan& plan, int c, int& block, unsigned lfs, bool inverse);
@@ -18,6 +19,9 @@ PassAGenericFn pick_static_pass_a_c (const GenericPlan& plan, int c, int& block,
 PassBGenericFn pick_static_pass_b_a (const GenericPlan& plan, int c, int& block, unsigned lfs, bool inverse);
 PassBGenericFn pick_static_pass_b_b (const GenericPlan& plan, int c, int& block, unsigned lfs, bool inverse);
 PassBGenericFn pick_static_pass_b_c (const GenericPlan& plan, int c, int& block, unsigned lfs, bool inverse);
+ColumnFftFn pick_static_column_a (const GenericPlan& plan, int c, int& block, unsigned lfs, bool inverse);
+ColumnFftFn pick_static_column_b (const GenericPlan& plan, int c, int& block, unsigned lfs, bool inverse);
+ColumnFftFn pick_static_column_c (const GenericPlan& plan, int c, int& block, unsigned lfs, bool inverse);
 // CHOWDSP_FFT_TILE_STATIC = 0: the run-time list everywhere (A/B)
 inline bool static_tiles_off()
 {
@@ -43,5 +47,31 @@ inline PassBGenericFn pick_static_pass_b (const GenericPlan& plan, int c, int& b
     if (auto k = pick_static_pass_b_b (plan, c, block, lfs, inverse))
         return k;
     return pick_static_pass_b_c (plan, c, block, lfs, inverse);
+}
+inline ColumnFftFn pick_static_column (const GenericPlan& plan, int c, int& block, unsigned lfs, bool inverse)
+{
+    if (static_tiles_off())
+        return nullptr;
+    if (auto k = pick_static_column_a (plan, c, block, lfs, inverse))
+        return k;
+    if (auto k = pick_static_column_b (plan, c, block, lfs, inverse))
+        return k;
+    return pick_static_column_c (plan, c, block, lfs, inverse);
+}
+// PIPE variants of the tile kernels need an LDS copy of the n - 1 stage twiddles behind the two images: granted where that leaves
+// the workgroups per CU as they are (by LDS or by the CU's 32 waves, whichever binds).  CHOWDSP_FFT_TILE_PIPE (experiments): bit 0 =
+// pass A / the 2-D column pass, bit 1 = pass B; a set bit grants it wherever the copy fits at all, a clear one withholds it.
+inline bool tile_pipe_fits (size_t images_bytes, size_t n, size_t lds_per_cu, int which, int block)
+{
+    static const int forced = [] {
+        const char* e = std::getenv ("CHOWDSP_FFT_TILE_PIPE");
+        return e != nullptr ? std::atoi (e) : -1;
+    }();
+    const size_t with_tw = images_bytes + (n - 1) * sizeof (float2);
+    if ((forced >= 0 && (forced & which) == 0) || with_tw > lds_per_cu)
+        return false;
+    const size_t by_waves = (size_t) 2048 / (size_t) block; // 32 waves per CU
+    const size_t a = lds_per_cu / with_tw, b = lds_per_cu / images_bytes;
+    return forced >= 0 || (a < by_waves ? a : by_waves) == (b < by_waves ? b : by_waves);
 }
 } // namespace cfft::host

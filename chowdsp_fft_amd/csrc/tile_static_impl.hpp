@@ -1,6 +1,6 @@
 // Body of kernels_tile_static_{a,b,c}.hip: the tile kernels with compile-time stage lists for ONE group of lengths.
-// The including file defines CFFT_TILE_GROUP (the list macro of tables.hpp) and CFFT_TILE_PICK_A / CFFT_TILE_PICK_B (the names
-// of the two functions it provides; tile_static.hpp declares them).
+// The including file defines CFFT_TILE_GROUP (the list macro of tables.hpp) and CFFT_TILE_PICK_A / CFFT_TILE_PICK_B / CFFT_TILE_PICK_COL (the
+// names of the three functions it provides; tile_static.hpp declares them).
 #include "tile_static.hpp"
 #include "launch_util.hpp"
 #include "tables.hpp"
@@ -53,6 +53,16 @@ PassBGenericFn CFFT_TILE_PICK_B (const GenericPlan& plan, int c, int& block, uns
     if (static_tile_matches<N_> (plan, c, lfs))                                                                                       \
         return block = StaticTile<N_>::block, inverse ? pass_b_generic_kernel<true, StaticTile<N_>::c, StaticTile<N_>::block, true, typename StaticPlanFor<N_>::type> \
                        : pass_b_generic_kernel<false, StaticTile<N_>::c, StaticTile<N_>::block, true, typename StaticPlanFor<N_>::type>;
+    CFFT_TILE_GROUP (CFFT_TRY)
+#undef CFFT_TRY
+    return nullptr;
+}
+ColumnFftFn CFFT_TILE_PICK_COL (const GenericPlan& plan, int c, int& block, unsigned lfs, bool inverse)
+{
+#define CFFT_TRY(N_)                                                                                                                  \
+    if (static_tile_matches<N_> (plan, c, lfs))                                                                                       \
+        return block = StaticTile<N_>::block, inverse ? column_fft_kernel<true, StaticTile<N_>::c, StaticTile<N_>::block, true, typename StaticPlanFor<N_>::type> \
+                       : column_fft_kernel<false, StaticTile<N_>::c, StaticTile<N_>::block, true, typename StaticPlanFor<N_>::type>;
     CFFT_TILE_GROUP (CFFT_TRY)
 #undef CFFT_TRY
     return nullptr;
