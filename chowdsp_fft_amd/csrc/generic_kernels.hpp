@@ -1100,6 +1100,26 @@ static constexpr int kTilePrefetchB = CFFT_TILE_PREFETCH_B;
 static constexpr int kTilePrefetchA = CFFT_TILE_PREFETCH_A;
 static constexpr int kTileStoreBatch = 10;
 
+// XCD-aware order of the tiles (speed only: a bijection of [0, nwork)).  Workgroups are dealt round-robin over the 8 XCDs, each
+// with an L2 of its own; item v of the persistent loops (v = blockIdx + k gridDim, gridDim a multiple of 8 on a full chip) is
+// mapped so that the tiles ONE XCD works on at a time are consecutive ones: where a tile is 8 or 4 columns wide (64- / 32-byte
+// pieces of 128-byte lines) the neighbours' pieces of a line then meet in one L2 instead of being fetched / written by two.
+// Measured on MI355X against the plain order (profiles/r03_general_two_pass.txt): the in-place column pass of the 2-D transforms
+// gains 17-20 % with narrow tiles (1024 x 1024 0.214 -> 0.253 of 8 TB/s, 1080 x 1920 0.215 -> 0.250, 2048 x 2048 0.092 -> 0.111)
+// and nothing with 16 columns; the two passes of the long 1-D plans, which hand a workspace from one order to the other, move
+// by -7 .. +6 % with no pattern (c655360 +4 %, c2^21 -7 %, c1000000 -4 %) and keep the plain order.
+#ifndef CFFT_TILE_XCD_ORDER
+#define CFFT_TILE_XCD_ORDER 1 // bit 0: the column pass, bit 1: pass A / pass B
+#endif
+template <int WHICH>
+__device__ __forceinline__ size_t tile_xcd_order (size_t v, size_t nwork)
+{
+    if ((CFFT_TILE_XCD_ORDER & WHICH) == 0)
+        return v;
+    const size_t q = nwork / 8, r = nwork % 8, x = v % 8;
+    return x * q + (x < r ? x : r) + v / 8; // XCD x owns q (+ 1 while x < r) consecutive tiles from x q + min (x, r)
+}
+
 // SP (tile kernels): compile-time stage list of the tile's frame length (the lists of StaticPlanFor, checked against the
 // planner's by the launcher): the radix switch, the stage loop and every division fold away, and the tile is requested with
 // exactly as many loads per work-item as it has.  SP = void: the run-time list of GenericPlan.
@@ -1168,7 +1188,8 @@ __global__ __launch_bounds__ (BLOCK, PIPE ? 4 : 1) void pass_a_generic_kernel (c
     constexpr int PF = tile_slots<SP, CA, BLOCK> (kTilePrefetchA);
     constexpr int SB = tile_slots<SP, CA, BLOCK> (CA == 16 ? kTileStoreBatch : 8); // (run-time list: 10 spills a few bytes in the narrow-tile variants)
     float2 pre[PF];
-    const auto request = [&] (size_t w) {
+    const auto request = [&] (size_t v) {
+        const size_t w = tile_xcd_order<2> (v, nwork);
         const unsigned f = (unsigned) (w / tiles), tile = (unsigned) (w % tiles);
         const int valid = (int) min ((unsigned) CA, n1 - tile * CA);
         const float2* __restrict__ src = in + (size_t) f * in_stride + (size_t) tile * CA;
@@ -1197,8 +1218,9 @@ __global__ __launch_bounds__ (BLOCK, PIPE ? 4 : 1) void pass_a_generic_kernel (c
         if (blockIdx.x < nwork)
             request (blockIdx.x);
     }
-    for (size_t w = blockIdx.x; w < nwork; w += gridDim.x)
+    for (size_t v = blockIdx.x; v < nwork; v += gridDim.x)
     {
+        const size_t w = tile_xcd_order<2> (v, nwork);
         const unsigned f = (unsigned) (w / tiles);
         const unsigned tile = (unsigned) (w % tiles);
         const int valid = (int) min ((unsigned) CA, n1 - tile * CA); // columns of this tile that exist (n1 need not be a multiple of CA)
@@ -1240,8 +1262,8 @@ __global__ __launch_bounds__ (BLOCK, PIPE ? 4 : 1) void pass_a_generic_kernel (c
         const float2* res;
         if constexpr (PIPE)
         {
-            if (w + gridDim.x < nwork)
-                request (w + gridDim.x);
+            if (v + gridDim.x < nwork)
+                request (v + gridDim.x);
             if constexpr (STATIC)
                 res = static_core<SP, BLOCK, false, false, false, 0, false, SP_N_OR_ZERO<SP>::value + 1> (twl, bufA, bufB, nullptr, nullptr, CA, tid, 0u, 0u);
             else
@@ -1318,7 +1340,8 @@ __global__ __launch_bounds__ (BLOCK) void pass_b_generic_kernel (const float2* _
         const unsigned tA = (unsigned) fast_div ((int) a, magic_ca), c = a - tA * ca;
         return src[((size_t) tA * n2 + kb0 + min (kbl, (unsigned) (valid - 1))) * ca + c];
     };
-    const auto request = [&] (size_t w) {
+    const auto request = [&] (size_t v) {
+        const size_t w = tile_xcd_order<2> (v, nwork);
         const unsigned f = (unsigned) (w / tiles), kb0 = (unsigned) (w % tiles) * CB;
         const int valid = (int) min ((unsigned) CB, n2 - kb0);
         const float2* __restrict__ src = work + (size_t) f * ws_frame_len;
@@ -1331,8 +1354,9 @@ __global__ __launch_bounds__ (BLOCK) void pass_b_generic_kernel (const float2* _
         if (blockIdx.x < nwork)
             request (blockIdx.x);
     }
-    for (size_t w = blockIdx.x; w < nwork; w += gridDim.x)
+    for (size_t v = blockIdx.x; v < nwork; v += gridDim.x)
     {
+        const size_t w = tile_xcd_order<2> (v, nwork);
         const unsigned f = (unsigned) (w / tiles);
         const unsigned tile = (unsigned) (w % tiles);
         const unsigned kb0 = tile * CB;
@@ -1370,8 +1394,8 @@ __global__ __launch_bounds__ (BLOCK) void pass_b_generic_kernel (const float2* _
         const float2* res;
         if constexpr (PIPE)
         {
-            if (w + gridDim.x < nwork)
-                request (w + gridDim.x);
+            if (v + gridDim.x < nwork)
+                request (v + gridDim.x);
             if constexpr (STATIC)
                 res = static_core<SP, BLOCK, false, false, false, 0, false, SP_N_OR_ZERO<SP>::value + 1> (twl, bufA, bufB, nullptr, nullptr, CB, tid, 0u, 0u);
             else
@@ -1426,7 +1450,8 @@ __global__ __launch_bounds__ (BLOCK, PIPE ? 4 : 1) void column_fft_kernel (float
     const int total = C * rows;
     constexpr int PF = tile_slots<SP, C, BLOCK> (kTilePrefetchA);
     float2 pre[PF];
-    const auto request = [&] (size_t w) {
+    const auto request = [&] (size_t v) {
+        const size_t w = tile_xcd_order<1> (v, nwork);
         const unsigned f = (unsigned) (w / tiles), tile = (unsigned) (w % tiles);
         const int valid = (int) min ((unsigned) C, cols - tile * C);
         const float2* __restrict__ src = data + (size_t) f * array_stride + (size_t) tile * C;
@@ -1453,8 +1478,9 @@ __global__ __launch_bounds__ (BLOCK, PIPE ? 4 : 1) void column_fft_kernel (float
         if (blockIdx.x < nwork)
             request (blockIdx.x);
     }
-    for (size_t w = blockIdx.x; w < nwork; w += gridDim.x)
+    for (size_t v = blockIdx.x; v < nwork; v += gridDim.x)
     {
+        const size_t w = tile_xcd_order<1> (v, nwork);
         const unsigned f = (unsigned) (w / tiles);
         const unsigned tile = (unsigned) (w % tiles);
         const int valid = (int) min ((unsigned) C, cols - tile * C);
@@ -1494,8 +1520,8 @@ __global__ __launch_bounds__ (BLOCK, PIPE ? 4 : 1) void column_fft_kernel (float
         const float2* res;
         if constexpr (PIPE)
         {
-            if (w + gridDim.x < nwork)
-                request (w + gridDim.x); // another tile: never the lines this one is about to store
+            if (v + gridDim.x < nwork)
+                request (v + gridDim.x); // another tile: never the lines this one is about to store
             if constexpr (STATIC)
                 res = static_core<SP, BLOCK, false, false, false, 0, false, SP_N_OR_ZERO<SP>::value + 1> (twl, bufA, bufB, nullptr, nullptr, C, tid, 0u, 0u);
             else
