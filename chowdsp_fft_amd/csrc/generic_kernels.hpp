@@ -532,6 +532,115 @@ struct SP_N_OR_ZERO<void>
 #define CFFT_GENERIC_CONV_PIPE 1
 #endif
 
+// ---- pair stage of the real transforms, kRealPairBatch pairs per work-item at a time ------------------------------------------
+// The plain `for (k = tid; k < half; k += BLOCK)` loops compiled to one round trip per pair: the operands (backward: two loads
+// of the spectrum per pair) and the pair twiddle sit behind a branch on k and an LDS access, so every iteration waited vmcnt(0) --
+// and in the forward direction that wait also drained the previous pair's stores (one in-order counter).  Here the loads of a
+// batch are issued first and unconditionally (indices clamped into the range), then the batch is computed and stored.
+#ifndef CFFT_REAL_PAIR_BATCH
+#define CFFT_REAL_PAIR_BATCH 4
+#endif
+static constexpr int kRealPairBatch = CFFT_REAL_PAIR_BATCH;
+
+// backward: spectrum frames in global memory (frame stride `is`) -> Z, re <-> im swapped, in the LDS image (frame stride n)
+template <int BLOCK>
+__device__ __forceinline__ void real_merge_frames (const float2* __restrict__ src, unsigned is, float2* __restrict__ img, const float2* wp, int n,
+                                                   int nframes, int tid)
+{
+    const int half = n / 2 + 1, total = nframes * half;
+    const unsigned magic_half = div_magic ((unsigned) half);
+    constexpr int U = kRealPairBatch;
+    for (int idx0 = tid; idx0 < total; idx0 += U * BLOCK)
+    {
+        float2 A[U], X[U], W[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+        {
+            const int idx = min (idx0 + u * BLOCK, total - 1);
+            const int f = nframes == 1 ? 0 : fast_div (idx, magic_half), k = idx - f * half;
+            const int kp = (k == 0) ? 0 : n - k;
+            A[u] = gload (&src[(size_t) f * is + k]);
+            X[u] = gload (&src[(size_t) f * is + kp]);
+            W[u] = wp[k];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+        {
+            const int idx = idx0 + u * BLOCK;
+            if (idx < total)
+            {
+                const int f = nframes == 1 ? 0 : fast_div (idx, magic_half), k = idx - f * half;
+                const int kp = (k == 0) ? 0 : n - k;
+                float2 zk, zp;
+                if (k == 0)
+                {
+                    zk = make_float2 (A[u].x + A[u].y, A[u].x - A[u].y); // Z[0] = (X0 + XM) + i (X0 - XM)
+                    zp = zk;
+                }
+                else if (2 * k == n)
+                {
+                    zk = make_float2 (2.f * A[u].x, -2.f * A[u].y); // Z[n/2] = 2 conj(X[n/2])
+                    zp = zk;
+                }
+                else
+                    real_merge_pair (A[u], X[u], W[u], zk, zp);
+                img[f * n + k] = make_float2 (zk.y, zk.x);
+                if (kp != k)
+                    img[f * n + kp] = make_float2 (zp.y, zp.x);
+            }
+        }
+    }
+}
+
+// forward: Z in the LDS image (frame stride n) -> packed spectrum frames in global memory (frame stride `os`)
+template <int BLOCK>
+__device__ __forceinline__ void real_split_frames (const float2* __restrict__ img, float2* __restrict__ dst, unsigned os, const float2* wp, int n,
+                                                   int nframes, int tid)
+{
+    const int half = n / 2 + 1, total = nframes * half;
+    const unsigned magic_half = div_magic ((unsigned) half);
+    constexpr int U = kRealPairBatch;
+    for (int idx0 = tid; idx0 < total; idx0 += U * BLOCK)
+    {
+        float2 W[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+        {
+            const int idx = min (idx0 + u * BLOCK, total - 1);
+            const int f = nframes == 1 ? 0 : fast_div (idx, magic_half);
+            W[u] = wp[idx - f * half];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+        {
+            const int idx = idx0 + u * BLOCK;
+            if (idx < total)
+            {
+                const int f = nframes == 1 ? 0 : fast_div (idx, magic_half), k = idx - f * half;
+                const int kp = (k == 0) ? 0 : n - k;
+                const float2 A = img[f * n + k];
+                const float2 Zp = img[f * n + kp];
+                float2 Xk, Xp;
+                if (k == 0)
+                {
+                    Xk = make_float2 (A.x + A.y, A.x - A.y); // [X0.re, X(N/2).re]
+                    Xp = Xk;
+                }
+                else if (2 * k == n)
+                {
+                    Xk = make_float2 (A.x, -A.y); // X[n/2] = conj(Z[n/2])
+                    Xp = Xk;
+                }
+                else
+                    real_split_pair (A, Zp, W[u], Xk, Xp);
+                gstore (&dst[(size_t) f * os + k], Xk);
+                if (kp != k)
+                    gstore (&dst[(size_t) f * os + kp], Xp);
+            }
+        }
+    }
+}
+
 // MODE 0: complex <-> complex (INV: backward).  MODE 1: real forward (packed spectrum out).  MODE 2: real backward.
 // For the real modes plan.n = N/2 and wtab holds W_N^k, k <= N/4 (pair stage formulas: real_kernels.hpp).
 // TWLDS: the plan's stage twiddles (n - 1 values: sum of (r - 1) p over the stages) are copied to LDS once per workgroup, behind
@@ -557,7 +666,6 @@ __global__ __launch_bounds__ (BLOCK) void generic_kernel (const float2* __restri
     }();
     const int F = plan.frames;
     const int half = n / 2 + 1; // pair-stage work items per frame: k = 0 .. n/2
-    const unsigned magic_half = div_magic ((unsigned) half);
     float2* bufA = smem;
     float2* bufB = smem + (size_t) F * n;
     float2* twl = smem + (size_t) 2 * F * n;
@@ -596,31 +704,8 @@ __global__ __launch_bounds__ (BLOCK) void generic_kernel (const float2* __restri
         if (MODE == 2)
         {
             // merge pairs straight from global memory (k and n-k), stored re<->im swapped for the inverse core
-            const auto merge_all = [&] (const float2* wp) { // wp: the pair twiddles, in LDS or in L2 (one instantiation each)
-                for (int idx = tid; idx < nframes * half; idx += BLOCK)
-                {
-                    const int f = fast_div (idx, magic_half), k = idx - f * half;
-                    const int kp = (k == 0) ? 0 : n - k;
-                    const float2 A = gload (&src[f * is + k]);
-                    const float2 Xp = gload (&src[f * is + kp]);
-                    float2 zk, zp;
-                    if (k == 0)
-                    {
-                        zk = make_float2 (A.x + A.y, A.x - A.y); // Z[0] = (X0 + XM) + i (X0 - XM)
-                        zp = zk;
-                    }
-                    else if (2 * k == n)
-                    {
-                        zk = make_float2 (2.f * A.x, -2.f * A.y); // Z[n/2] = 2 conj(X[n/2])
-                        zp = zk;
-                    }
-                    else
-                        real_merge_pair (A, Xp, wp[k], zk, zp);
-                    bufA[f * n + k] = make_float2 (zk.y, zk.x);
-                    if (kp != k)
-                        bufA[f * n + kp] = make_float2 (zp.y, zp.x);
-                }
-            };
+            // wp: the pair twiddles, in LDS or in L2 (one instantiation each)
+            const auto merge_all = [&] (const float2* wp) { real_merge_frames<BLOCK> (src, is, bufA, wp, n, nframes, tid); };
             if (pair_lds)
                 merge_all (wlds);
             else
@@ -724,31 +809,7 @@ __global__ __launch_bounds__ (BLOCK) void generic_kernel (const float2* __restri
             res = generic_core<BLOCK, IN_GLOBAL, OUT_GLOBAL, (MODE == 2) || INV> (plan, twtab, bufA, bufB, src, dst, nframes, tid, (unsigned) n);
         if (MODE == 1)
         {
-            const auto split_all = [&] (const float2* wp) {
-                for (int idx = tid; idx < nframes * half; idx += BLOCK)
-                {
-                    const int f = fast_div (idx, magic_half), k = idx - f * half;
-                    const int kp = (k == 0) ? 0 : n - k;
-                    const float2 A = res[f * n + k];
-                    const float2 Zp = res[f * n + kp];
-                    float2 Xk, Xp;
-                    if (k == 0)
-                    {
-                        Xk = make_float2 (A.x + A.y, A.x - A.y); // [X0.re, X(N/2).re]
-                        Xp = Xk;
-                    }
-                    else if (2 * k == n)
-                    {
-                        Xk = make_float2 (A.x, -A.y); // X[n/2] = conj(Z[n/2])
-                        Xp = Xk;
-                    }
-                    else
-                        real_split_pair (A, Zp, wp[k], Xk, Xp);
-                    gstore (&dst[f * os + k], Xk);
-                    if (kp != k)
-                        gstore (&dst[f * os + kp], Xp);
-                }
-            };
+            const auto split_all = [&] (const float2* wp) { real_split_frames<BLOCK> (res, dst, os, wp, n, nframes, tid); };
             if (pair_lds)
                 split_all (wlds);
             else
@@ -1006,7 +1067,6 @@ __global__ __launch_bounds__ (BLOCK, BLOCK == 512 ? 4 : 1) void generic_inplace_
         else
             return plan.n;
     }();
-    const int half = n / 2 + 1;
     float2* buf = smem;
     float2* twl = smem + n;
     if constexpr (TWLDS)
@@ -1024,28 +1084,7 @@ __global__ __launch_bounds__ (BLOCK, BLOCK == 512 ? 4 : 1) void generic_inplace_
         __syncthreads(); // previous frame's reads of the image are finished
         if (MODE == 2)
         {
-            for (int k = tid; k < half; k += BLOCK)
-            {
-                const int kp = (k == 0) ? 0 : n - k;
-                const float2 A = gload (&src[k]);
-                const float2 Xp = gload (&src[kp]);
-                float2 zk, zp;
-                if (k == 0)
-                {
-                    zk = make_float2 (A.x + A.y, A.x - A.y);
-                    zp = zk;
-                }
-                else if (2 * k == n)
-                {
-                    zk = make_float2 (2.f * A.x, -2.f * A.y);
-                    zp = zk;
-                }
-                else
-                    real_merge_pair (A, Xp, wtab[k], zk, zp);
-                buf[k] = make_float2 (zk.y, zk.x);
-                if (kp != k)
-                    buf[kp] = make_float2 (zp.y, zp.x);
-            }
+            real_merge_frames<BLOCK> (src, 0u, buf, wtab, n, 1, tid);
             __syncthreads();
         }
         constexpr bool IN_GLOBAL = (MODE != 2), OUT_GLOBAL = (MODE != 1);
@@ -1054,30 +1093,7 @@ __global__ __launch_bounds__ (BLOCK, BLOCK == 512 ? 4 : 1) void generic_inplace_
         else
             inplace_core<BLOCK, IN_GLOBAL, OUT_GLOBAL, (MODE == 2) || INV, TWLDS> (plan, twtab, twl, buf, src, dst, tid);
         if (MODE == 1)
-        {
-            for (int k = tid; k < half; k += BLOCK)
-            {
-                const int kp = (k == 0) ? 0 : n - k;
-                const float2 A = buf[k];
-                const float2 Zp = buf[kp];
-                float2 Xk, Xp;
-                if (k == 0)
-                {
-                    Xk = make_float2 (A.x + A.y, A.x - A.y);
-                    Xp = Xk;
-                }
-                else if (2 * k == n)
-                {
-                    Xk = make_float2 (A.x, -A.y);
-                    Xp = Xk;
-                }
-                else
-                    real_split_pair (A, Zp, wtab[k], Xk, Xp);
-                gstore (&dst[k], Xk);
-                if (kp != k)
-                    gstore (&dst[kp], Xp);
-            }
-        }
+            real_split_frames<BLOCK> (buf, dst, 0u, wtab, n, 1, tid);
     }
 }
 
