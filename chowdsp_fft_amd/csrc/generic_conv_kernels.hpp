@@ -81,13 +81,9 @@ __global__ __launch_bounds__ (BLOCK) void generic_conv_kernel (const float2* __r
     float2* twl = smem + (size_t) 2 * F * n;
     float2* wlds = twl + (n - 1);
     const bool pair_lds = REAL && plan.pair_lds != 0;
-    for (int i = tid; i < n - 1; i += BLOCK)
-        twl[i] = twtab[plan.tw_offset[0] + i];
+    lds_table_copy<BLOCK> (twl, twtab + plan.tw_offset[0], n - 1, tid);
     if (pair_lds)
-    {
-        for (int i = tid; i < n / 2 + 1; i += BLOCK)
-            wlds[i] = wtab[i];
-    }
+        lds_table_copy<BLOCK> (wlds, wtab, n / 2 + 1, tid);
     const unsigned ngroups = (batch + F - 1) / F;
     // software pipeline (generic_kernels.hpp: generic_first_prefetch): the next group's first-stage operands are requested while
     // this group's remaining forward stages, the product and the whole backward transform run
@@ -156,8 +152,7 @@ __global__ __launch_bounds__ (BLOCK, BLOCK == 512 ? 4 : 1) void generic_inplace_
     float2* twl = smem + n;
     if constexpr (TWLDS)
     {
-        for (int i = tid0; i < plan.lds_tw_len; i += BLOCK)
-            twl[i] = twtab[plan.tw_offset[0] + i];
+        lds_table_copy<BLOCK> (twl, twtab + plan.tw_offset[0], plan.lds_tw_len, tid0);
     }
     for (unsigned g = blockIdx.x; g < batch; g += gridDim.x)
     {

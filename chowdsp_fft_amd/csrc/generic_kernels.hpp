@@ -532,6 +532,28 @@ struct SP_N_OR_ZERO<void>
 #define CFFT_GENERIC_CONV_PIPE 1
 #endif
 
+// Copy of a twiddle table to LDS at kernel start, eight loads per work-item in flight (the plain loop is one round trip per
+// BLOCK entries: a 1919-entry table on 256 work-items costs eight serial trips to L2 before the first frame).
+template <int BLOCK>
+__device__ __forceinline__ void lds_table_copy (float2* __restrict__ dst, const float2* __restrict__ src, int count, int tid)
+{
+#ifndef CFFT_TABLE_COPY_BATCH
+#define CFFT_TABLE_COPY_BATCH 8
+#endif
+    constexpr int U = CFFT_TABLE_COPY_BATCH;
+    for (int i0 = tid; i0 < count; i0 += U * BLOCK)
+    {
+        float2 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            v[u] = src[min (i0 + u * BLOCK, count - 1)];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (i0 + u * BLOCK < count)
+                dst[i0 + u * BLOCK] = v[u];
+    }
+}
+
 // ---- pair stage of the real transforms, kRealPairBatch pairs per work-item at a time ------------------------------------------
 // The plain `for (k = tid; k < half; k += BLOCK)` loops compiled to one round trip per pair: the operands (backward: two loads
 // of the spectrum per pair) and the pair twiddle sit behind a branch on k and an LDS access, so every iteration waited vmcnt(0) --
@@ -676,12 +698,10 @@ __global__ __launch_bounds__ (BLOCK) void generic_kernel (const float2* __restri
     const bool pair_lds = TWLDS && MODE != 0 && plan.pair_lds != 0;
     if constexpr (TWLDS)
     {
-        for (int i = tid; i < n - 1; i += BLOCK)
-            twl[i] = twtab[plan.tw_offset[0] + i];
+        lds_table_copy<BLOCK> (twl, twtab + plan.tw_offset[0], n - 1, tid);
         if (pair_lds)
         {
-            for (int i = tid; i < half; i += BLOCK)
-                wlds[i] = wtab[i];
+            lds_table_copy<BLOCK> (wlds, wtab, half, tid);
         }
         // the first barrier of the group loop orders these writes before any stage
     }
@@ -1071,8 +1091,7 @@ __global__ __launch_bounds__ (BLOCK, BLOCK == 512 ? 4 : 1) void generic_inplace_
     float2* twl = smem + n;
     if constexpr (TWLDS)
     {
-        for (int i = tid0; i < plan.lds_tw_len; i += BLOCK)
-            twl[i] = twtab[plan.tw_offset[0] + i];
+        lds_table_copy<BLOCK> (twl, twtab + plan.tw_offset[0], plan.lds_tw_len, tid0);
         // the first barrier of the frame loop orders these writes before any stage
     }
     for (unsigned g = blockIdx.x; g < batch; g += gridDim.x)
@@ -1192,8 +1211,7 @@ __global__ __launch_bounds__ (BLOCK, PIPE ? 4 : 1) void pass_a_generic_kernel (c
     float2* twl = smem + (size_t) 2 * CA * lfs;
     if constexpr (PIPE)
     {
-        for (int i = tid; i < n2 - 1; i += BLOCK)
-            twl[i] = twtab[plan.tw_offset[0] + i]; // ordered before the stages by the tile loop's barriers
+        lds_table_copy<BLOCK> (twl, twtab + plan.tw_offset[0], n2 - 1, tid);
     }
     const unsigned tiles = (n1 + CA - 1) / CA;
     const size_t nwork = (size_t) batch * tiles;
@@ -1341,8 +1359,7 @@ __global__ __launch_bounds__ (BLOCK) void pass_b_generic_kernel (const float2* _
     float2* twl = smem + (size_t) 2 * CB * lfs; // PIPE (see pass_a_generic_kernel): the stage twiddles' LDS copy
     if constexpr (PIPE)
     {
-        for (int i = tid; i < n1 - 1; i += BLOCK)
-            twl[i] = twtab[plan.tw_offset[0] + i];
+        lds_table_copy<BLOCK> (twl, twtab + plan.tw_offset[0], n1 - 1, tid);
     }
     const unsigned tiles = (n2 + CB - 1) / CB;
     const unsigned magic_n1 = div_magic ((unsigned) n1), magic_ca = ca > 1 ? div_magic (ca) : 0u;
@@ -1458,8 +1475,7 @@ __global__ __launch_bounds__ (BLOCK, PIPE ? 4 : 1) void column_fft_kernel (float
     float2* twl = smem + (size_t) 2 * C * lfs;
     if constexpr (PIPE)
     {
-        for (int i = tid; i < rows - 1; i += BLOCK)
-            twl[i] = twtab[plan.tw_offset[0] + i];
+        lds_table_copy<BLOCK> (twl, twtab + plan.tw_offset[0], rows - 1, tid);
     }
     const unsigned tiles = (cols + C - 1) / C;
     const size_t nwork = (size_t) batch * tiles;
