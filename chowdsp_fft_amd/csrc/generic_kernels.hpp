@@ -1135,6 +1135,65 @@ static constexpr int kTilePrefetchB = CFFT_TILE_PREFETCH_B;
 static constexpr int kTilePrefetchA = CFFT_TILE_PREFETCH_A;
 static constexpr int kTileStoreBatch = 10;
 
+// ---- in-place stages over a TILE of C frames (compile-time lists only) ----------------------------------------------------------
+// The two-image Stockham form needs 2 x C x (n + 1) points of LDS: beyond n = 639 that forces 8-column tiles (64-byte pieces of
+// the callers' rows) and from n = 324 on it leaves ONE workgroup per CU.  Here every work-item reads the operands of its
+// butterflies of a stage into registers, the workgroup meets at a barrier, and the results overwrite the SAME image (the scheme
+// of inplace_stage above, across C frames): one image, so 16-column tiles up to n = 1200 and two or three workgroups per CU up
+// to n = 600.  J x R <= 24 points per work-item and stage for every length of the lists.
+template <int R, int BLOCK, int C, int N, int P, int LFS>
+__device__ __forceinline__ void tile_inplace_stage (float2* __restrict__ buf, const float2* __restrict__ tw, int tid)
+{
+    constexpr int M = N / R;        // butterflies per frame
+    constexpr int TOTAL = C * M;    // ... per tile
+    constexpr int J = (TOTAL + BLOCK - 1) / BLOCK;
+    float2 u[J][R];
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+    {
+        const int idx = tid + j * BLOCK;
+        if (J * BLOCK == TOTAL || idx < TOTAL)
+        {
+            const int f = idx / M, i = idx - f * M;
+#pragma unroll
+            for (int a = 0; a < R; ++a)
+                u[j][a] = buf[f * LFS + i + a * M];
+        }
+    }
+    __syncthreads(); // every operand of this stage has left the image
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+    {
+        const int idx = tid + j * BLOCK;
+        if (J * BLOCK == TOTAL || idx < TOTAL)
+        {
+            const int f = idx / M, i = idx - f * M;
+            const int k = i % P, jj = (i - k) * R + k;
+            if constexpr (P > 1)
+            {
+#pragma unroll
+                for (int a = 1; a < R; ++a)
+                    u[j][a] = cmul (u[j][a], tw[(a - 1) * P + k]);
+            }
+            fft_reg<R> (u[j]);
+#pragma unroll
+            for (int b = 0; b < R; ++b)
+                buf[f * LFS + jj + b * P] = u[j][b];
+        }
+    }
+    __syncthreads(); // the image holds this stage's result
+}
+
+template <class SP, int BLOCK, int C, int LFS, int S = 0>
+__device__ __forceinline__ void static_tile_inplace_core (const float2* twl, float2* buf, int tid)
+{
+    if constexpr (S < SP::ns)
+    {
+        tile_inplace_stage<SP::radix (S), BLOCK, C, SP::n, SP::period (S), LFS> (buf, twl + SP::tw_offset (S), tid);
+        static_tile_inplace_core<SP, BLOCK, C, LFS, S + 1> (twl, buf, tid);
+    }
+}
+
 // XCD-aware order of the tiles (speed only: a bijection of [0, nwork)).  Workgroups are dealt round-robin over the 8 XCDs, each
 // with an L2 of its own; item v of the persistent loops (v = blockIdx + k gridDim, gridDim a multiple of 8 on a full chip) is
 // mapped so that the tiles ONE XCD works on at a time are consecutive ones: where a tile is 8 or 4 columns wide (64- / 32-byte
@@ -1166,14 +1225,18 @@ __device__ __forceinline__ int tile_frame_len (const GenericPlan& plan)
     else
         return SP::n;
 }
+// operands (or results) of a tile per work-item; the one-image kernels hold up to 19 and request at most `cap` of them ahead
 template <class SP, int C, int BLOCK>
-constexpr int tile_slots (int dynamic)
+constexpr int tile_slots (int dynamic, int cap = 1 << 20)
 {
     if constexpr (std::is_void<SP>::value)
         return dynamic;
     else
-        return (C * SP::n + BLOCK - 1) / BLOCK;
+        return (C * SP::n + BLOCK - 1) / BLOCK < cap ? (C * SP::n + BLOCK - 1) / BLOCK : cap;
 }
+#ifndef CFFT_TILE_INPLACE_PREFETCH
+#define CFFT_TILE_INPLACE_PREFETCH 20
+#endif
 
 // ---- long mixed-radix frames (complex length > 20000): pass A of the two-pass plan -----------------------------------
 // N = n1 * n2 as in multipass_kernels.hpp, with n2 = (odd part) * 2^j a mixed-radix length and n1 a power of two:
@@ -1187,7 +1250,7 @@ constexpr int tile_slots (int dynamic)
 // 65-80 % of their wave cycles: a workgroup had loads in flight only during its own load phase).  vmcnt is one in-order
 // counter, so nothing between the request and the end of the stages may wait on a younger load: the stage twiddles are then
 // read from an LDS copy behind the images (plan.n - 1 entries; the launcher grants PIPE where that costs no workgroup per CU).
-template <bool SWAP_IN, int CA, int BLOCK, bool PIPE = false, class SP = void>
+template <bool SWAP_IN, int CA, int BLOCK, bool PIPE = false, class SP = void, bool INPLACE = false>
 __global__ __launch_bounds__ (BLOCK, PIPE ? 4 : 1) void pass_a_generic_kernel (const float2* __restrict__ in,
                                                               float2* __restrict__ work,
                                                               const float2* __restrict__ twtab,
@@ -1200,18 +1263,19 @@ __global__ __launch_bounds__ (BLOCK, PIPE ? 4 : 1) void pass_a_generic_kernel (c
                                                               size_t ws_frame_len) // float2 per frame in the workspace: tiles * n2 * CA (>= n1 * n2: the last tile may be ragged)
 {
     extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
-    const int tid = threadIdx.x;
+    const int tid0 = threadIdx.x;
     constexpr bool STATIC = ! std::is_void<SP>::value;
     static_assert (! STATIC || PIPE, "compile-time lists come with the pipelined form only");
+    static_assert (! INPLACE || STATIC, "one-image tiles exist for compile-time lists only");
     const int n2 = tile_frame_len<SP> (plan);
     if constexpr (STATIC)
         lfs = SP::n + 1;
     float2* bufA = smem;
-    float2* bufB = smem + (size_t) CA * lfs;
-    float2* twl = smem + (size_t) 2 * CA * lfs;
+    float2* bufB = smem + (size_t) CA * lfs; // (INPLACE: no second image, the twiddle copy sits here)
+    float2* twl = smem + (size_t) (INPLACE ? 1 : 2) * CA * lfs;
     if constexpr (PIPE)
     {
-        lds_table_copy<BLOCK> (twl, twtab + plan.tw_offset[0], n2 - 1, tid);
+        lds_table_copy<BLOCK> (twl, twtab + plan.tw_offset[0], n2 - 1, tid0);
     }
     const unsigned tiles = (n1 + CA - 1) / CA;
     const size_t nwork = (size_t) batch * tiles;
@@ -1219,10 +1283,13 @@ __global__ __launch_bounds__ (BLOCK, PIPE ? 4 : 1) void pass_a_generic_kernel (c
     // Every tile shape the launchers choose has at most 10 operands per work-item (16 x 160 / 256, 16 x 639 / 1024, 8 x 1280 /
     // 1024, 4 x 2559 / 1024), so the whole tile is requested ahead.  Slots beyond the tile re-read its last element: a
     // test around a load -- even a workgroup-uniform one -- makes the compiler wait for every load before the next.
-    constexpr int PF = tile_slots<SP, CA, BLOCK> (kTilePrefetchA);
-    constexpr int SB = tile_slots<SP, CA, BLOCK> (CA == 16 ? kTileStoreBatch : 8); // (run-time list: 10 spills a few bytes in the narrow-tile variants)
+    constexpr int PF = tile_slots<SP, CA, BLOCK> (kTilePrefetchA, INPLACE ? CFFT_TILE_INPLACE_PREFETCH : 1 << 20);
+    constexpr int SB = tile_slots<SP, CA, BLOCK> (CA == 16 ? kTileStoreBatch : 8, INPLACE ? 10 : 1 << 20); // (run-time list: 10 spills a few bytes in the narrow-tile variants)
     float2 pre[PF];
     const auto request = [&] (size_t v) {
+        int tid = tid0;
+        if constexpr (INPLACE) // (per tile: nothing derived from the work-item index is lifted out of the tile loop and held -- the
+            CFFT_LAUNDER_INDEX (tid); // one-image kernels spill otherwise; the two-image ones are 10-15 % faster with the offsets held)
         const size_t w = tile_xcd_order<2> (v, nwork);
         const unsigned f = (unsigned) (w / tiles), tile = (unsigned) (w % tiles);
         const int valid = (int) min ((unsigned) CA, n1 - tile * CA);
@@ -1254,6 +1321,9 @@ __global__ __launch_bounds__ (BLOCK, PIPE ? 4 : 1) void pass_a_generic_kernel (c
     }
     for (size_t v = blockIdx.x; v < nwork; v += gridDim.x)
     {
+        int tid = tid0;
+        if constexpr (INPLACE)
+            CFFT_LAUNDER_INDEX (tid);
         const size_t w = tile_xcd_order<2> (v, nwork);
         const unsigned f = (unsigned) (w / tiles);
         const unsigned tile = (unsigned) (w % tiles);
@@ -1298,7 +1368,12 @@ __global__ __launch_bounds__ (BLOCK, PIPE ? 4 : 1) void pass_a_generic_kernel (c
         {
             if (v + gridDim.x < nwork)
                 request (v + gridDim.x);
-            if constexpr (STATIC)
+            if constexpr (INPLACE)
+            {
+                static_tile_inplace_core<SP, BLOCK, CA, SP_N_OR_ZERO<SP>::value + 1> (twl, bufA, tid);
+                res = bufA;
+            }
+            else if constexpr (STATIC)
                 res = static_core<SP, BLOCK, false, false, false, 0, false, SP_N_OR_ZERO<SP>::value + 1> (twl, bufA, bufB, nullptr, nullptr, CA, tid, 0u, 0u);
             else
                 res = generic_core<BLOCK, false, false, false> (plan, twl, bufA, bufB, nullptr, nullptr, CA, tid, lfs, plan.tw_offset[0]);
@@ -1335,7 +1410,7 @@ __global__ __launch_bounds__ (BLOCK, PIPE ? 4 : 1) void pass_a_generic_kernel (c
 // Row pass of the same plans when the row length n1 is not a power of two either (and for powers of two beyond the
 // compile-time cores): n1-point FFTs of CB adjacent rows kb with the run-time stage list, read from pass A's tile-major
 // workspace [tile tA][kb][c] (CA columns per tile), stored transposed to X[n2 ka + kb].  n2 need not be a multiple of CB.
-template <bool SWAP_OUT, int CB, int BLOCK, bool PIPE = false, class SP = void>
+template <bool SWAP_OUT, int CB, int BLOCK, bool PIPE = false, class SP = void, bool INPLACE = false>
 __global__ __launch_bounds__ (BLOCK) void pass_b_generic_kernel (const float2* __restrict__ work,
                                                               float2* __restrict__ out,
                                                               const float2* __restrict__ twtab,
@@ -1348,24 +1423,25 @@ __global__ __launch_bounds__ (BLOCK) void pass_b_generic_kernel (const float2* _
                                                               size_t ws_frame_len)
 {
     extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
-    const int tid = threadIdx.x;
+    const int tid0 = threadIdx.x;
     constexpr bool STATIC = ! std::is_void<SP>::value;
     static_assert (! STATIC || PIPE, "compile-time lists come with the pipelined form only");
+    static_assert (! INPLACE || STATIC, "one-image tiles exist for compile-time lists only");
     const int n1 = tile_frame_len<SP> (plan);
     if constexpr (STATIC)
         lfs = SP::n + 1;
     float2* bufA = smem;
-    float2* bufB = smem + (size_t) CB * lfs;
-    float2* twl = smem + (size_t) 2 * CB * lfs; // PIPE (see pass_a_generic_kernel): the stage twiddles' LDS copy
+    float2* bufB = smem + (size_t) CB * lfs; // (INPLACE: no second image, the twiddle copy sits here)
+    float2* twl = smem + (size_t) (INPLACE ? 1 : 2) * CB * lfs; // PIPE (see pass_a_generic_kernel): the stage twiddles' LDS copy
     if constexpr (PIPE)
     {
-        lds_table_copy<BLOCK> (twl, twtab + plan.tw_offset[0], n1 - 1, tid);
+        lds_table_copy<BLOCK> (twl, twtab + plan.tw_offset[0], n1 - 1, tid0);
     }
     const unsigned tiles = (n2 + CB - 1) / CB;
     const unsigned magic_n1 = div_magic ((unsigned) n1), magic_ca = ca > 1 ? div_magic (ca) : 0u;
     const size_t nwork = (size_t) batch * tiles;
     const int total = CB * n1;
-    constexpr int PF = tile_slots<SP, CB, BLOCK> (kTilePrefetchB); // (run-time list: 8 costs pass B a workgroup per CU with 256 work-items and spills with 1024)
+    constexpr int PF = tile_slots<SP, CB, BLOCK> (kTilePrefetchB, INPLACE ? CFFT_TILE_INPLACE_PREFETCH : 1 << 20); // (run-time list: 8 costs pass B a workgroup per CU with 256 work-items and spills with 1024)
     float2 pre[PF];
     // element (row kbl, column a): c = a % ca fastest (contiguous in the workspace), then the row, then pass A's tile
     const auto element = [&] (const float2* __restrict__ src, unsigned kb0, int valid, int e) {
@@ -1374,6 +1450,9 @@ __global__ __launch_bounds__ (BLOCK) void pass_b_generic_kernel (const float2* _
         return src[((size_t) tA * n2 + kb0 + min (kbl, (unsigned) (valid - 1))) * ca + c];
     };
     const auto request = [&] (size_t v) {
+        int tid = tid0;
+        if constexpr (INPLACE) // (per tile: nothing derived from the work-item index is lifted out of the tile loop and held -- the
+            CFFT_LAUNDER_INDEX (tid); // one-image kernels spill otherwise; the two-image ones are 10-15 % faster with the offsets held)
         const size_t w = tile_xcd_order<2> (v, nwork);
         const unsigned f = (unsigned) (w / tiles), kb0 = (unsigned) (w % tiles) * CB;
         const int valid = (int) min ((unsigned) CB, n2 - kb0);
@@ -1389,6 +1468,9 @@ __global__ __launch_bounds__ (BLOCK) void pass_b_generic_kernel (const float2* _
     }
     for (size_t v = blockIdx.x; v < nwork; v += gridDim.x)
     {
+        int tid = tid0;
+        if constexpr (INPLACE)
+            CFFT_LAUNDER_INDEX (tid);
         const size_t w = tile_xcd_order<2> (v, nwork);
         const unsigned f = (unsigned) (w / tiles);
         const unsigned tile = (unsigned) (w % tiles);
@@ -1429,13 +1511,19 @@ __global__ __launch_bounds__ (BLOCK) void pass_b_generic_kernel (const float2* _
         {
             if (v + gridDim.x < nwork)
                 request (v + gridDim.x);
-            if constexpr (STATIC)
+            if constexpr (INPLACE)
+            {
+                static_tile_inplace_core<SP, BLOCK, CB, SP_N_OR_ZERO<SP>::value + 1> (twl, bufA, tid);
+                res = bufA;
+            }
+            else if constexpr (STATIC)
                 res = static_core<SP, BLOCK, false, false, false, 0, false, SP_N_OR_ZERO<SP>::value + 1> (twl, bufA, bufB, nullptr, nullptr, CB, tid, 0u, 0u);
             else
                 res = generic_core<BLOCK, false, false, false> (plan, twl, bufA, bufB, nullptr, nullptr, CB, tid, lfs, plan.tw_offset[0]);
         }
         else
             res = generic_core<BLOCK, false, false, false> (plan, twtab, bufA, bufB, nullptr, nullptr, CB, tid, lfs);
+#pragma unroll 4 // (compile-time trip counts: fully unrolled, the 64-bit store addresses of up to 19 rounds are formed early and held)
         for (int e = tid; e < CB * n1; e += BLOCK)
         {
             const int c = e % CB, k = e / CB;
@@ -1454,7 +1542,7 @@ __global__ __launch_bounds__ (BLOCK) void pass_b_generic_kernel (const float2* _
 // every global access touches C * 8 contiguous bytes, the FFTs by the run-time stage list -- without the inter-pass
 // twiddle, and stored back where it came from.  cols need not be a multiple of C.
 // PIPE / SP: as in pass_a_generic_kernel (the next tile requested across the stages, stage twiddles in LDS; compile-time list).
-template <bool SWAP, int C, int BLOCK, bool PIPE = false, class SP = void>
+template <bool SWAP, int C, int BLOCK, bool PIPE = false, class SP = void, bool INPLACE = false>
 __global__ __launch_bounds__ (BLOCK, PIPE ? 4 : 1) void column_fft_kernel (float2* __restrict__ data,
                                                           const float2* __restrict__ twtab,
                                                           GenericPlan plan, // n = rows, frames = C
@@ -1464,25 +1552,29 @@ __global__ __launch_bounds__ (BLOCK, PIPE ? 4 : 1) void column_fft_kernel (float
                                                           unsigned lfs)
 {
     extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
-    const int tid = threadIdx.x;
+    const int tid0 = threadIdx.x;
     constexpr bool STATIC = ! std::is_void<SP>::value;
     static_assert (! STATIC || PIPE, "compile-time lists come with the pipelined form only");
+    static_assert (! INPLACE || STATIC, "one-image tiles exist for compile-time lists only");
     const int rows = tile_frame_len<SP> (plan);
     if constexpr (STATIC)
         lfs = SP::n + 1;
     float2* bufA = smem;
-    float2* bufB = smem + (size_t) C * lfs;
-    float2* twl = smem + (size_t) 2 * C * lfs;
+    float2* bufB = smem + (size_t) C * lfs; // (INPLACE: no second image, the twiddle copy sits here)
+    float2* twl = smem + (size_t) (INPLACE ? 1 : 2) * C * lfs;
     if constexpr (PIPE)
     {
-        lds_table_copy<BLOCK> (twl, twtab + plan.tw_offset[0], rows - 1, tid);
+        lds_table_copy<BLOCK> (twl, twtab + plan.tw_offset[0], rows - 1, tid0);
     }
     const unsigned tiles = (cols + C - 1) / C;
     const size_t nwork = (size_t) batch * tiles;
     const int total = C * rows;
-    constexpr int PF = tile_slots<SP, C, BLOCK> (kTilePrefetchA);
+    constexpr int PF = tile_slots<SP, C, BLOCK> (kTilePrefetchA, INPLACE ? CFFT_TILE_INPLACE_PREFETCH : 1 << 20);
     float2 pre[PF];
     const auto request = [&] (size_t v) {
+        int tid = tid0;
+        if constexpr (INPLACE) // (per tile: nothing derived from the work-item index is lifted out of the tile loop and held -- the
+            CFFT_LAUNDER_INDEX (tid); // one-image kernels spill otherwise; the two-image ones are 10-15 % faster with the offsets held)
         const size_t w = tile_xcd_order<1> (v, nwork);
         const unsigned f = (unsigned) (w / tiles), tile = (unsigned) (w % tiles);
         const int valid = (int) min ((unsigned) C, cols - tile * C);
@@ -1512,6 +1604,9 @@ __global__ __launch_bounds__ (BLOCK, PIPE ? 4 : 1) void column_fft_kernel (float
     }
     for (size_t v = blockIdx.x; v < nwork; v += gridDim.x)
     {
+        int tid = tid0;
+        if constexpr (INPLACE)
+            CFFT_LAUNDER_INDEX (tid);
         const size_t w = tile_xcd_order<1> (v, nwork);
         const unsigned f = (unsigned) (w / tiles);
         const unsigned tile = (unsigned) (w % tiles);
@@ -1554,13 +1649,19 @@ __global__ __launch_bounds__ (BLOCK, PIPE ? 4 : 1) void column_fft_kernel (float
         {
             if (v + gridDim.x < nwork)
                 request (v + gridDim.x); // another tile: never the lines this one is about to store
-            if constexpr (STATIC)
+            if constexpr (INPLACE)
+            {
+                static_tile_inplace_core<SP, BLOCK, C, SP_N_OR_ZERO<SP>::value + 1> (twl, bufA, tid);
+                res = bufA;
+            }
+            else if constexpr (STATIC)
                 res = static_core<SP, BLOCK, false, false, false, 0, false, SP_N_OR_ZERO<SP>::value + 1> (twl, bufA, bufB, nullptr, nullptr, C, tid, 0u, 0u);
             else
                 res = generic_core<BLOCK, false, false, false> (plan, twl, bufA, bufB, nullptr, nullptr, C, tid, lfs, plan.tw_offset[0]);
         }
         else
             res = generic_core<BLOCK, false, false, false> (plan, twtab, bufA, bufB, nullptr, nullptr, C, tid, lfs);
+#pragma unroll 4
         for (int e = tid; e < total; e += BLOCK)
         {
             const int c = e % C, k = e / C;

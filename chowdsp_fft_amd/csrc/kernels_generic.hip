@@ -305,21 +305,30 @@ hipError_t launch_column_fft (bool inverse, int rows, int cols, const DeviceTabl
         plan.radix[i] = t.gen_radix[i];
         plan.tw_offset[i] = t.gen_tw_offset[i];
     }
-    unsigned lfs = (unsigned) rows + 1u;
-    if ((size_t) 2 * c * lfs * sizeof (float2) > dev.lds_per_cu)
-        lfs = (unsigned) rows;
-    size_t lds = (size_t) 2 * c * lfs * sizeof (float2);
-    if (lds > dev.lds_per_cu)
-        return hipErrorInvalidValue;
-    int block = generic_tile_block (lds, dev.lds_per_cu);
-    const bool pipe = tile_pipe_fits (lds, (size_t) rows, dev.lds_per_cu, 1, block);
-    if (pipe)
-        lds += (size_t) (rows - 1) * sizeof (float2);
-    ColumnFftFn k = pick_column (c, block, inverse, pipe);
-    if (pipe)
+    unsigned lfs = 0;
+    size_t lds = 0;
+    int block = 0;
+    StaticTileLaunch sl {};
+    ColumnFftFn k = pick_static_column (plan, c, dev.lds_per_cu, inverse, sl);
+    if (k != nullptr)
     {
-        if (auto ks = pick_static_column (plan, c, block, lfs, inverse))
-            k = ks;
+        lfs = sl.lfs;
+        lds = sl.lds_bytes;
+        block = sl.block;
+    }
+    else
+    {
+        lfs = (unsigned) rows + 1u;
+        if ((size_t) 2 * c * lfs * sizeof (float2) > dev.lds_per_cu)
+            lfs = (unsigned) rows;
+        lds = (size_t) 2 * c * lfs * sizeof (float2);
+        if (lds > dev.lds_per_cu)
+            return hipErrorInvalidValue;
+        block = generic_tile_block (lds, dev.lds_per_cu);
+        const bool pipe = tile_pipe_fits (lds, (size_t) rows, dev.lds_per_cu, 1, block);
+        if (pipe)
+            lds += (size_t) (rows - 1) * sizeof (float2);
+        k = pick_column (c, block, inverse, pipe);
     }
     const unsigned grid = persistent_grid (k, block, lds, batch * (size_t) ((cols + c - 1) / c));
     if (grid == 0)

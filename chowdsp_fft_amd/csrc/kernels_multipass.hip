@@ -645,22 +645,32 @@ hipError_t launch_mixed_big_c2c (const DeviceTables& t, bool inverse, const floa
     DeviceInfo dev;
     if (! current_device_info (dev))
         return hipErrorNoDevice;
-    unsigned lfs = (unsigned) n2 + 1u;
-    if ((size_t) 2 * ca * lfs * sizeof (float2) > dev.lds_per_cu)
-        lfs = (unsigned) n2;
-    size_t lds = (size_t) 2 * ca * lfs * sizeof (float2);
-    if (lds > dev.lds_per_cu)
-        return hipErrorInvalidValue;
     const size_t ws_frame_len = (size_t) ((n1 + ca - 1) / ca) * (size_t) ca * (size_t) n2; // = n1 * n2 unless the last tile is ragged
-    int block_a = generic_tile_block (lds, dev.lds_per_cu);
-    const bool pipe_a = tile_pipe_fits (lds, (size_t) n2, dev.lds_per_cu, 1, block_a);
-    if (pipe_a)
-        lds += (size_t) (n2 - 1) * sizeof (float2);
-    auto ka = pick_pass_a (ca, block_a, inverse, pipe_a);
-    if (pipe_a)
+    // a compile-time stage list for this column length (kernels_tile_static_*.hip) brings its own geometry; else the run-time list
+    unsigned lfs = 0;
+    size_t lds = 0;
+    int block_a = 0;
+    StaticTileLaunch sl {};
+    PassAGenericFn ka = pick_static_pass_a (plan, ca, dev.lds_per_cu, inverse, sl);
+    if (ka != nullptr)
     {
-        if (auto ks = pick_static_pass_a (plan, ca, block_a, lfs, inverse))
-            ka = ks;
+        lfs = sl.lfs;
+        lds = sl.lds_bytes;
+        block_a = sl.block;
+    }
+    else
+    {
+        lfs = (unsigned) n2 + 1u;
+        if ((size_t) 2 * ca * lfs * sizeof (float2) > dev.lds_per_cu)
+            lfs = (unsigned) n2;
+        lds = (size_t) 2 * ca * lfs * sizeof (float2);
+        if (lds > dev.lds_per_cu)
+            return hipErrorInvalidValue;
+        block_a = generic_tile_block (lds, dev.lds_per_cu);
+        const bool pipe_a = tile_pipe_fits (lds, (size_t) n2, dev.lds_per_cu, 1, block_a);
+        if (pipe_a)
+            lds += (size_t) (n2 - 1) * sizeof (float2);
+        ka = pick_pass_a (ca, block_a, inverse, pipe_a);
     }
     unsigned grid = persistent_grid (ka, block_a, lds, batch * (size_t) ((n1 + ca - 1) / ca));
     if (grid == 0)
@@ -686,21 +696,30 @@ hipError_t launch_mixed_big_c2c (const DeviceTables& t, bool inverse, const floa
             pb.radix[i] = t.gen2_radix[i];
             pb.tw_offset[i] = t.gen2_tw_offset[i];
         }
-        unsigned lfsb = (unsigned) n1 + 1u;
-        if ((size_t) 2 * cb * lfsb * sizeof (float2) > dev.lds_per_cu)
-            lfsb = (unsigned) n1;
-        size_t ldsb = (size_t) 2 * cb * lfsb * sizeof (float2);
-        if (ldsb > dev.lds_per_cu)
-            return hipErrorInvalidValue;
-        int block_b = generic_tile_block (ldsb, dev.lds_per_cu);
-        const bool pipe_b = tile_pipe_fits (ldsb, (size_t) n1, dev.lds_per_cu, 2, block_b);
-        if (pipe_b)
-            ldsb += (size_t) (n1 - 1) * sizeof (float2);
-        auto kb = pick_pass_b (cb, block_b, inverse, pipe_b);
-        if (pipe_b)
+        unsigned lfsb = 0;
+        size_t ldsb = 0;
+        int block_b = 0;
+        StaticTileLaunch slb {};
+        PassBGenericFn kb = pick_static_pass_b (pb, cb, dev.lds_per_cu, inverse, slb);
+        if (kb != nullptr)
         {
-            if (auto ks = pick_static_pass_b (pb, cb, block_b, lfsb, inverse))
-                kb = ks;
+            lfsb = slb.lfs;
+            ldsb = slb.lds_bytes;
+            block_b = slb.block;
+        }
+        else
+        {
+            lfsb = (unsigned) n1 + 1u;
+            if ((size_t) 2 * cb * lfsb * sizeof (float2) > dev.lds_per_cu)
+                lfsb = (unsigned) n1;
+            ldsb = (size_t) 2 * cb * lfsb * sizeof (float2);
+            if (ldsb > dev.lds_per_cu)
+                return hipErrorInvalidValue;
+            block_b = generic_tile_block (ldsb, dev.lds_per_cu);
+            const bool pipe_b = tile_pipe_fits (ldsb, (size_t) n1, dev.lds_per_cu, 2, block_b);
+            if (pipe_b)
+                ldsb += (size_t) (n1 - 1) * sizeof (float2);
+            kb = pick_pass_b (cb, block_b, inverse, pipe_b);
         }
         unsigned gridb = persistent_grid (kb, block_b, ldsb, batch * (size_t) ((n2 + cb - 1) / cb));
         if (gridb == 0)

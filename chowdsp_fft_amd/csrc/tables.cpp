@@ -85,6 +85,12 @@ bool has_static_tile (int n)
     return false;
 }
 
+bool tile_runs_inplace (int n)
+{
+    static const bool off = [] { const char* e = std::getenv ("CHOWDSP_FFT_TILE_STATIC"); return e != nullptr && std::atoi (e) == 0; }();
+    return ! off && n >= kTileInplaceMinN && has_static_tile (n);
+}
+
 bool split_static_pair (int n_complex, int max_factor, int& n1, int& n2)
 {
     n1 = n2 = 0;

@@ -118,6 +118,18 @@ bool split_general (int n_complex, int& n1, int& n2);
     X (1024) X (1080) X (1125)
 #define CFFT_STATIC_TILE_SIZES(X) CFFT_STATIC_TILE_SIZES_A (X) CFFT_STATIC_TILE_SIZES_B (X) CFFT_STATIC_TILE_SIZES_C (X)
 bool has_static_tile (int n);
+// Static tile lengths from kTileInplaceMinN on run their stages in ONE LDS image (generic_kernels.hpp: tile_inplace_stage): tiles of
+// 16 columns / rows up to 1200 points, where two images allow 8 beyond 639.  Measured on MI355X (tools/gpu_r3_tile_inplace_ab.sh,
+// fraction of 8 TB/s, 8-column two-image / 16-column one-image): 2-D 720 x 1280 0.245 / 0.282, 1080 x 1920 0.250 / 0.297,
+// c1327104 0.210 / 0.222, c655360 0.238 / 0.244.  For n = 324 .. 639, where one image would let two or three 512-work-item
+// workgroups share a CU instead of one of 1024, the two-image form stays ahead (c230400 0.286 against 0.269, c192000 0.275 / 0.255,
+// 2-D 512 x 512 0.310 / 0.284): the threshold is 640.  false for every length when CHOWDSP_FFT_TILE_STATIC = 0 (then the run-time
+// kernels and their widths apply).
+#ifndef CFFT_TILE_INPLACE_MIN_N
+#define CFFT_TILE_INPLACE_MIN_N 640
+#endif
+static constexpr int kTileInplaceMinN = CFFT_TILE_INPLACE_MIN_N;
+bool tile_runs_inplace (int n);
 // n = n1 * n2 with both factors static tile lengths of at most max_factor, n2 <= n1, as close to each other as possible
 bool split_static_pair (int n_complex, int max_factor, int& n1, int& n2);
 static constexpr int kGeneralMaxFactor = 2559; // two LDS images of 4 frames of n + 1 points
@@ -130,10 +142,10 @@ static constexpr int kMaxComplexLen = 1 << 21;
 static constexpr int kMaxHugeComplexLen = 1 << 27;
 bool split_huge (int n_complex, int& r, int& c);
 // tile width (columns or rows) for a frame length n of the generic passes: as wide as two padded LDS images allow
-inline int general_tile_width (int n) { return n <= 639 ? 16 : (n <= 1279 ? 8 : 4); }
+inline int general_tile_width (int n) { return (n <= 639 || tile_runs_inplace (n)) ? 16 : (n <= 1279 ? 8 : 4); }
 // columns per pass-A tile of the mixed two-pass plans: 16 (128-byte rows) while two LDS images of 16 padded columns,
 // 2 * 16 * (n2 + 1) * 8 bytes, fit the CU's 160 KiB (n2 <= 639), else 8 (n2 <= 1280; n2 = 1280 runs unpadded)
 static constexpr int kMixedMaxN2Wide = 639;
 static constexpr int kMixedMaxN2 = 1280;
-inline int mixed_tile_width (int n2) { return n2 <= kMixedMaxN2Wide ? 16 : 8; }
+inline int mixed_tile_width (int n2) { return (n2 <= kMixedMaxN2Wide || tile_runs_inplace (n2)) ? 16 : 8; }
 } // namespace cfft::host

@@ -11,52 +11,58 @@ namespace cfft::host
 using PassAGenericFn = void (*) (const float2*, float2*, const float2*, const float2*, GenericPlan, unsigned, unsigned, size_t, unsigned, size_t);
 using PassBGenericFn = void (*) (const float2*, float2*, const float2*, GenericPlan, unsigned, unsigned, unsigned, size_t, unsigned, size_t);
 using ColumnFftFn = void (*) (float2*, const float2*, GenericPlan, unsigned, unsigned, size_t, unsigned); // the 2-D transforms' column pass
-// nullptr: no compile-time list for this (plan, tile width, frame pitch) in the group.  Otherwise `block` becomes the workgroup
-// size the kernel was instantiated for.
-PassAGenericFn pick_static_pass_a_a (const GenericPlan& plan, int c, int& block, unsigned lfs, bool inverse);
-PassAGenericFn pick_static_pass_a_b (const GenericPlan& plan, int c, int& block, unsigned lfs, bool inverse);
-PassAGenericFn pick_static_pass_a_c (const GenericPlan& plan, int c, int& block, unsigned lfs, bool inverse);
-PassBGenericFn pick_static_pass_b_a (const GenericPlan& plan, int c, int& block, unsigned lfs, bool inverse);
-PassBGenericFn pick_static_pass_b_b (const GenericPlan& plan, int c, int& block, unsigned lfs, bool inverse);
-PassBGenericFn pick_static_pass_b_c (const GenericPlan& plan, int c, int& block, unsigned lfs, bool inverse);
-ColumnFftFn pick_static_column_a (const GenericPlan& plan, int c, int& block, unsigned lfs, bool inverse);
-ColumnFftFn pick_static_column_b (const GenericPlan& plan, int c, int& block, unsigned lfs, bool inverse);
-ColumnFftFn pick_static_column_c (const GenericPlan& plan, int c, int& block, unsigned lfs, bool inverse);
+// nullptr: no compile-time list for this (plan, tile width) in the group, or its LDS does not fit the device.  Otherwise `launch`
+// holds what the kernel was instantiated for.
+struct StaticTileLaunch
+{
+    int block;        // work-items per workgroup
+    unsigned lfs;     // frame pitch inside the LDS image(s)
+    size_t lds_bytes; // dynamic LDS: the image(s) and the stage twiddles' copy
+};
+PassAGenericFn pick_static_pass_a_a (const GenericPlan& plan, int c, size_t lds_per_cu, bool inverse, StaticTileLaunch& launch);
+PassAGenericFn pick_static_pass_a_b (const GenericPlan& plan, int c, size_t lds_per_cu, bool inverse, StaticTileLaunch& launch);
+PassAGenericFn pick_static_pass_a_c (const GenericPlan& plan, int c, size_t lds_per_cu, bool inverse, StaticTileLaunch& launch);
+PassBGenericFn pick_static_pass_b_a (const GenericPlan& plan, int c, size_t lds_per_cu, bool inverse, StaticTileLaunch& launch);
+PassBGenericFn pick_static_pass_b_b (const GenericPlan& plan, int c, size_t lds_per_cu, bool inverse, StaticTileLaunch& launch);
+PassBGenericFn pick_static_pass_b_c (const GenericPlan& plan, int c, size_t lds_per_cu, bool inverse, StaticTileLaunch& launch);
+ColumnFftFn pick_static_column_a (const GenericPlan& plan, int c, size_t lds_per_cu, bool inverse, StaticTileLaunch& launch);
+ColumnFftFn pick_static_column_b (const GenericPlan& plan, int c, size_t lds_per_cu, bool inverse, StaticTileLaunch& launch);
+ColumnFftFn pick_static_column_c (const GenericPlan& plan, int c, size_t lds_per_cu, bool inverse, StaticTileLaunch& launch);
 // CHOWDSP_FFT_TILE_STATIC = 0: the run-time list everywhere (A/B)
 inline bool static_tiles_off()
 {
     static const bool off = [] { const char* e = std::getenv ("CHOWDSP_FFT_TILE_STATIC"); return e != nullptr && std::atoi (e) == 0; }();
     return off;
 }
-inline PassAGenericFn pick_static_pass_a (const GenericPlan& plan, int c, int& block, unsigned lfs, bool inverse)
+inline PassAGenericFn pick_static_pass_a (const GenericPlan& plan, int c, size_t lds_per_cu, bool inverse, StaticTileLaunch& launch)
 {
     if (static_tiles_off())
         return nullptr;
-    if (auto k = pick_static_pass_a_a (plan, c, block, lfs, inverse))
+    if (auto k = pick_static_pass_a_a (plan, c, lds_per_cu, inverse, launch))
         return k;
-    if (auto k = pick_static_pass_a_b (plan, c, block, lfs, inverse))
+    if (auto k = pick_static_pass_a_b (plan, c, lds_per_cu, inverse, launch))
         return k;
-    return pick_static_pass_a_c (plan, c, block, lfs, inverse);
+    return pick_static_pass_a_c (plan, c, lds_per_cu, inverse, launch);
 }
-inline PassBGenericFn pick_static_pass_b (const GenericPlan& plan, int c, int& block, unsigned lfs, bool inverse)
+inline PassBGenericFn pick_static_pass_b (const GenericPlan& plan, int c, size_t lds_per_cu, bool inverse, StaticTileLaunch& launch)
 {
     if (static_tiles_off())
         return nullptr;
-    if (auto k = pick_static_pass_b_a (plan, c, block, lfs, inverse))
+    if (auto k = pick_static_pass_b_a (plan, c, lds_per_cu, inverse, launch))
         return k;
-    if (auto k = pick_static_pass_b_b (plan, c, block, lfs, inverse))
+    if (auto k = pick_static_pass_b_b (plan, c, lds_per_cu, inverse, launch))
         return k;
-    return pick_static_pass_b_c (plan, c, block, lfs, inverse);
+    return pick_static_pass_b_c (plan, c, lds_per_cu, inverse, launch);
 }
-inline ColumnFftFn pick_static_column (const GenericPlan& plan, int c, int& block, unsigned lfs, bool inverse)
+inline ColumnFftFn pick_static_column (const GenericPlan& plan, int c, size_t lds_per_cu, bool inverse, StaticTileLaunch& launch)
 {
     if (static_tiles_off())
         return nullptr;
-    if (auto k = pick_static_column_a (plan, c, block, lfs, inverse))
+    if (auto k = pick_static_column_a (plan, c, lds_per_cu, inverse, launch))
         return k;
-    if (auto k = pick_static_column_b (plan, c, block, lfs, inverse))
+    if (auto k = pick_static_column_b (plan, c, lds_per_cu, inverse, launch))
         return k;
-    return pick_static_column_c (plan, c, block, lfs, inverse);
+    return pick_static_column_c (plan, c, lds_per_cu, inverse, launch);
 }
 // PIPE variants of the tile kernels need an LDS copy of the n - 1 stage twiddles behind the two images: granted where that leaves
 // the workgroups per CU as they are (by LDS or by the CU's 32 waves, whichever binds).  CHOWDSP_FFT_TILE_PIPE (experiments): bit 0 =

@@ -14,22 +14,25 @@ namespace
 template <int N_>
 struct StaticTile
 {
-    static constexpr int c = N_ <= 639 ? 16 : 8;
-    static constexpr size_t lds = (size_t) 2 * c * (N_ + 1) * sizeof (float2);
-    // work-items per workgroup: 256 where four workgroups fit a CU, 1024 where only one does, and 512 between (n = 160 .. 288:
-    // two or three workgroups of 8 waves each work through their phases independently; measured against 1024 / 256 on MI355X,
-    // fraction of 8 TB/s: c23040 0.355 / 0.305 / 0.353, c57600 0.336 / 0.305 / 0.284, c82944 0.317 / 0.287 / 0.220,
+    // from kTileInplaceMinN on: one LDS image, stages in place (generic_kernels.hpp: tile_inplace_stage), always 16 columns
+    static constexpr bool inplace = N_ >= kTileInplaceMinN;
+    static constexpr int c = (inplace || N_ <= 639) ? 16 : 8;
+    static constexpr size_t images = (size_t) (inplace ? 1 : 2) * c * (N_ + 1) * sizeof (float2);
+    static constexpr size_t lds = images + (size_t) (N_ - 1) * sizeof (float2); // + the stage twiddles' copy
+    // work-items per workgroup: 256 where four workgroups fit a CU, 1024 where only one does, and 512 between (two or three
+    // workgroups of 8 waves each work through their phases independently; measured against 1024 / 256 on MI355X with two
+    // images, fraction of 8 TB/s: c23040 0.355 / 0.305 / 0.353, c57600 0.336 / 0.305 / 0.284, c82944 0.317 / 0.287 / 0.220,
     // c61440 0.321 / 0.298 / 0.283, c245760 0.285 / 0.276 / 0.257)
 #ifndef CFFT_STATIC_TILE_MID_BLOCK
 #define CFFT_STATIC_TILE_MID_BLOCK 512
 #endif
-    static constexpr int block = 4 * lds <= 160 * 1024 ? 256 : (2 * (lds + N_ * sizeof (float2)) <= 160 * 1024 ? CFFT_STATIC_TILE_MID_BLOCK : 1024);
+    static constexpr int block = 4 * images <= 160 * 1024 ? 256 : (2 * lds <= 160 * 1024 ? CFFT_STATIC_TILE_MID_BLOCK : 1024);
 };
 template <int N_>
-bool static_tile_matches (const GenericPlan& plan, int c, unsigned lfs)
+bool static_tile_matches (const GenericPlan& plan, int c, size_t lds_per_cu)
 {
     using SP = typename StaticPlanFor<N_>::type;
-    bool same = plan.n == N_ && plan.ns == SP::ns && c == StaticTile<N_>::c && lfs == (unsigned) N_ + 1u;
+    bool same = plan.n == N_ && plan.ns == SP::ns && c == StaticTile<N_>::c && StaticTile<N_>::lds <= lds_per_cu;
     for (int i = 0; same && i < SP::ns; ++i)
         same = plan.radix[i] == SP::radix (i);
     return same;
@@ -37,32 +40,41 @@ bool static_tile_matches (const GenericPlan& plan, int c, unsigned lfs)
 // (the lengths: CFFT_STATIC_TILE_SIZES in tables.hpp -- every length of StaticPlanFor up to 1200; n = 1280 runs unpadded: run-time list)
 } // namespace
 
-PassAGenericFn CFFT_TILE_PICK_A (const GenericPlan& plan, int c, int& block, unsigned lfs, bool inverse)
+PassAGenericFn CFFT_TILE_PICK_A (const GenericPlan& plan, int c, size_t lds_per_cu, bool inverse, StaticTileLaunch& launch)
 {
 #define CFFT_TRY(N_)                                                                                                                  \
-    if (static_tile_matches<N_> (plan, c, lfs))                                                                                       \
-        return block = StaticTile<N_>::block, inverse ? pass_a_generic_kernel<true, StaticTile<N_>::c, StaticTile<N_>::block, true, typename StaticPlanFor<N_>::type> \
-                       : pass_a_generic_kernel<false, StaticTile<N_>::c, StaticTile<N_>::block, true, typename StaticPlanFor<N_>::type>;
+    if (static_tile_matches<N_> (plan, c, lds_per_cu))                                                                                \
+    {                                                                                                                                 \
+        launch = StaticTileLaunch { StaticTile<N_>::block, (unsigned) N_ + 1u, StaticTile<N_>::lds };                                 \
+        return inverse ? pass_a_generic_kernel<true, StaticTile<N_>::c, StaticTile<N_>::block, true, typename StaticPlanFor<N_>::type, StaticTile<N_>::inplace> \
+                       : pass_a_generic_kernel<false, StaticTile<N_>::c, StaticTile<N_>::block, true, typename StaticPlanFor<N_>::type, StaticTile<N_>::inplace>; \
+    }
     CFFT_TILE_GROUP (CFFT_TRY)
 #undef CFFT_TRY
     return nullptr;
 }
-PassBGenericFn CFFT_TILE_PICK_B (const GenericPlan& plan, int c, int& block, unsigned lfs, bool inverse)
+PassBGenericFn CFFT_TILE_PICK_B (const GenericPlan& plan, int c, size_t lds_per_cu, bool inverse, StaticTileLaunch& launch)
 {
 #define CFFT_TRY(N_)                                                                                                                  \
-    if (static_tile_matches<N_> (plan, c, lfs))                                                                                       \
-        return block = StaticTile<N_>::block, inverse ? pass_b_generic_kernel<true, StaticTile<N_>::c, StaticTile<N_>::block, true, typename StaticPlanFor<N_>::type> \
-                       : pass_b_generic_kernel<false, StaticTile<N_>::c, StaticTile<N_>::block, true, typename StaticPlanFor<N_>::type>;
+    if (static_tile_matches<N_> (plan, c, lds_per_cu))                                                                                \
+    {                                                                                                                                 \
+        launch = StaticTileLaunch { StaticTile<N_>::block, (unsigned) N_ + 1u, StaticTile<N_>::lds };                                 \
+        return inverse ? pass_b_generic_kernel<true, StaticTile<N_>::c, StaticTile<N_>::block, true, typename StaticPlanFor<N_>::type, StaticTile<N_>::inplace> \
+                       : pass_b_generic_kernel<false, StaticTile<N_>::c, StaticTile<N_>::block, true, typename StaticPlanFor<N_>::type, StaticTile<N_>::inplace>; \
+    }
     CFFT_TILE_GROUP (CFFT_TRY)
 #undef CFFT_TRY
     return nullptr;
 }
-ColumnFftFn CFFT_TILE_PICK_COL (const GenericPlan& plan, int c, int& block, unsigned lfs, bool inverse)
+ColumnFftFn CFFT_TILE_PICK_COL (const GenericPlan& plan, int c, size_t lds_per_cu, bool inverse, StaticTileLaunch& launch)
 {
 #define CFFT_TRY(N_)                                                                                                                  \
-    if (static_tile_matches<N_> (plan, c, lfs))                                                                                       \
-        return block = StaticTile<N_>::block, inverse ? column_fft_kernel<true, StaticTile<N_>::c, StaticTile<N_>::block, true, typename StaticPlanFor<N_>::type> \
-                       : column_fft_kernel<false, StaticTile<N_>::c, StaticTile<N_>::block, true, typename StaticPlanFor<N_>::type>;
+    if (static_tile_matches<N_> (plan, c, lds_per_cu))                                                                                \
+    {                                                                                                                                 \
+        launch = StaticTileLaunch { StaticTile<N_>::block, (unsigned) N_ + 1u, StaticTile<N_>::lds };                                 \
+        return inverse ? column_fft_kernel<true, StaticTile<N_>::c, StaticTile<N_>::block, true, typename StaticPlanFor<N_>::type, StaticTile<N_>::inplace> \
+                       : column_fft_kernel<false, StaticTile<N_>::c, StaticTile<N_>::block, true, typename StaticPlanFor<N_>::type, StaticTile<N_>::inplace>; \
+    }
     CFFT_TILE_GROUP (CFFT_TRY)
 #undef CFFT_TRY
     return nullptr;
