@@ -418,6 +418,7 @@ template <> struct StaticPlanFor<1000> { using type = StaticPlan<1000, 10, 10, 1
 template <> struct StaticPlanFor<1024> { using type = StaticPlan<1024, 16, 8, 8>; };
 template <> struct StaticPlanFor<1080> { using type = StaticPlan<1080, 12, 10, 9>; };
 template <> struct StaticPlanFor<1125> { using type = StaticPlan<1125, 15, 15, 5>; };
+template <> struct StaticPlanFor<2048> { using type = StaticPlan<2048, 16, 16, 8>; };
 
 // all stages of a static plan; twl: the workgroup's LDS copy of the plan's twiddles.  Returns the image that holds the result.
 // ---- software pipeline of the compile-time lists (round 3): the first stage's operands of the NEXT group of frames are

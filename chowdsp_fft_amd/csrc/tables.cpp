@@ -153,7 +153,7 @@ bool split_general (int n_complex, int& n1, int& n2)
         return false;
     // two static tile lengths where the length has such a factorisation (38400 = 240 x 160 rather than 200 x 192), both of at
     // most 639 points (16-column tiles on both sides) if possible ...
-    if (split_static_pair (n_complex, kMixedMaxN2Wide, n1, n2) || split_static_pair (n_complex, 1200, n1, n2))
+    if (split_static_pair (n_complex, kMixedMaxN2Wide, n1, n2) || split_static_pair (n_complex, kTileInplaceWideMaxN, n1, n2) || split_static_pair (n_complex, 2048, n1, n2))
         return true;
     // ... else the divisor closest to sqrt(n) from below becomes the column length n2, the cofactor the row length n1
     int best = 0;

@@ -106,7 +106,7 @@ bool split_general (int n_complex, int& n1, int& n2);
 // Column / row lengths for which the tile kernels have a compile-time stage list (generic_kernels.hpp: StaticPlanFor holds the
 // lists): every 2-3-5-smooth length from 144 to 1200 and the shorter multiples of 16 (shorter lengths never come out of a split) -- so every accepted length up to about
 // 1.4 million points has a factorisation into two of them.  The splits below prefer those: such a pass runs 1.4-1.7x faster.
-// Three groups, instantiated by kernels_tile_static_a/b/c.hip (three translation units build side by side).
+// Four groups, instantiated by kernels_tile_static_a/b/c/d.hip (four translation units build side by side).
 #define CFFT_STATIC_TILE_SIZES_A(X) \
     X (48) X (80) X (96) X (144) X (160) X (192) X (240) X (288) X (320) X (384) X (400) X (432) X (480) X (576) X (640) X (720) \
     X (768) X (800) X (864) X (960) X (1152) X (1200)
@@ -116,7 +116,9 @@ bool split_general (int n_complex, int& n1, int& n2);
 #define CFFT_STATIC_TILE_SIZES_C(X) \
     X (405) X (450) X (486) X (500) X (512) X (540) X (600) X (625) X (648) X (675) X (729) X (750) X (810) X (900) X (972) X (1000) \
     X (1024) X (1080) X (1125)
-#define CFFT_STATIC_TILE_SIZES(X) CFFT_STATIC_TILE_SIZES_A (X) CFFT_STATIC_TILE_SIZES_B (X) CFFT_STATIC_TILE_SIZES_C (X)
+// ... and the lengths beyond 1200 that have a list (8-column tiles, one image: kTileInplaceMinN below)
+#define CFFT_STATIC_TILE_SIZES_D(X) X (1280) X (1296) X (1440) X (1536) X (1600) X (1728) X (1920) X (2000) X (2048)
+#define CFFT_STATIC_TILE_SIZES(X) CFFT_STATIC_TILE_SIZES_A (X) CFFT_STATIC_TILE_SIZES_B (X) CFFT_STATIC_TILE_SIZES_C (X) CFFT_STATIC_TILE_SIZES_D (X)
 bool has_static_tile (int n);
 // Static tile lengths from kTileInplaceMinN on run their stages in ONE LDS image (generic_kernels.hpp: tile_inplace_stage): tiles of
 // 16 columns / rows up to 1200 points, where two images allow 8 beyond 639.  Measured on MI355X (tools/gpu_r3_tile_inplace_ab.sh,
@@ -142,10 +144,11 @@ static constexpr int kMaxComplexLen = 1 << 21;
 static constexpr int kMaxHugeComplexLen = 1 << 27;
 bool split_huge (int n_complex, int& r, int& c);
 // tile width (columns or rows) for a frame length n of the generic passes: as wide as two padded LDS images allow
-inline int general_tile_width (int n) { return (n <= 639 || tile_runs_inplace (n)) ? 16 : (n <= 1279 ? 8 : 4); }
+static constexpr int kTileInplaceWideMaxN = 1200; // one image of 16 frames of n + 1 points and the n - 1 stage twiddles within 160 KiB
+inline int general_tile_width (int n) { return tile_runs_inplace (n) ? (n <= kTileInplaceWideMaxN ? 16 : 8) : (n <= 639 ? 16 : (n <= 1279 ? 8 : 4)); }
 // columns per pass-A tile of the mixed two-pass plans: 16 (128-byte rows) while two LDS images of 16 padded columns,
 // 2 * 16 * (n2 + 1) * 8 bytes, fit the CU's 160 KiB (n2 <= 639), else 8 (n2 <= 1280; n2 = 1280 runs unpadded)
 static constexpr int kMixedMaxN2Wide = 639;
 static constexpr int kMixedMaxN2 = 1280;
-inline int mixed_tile_width (int n2) { return (n2 <= kMixedMaxN2Wide || tile_runs_inplace (n2)) ? 16 : 8; }
+inline int mixed_tile_width (int n2) { return (n2 <= kMixedMaxN2Wide || (tile_runs_inplace (n2) && n2 <= kTileInplaceWideMaxN)) ? 16 : 8; }
 } // namespace cfft::host

@@ -1,6 +1,6 @@
 // Tile kernels (pass A / pass B of the long mixed-radix plans, generic_kernels.hpp) with a compile-time stage list: chosen by
-// kernels_multipass.hip, instantiated in three translation units of their own (kernels_tile_static_{a,b,c}.hip, one per group of
-// lengths) so that the 240-odd kernels build beside the others.
+// kernels_multipass.hip, instantiated in four translation units of their own (kernels_tile_static_{a,b,c,d}.hip, one per group of
+// lengths) so that the 380-odd kernels build beside the others.
 #pragma once
 #include "generic_kernels.hpp"
 
@@ -22,12 +22,15 @@ struct StaticTileLaunch
 PassAGenericFn pick_static_pass_a_a (const GenericPlan& plan, int c, size_t lds_per_cu, bool inverse, StaticTileLaunch& launch);
 PassAGenericFn pick_static_pass_a_b (const GenericPlan& plan, int c, size_t lds_per_cu, bool inverse, StaticTileLaunch& launch);
 PassAGenericFn pick_static_pass_a_c (const GenericPlan& plan, int c, size_t lds_per_cu, bool inverse, StaticTileLaunch& launch);
+PassAGenericFn pick_static_pass_a_d (const GenericPlan& plan, int c, size_t lds_per_cu, bool inverse, StaticTileLaunch& launch);
 PassBGenericFn pick_static_pass_b_a (const GenericPlan& plan, int c, size_t lds_per_cu, bool inverse, StaticTileLaunch& launch);
 PassBGenericFn pick_static_pass_b_b (const GenericPlan& plan, int c, size_t lds_per_cu, bool inverse, StaticTileLaunch& launch);
 PassBGenericFn pick_static_pass_b_c (const GenericPlan& plan, int c, size_t lds_per_cu, bool inverse, StaticTileLaunch& launch);
+PassBGenericFn pick_static_pass_b_d (const GenericPlan& plan, int c, size_t lds_per_cu, bool inverse, StaticTileLaunch& launch);
 ColumnFftFn pick_static_column_a (const GenericPlan& plan, int c, size_t lds_per_cu, bool inverse, StaticTileLaunch& launch);
 ColumnFftFn pick_static_column_b (const GenericPlan& plan, int c, size_t lds_per_cu, bool inverse, StaticTileLaunch& launch);
 ColumnFftFn pick_static_column_c (const GenericPlan& plan, int c, size_t lds_per_cu, bool inverse, StaticTileLaunch& launch);
+ColumnFftFn pick_static_column_d (const GenericPlan& plan, int c, size_t lds_per_cu, bool inverse, StaticTileLaunch& launch);
 // CHOWDSP_FFT_TILE_STATIC = 0: the run-time list everywhere (A/B)
 inline bool static_tiles_off()
 {
@@ -42,7 +45,9 @@ inline PassAGenericFn pick_static_pass_a (const GenericPlan& plan, int c, size_t
         return k;
     if (auto k = pick_static_pass_a_b (plan, c, lds_per_cu, inverse, launch))
         return k;
-    return pick_static_pass_a_c (plan, c, lds_per_cu, inverse, launch);
+    if (auto k = pick_static_pass_a_c (plan, c, lds_per_cu, inverse, launch))
+        return k;
+    return pick_static_pass_a_d (plan, c, lds_per_cu, inverse, launch);
 }
 inline PassBGenericFn pick_static_pass_b (const GenericPlan& plan, int c, size_t lds_per_cu, bool inverse, StaticTileLaunch& launch)
 {
@@ -52,7 +57,9 @@ inline PassBGenericFn pick_static_pass_b (const GenericPlan& plan, int c, size_t
         return k;
     if (auto k = pick_static_pass_b_b (plan, c, lds_per_cu, inverse, launch))
         return k;
-    return pick_static_pass_b_c (plan, c, lds_per_cu, inverse, launch);
+    if (auto k = pick_static_pass_b_c (plan, c, lds_per_cu, inverse, launch))
+        return k;
+    return pick_static_pass_b_d (plan, c, lds_per_cu, inverse, launch);
 }
 inline ColumnFftFn pick_static_column (const GenericPlan& plan, int c, size_t lds_per_cu, bool inverse, StaticTileLaunch& launch)
 {
@@ -62,7 +69,9 @@ inline ColumnFftFn pick_static_column (const GenericPlan& plan, int c, size_t ld
         return k;
     if (auto k = pick_static_column_b (plan, c, lds_per_cu, inverse, launch))
         return k;
-    return pick_static_column_c (plan, c, lds_per_cu, inverse, launch);
+    if (auto k = pick_static_column_c (plan, c, lds_per_cu, inverse, launch))
+        return k;
+    return pick_static_column_d (plan, c, lds_per_cu, inverse, launch);
 }
 // PIPE variants of the tile kernels need an LDS copy of the n - 1 stage twiddles behind the two images: granted where that leaves
 // the workgroups per CU as they are (by LDS or by the CU's 32 waves, whichever binds).  CHOWDSP_FFT_TILE_PIPE (experiments): bit 0 =

@@ -16,7 +16,7 @@ struct StaticTile
 {
     // from kTileInplaceMinN on: one LDS image, stages in place (generic_kernels.hpp: tile_inplace_stage), always 16 columns
     static constexpr bool inplace = N_ >= kTileInplaceMinN;
-    static constexpr int c = (inplace || N_ <= 639) ? 16 : 8;
+    static constexpr int c = inplace ? (N_ <= kTileInplaceWideMaxN ? 16 : 8) : (N_ <= 639 ? 16 : 8);
     static constexpr size_t images = (size_t) (inplace ? 1 : 2) * c * (N_ + 1) * sizeof (float2);
     static constexpr size_t lds = images + (size_t) (N_ - 1) * sizeof (float2); // + the stage twiddles' copy
     // work-items per workgroup: 256 where four workgroups fit a CU, 1024 where only one does, and 512 between (two or three

@@ -28,10 +28,11 @@ def _oracle_2d(oracle, x, rows, cols, direction):
 
 # The second line: enough column tiles that every persistent workgroup of the column pass walks through several (it requests
 # its next tile while the current one is in the stages) -- compile-time lists with 256 / 512 / 1024 work-items and 16- / 8-column
-# tiles (144, 256, 480, 1080 rows), the run-time list (30 rows; 2048 rows in 4-column tiles).
+# tiles (144, 256, 480 rows; one-image kernels: 640, 1080 rows in 16-column, 1536, 2000, 2048 rows in 8-column tiles), the run-time list (30 rows).
 @pytest.mark.parametrize("rows,cols,batch", [(16, 16, 5), (64, 256, 3), (48, 80, 4), (256, 4096, 2), (1024, 64, 2), (720, 48, 2),
                                              (2048, 16, 1), (17 - 1, 32768, 1), (96, 65536, 1), (30, 100 * 16, 3), (9, 4096, 2),
-                                             (144, 1024, 64), (256, 256, 256), (480, 640, 16), (1080, 256, 24), (2048, 64, 64), (30, 256, 400)])
+                                             (144, 1024, 64), (256, 256, 256), (480, 640, 16), (1080, 256, 24), (2048, 64, 64), (30, 256, 400),
+                                             (1536, 64, 128), (2000, 32, 256), (640, 640, 8)])
 def test_2d_vs_oracle_axes_and_float64(gpu, oracle, rows, cols, batch):
     api, torch, dev = gpu
     s = api.fft_new_setup(cols, api.FFT_COMPLEX)

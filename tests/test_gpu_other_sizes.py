@@ -311,7 +311,7 @@ STATIC_TILE_SIZES = [20480, 20736, 21600, 23040, 23328, 24000, 24576, 25600, 259
                      230400, 248832, 250000, 259200, 276480, 279936, 291600, 300000, 314928, 320000, 331776, 360000, 368640, 384000, 400000, 414720,
                      419904, 432000, 450000, 480000, 486000, 497664, 500000, 524880, 559872, 576000, 614400, 622080, 629856, 640000, 699840, 720000,
                      746496, 750000, 768000, 810000, 839808, 921600, 944784, 995328, 1000000, 1036800, 1105920, 1119744, 1152000, 1166400, 1179648,
-                     1200000, 1296000]
+                     1200000, 1250000, 1259712, 1280000, 1296000, 1310720, 1572864, 1600000, 1620000, 1679616, 1944000, 2073600, 2097152]
 
 
 @pytest.mark.parametrize("n", STATIC_TILE_SIZES)
