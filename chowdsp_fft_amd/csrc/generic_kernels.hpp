@@ -1131,7 +1131,7 @@ static constexpr int kTileLoadsInFlight = CFFT_TILE_LOADS_IN_FLIGHT;
 #endif
 static constexpr int kTilePrefetchB = CFFT_TILE_PREFETCH_B;
 #ifndef CFFT_TILE_PREFETCH_A
-#define CFFT_TILE_PREFETCH_A 10
+#define CFFT_TILE_PREFETCH_A 8
 #endif
 static constexpr int kTilePrefetchA = CFFT_TILE_PREFETCH_A;
 static constexpr int kTileStoreBatch = 10;
@@ -1281,9 +1281,10 @@ __global__ __launch_bounds__ (BLOCK, PIPE ? 4 : 1) void pass_a_generic_kernel (c
     const unsigned tiles = (n1 + CA - 1) / CA;
     const size_t nwork = (size_t) batch * tiles;
     const int total = CA * n2;
-    // Every tile shape the launchers choose has at most 10 operands per work-item (16 x 160 / 256, 16 x 639 / 1024, 8 x 1280 /
-    // 1024, 4 x 2559 / 1024), so the whole tile is requested ahead.  Slots beyond the tile re-read its last element: a
-    // test around a load -- even a workgroup-uniform one -- makes the compiler wait for every load before the next.
+    // Compile-time lists request the whole tile ahead (exactly its count of operands per work-item); the run-time list requests
+    // kTilePrefetchA = 8 of the at most 10 a tile shape has (16 x 160 / 256, 16 x 639 / 1024, 8 x 1280 / 1024, 4 x 2559 / 1024: ten
+    // spill 8-12 bytes in the narrow-tile variants) and loads the rest when the tile is committed.  Slots beyond the tile re-read
+    // its last element: a test around a load -- even a workgroup-uniform one -- makes the compiler wait for every load before the next.
     constexpr int PF = tile_slots<SP, CA, BLOCK> (kTilePrefetchA, INPLACE ? CFFT_TILE_INPLACE_PREFETCH : 1 << 20);
     constexpr int SB = tile_slots<SP, CA, BLOCK> (CA == 16 ? kTileStoreBatch : 8, INPLACE ? 10 : 1 << 20); // (run-time list: 10 spills a few bytes in the narrow-tile variants)
     float2 pre[PF];

@@ -13,7 +13,8 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "chowdsp_fft_amd", "csrc")
-UNITS = {"kernels_c2c": 0, "kernels_real": 0, "kernels_conv": 0, "kernels_multipass": 1, "kernels_generic": 0, "kernels_split": 0}  # -> CFFT_PACKED as in the Makefile
+UNITS = {"kernels_c2c": 0, "kernels_real": 0, "kernels_conv": 0, "kernels_multipass": 1, "kernels_generic": 0, "kernels_split": 0,
+         "kernels_tile_static_d": 1}  # -> CFFT_PACKED as in the Makefile (of the four tile_static units the one with the longest frames)
 
 
 def _resource_usage(unit, packed):
@@ -43,7 +44,10 @@ def test_no_scratch_and_bounded_registers(unit):
     assert len(kernels) >= 4 or unit == "kernels_split"
     for k in kernels:
         assert k.get("scratch", 0) == 0, f"{k['name']} uses {k['scratch']} B/lane of scratch"
-        assert k.get("vgpr", 0) + k.get("agpr", 0) <= 256, f"{k['name']}: {k.get('vgpr')} VGPR + {k.get('agpr')} AGPR"
+        # groupfast_kernel (group_fast_kernels.hpp) is launched one 256-work-item workgroup per CU by design (__launch_bounds__ (256, 1):
+        # one wave per SIMD owns the unified 512-entry file); every other kernel must leave room for a second wave
+        limit = 512 if "groupfast_kernel" in k["name"] else 256
+        assert k.get("vgpr", 0) + k.get("agpr", 0) <= limit, f"{k['name']}: {k.get('vgpr')} VGPR + {k.get('agpr')} AGPR"
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not installed")

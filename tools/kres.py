@@ -5,7 +5,8 @@ usage: tools/kres.py file.hip [extra hipcc flags...]
 """
 import re, subprocess, sys
 src = sys.argv[1]
-cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", "/tmp/kres.o",
+# the library's own flags (csrc/Makefile): without -fno-slp-vectorize / -ffp-contract=fast the register counts are not the build's
+cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-ffp-contract=fast", "-c", src, "-o", "/tmp/kres.o",
        "-Rpass-analysis=kernel-resource-usage"] + sys.argv[2:]
 p = subprocess.run(cmd, capture_output=True, text=True)
 txt = p.stderr
