@@ -1282,9 +1282,9 @@ int fft_gpu_plan_describe (int N, fft_transform_t transform, int desc[8])
         return FFT_GPU_EINVAL;
     const int nc = (transform == FFT_COMPLEX) ? N : N / 2;
     int q1 = 0, q2 = 0;
-    if (nc > cfft::host::kMaxComplexLen)
+    if (cfft::host::runs_as_huge (nc))
     {
-        // beyond 2^21 complex points: the plans of two factors + three transposes ("3": more than two passes through device memory)
+        // beyond 2^21 complex points (and not the product of two static tile lengths): the plans of two factors + three transposes ("3": more than two passes through device memory)
         if (! split_huge (nc, q1, q2))
             return FFT_GPU_EINVAL;
         desc[0] = nc;

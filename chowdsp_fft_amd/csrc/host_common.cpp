@@ -131,7 +131,7 @@ const DeviceTables* acquire_tables (int device, int N, int transform)
     {
         const int nc = (transform == 0) ? N / 2 : N;
         int hr = 0, hc = 0;
-        if (nc > kMaxComplexLen && size_supported (N, transform) && split_huge (nc, hr, hc))
+        if (runs_as_huge (nc) && size_supported (N, transform) && split_huge (nc, hr, hc))
         {
             sub_r = acquire_tables (device, hr, 1);
             sub_c = acquire_tables (device, hc, 1);

@@ -180,10 +180,18 @@ static bool is_235_smooth (int n)
 
 static constexpr int kGenericMaxComplexLen = 20000; // = cfft::kGenericMaxN (one LDS image per workgroup, in-place stages)
 
+bool runs_as_huge (int n_complex)
+{
+    if (n_complex <= kMaxComplexLen)
+        return false;
+    int a = 0, b = 0;
+    return ! (n_complex <= kMaxStaticTwoPassLen && split_static_pair (n_complex, 2048, a, b));
+}
+
 bool split_huge (int n_complex, int& r, int& c)
 {
     r = c = 0;
-    if (n_complex <= kMaxComplexLen || n_complex > kMaxHugeComplexLen)
+    if (! runs_as_huge (n_complex) || n_complex > kMaxHugeComplexLen)
         return false;
     // the divisor pair closest to sqrt(n) whose members are both accepted complex lengths (multiples of 16, at most 2^21)
     for (long long d = (long long) std::sqrt ((double) n_complex) + 1; d >= 16; --d)
@@ -212,7 +220,7 @@ bool size_supported (int N, int transform)
     const int nc = real ? N / 2 : N;
     if (! is_235_smooth (N))
         return false;
-    if (nc > kMaxComplexLen)
+    if (runs_as_huge (nc))
     {
         int hr = 0, hc = 0;
         if (real && nc > (1 << 24))
@@ -346,7 +354,7 @@ bool build_host_tables (int N, int transform, HostTables& out)
             out.real_twiddles.push_back (unit_root (k, N));
     }
 
-    if (nc > kMaxComplexLen)
+    if (runs_as_huge (nc))
     {
         if (! split_huge (nc, out.huge_r, out.huge_c))
             return false;

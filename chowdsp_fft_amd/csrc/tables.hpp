@@ -143,6 +143,10 @@ static constexpr int kMaxComplexLen = 1 << 21;
 // frame).  false if no such pair of factors exists (then the size is not supported).
 static constexpr int kMaxHugeComplexLen = 1 << 27;
 bool split_huge (int n_complex, int& r, int& c);
+// ... except the lengths up to 2^22 that are the product of two static tile lengths (at most 2048 points each, tables below): those
+// stay two-pass plans of the general form (2^22 = 2048 x 2048, 2304000 = 2048 x 1125: two sweeps instead of five)
+static constexpr int kMaxStaticTwoPassLen = 1 << 22;
+bool runs_as_huge (int n_complex);
 // tile width (columns or rows) for a frame length n of the generic passes: as wide as two padded LDS images allow
 static constexpr int kTileInplaceWideMaxN = 1200; // one image of 16 frames of n + 1 points and the n - 1 stage twiddles within 160 KiB
 inline int general_tile_width (int n) { return tile_runs_inplace (n) ? (n <= kTileInplaceWideMaxN ? 16 : 8) : (n <= 639 ? 16 : (n <= 1279 ? 8 : 4)); }

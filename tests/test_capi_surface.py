@@ -88,12 +88,17 @@ def test_size_rule_host_logic():
         assert not api.size_supported(n, api.FFT_COMPLEX)
     # beyond 2^21 complex points: N = R x C with both factors accepted lengths (two plans + transposes), up to 2^27 complex
     # points (real: N <= 2^25)
-    for n in (1 << 22, 3 << 21, 5 << 21, 1 << 24, 1 << 27, 15 << 20):
-        assert api.size_supported(n, api.FFT_COMPLEX), n
+    for n in (3 << 21, 5 << 21, 1 << 24, 1 << 27, 15 << 20, (1 << 22) - 2048):
+        assert api.size_supported(n, api.FFT_COMPLEX) == _smooth(n), n
+        if not _smooth(n):
+            continue
         d = api.plan_describe(n, api.FFT_COMPLEX)
         assert d["passes"] == 3 and d["n1"] * d["n2"] == n and max(d["n1"], d["n2"]) <= 1 << 21 and d["n1"] % 16 == 0 and d["n2"] % 16 == 0, (n, d)
     assert api.size_supported(1 << 25, api.FFT_REAL) and not api.size_supported(1 << 26, api.FFT_REAL)
-    assert api.plan_describe(1 << 22, api.FFT_COMPLEX)["n1"] == 2048
+    # ... except, up to 2^22, the products of two tile lengths with compile-time stage lists (at most 2048 points each): two passes
+    for n, pair in ((1 << 22, (2048, 2048)), (2304000, (1440, 1600)), (3 << 20, (1536, 2048)), (2560000, (1600, 1600))):
+        d = api.plan_describe(n, api.FFT_COMPLEX)
+        assert d["passes"] == 2 and tuple(sorted((d["n1"], d["n2"]))) == pair, (n, d)
     # the reference's "Other sizes" test list (test/test.cpp:279-285)
     for n in (96, 192, 384, 480, 640, 768, 9216):
         assert api.size_supported(n, api.FFT_COMPLEX) and api.size_supported(n, api.FFT_REAL)
