@@ -116,10 +116,12 @@ int fft_gpu_size_supported (int N, fft_transform_t transform);
      two pass : 65536 ... 2^20: power-of-two columns x power-of-two rows (65536 in ONE launch for large batches);
                 other lengths: generic columns x power-of-two rows where N = (odd * 2^j <= 1280, j >= 4) x (2^6..2^10)
                 exists (24576 = 48 x 512), else generic columns x generic rows, both factors near sqrt(N)
-                (20736 = 144 x 144, 2^21 = 2048 x 1024)
+                (20736 = 144 x 144, 46080 = 240 x 192, 2^21 = 2048 x 1024): two tile lengths with compile-time stage lists
+                (every 2-3-5-smooth length 144 ... 1200 and nine up to 2048) where N factors into them, which also covers
+                such products beyond 2^21, up to 2^22 complex points (2^22 = 2048 x 2048, 2304000 = 1600 x 1440)
      "3"      : beyond 2^21 complex points: n1 x n2 with both factors accepted lengths, n2 batched n1-point transforms and
                 n1 batched n2-point transforms by those lengths' own plans, a twiddle and three transposes in between
-                (2^22 = 2048 x 2048, 3 x 2^21 = 3072 x 2048): five or more sweeps over the frame -- completeness, not speed
+                (3 x 2^21 = 3072 x 2048, 2^24 = 4096 x 4096): five or more sweeps over the frame -- completeness, not speed
    Returns 0, or FFT_GPU_EINVAL for an unsupported size.  Pure host logic. */
 int fft_gpu_plan_describe (int N, fft_transform_t transform, int desc[8]);
 int fft_gpu_setup_size (void* setup);              /* N, or negative error */
