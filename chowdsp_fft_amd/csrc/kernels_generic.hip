@@ -159,16 +159,21 @@ hipError_t launch_generic_inplace (GenericPlan plan, const DeviceTables& t, cons
             stages = s + 1;
             p *= plan.radix[s];
         }
-        if (stages > 1 // stage 0 has no twiddles (p == 1)
-            && blocks_per_cu_cached ((const void*) generic_inplace_kernel<MODE, INV, BLOCK, true>, BLOCK, image + len * sizeof (float2)) >= wgs)
+        const bool table_granted = stages > 1 // stage 0 has no twiddles (p == 1)
+                                   && blocks_per_cu_cached ((const void*) generic_inplace_kernel<MODE, INV, BLOCK, true>, BLOCK, image + len * sizeof (float2)) >= wgs;
+        if (table_granted)
         {
             plan.lds_stages = stages;
             plan.lds_tw_len = (int) len;
-            // compile-time stage lists (generic_kernels.hpp: StaticInplacePlanFor), where the planner's list is the template's
-            static const bool static_off = [] {
-                const char* e = std::getenv ("CHOWDSP_FFT_GENERIC_STATIC");
-                return e != nullptr && std::atoi (e) == 0;
-            }();
+        }
+        // compile-time stage lists (generic_kernels.hpp: StaticInplacePlanFor), where the planner's list is the template's -- with
+        // the leading stages' tables in LDS where granted, every table from L2 where not (n = 5120 and 10240: the image alone
+        // takes the workgroup's share of the CU's LDS; until round 3 those two fell back to the run-time list: 9000 scalar and
+        // 1850 table-load instructions per wave)
+        static const bool static_off = [] {
+            const char* e = std::getenv ("CHOWDSP_FFT_GENERIC_STATIC");
+            return e != nullptr && std::atoi (e) == 0;
+        }();
 #define CFFT_TRY_STATIC_INPLACE(N_, B_)                                                                            \
     if constexpr (BLOCK == B_)                                                                                     \
     {                                                                                                              \
@@ -182,19 +187,19 @@ hipError_t launch_generic_inplace (GenericPlan plan, const DeviceTables& t, cons
                 return launch_generic_inplace_tw<MODE, INV, BLOCK, true, SP> (plan, t, in, out, batch, stream);    \
         }                                                                                                          \
     }
-            CFFT_TRY_STATIC_INPLACE (4608, 256)
-            CFFT_TRY_STATIC_INPLACE (9216, 512)
-            CFFT_TRY_STATIC_INPLACE (5120, 256)
-            CFFT_TRY_STATIC_INPLACE (12288, 1024)
-            CFFT_TRY_STATIC_INPLACE (19200, 1024)
-            CFFT_TRY_STATIC_INPLACE (6144, 512)
-            CFFT_TRY_STATIC_INPLACE (7680, 512)
-            CFFT_TRY_STATIC_INPLACE (10240, 512)
-            CFFT_TRY_STATIC_INPLACE (15360, 1024)
-            CFFT_TRY_STATIC_INPLACE (18432, 1024)
+        CFFT_TRY_STATIC_INPLACE (4608, 256)
+        CFFT_TRY_STATIC_INPLACE (9216, 512)
+        CFFT_TRY_STATIC_INPLACE (5120, 256)
+        CFFT_TRY_STATIC_INPLACE (12288, 1024)
+        CFFT_TRY_STATIC_INPLACE (19200, 1024)
+        CFFT_TRY_STATIC_INPLACE (6144, 512)
+        CFFT_TRY_STATIC_INPLACE (7680, 512)
+        CFFT_TRY_STATIC_INPLACE (10240, 512)
+        CFFT_TRY_STATIC_INPLACE (15360, 1024)
+        CFFT_TRY_STATIC_INPLACE (18432, 1024)
 #undef CFFT_TRY_STATIC_INPLACE
+        if (table_granted)
             return launch_generic_inplace_tw<MODE, INV, BLOCK, true> (plan, t, in, out, batch, stream);
-        }
     }
     return launch_generic_inplace_tw<MODE, INV, BLOCK, false> (plan, t, in, out, batch, stream);
 }

@@ -75,10 +75,14 @@ hipError_t launch_conv_inplace (GenericPlan plan, const DeviceTables& t, const f
         stages = s + 1;
         p *= plan.radix[s];
     }
-    if (stages > 1 && blocks_per_cu_cached ((const void*) generic_inplace_conv_kernel<REAL, BLOCK, true>, BLOCK, image + len * sizeof (float2)) >= wgs)
+    const bool table_granted = stages > 1 && blocks_per_cu_cached ((const void*) generic_inplace_conv_kernel<REAL, BLOCK, true>, BLOCK, image + len * sizeof (float2)) >= wgs;
+    if (table_granted)
     {
         plan.lds_stages = stages;
         plan.lds_tw_len = (int) len;
+    }
+    // compile-time lists with or without the leading stages' tables in LDS (kernels_generic.hip: launch_generic_inplace)
+    {
 #define CFFT_TRY_STATIC_INPLACE_CONV(N_, B_)                                                                       \
     if constexpr (BLOCK == B_)                                                                                     \
     {                                                                                                              \
@@ -103,8 +107,9 @@ hipError_t launch_conv_inplace (GenericPlan plan, const DeviceTables& t, const f
         CFFT_TRY_STATIC_INPLACE_CONV (15360, 1024)
         CFFT_TRY_STATIC_INPLACE_CONV (18432, 1024)
 #undef CFFT_TRY_STATIC_INPLACE_CONV
-        return launch_conv_inplace_tw<REAL, BLOCK, true> (plan, t, in, H, out, scaling, batch, stream);
     }
+    if (table_granted)
+        return launch_conv_inplace_tw<REAL, BLOCK, true> (plan, t, in, H, out, scaling, batch, stream);
     return launch_conv_inplace_tw<REAL, BLOCK, false> (plan, t, in, H, out, scaling, batch, stream);
 }
 

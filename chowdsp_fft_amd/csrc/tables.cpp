@@ -125,6 +125,10 @@ bool split_mixed (int n_complex, int& n1, int& n2)
             int s1 = 0, s2 = 0;
             if (c2 > kMixedMaxN2Wide && split_static_pair (n_complex, kMixedMaxN2Wide, s1, s2))
                 return false;
+            // experiment (CHOWDSP_FFT_MIXED_TO_GENERAL = 1): the general form wherever two static lengths exist
+            static const bool to_general = [] { const char* e = std::getenv ("CHOWDSP_FFT_MIXED_TO_GENERAL"); return e != nullptr && std::atoi (e) == 1; }();
+            if (to_general && split_static_pair (n_complex, 2048, s1, s2))
+                return false;
             n1 = r1;
             n2 = (int) c2;
             return true;
