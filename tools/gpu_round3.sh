@@ -47,6 +47,9 @@ PY
 echo "== all-sizes rate table"
 timeout -k 10 900 python tools/all_sizes_rate.py > "$OUT/all_sizes.txt" 2>/dev/null || true
 tail -3 "$OUT/all_sizes.txt"
+echo "== 2-D rates"
+timeout -k 10 300 python tools/rate_2d.py > "$OUT/rates_2d.txt" 2>/dev/null || true
+tail -3 "$OUT/rates_2d.txt"
 echo "== fused-convolution rates"
 timeout -k 10 300 python tools/conv_frames_rate.py c4096 r4096 r8192 c8192 c16384 c32768 r65536 c96 c480 c768 c1536 c9216 c19200 r960 r9216 c65536 > "$OUT/conv_frames_rates.txt" 2>/dev/null || true
 tail -4 "$OUT/conv_frames_rates.txt"
