@@ -346,14 +346,18 @@ struct StaticPlan
         return o;
     }
 };
+// two-stage lists are ordered for full-line stores in the last stage where one order gives them (tables.cpp: generic_radices)
+#ifndef CFFT_TWO_STAGE_FULL_LINE
+#define CFFT_TWO_STAGE_FULL_LINE 1
+#endif
 template <int N_> struct StaticPlanFor { using type = void; };
 template <> struct StaticPlanFor<48> { using type = StaticPlan<48, 6, 8>; };
 template <> struct StaticPlanFor<80> { using type = StaticPlan<80, 10, 8>; };
 template <> struct StaticPlanFor<96> { using type = StaticPlan<96, 12, 8>; };
 template <> struct StaticPlanFor<144> { using type = StaticPlan<144, 12, 12>; };
 template <> struct StaticPlanFor<160> { using type = StaticPlan<160, 10, 16>; };
-template <> struct StaticPlanFor<192> { using type = StaticPlan<192, 12, 16>; };
-template <> struct StaticPlanFor<240> { using type = StaticPlan<240, 15, 16>; };
+template <> struct StaticPlanFor<192> { using type = std::conditional<CFFT_TWO_STAGE_FULL_LINE != 0, StaticPlan<192, 16, 12>, StaticPlan<192, 12, 16>>::type; };
+template <> struct StaticPlanFor<240> { using type = std::conditional<CFFT_TWO_STAGE_FULL_LINE != 0, StaticPlan<240, 16, 15>, StaticPlan<240, 15, 16>>::type; };
 template <> struct StaticPlanFor<288> { using type = StaticPlan<288, 6, 6, 8>; };
 template <> struct StaticPlanFor<320> { using type = StaticPlan<320, 5, 8, 8>; };
 template <> struct StaticPlanFor<384> { using type = StaticPlan<384, 6, 8, 8>; };
@@ -419,6 +423,10 @@ template <> struct StaticPlanFor<1024> { using type = StaticPlan<1024, 16, 8, 8>
 template <> struct StaticPlanFor<1080> { using type = StaticPlan<1080, 12, 10, 9>; };
 template <> struct StaticPlanFor<1125> { using type = StaticPlan<1125, 15, 15, 5>; };
 template <> struct StaticPlanFor<2048> { using type = StaticPlan<2048, 16, 16, 8>; };
+// the tile kernels' lists (stages LDS to LDS): the sorted order for the two lengths whose whole-frame kernels use the full-line order
+template <int N_> struct StaticTilePlanFor { using type = typename StaticPlanFor<N_>::type; };
+template <> struct StaticTilePlanFor<192> { using type = StaticPlan<192, 12, 16>; };
+template <> struct StaticTilePlanFor<240> { using type = StaticPlan<240, 15, 16>; };
 
 // all stages of a static plan; twl: the workgroup's LDS copy of the plan's twiddles.  Returns the image that holds the result.
 // ---- software pipeline of the compile-time lists (round 3): the first stage's operands of the NEXT group of frames are
@@ -499,6 +507,9 @@ __device__ __forceinline__ float2* static_core (const float2* twl, float2* a, fl
     }
 }
 
+#ifndef CFFT_GENERIC_STAGED_160
+#define CFFT_GENERIC_STAGED_160 1
+#endif
 #ifndef CFFT_GENERIC_STAGED_MAX_N
 #define CFFT_GENERIC_STAGED_MAX_N 256
 #endif
@@ -506,7 +517,7 @@ __device__ __forceinline__ float2* static_core (const float2* twl, float2* a, fl
 // (profiles/r02_generic_staged_io_ab.txt, staged against direct, GB/s): 96 5419 / 4509, 144 5169 / 4304, 160 5494 / 4556 -- but
 // 48 4142 / 4189, 80 4139 / 4214 (no difference) and 192 3858 / 4442, 240 3813 / 4396 (their radix-16 last stage writes the
 // image at a pitch of 12 / 15 points: LDS conflicts cost more than the half-used lines did).
-__host__ __device__ constexpr bool generic_staged_io (int n) { return n <= CFFT_GENERIC_STAGED_MAX_N && (n == 96 || n == 144 || n == 160); }
+__host__ __device__ constexpr bool generic_staged_io (int n) { return n <= CFFT_GENERIC_STAGED_MAX_N && (n == 96 || n == 144 || (CFFT_GENERIC_STAGED_160 != 0 && n == 160)); }
 // ... and whose REAL transforms (N = 2 n) do: real N = 192 4677 / 4423, 288 4767 / 4407 -- but 320 3368 / 3856
 __host__ __device__ constexpr bool generic_staged_io_real (int n) { return n <= CFFT_GENERIC_STAGED_MAX_N && (n == 96 || n == 144); }
 template <class SP>

@@ -320,6 +320,19 @@ static void generic_radices (int n, std::vector<int>& radix, int frames_override
             return oa;
         return a > b;
     });
+    // two-stage plans: the last stage stores runs of n / (its radix) consecutive points per butterfly output.  Where that is not
+    // a whole number of 128-byte lines but the other order makes it one (192 = 12 x 16: runs of 12 points; = 16 x 12: runs of 16),
+    // the order with full-line stores is taken (the first stage then READS runs of 12, which costs less than partial-line stores)
+#ifndef CFFT_TWO_STAGE_FULL_LINE
+#define CFFT_TWO_STAGE_FULL_LINE 1 // (0: the sorted order -- with the matching lists of generic_kernels.hpp -- for A/B builds)
+#endif
+    // Measured on MI355X (tools/gpu_r3_two_stage_order_ab.sh, fraction of 8 TB/s, sorted / full-line order): c192 0.576 / 0.630,
+    // c240 0.551 / 0.564, real N = 384 0.618 / 0.645, real N = 480 0.607 / 0.653, real N = 320 0.568 / 0.579.  n = 160 keeps the
+    // sorted order: it runs the staged-I/O form (generic_kernels.hpp: generic_staged_io), which is faster with it (0.616 / 0.592;
+    // direct I/O in the full-line order: 0.584).
+    // (frames_override > 0: the list of a tile kernel, whose stages run LDS to LDS -- the sorted order stays)
+    if (CFFT_TWO_STAGE_FULL_LINE && frames_override == 0 && best.size() == 2 && n != 160 && (n / best[1]) % 16 != 0 && (n / best[0]) % 16 == 0)
+        std::swap (best[0], best[1]);
     radix = best;
 }
 

@@ -31,7 +31,7 @@ struct StaticTile
 template <int N_>
 bool static_tile_matches (const GenericPlan& plan, int c, size_t lds_per_cu)
 {
-    using SP = typename StaticPlanFor<N_>::type;
+    using SP = typename StaticTilePlanFor<N_>::type;
     bool same = plan.n == N_ && plan.ns == SP::ns && c == StaticTile<N_>::c && StaticTile<N_>::lds <= lds_per_cu;
     for (int i = 0; same && i < SP::ns; ++i)
         same = plan.radix[i] == SP::radix (i);
@@ -46,8 +46,8 @@ PassAGenericFn CFFT_TILE_PICK_A (const GenericPlan& plan, int c, size_t lds_per_
     if (static_tile_matches<N_> (plan, c, lds_per_cu))                                                                                \
     {                                                                                                                                 \
         launch = StaticTileLaunch { StaticTile<N_>::block, (unsigned) N_ + 1u, StaticTile<N_>::lds };                                 \
-        return inverse ? pass_a_generic_kernel<true, StaticTile<N_>::c, StaticTile<N_>::block, true, typename StaticPlanFor<N_>::type, StaticTile<N_>::inplace> \
-                       : pass_a_generic_kernel<false, StaticTile<N_>::c, StaticTile<N_>::block, true, typename StaticPlanFor<N_>::type, StaticTile<N_>::inplace>; \
+        return inverse ? pass_a_generic_kernel<true, StaticTile<N_>::c, StaticTile<N_>::block, true, typename StaticTilePlanFor<N_>::type, StaticTile<N_>::inplace> \
+                       : pass_a_generic_kernel<false, StaticTile<N_>::c, StaticTile<N_>::block, true, typename StaticTilePlanFor<N_>::type, StaticTile<N_>::inplace>; \
     }
     CFFT_TILE_GROUP (CFFT_TRY)
 #undef CFFT_TRY
@@ -59,8 +59,8 @@ PassBGenericFn CFFT_TILE_PICK_B (const GenericPlan& plan, int c, size_t lds_per_
     if (static_tile_matches<N_> (plan, c, lds_per_cu))                                                                                \
     {                                                                                                                                 \
         launch = StaticTileLaunch { StaticTile<N_>::block, (unsigned) N_ + 1u, StaticTile<N_>::lds };                                 \
-        return inverse ? pass_b_generic_kernel<true, StaticTile<N_>::c, StaticTile<N_>::block, true, typename StaticPlanFor<N_>::type, StaticTile<N_>::inplace> \
-                       : pass_b_generic_kernel<false, StaticTile<N_>::c, StaticTile<N_>::block, true, typename StaticPlanFor<N_>::type, StaticTile<N_>::inplace>; \
+        return inverse ? pass_b_generic_kernel<true, StaticTile<N_>::c, StaticTile<N_>::block, true, typename StaticTilePlanFor<N_>::type, StaticTile<N_>::inplace> \
+                       : pass_b_generic_kernel<false, StaticTile<N_>::c, StaticTile<N_>::block, true, typename StaticTilePlanFor<N_>::type, StaticTile<N_>::inplace>; \
     }
     CFFT_TILE_GROUP (CFFT_TRY)
 #undef CFFT_TRY
@@ -72,8 +72,8 @@ ColumnFftFn CFFT_TILE_PICK_COL (const GenericPlan& plan, int c, size_t lds_per_c
     if (static_tile_matches<N_> (plan, c, lds_per_cu))                                                                                \
     {                                                                                                                                 \
         launch = StaticTileLaunch { StaticTile<N_>::block, (unsigned) N_ + 1u, StaticTile<N_>::lds };                                 \
-        return inverse ? column_fft_kernel<true, StaticTile<N_>::c, StaticTile<N_>::block, true, typename StaticPlanFor<N_>::type, StaticTile<N_>::inplace> \
-                       : column_fft_kernel<false, StaticTile<N_>::c, StaticTile<N_>::block, true, typename StaticPlanFor<N_>::type, StaticTile<N_>::inplace>; \
+        return inverse ? column_fft_kernel<true, StaticTile<N_>::c, StaticTile<N_>::block, true, typename StaticTilePlanFor<N_>::type, StaticTile<N_>::inplace> \
+                       : column_fft_kernel<false, StaticTile<N_>::c, StaticTile<N_>::block, true, typename StaticTilePlanFor<N_>::type, StaticTile<N_>::inplace>; \
     }
     CFFT_TILE_GROUP (CFFT_TRY)
 #undef CFFT_TRY
