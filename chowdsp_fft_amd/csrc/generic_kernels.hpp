@@ -358,29 +358,29 @@ template <> struct StaticPlanFor<144> { using type = StaticPlan<144, 12, 12>; };
 template <> struct StaticPlanFor<160> { using type = StaticPlan<160, 10, 16>; };
 template <> struct StaticPlanFor<192> { using type = std::conditional<CFFT_TWO_STAGE_FULL_LINE != 0, StaticPlan<192, 16, 12>, StaticPlan<192, 12, 16>>::type; };
 template <> struct StaticPlanFor<240> { using type = std::conditional<CFFT_TWO_STAGE_FULL_LINE != 0, StaticPlan<240, 16, 15>, StaticPlan<240, 15, 16>>::type; };
-template <> struct StaticPlanFor<288> { using type = StaticPlan<288, 6, 6, 8>; };
-template <> struct StaticPlanFor<320> { using type = StaticPlan<320, 5, 8, 8>; };
+template <> struct StaticPlanFor<288> { using type = std::conditional<CFFT_TWO_STAGE_FULL_LINE != 0, StaticPlan<288, 6, 8, 6>, StaticPlan<288, 6, 6, 8>>::type; };
+template <> struct StaticPlanFor<320> { using type = std::conditional<CFFT_TWO_STAGE_FULL_LINE != 0, StaticPlan<320, 8, 8, 5>, StaticPlan<320, 5, 8, 8>>::type; };
 template <> struct StaticPlanFor<384> { using type = StaticPlan<384, 6, 8, 8>; };
-template <> struct StaticPlanFor<400> { using type = StaticPlan<400, 10, 5, 8>; };
-template <> struct StaticPlanFor<432> { using type = StaticPlan<432, 9, 6, 8>; };
-template <> struct StaticPlanFor<480> { using type = StaticPlan<480, 10, 6, 8>; };
-template <> struct StaticPlanFor<576> { using type = StaticPlan<576, 9, 8, 8>; };
+template <> struct StaticPlanFor<400> { using type = std::conditional<CFFT_TWO_STAGE_FULL_LINE != 0, StaticPlan<400, 10, 8, 5>, StaticPlan<400, 10, 5, 8>>::type; };
+template <> struct StaticPlanFor<432> { using type = std::conditional<CFFT_TWO_STAGE_FULL_LINE != 0, StaticPlan<432, 6, 8, 9>, StaticPlan<432, 9, 6, 8>>::type; };
+template <> struct StaticPlanFor<480> { using type = std::conditional<CFFT_TWO_STAGE_FULL_LINE != 0, StaticPlan<480, 10, 8, 6>, StaticPlan<480, 10, 6, 8>>::type; };
+template <> struct StaticPlanFor<576> { using type = std::conditional<CFFT_TWO_STAGE_FULL_LINE != 0, StaticPlan<576, 8, 8, 9>, StaticPlan<576, 9, 8, 8>>::type; };
 template <> struct StaticPlanFor<640> { using type = StaticPlan<640, 10, 8, 8>; };
-template <> struct StaticPlanFor<720> { using type = StaticPlan<720, 10, 9, 8>; };
+template <> struct StaticPlanFor<720> { using type = std::conditional<CFFT_TWO_STAGE_FULL_LINE != 0, StaticPlan<720, 10, 8, 9>, StaticPlan<720, 10, 9, 8>>::type; };
 template <> struct StaticPlanFor<768> { using type = StaticPlan<768, 12, 8, 8>; };
-template <> struct StaticPlanFor<800> { using type = StaticPlan<800, 10, 10, 8>; };
-template <> struct StaticPlanFor<864> { using type = StaticPlan<864, 12, 9, 8>; };
-template <> struct StaticPlanFor<960> { using type = StaticPlan<960, 12, 10, 8>; };
+template <> struct StaticPlanFor<800> { using type = std::conditional<CFFT_TWO_STAGE_FULL_LINE != 0, StaticPlan<800, 10, 8, 10>, StaticPlan<800, 10, 10, 8>>::type; };
+template <> struct StaticPlanFor<864> { using type = std::conditional<CFFT_TWO_STAGE_FULL_LINE != 0, StaticPlan<864, 12, 8, 9>, StaticPlan<864, 12, 9, 8>>::type; };
+template <> struct StaticPlanFor<960> { using type = std::conditional<CFFT_TWO_STAGE_FULL_LINE != 0, StaticPlan<960, 12, 8, 10>, StaticPlan<960, 12, 10, 8>>::type; };
 template <> struct StaticPlanFor<1152> { using type = StaticPlan<1152, 12, 12, 8>; };
 template <> struct StaticPlanFor<1200> { using type = StaticPlan<1200, 12, 10, 10>; };
 template <> struct StaticPlanFor<1280> { using type = StaticPlan<1280, 10, 16, 8>; };
 template <> struct StaticPlanFor<1296> { using type = StaticPlan<1296, 12, 12, 9>; };
 template <> struct StaticPlanFor<1440> { using type = StaticPlan<1440, 12, 12, 10>; };
 template <> struct StaticPlanFor<1536> { using type = StaticPlan<1536, 12, 16, 8>; };
-template <> struct StaticPlanFor<1600> { using type = StaticPlan<1600, 10, 10, 16>; };
+template <> struct StaticPlanFor<1600> { using type = std::conditional<CFFT_TWO_STAGE_FULL_LINE != 0, StaticPlan<1600, 10, 16, 10>, StaticPlan<1600, 10, 10, 16>>::type; };
 template <> struct StaticPlanFor<1728> { using type = StaticPlan<1728, 12, 12, 12>; };
-template <> struct StaticPlanFor<1920> { using type = StaticPlan<1920, 12, 10, 16>; };
-template <> struct StaticPlanFor<2000> { using type = StaticPlan<2000, 10, 5, 5, 8>; };
+template <> struct StaticPlanFor<1920> { using type = std::conditional<CFFT_TWO_STAGE_FULL_LINE != 0, StaticPlan<1920, 12, 16, 10>, StaticPlan<1920, 12, 10, 16>>::type; };
+template <> struct StaticPlanFor<2000> { using type = std::conditional<CFFT_TWO_STAGE_FULL_LINE != 0, StaticPlan<2000, 10, 5, 8, 5>, StaticPlan<2000, 10, 5, 5, 8>>::type; };
 // lengths that only occur as the column / row length of a long plan's tile kernels (kernels_tile_static*.hip): every other
 // 2-3-5-smooth length from 100 to 1125, same planner rule (tables.cpp: generic_radices; the launcher checks the list)
 template <> struct StaticPlanFor<100> { using type = StaticPlan<100, 10, 10>; };
@@ -427,6 +427,19 @@ template <> struct StaticPlanFor<2048> { using type = StaticPlan<2048, 16, 16, 8
 template <int N_> struct StaticTilePlanFor { using type = typename StaticPlanFor<N_>::type; };
 template <> struct StaticTilePlanFor<192> { using type = StaticPlan<192, 12, 16>; };
 template <> struct StaticTilePlanFor<240> { using type = StaticPlan<240, 15, 16>; };
+template <> struct StaticTilePlanFor<288> { using type = StaticPlan<288, 6, 6, 8>; };
+template <> struct StaticTilePlanFor<320> { using type = StaticPlan<320, 5, 8, 8>; };
+template <> struct StaticTilePlanFor<400> { using type = StaticPlan<400, 10, 5, 8>; };
+template <> struct StaticTilePlanFor<432> { using type = StaticPlan<432, 9, 6, 8>; };
+template <> struct StaticTilePlanFor<480> { using type = StaticPlan<480, 10, 6, 8>; };
+template <> struct StaticTilePlanFor<576> { using type = StaticPlan<576, 9, 8, 8>; };
+template <> struct StaticTilePlanFor<720> { using type = StaticPlan<720, 10, 9, 8>; };
+template <> struct StaticTilePlanFor<800> { using type = StaticPlan<800, 10, 10, 8>; };
+template <> struct StaticTilePlanFor<864> { using type = StaticPlan<864, 12, 9, 8>; };
+template <> struct StaticTilePlanFor<960> { using type = StaticPlan<960, 12, 10, 8>; };
+template <> struct StaticTilePlanFor<1600> { using type = StaticPlan<1600, 10, 10, 16>; };
+template <> struct StaticTilePlanFor<1920> { using type = StaticPlan<1920, 12, 10, 16>; };
+template <> struct StaticTilePlanFor<2000> { using type = StaticPlan<2000, 10, 5, 5, 8>; };
 
 // all stages of a static plan; twl: the workgroup's LDS copy of the plan's twiddles.  Returns the image that holds the result.
 // ---- software pipeline of the compile-time lists (round 3): the first stage's operands of the NEXT group of frames are

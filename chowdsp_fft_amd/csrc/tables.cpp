@@ -333,6 +333,27 @@ static void generic_radices (int n, std::vector<int>& radix, int frames_override
     // (frames_override > 0: the list of a tile kernel, whose stages run LDS to LDS -- the sorted order stays)
     if (CFFT_TWO_STAGE_FULL_LINE && frames_override == 0 && best.size() == 2 && n != 160 && (n / best[1]) % 16 != 0 && (n / best[0]) % 16 == 0)
         std::swap (best[0], best[1]);
+    // Three and more stages, same idea: the last stage stores runs of n / (its radix) points; where that is not a whole number of
+    // 128-byte lines and moving another radix of the list to the end makes it one, the smallest such radix goes last
+    // (480 = 10 x 6 x 8 -> 10 x 8 x 6: runs of 80 points instead of 60; c480 0.594 -> 0.652 of 8 TB/s).  Lengths in
+    // kKeepSortedOrder measured no gain or a loss (profiles/r03_last_stage_order_ab.txt).
+    if (CFFT_TWO_STAGE_FULL_LINE && frames_override == 0 && best.size() >= 3 && (n / best.back()) % 16 != 0)
+    {
+        static const int kKeepSortedOrder[] = { 0 };
+        bool keep = false;
+        for (int k : kKeepSortedOrder)
+            keep = keep || k == n;
+        int pick = -1;
+        for (size_t i = 0; i < best.size() && ! keep; ++i)
+            if ((n / best[i]) % 16 == 0 && (pick < 0 || best[i] < best[(size_t) pick]))
+                pick = (int) i;
+        if (pick >= 0)
+        {
+            const int r = best[(size_t) pick];
+            best.erase (best.begin() + pick);
+            best.push_back (r);
+        }
+    }
     radix = best;
 }
 
