@@ -5,6 +5,7 @@
 #include "plans.hpp"
 
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 
 namespace cfft::host
@@ -93,14 +94,35 @@ bool tile_runs_inplace (int n)
 
 bool split_static_pair (int n_complex, int max_factor, int& n1, int& n2)
 {
+    // Among the factorisations into two static tile lengths of at most max_factor points: the most balanced one in which a factor
+    // is a multiple of 16 (and the other at most five times as long) -- both, if the length allows --, else the most balanced one.  The COLUMN
+    // length n2 is the pitch of pass B's 16-point store runs: the smaller factor, unless that is not a multiple of 8 while the
+    // other has more factors of two (100000 = 250 x 400, not 400 x 250; but 48000 = 240 x 200: 0.300 against 200 x 240 0.285).  Measured on MI355X (tools/gpu_r3_general_split_ab.sh, n1 x n2, fraction
+    // of 8 TB/s): 34992 = 216 x 162 0.222, 162 x 216 0.253, 243 x 144 0.267; 100000 = 400 x 250 0.223, 250 x 400 0.252;
+    // 30000 = 200 x 150 0.236, 150 x 200 0.259, 375 x 80 0.265 -- but 625 x 48 0.209 and 50000 = 625 x 80 0.210 against
+    // 250 x 200 0.257 (too lopsided).
     n1 = n2 = 0;
+    int best_d[3] = { 0, 0, 0 }; // by the number of factors that are multiples of 16; within a class the largest d (closest to sqrt(n))
     for (int d = 1; (long long) d * d <= (long long) n_complex; ++d)
-        if (n_complex % d == 0 && n_complex / d <= max_factor && has_static_tile (d) && has_static_tile (n_complex / d))
-        {
-            n2 = d; // the largest such d wins: closest to sqrt(n)
-            n1 = n_complex / d;
-        }
-    return n2 != 0;
+    {
+        if (n_complex % d != 0)
+            continue;
+        const int e = n_complex / d;
+        if (e > max_factor || ! has_static_tile (d) || ! has_static_tile (e))
+            continue;
+        const int aligned = (d % 16 == 0 ? 1 : 0) + (e % 16 == 0 ? 1 : 0);
+        best_d[(aligned > 0 && (long long) e > 5ll * d) ? 0 : aligned] = d;
+    }
+    const int d = best_d[2] != 0 ? best_d[2] : (best_d[1] != 0 ? best_d[1] : best_d[0]);
+    if (d == 0)
+        return false;
+    const int e = n_complex / d;
+    const auto twos = [] (int v) { int c = 0; while (v % 2 == 0) { v /= 2; ++c; } return c; };
+    // d <= e: the smaller factor is the column length unless it is not even a multiple of 8 and the other has more factors of two
+    const bool d_is_column = twos (d) >= 3 || twos (d) >= twos (e);
+    n2 = d_is_column ? d : e;
+    n1 = d_is_column ? e : d;
+    return true;
 }
 
 bool split_mixed (int n_complex, int& n1, int& n2)
@@ -155,6 +177,17 @@ bool split_general (int n_complex, int& n1, int& n2)
     n1 = n2 = 0;
     if (n_complex <= 0)
         return false;
+    // developer knob: CHOWDSP_FFT_GENERAL_SPLIT = "<n1>x<n2>" forces the general split of the one length it multiplies to (A/B of splits)
+    if (const char* e = std::getenv ("CHOWDSP_FFT_GENERAL_SPLIT"))
+    {
+        int a = 0, b = 0;
+        if (std::sscanf (e, "%dx%d", &a, &b) == 2 && a > 1 && b > 1 && (long long) a * b == (long long) n_complex)
+        {
+            n1 = a;
+            n2 = b;
+            return n1 <= kGeneralMaxFactor && n2 <= kGeneralMaxFactor;
+        }
+    }
     // two static tile lengths where the length has such a factorisation (38400 = 240 x 160 rather than 200 x 192), both of at
     // most 639 points (16-column tiles on both sides) if possible ...
     if (split_static_pair (n_complex, kMixedMaxN2Wide, n1, n2) || split_static_pair (n_complex, kTileInplaceWideMaxN, n1, n2) || split_static_pair (n_complex, 2048, n1, n2))

@@ -132,7 +132,8 @@ bool has_static_tile (int n);
 #endif
 static constexpr int kTileInplaceMinN = CFFT_TILE_INPLACE_MIN_N;
 bool tile_runs_inplace (int n);
-// n = n1 * n2 with both factors static tile lengths of at most max_factor, n2 <= n1, as close to each other as possible
+// n = n1 * n2 with both factors static tile lengths of at most max_factor (which pair and which of them is the column length
+// n2: see tables.cpp)
 bool split_static_pair (int n_complex, int max_factor, int& n1, int& n2);
 static constexpr int kGeneralMaxFactor = 2559; // two LDS images of 4 frames of n + 1 points
 static constexpr int kMaxComplexLen = 1 << 21;

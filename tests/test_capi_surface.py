@@ -166,7 +166,9 @@ def test_plan_describe_host_logic():
     # factors into their neighbours, stages with an odd factor first
     d = api.plan_describe(480, api.FFT_COMPLEX)
     assert (d["complex_len"], d["passes"], d["n1"], d["n2"]) == (480, 1, 0, 0)
-    assert sorted(d["radices"]) == [6, 8, 10] and d["radices"][-1] == 8
+    # ... ordered so that the last stage stores whole 128-byte lines: runs of 480 / 6 = 80 points (tables.cpp: generic_radices)
+    assert d["radices"][:3] == [10, 8, 6] and (480 // d["radices"][2]) % 16 == 0
+    assert api.plan_describe(192, api.FFT_COMPLEX)["radices"][:2] == [16, 12] and api.plan_describe(160, api.FFT_COMPLEX)["radices"][:2] == [10, 16]
     assert api.plan_describe(9216, api.FFT_COMPLEX)["radices"] == [12, 12, 8, 8]
     assert api.plan_describe(96, api.FFT_REAL)["complex_len"] == 48
 

@@ -234,15 +234,15 @@ def test_fused_convolution_mixed_radix(gpu, oracle, n, tr):
 
 def test_workspace_bytes_reports_what_is_allocated(gpu):
     """fft_gpu_workspace_bytes and the allocation share one helper (capi.cpp workspace_frame_bytes).  Known answers: the
-    ragged generic-column plan 34992 = 216 x 162 pads its 216 columns to 14 tiles of 16 (224 x 162 x 8 bytes per frame, not
+    ragged generic-column plan 34992 = 243 x 144 pads its 243 columns to 16 tiles of 16 (256 x 144 x 8 bytes per frame, not
     34992 x 8); N = 2^17 keeps the plain frame; single-pass plans cache nothing; and the device's free memory drops by
     about that much on the first call."""
     api, torch, dev = gpu
     s = api.fft_new_setup(34992, api.FFT_COMPLEX)
     desc = api.plan_describe(34992, api.FFT_COMPLEX)
-    assert desc["passes"] == 2 and sorted((desc["n1"], desc["n2"])) == [162, 216]
+    assert desc["passes"] == 2 and (desc["n1"], desc["n2"]) == (243, 144)
     batch = 64
-    frame = 224 * 162 * 8
+    frame = 256 * 144 * 8
     want = 2 * batch * frame  # two lanes, the whole batch in one chunk per lane at most
     got = api.workspace_bytes(s, batch)
     assert got in (want, batch * frame * 2), (got, want)
@@ -305,13 +305,12 @@ def test_frames_beyond_2_21(gpu, oracle, n, tr):
 # fft_gpu_plan_describe over the products of two static lengths).  The workgroups are persistent and request their NEXT tile
 # while the current one is in the stages, so the batch is made large enough that every workgroup walks through several tiles (a
 # batch of a few frames would end after the first); the frames repeat five distinct ones, each checked against the oracle.
-STATIC_TILE_SIZES = [20480, 20736, 21600, 23040, 23328, 24000, 24576, 25600, 25920, 27648, 28800, 30000, 30720, 31104, 32400, 34992, 38400, 40000,
-                     46080, 46656, 50000, 54000, 58320, 62208, 64000, 64800, 69120, 69984, 76800, 77760, 80000, 82944, 90000, 93312, 98304, 100000,
-                     103680, 104976, 108000, 120000, 124416, 129600, 139968, 144000, 153600, 155520, 174960, 180000, 184320, 200000, 209952, 216000,
-                     230400, 248832, 250000, 259200, 276480, 279936, 291600, 300000, 314928, 320000, 331776, 360000, 368640, 384000, 400000, 414720,
-                     419904, 432000, 450000, 480000, 486000, 497664, 500000, 524880, 559872, 576000, 614400, 622080, 629856, 640000, 699840, 720000,
-                     746496, 750000, 768000, 810000, 839808, 921600, 944784, 995328, 1000000, 1036800, 1105920, 1119744, 1152000, 1166400, 1179648,
-                     1200000, 1250000, 1259712, 1280000, 1296000, 1310720, 1572864, 1600000, 1620000, 1679616, 1944000, 2073600, 2097152]
+STATIC_TILE_SIZES = [20480, 20736, 21600, 23040, 23328, 24000, 24576, 25600, 27648, 28800, 30000, 30720, 31104, 32000, 32400, 34560, 34992, 40000,
+                     41472, 48000, 50000, 51840, 62208, 64800, 69984, 76800, 80000, 86400, 93312, 98304, 100000, 116640, 144000, 180000, 184320,
+                     200000, 209952, 216000, 248832, 250000, 256000, 259200, 279936, 291600, 307200, 314928, 324000, 349920, 373248, 384000, 388800,
+                     400000, 414720, 432000, 450000, 466560, 480000, 500000, 540000, 552960, 559872, 614400, 629856, 648000, 720000, 750000, 768000,
+                     800000, 810000, 839808, 921600, 944784, 995328, 1000000, 1024000, 1049760, 1119744, 1250000, 1259712, 1280000, 1310720, 1399680,
+                     1474560, 1572864, 1600000, 1620000, 1728000, 1800000, 1944000, 2097152, 2160000, 2239488, 2359296, 2949120, 4194304]
 
 
 @pytest.mark.parametrize("n", STATIC_TILE_SIZES)
