@@ -75,6 +75,13 @@ __device__ __forceinline__ void tile_fft_frames (float2* __restrict__ smem, cons
 // -> pass A stores one fully contiguous n2*CA block per tile, pass B gathers CB*CA-element (2 KiB) runs.
 // The inter-pass twiddle table uses the same order, so its reads are contiguous as well.
 
+// loads in flight per work-item in the tile loops of pass_a_kernel / pass_b_kernel.  A/B on MI355X (tools/gpu_r3_pow2_tile_unroll_ab.sh,
+// 4 / 8 / 16, fraction of 8 TB/s): c61440 0.319 / 0.327 / 0.310, c245760 0.289 / 0.287 / 0.164, c24576 0.320 / 0.171 / 0.180,
+// c655360 0.246 / 0.240 / 0.149 -- more than four gains nothing and spills in the 1024-work-item variants
+#ifndef CFFT_POW2_TILE_UNROLL
+#define CFFT_POW2_TILE_UNROLL 4
+#endif
+
 // ---- pass A: n2-point column FFTs of CA adjacent columns, times W_N^{a*kb} ----------------------------
 template <class P, int CA, bool SWAP_IN, int BLOCK>
 __global__ __launch_bounds__ (BLOCK) void pass_a_kernel (const float2* __restrict__ in,
@@ -107,7 +114,7 @@ __global__ __launch_bounds__ (BLOCK) void pass_a_kernel (const float2* __restric
         const float2* __restrict__ twp = big_tw + (size_t) tile * (n2 * CA);
 
         __syncthreads(); // previous tile fully stored
-#pragma unroll 4
+#pragma unroll CFFT_POW2_TILE_UNROLL
         for (int e = tid; e < CA * n2; e += BLOCK)
         {
             const int c = e % CA, j = e / CA;
@@ -117,7 +124,7 @@ __global__ __launch_bounds__ (BLOCK) void pass_a_kernel (const float2* __restric
         __syncthreads();
         tile_fft_frames<P, CA, BLOCK> (smem, tw, stage_tw, team, t);
         __syncthreads();
-#pragma unroll 4
+#pragma unroll CFFT_POW2_TILE_UNROLL
         for (int e = tid; e < CA * n2; e += BLOCK)
         {
             const int c = e % CA, k = e / CA;
@@ -159,7 +166,7 @@ __global__ __launch_bounds__ (BLOCK) void pass_b_kernel (const float2* __restric
         float2* __restrict__ dst = out + (size_t) f * out_stride + kb0;
 
         __syncthreads();
-#pragma unroll 4
+#pragma unroll CFFT_POW2_TILE_UNROLL
         for (int e = tid; e < CB * n1; e += BLOCK)
         {
             // c fastest (ca), then the tile's row kbl (CB), then pass A's tile index tA
@@ -172,7 +179,7 @@ __global__ __launch_bounds__ (BLOCK) void pass_b_kernel (const float2* __restric
         __syncthreads();
         tile_fft_frames<P, CB, BLOCK> (smem, tw, stage_tw, team, t);
         __syncthreads();
-#pragma unroll 4
+#pragma unroll CFFT_POW2_TILE_UNROLL
         for (int e = tid; e < CB * n1; e += BLOCK)
         {
             const int c = e % CB, k = e / CB;
