@@ -520,6 +520,11 @@ __device__ __forceinline__ float2* static_core (const float2* twl, float2* a, fl
     }
 }
 
+// 48 and 80 (round 3, tools/gpu_r3_staged_48_80_ab.sh, direct / staged, fraction of 8 TB/s): c48 0.538 / 0.561, c80 0.546 / 0.558,
+// real N = 96 0.537 / 0.594, real N = 160 0.540 / 0.620 (round 2 had measured no difference for the complex ones)
+#ifndef CFFT_GENERIC_STAGED_48_80
+#define CFFT_GENERIC_STAGED_48_80 1
+#endif
 #ifndef CFFT_GENERIC_STAGED_160
 #define CFFT_GENERIC_STAGED_160 1
 #endif
@@ -530,9 +535,9 @@ __device__ __forceinline__ float2* static_core (const float2* twl, float2* a, fl
 // (profiles/r02_generic_staged_io_ab.txt, staged against direct, GB/s): 96 5419 / 4509, 144 5169 / 4304, 160 5494 / 4556 -- but
 // 48 4142 / 4189, 80 4139 / 4214 (no difference) and 192 3858 / 4442, 240 3813 / 4396 (their radix-16 last stage writes the
 // image at a pitch of 12 / 15 points: LDS conflicts cost more than the half-used lines did).
-__host__ __device__ constexpr bool generic_staged_io (int n) { return n <= CFFT_GENERIC_STAGED_MAX_N && (n == 96 || n == 144 || (CFFT_GENERIC_STAGED_160 != 0 && n == 160)); }
+__host__ __device__ constexpr bool generic_staged_io (int n) { return n <= CFFT_GENERIC_STAGED_MAX_N && (n == 96 || n == 144 || (CFFT_GENERIC_STAGED_160 != 0 && n == 160) || (CFFT_GENERIC_STAGED_48_80 != 0 && (n == 48 || n == 80))); }
 // ... and whose REAL transforms (N = 2 n) do: real N = 192 4677 / 4423, 288 4767 / 4407 -- but 320 3368 / 3856
-__host__ __device__ constexpr bool generic_staged_io_real (int n) { return n <= CFFT_GENERIC_STAGED_MAX_N && (n == 96 || n == 144); }
+__host__ __device__ constexpr bool generic_staged_io_real (int n) { return n <= CFFT_GENERIC_STAGED_MAX_N && (n == 96 || n == 144 || (CFFT_GENERIC_STAGED_48_80 != 0 && (n == 48 || n == 80))); }
 template <class SP>
 struct SP_N_OR_ZERO
 {
