@@ -117,7 +117,7 @@ template <bool REAL>
 hipError_t launch_conv_m (GenericPlan& plan, const DeviceTables& t, const float2* in, const float2* H, float2* out, float scaling, size_t batch, hipStream_t stream)
 {
     int block = 256;
-    generic_geometry (plan.n, plan.frames, block, REAL);
+    generic_geometry (plan.n, plan.frames, block, REAL, true);
     if (generic_uses_inplace (plan.n))
     {
         if ((plan.n + block - 1) / block > kInplaceMaxPoints)

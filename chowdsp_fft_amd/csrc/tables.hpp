@@ -51,7 +51,7 @@ bool size_supported (int N, int transform);
 bool core_radices (int n, int radix[4]);
 // launch geometry of the generic mixed-radix kernel for complex length n: frames per workgroup pass and work-items
 // per workgroup (shared by the radix choice in tables.cpp and the launcher in kernels_generic.hip)
-inline void generic_geometry (int n, int& frames, int& block, bool real_transform = false)
+inline void generic_geometry (int n, int& frames, int& block, bool real_transform = false, bool fused_conv = false)
 {
     // Long frames (n > 2048): one frame per workgroup in ONE LDS image with in-place stages (generic_inplace_kernel); the
     // workgroup grows with n so that a work-item never holds more than 20 points of a stage.
@@ -76,15 +76,21 @@ inline void generic_geometry (int n, int& frames, int& block, bool real_transfor
     //   n = 96 (complex 96, real 192): 1536 -> +1.5 % / +8 %;  n = 144: +11 % / +11 %;  n = 160: 0 / +16 %;
     //   complex 48 / 80 / 192 / 432 / 576 / 768 / 800 / 960: 3072 -> +5 / +10 / +4 / +8 / +7 / +10 / +5 / +6 %
     //   (their real counterparts lose 10-20 % with 3072 and keep 2048).  CFFT_GENERIC_POINTS_TUNED = 0: 2048 everywhere.
+    // Round 3, after the radix lists were re-ordered and 48 / 80 moved to the staged-I/O form (tools/gpu_r3_points_ab.sh,
+    // profiles/r03_generic_points_ab.txt): complex 48 / 80 now do best with 1536 (0.56 -> 0.66 / 0.64); complex 240 / 320 / 400 /
+    // 640 / 864 gain 8 / 5 / 2 / 7 / 5 % with 3072; the real transforms keep their choices.
 #ifndef CFFT_GENERIC_POINTS_TUNED
 #define CFFT_GENERIC_POINTS_TUNED 1
 #endif
     int points = CFFT_GENERIC_POINTS;
     if (CFFT_GENERIC_POINTS_TUNED)
     {
-        if (n == 96 || n == 144 || n == 160)
+        // (fused_conv: the one-launch convolution keeps the round-2 choices -- it was not part of the round-3 re-measurement, and
+        // c240 lost 5 % with 3072)
+        if (n == 96 || n == 144 || n == 160 || (! real_transform && ! fused_conv && (n == 48 || n == 80)))
             points = 1536;
-        else if (! real_transform && (n == 48 || n == 80 || n == 192 || n == 432 || n == 576 || n == 768 || n == 800 || n == 960))
+        else if (! real_transform && (n == 192 || n == 432 || n == 576 || n == 768 || n == 800 || n == 960 || (fused_conv && (n == 48 || n == 80))
+                                      || (! fused_conv && (n == 240 || n == 320 || n == 400 || n == 640 || n == 864))))
             points = 3072;
     }
     frames = (n <= CFFT_GENERIC_MULTI_MAX) ? (points / n > 1 ? points / n : 1) : 1;
