@@ -266,3 +266,25 @@ def test_header_is_consumable_and_links(tmp_path, lang, compiler, std, src):
     assert r.returncode == 0, r.stderr
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+
+
+def test_round3_planner_rules_host_logic():
+    """Planner rules of round 3, through fft_gpu_plan_describe (pure host logic).
+    (a) single-pass mixed-radix plans: where some order of the plan's radices lets the last stage store whole 128-byte lines
+        (runs of n / r_last points, a multiple of 16), the plan has such an order (tables.cpp: generic_radices; 160 is the one
+        exception: it runs the staged-I/O form with the sorted list);
+    (b) long plans: the pair of tile lengths and which of them is the column length n2 (tables.cpp: split_static_pair)."""
+    for n in (192, 240, 288, 320, 384, 400, 432, 480, 576, 640, 720, 768, 800, 864, 960, 1152, 1280, 1536, 1600, 1920, 2000):
+        d = api.plan_describe(n, api.FFT_COMPLEX)
+        rad = [r for r in d["radices"] if r]
+        prod = 1
+        for r in rad:
+            prod *= r
+        assert d["passes"] == 1 and prod == n, (n, d)
+        if any((n // r) % 16 == 0 for r in rad):
+            assert (n // rad[-1]) % 16 == 0, (n, rad)
+    assert api.plan_describe(160, api.FFT_COMPLEX)["radices"][:2] == [10, 16]
+    for n, want in ((34992, (243, 144)), (100000, (250, 400)), (48000, (240, 200)), (46080, (240, 192)), (38400, (240, 160)),
+                    (20736, (144, 144)), (30000, (375, 80)), (1 << 22, (2048, 2048)), (245760, (1024, 240))):
+        d = api.plan_describe(n, api.FFT_COMPLEX)
+        assert d["passes"] == 2 and (d["n1"], d["n2"]) == want, (n, d)
