@@ -18,11 +18,13 @@ def source_files():
     files = []
     for pat in ("*.hpp", "*.hip", "*.cpp", "Makefile"):
         files += glob.glob(os.path.join(csrc, pat))
-    return sorted(files)
+    # the public headers are prerequisites of every object (Makefile HDRS)
+    files += glob.glob(os.path.join(_HERE, "..", "include", "*.h"))
+    return sorted(os.path.normpath(f) for f in files)
 
 
 def source_sha256() -> str:
-    """sha256 over the names and contents of csrc/*.{hpp,hip,cpp} + Makefile (what the shared object is built from)"""
+    """sha256 over the names and contents of csrc/*.{hpp,hip,cpp} + Makefile + include/*.h (what the shared object is built from)"""
     h = hashlib.sha256()
     for path in source_files():
         h.update(os.path.basename(path).encode() + b"\0")

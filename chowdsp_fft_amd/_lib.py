@@ -66,6 +66,7 @@ PROTOTYPES = {
     "fft_transform_host_batch": (_i, [_vp, _fp, _fp, _sz, _i]),
     "fft_gpu_shard_range": (_i, [_sz, _i, _i, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "fft_transform_batch_multi_gpu": (_i, [C.POINTER(C.c_void_p), _i, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), _i]),
+    "fft_convolve_frames_batch_multi_gpu": (_i, [C.POINTER(C.c_void_p), _i, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), _f]),
     "fft_gather_multi_gpu": (_i, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_size_t), _i, C.POINTER(C.c_void_p), C.POINTER(C.c_int), _i]),
     "fft_conv_engine_create": (_vp, [_i, _i, _fp, _i, _i, _vp]),
     "fft_conv_engine_process": (_i, [_vp, _fp, _fp, _vp]),

@@ -277,6 +277,16 @@ def fft_transform_batch_multi_gpu(setups, inputs, outputs, counts, direction: in
                                                     (C.c_size_t * n)(*counts), direction), "fft_transform_batch_multi_gpu")
 
 
+def fft_convolve_frames_batch_multi_gpu(setups, xs, dft_filters, ys, counts, scaling: float) -> None:
+    """fft_convolve_frames_batch_multi_gpu: shard d = counts[d] frames, ys[d] = BACKWARD(FORWARD(xs[d]) * dft_filters[d] * scaling)
+    on the device of setups[d]; dft_filters[d] = the filter spectrum replicated on that device"""
+    n = len(setups)
+    vp = C.c_void_p * n
+    _check(_lib.lib().fft_convolve_frames_batch_multi_gpu(vp(*setups), n, vp(*[_ptr(a) for a in xs]), vp(*[_ptr(a) for a in dft_filters]),
+                                                          vp(*[_ptr(a) for a in ys]), (C.c_size_t * n)(*counts), scaling),
+           "fft_convolve_frames_batch_multi_gpu")
+
+
 def fft_gather_multi_gpu(shards, shard_devices, dsts, dst_devices) -> None:
     """fft_gather_multi_gpu: every shard tensor is copied, in order, into every non-None destination tensor"""
     n, m = len(shards), len(dsts)

@@ -332,6 +332,30 @@ unsigned take_fused_error (hipStream_t stream)
     return word;
 }
 
+} // namespace
+namespace cfft::host
+{
+// THE way a synchronous library entry point waits for a stream: hipStreamSynchronize + the hand-off report of the one-launch
+// two-pass forms (which validate their results only at a library synchronisation).  A launch whose bounded waits ran out
+// turns into FFT_GPU_ELAUNCH here, with its number in fft_gpu_last_error(); the word is cleared, the next call starts clean.
+int sync_stream_checked (hipStream_t stream, const char* what)
+{
+    const hipError_t e = hipStreamSynchronize (stream);
+    if (e != hipSuccess)
+    {
+        set_last_error (what, e);
+        return cf::FFT_GPU_ELAUNCH;
+    }
+    if (const unsigned w = take_fused_error (stream))
+    {
+        set_last_error (fused_error_text (w).c_str());
+        return cf::FFT_GPU_ELAUNCH;
+    }
+    return cf::FFT_GPU_OK;
+}
+} // namespace cfft::host
+namespace
+{
 // caller holds g_ws_mutex
 Lanes* get_fused (int device, hipStream_t stream, size_t ws_bytes)
 {
@@ -893,11 +917,16 @@ int deferred_flush()
             rc = run_transform (s, din, dout, count, (cf::fft_direction_t) gdir, nullptr, 0, 0);
         if (rc == cf::FFT_GPU_OK && hipMemcpyAsync (pin_out + pos, dout, count * nf * sizeof (float), hipMemcpyDeviceToHost, nullptr) != hipSuccess)
             rc = cf::FFT_GPU_ELAUNCH;
-        if (rc == cf::FFT_GPU_OK && hipStreamSynchronize (nullptr) != hipSuccess)
-            rc = cf::FFT_GPU_ELAUNCH;
+        bool said = false;
+        if (rc == cf::FFT_GPU_OK)
+        {
+            rc = sync_stream_checked (nullptr, "fft_gpu_defer_flush: synchronisation");
+            said = rc != cf::FFT_GPU_OK; // (keeps the hand-off report's text: it names the launch)
+        }
         if (rc != cf::FFT_GPU_OK)
         {
-            set_last_error ("fft_gpu_defer_flush: a batched transform failed; the recorded calls' outputs were not written");
+            if (! said)
+                set_last_error ("fft_gpu_defer_flush: a batched transform failed; the recorded calls' outputs were not written");
             return rc;
         }
         pos += count * nf;
@@ -973,11 +1002,7 @@ void legacy_transform (void* setup, const float* input, float* output, cf::fft_d
     {
         if (run_transform (s, input, output, 1, direction, nullptr) == cf::FFT_GPU_OK)
         {
-            CFFT_HIP_TRY (hipStreamSynchronize (nullptr), (void) 0);
-            // (a one-launch two-pass transform validates its hand-offs at a library synchronisation: this is one)
-            if (fused_enabled())
-                if (const unsigned w = take_fused_error (nullptr))
-                    set_last_error (fused_error_text (w).c_str());
+            (void) sync_stream_checked (nullptr, "fft_transform: synchronisation"); // records its reason (void entry point)
         }
         return;
     }
@@ -989,7 +1014,8 @@ void legacy_transform (void* setup, const float* input, float* output, cf::fft_d
             std::memcpy (pin, input, nf * sizeof (float));
             if (run_transform (s, pin, pin + nf, 1, direction, nullptr) != cf::FFT_GPU_OK)
                 return; // run_transform recorded the error
-            CFFT_HIP_TRY (hipStreamSynchronize (nullptr), (void) 0);
+            if (sync_stream_checked (nullptr, "fft_transform: synchronisation") != cf::FFT_GPU_OK)
+                return;
             std::memcpy (output, pin + nf, nf * sizeof (float));
             return;
         }
@@ -1013,7 +1039,7 @@ void legacy_transform (void* setup, const float* input, float* output, cf::fft_d
         return;
     if (! out_dev)
         CFFT_HIP_TRY (hipMemcpyAsync (output, dout, nf * sizeof (float), hipMemcpyDeviceToHost, nullptr), (void) 0);
-    CFFT_HIP_TRY (hipStreamSynchronize (nullptr), (void) 0);
+    (void) sync_stream_checked (nullptr, "fft_transform: synchronisation");
 }
 
 // legacy three-operand entry (convolve / accumulate): stage whichever operands live in host memory.
@@ -1261,15 +1287,9 @@ int fft_gpu_memcpy (void* dst, const void* src, size_t nb_bytes, int kind, void*
 
 int fft_gpu_stream_synchronize (void* stream)
 {
-    CFFT_HIP_TRY (hipStreamSynchronize ((hipStream_t) stream), FFT_GPU_ELAUNCH);
     // the one-launch two-pass forms validate their hand-offs here: a launch whose bounded waits ran out is reported by the
     // synchronisation that follows it, by number
-    if (const unsigned w = take_fused_error ((hipStream_t) stream))
-    {
-        set_last_error (fused_error_text (w).c_str());
-        return FFT_GPU_ELAUNCH;
-    }
-    return FFT_GPU_OK;
+    return sync_stream_checked ((hipStream_t) stream, "fft_gpu_stream_synchronize");
 }
 
 const char* fft_gpu_last_error (void) { return last_error(); }
@@ -1480,6 +1500,8 @@ int fft_gpu_set_option (const char* name, long value)
         set_group_options (value != 0 ? 1 : 0, -1);
     else if (std::strcmp (name, "group_reg_polls") == 0 && value >= 0 && value <= 1000000)
         set_group_options (-1, (int) value);
+    else if (std::strcmp (name, "group_spin_limit") == 0 && value >= 0 && value < 65536)
+        set_group_spin_limit ((int) value); // developer option: tests force the hand-off waits to run out (1); 0 = built-in limit
     else if (std::strcmp (name, "wave4096") == 0)
         set_wave4096 (value != 0);
     else if (std::strcmp (name, "split16384") == 0)
@@ -1513,6 +1535,8 @@ long fft_gpu_get_option (const char* name)
         return o.enabled.load();
     if (std::strcmp (name, "fused_min_batch") == 0)
         return o.min_batch.load();
+    if (std::strcmp (name, "group_spin_limit") == 0)
+        return get_group_spin_limit();
     if (std::strcmp (name, "fused_lag") == 0)
         return o.lag.load();
     if (std::strcmp (name, "fused_slots") == 0)
@@ -1570,6 +1594,10 @@ size_t fft_gpu_workspace_bytes (void* setup, size_t batch)
         split_large (complex_len (s), n1, n2);
     if (s->transform == FFT_COMPLEX && fused_enabled() && fused_supported (n1, n2) && batch >= fused_min_batch())
         return (fused_form() == 2 ? group_workspace_bytes() : fused_workspace_bytes (complex_len (s), fused_slots())) + std::max (fused_state_bytes(), group_state_bytes());
+    // (the same conditions as big_c2c_chunked's register-direct group branch, N = 2^17 / 2^18)
+    if (s->transform == FFT_COMPLEX && s->tables->mixed_n2 == 0 && fused_form() == 2 && s->tables->fast_n1 > 0 && groupfast_supported (n1, n2) && g_group_fast.load() != 0
+        && batch >= std::max<size_t> (1, fused_min_batch() / 4))
+        return groupfast_workspace_bytes (n1, n2) + std::max (fused_state_bytes(), group_state_bytes());
     size_t chunk = workspace_cap() / (size_t) lane_count() / frame_bytes;
     if (s->transform == FFT_REAL && s->tables->real4_r1 == 0)
         chunk /= pair_chunk_divisor(); // the pair stage's operands share the cache with the two workspaces

@@ -39,13 +39,13 @@ __device__ __forceinline__ bool flags_reached_m (const unsigned* flags, unsigned
     return __all (f >= need) != 0;
 }
 template <int M, int SLEEP>
-__device__ __forceinline__ void group_wait_m (const unsigned* flags, unsigned need, int lane, GroupState* st, unsigned* host_err, unsigned seq, unsigned code)
+__device__ __forceinline__ void group_wait_m (const unsigned* flags, unsigned need, int lane, GroupState* st, unsigned* host_err, unsigned seq, unsigned code, unsigned spin_limit)
 {
     unsigned n = 0;
     while (! flags_reached_m<M> (flags, need, lane))
     {
         __builtin_amdgcn_s_sleep (SLEEP);
-        if (++n > kFusedSpinLimit)
+        if (++n > spin_limit)
         {
             if (lane == 0)
                 group_fail (st, host_err, seq, code);
@@ -83,6 +83,8 @@ __global__ __launch_bounds__ (256, 1) void groupfast_kernel (const float2* __res
     const int sub_b = tid0 / FB::threads, tb0 = tid0 % FB::threads;
     float* __restrict__ plane_a = gf_plane + (size_t) sub_a * GF::plane_a;
     float* __restrict__ plane_b = gf_plane + (size_t) sub_b * GF::plane_b;
+    const unsigned spin_limit = group_spin_limit (force_solo);
+    force_solo &= 255u;
     if (tid0 == 0)
         group_register (st, info, reg_polls, force_solo, (unsigned) GF::M);
     __syncthreads();
@@ -173,7 +175,7 @@ __global__ __launch_bounds__ (256, 1) void groupfast_kernel (const float2* __res
             ft_stage1_all<FA> (v, wa, wa, wa, wa);
             CFFT_PHASE_FENCE();
             if (k != 0)
-                group_wait_m<GF::M, 1> (bf, k, tid0 & 63, st, host_err, seq, 2u); // every member has read frame k - 1 out of the slot
+                group_wait_m<GF::M, 1> (bf, k, tid0 & 63, st, host_err, seq, 2u, spin_limit); // every member has read frame k - 1 out of the slot
             CFFT_GF_PASS_A_STORE (v, a0, slot, bw, ta)
             // With one workgroup per CU the wait for the group is idle time for the whole CU: the next frame's operands can be in
             // flight during it.  Vector memory operations retire in issue order, so the polling wave's flag loads would come back
@@ -191,7 +193,7 @@ __global__ __launch_bounds__ (256, 1) void groupfast_kernel (const float2* __res
             if (tid0 == 0)
                 flag_store (&af[member], k + 1u);
             if (tid0 < 64)
-                group_wait_m<GF::M, 2> (af, k + 1u, tid0, st, host_err, seq, 1u);
+                group_wait_m<GF::M, 2> (af, k + 1u, tid0, st, host_err, seq, 1u, spin_limit);
             __syncthreads();
             // ---- pass B: rows [kb0, kb0 + 16) of the slot
             {

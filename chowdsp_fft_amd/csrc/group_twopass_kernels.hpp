@@ -161,6 +161,14 @@ __device__ __forceinline__ void group_register (GroupState* __restrict__ st, uns
             total += g;
         }
         valid = (r / members < mine) ? 1u : 0u; // a rank beyond the last complete group has nothing to do
+        // No XCD has a complete group (a small grid: CU mask, an occupancy drop, a small partition): nobody would transform
+        // anything.  The counts are final and the same for every workgroup, so every workgroup takes this decision alike:
+        // the launch runs in the fall-back mode.
+        if (total == 0)
+        {
+            mode = 2;
+            valid = 1;
+        }
     }
     info[0] = mode;
     info[1] = xcc;
@@ -170,15 +178,24 @@ __device__ __forceinline__ void group_register (GroupState* __restrict__ st, uns
     info[5] = valid;
 }
 
+// The `force_solo` kernel argument of the group kernels carries two developer fields besides bit 0 (force the fall-back mode):
+// bits 8..15 the timing-only switches of CFFT_GROUP_EXPERIMENT builds, bits 16..31 a spin limit that replaces kFusedSpinLimit
+// (option "group_spin_limit"; tests set 1 so that a bounded wait DOES run out and the failure path can be exercised end to end).
+__device__ __forceinline__ unsigned group_spin_limit (unsigned force_solo_arg)
+{
+    const unsigned v = force_solo_arg >> 16;
+    return v != 0 ? v : kFusedSpinLimit;
+}
+
 // one wave: wait until the group's 16 flags at `flags` have reached `need` (bounded; uniform)
 template <int SLEEP>
-__device__ __forceinline__ void group_wait (const unsigned* flags, unsigned need, int lane, GroupState* st, unsigned* host_err, unsigned seq, unsigned code)
+__device__ __forceinline__ void group_wait (const unsigned* flags, unsigned need, int lane, GroupState* st, unsigned* host_err, unsigned seq, unsigned code, unsigned spin_limit)
 {
     unsigned n = 0;
     while (! flags_reached (flags, need, lane))
     {
         __builtin_amdgcn_s_sleep (SLEEP);
-        if (++n > kFusedSpinLimit)
+        if (++n > spin_limit)
         {
             if (lane == 0)
                 group_fail (st, host_err, seq, code);
@@ -235,10 +252,11 @@ __global__ __launch_bounds__ (256, 2) void group256_kernel (const float2* __rest
     const int kbl = tid & 15, tb = tid >> 4;
     const unsigned two_slots = form & 1u;
     const bool early = (form & 2u) != 0, w0late = (form & 4u) != 0, spread = (form & 8u) != 0;
+    const unsigned spin_limit = group_spin_limit (force_solo);
 #if CFFT_GROUP_EXPERIMENT
-    const unsigned dbg = force_solo >> 8;
-    force_solo &= 255u;
+    const unsigned dbg = (force_solo >> 8) & 255u;
 #endif
+    force_solo &= 255u;
 
     if (tid < 240)
         tw1[tid] = stage_tw[Plan256::tw_offset (1) + tid];
@@ -292,7 +310,7 @@ __global__ __launch_bounds__ (256, 2) void group256_kernel (const float2* __rest
                 while (! flags_reached (bf, k, tid & 63))
                 {
                     __builtin_amdgcn_s_sleep (1);
-                    if (++n > kFusedSpinLimit)
+                    if (++n > spin_limit)
                     {
                         if ((tid & 63) == 0)
                             group_fail (st, host_err, seq, 2u);
@@ -331,7 +349,7 @@ __global__ __launch_bounds__ (256, 2) void group256_kernel (const float2* __rest
                 while (! flags_reached (af, k + 1u, tid))
                 {
                     __builtin_amdgcn_s_sleep (2);
-                    if (++n > kFusedSpinLimit)
+                    if (++n > spin_limit)
                     {
                         if (tid == 0)
                             group_fail (st, host_err, seq, 1u);
@@ -503,6 +521,8 @@ __global__ __launch_bounds__ (256, 2) void group256_conv_kernel (const float2* _
     constexpr unsigned N = 65536;
     const int tid = threadIdx.x;
     const int lo = tid & 15, hi = tid >> 4;
+    const unsigned spin_limit = group_spin_limit (force_solo);
+    force_solo &= 255u;
     if (tid < 240)
         tw1[tid] = stage_tw[Plan256::tw_offset (1) + tid];
     if (tid == 0)
@@ -578,7 +598,7 @@ __global__ __launch_bounds__ (256, 2) void group256_conv_kernel (const float2* _
             // ---- A: columns [16 tile, 16 tile + 16) of frame f -> block `tile` of the slot
             fft256_two_stage_lds (v, tw1, lo, smem, lo, hi, hi, lo);
             if (k != 0)
-                group_wait<1> (bf, 2u * k, tid & 63, st, host_err, seq, 2u); // every member has read frame k - 1's second intermediate
+                group_wait<1> (bf, 2u * k, tid & 63, st, host_err, seq, 2u, spin_limit); // every member has read frame k - 1's second intermediate
 #pragma unroll
             for (int b = 0; b < 16; ++b)
                 slot[(size_t) tile * 4096u + b * 256 + tid] = cmul (v[b], bwa[b]);
@@ -587,7 +607,7 @@ __global__ __launch_bounds__ (256, 2) void group256_conv_kernel (const float2* _
             if (tid == 0)
                 flag_store (&af[tile], 2u * k + 1u);
             if (tid < 64)
-                group_wait<2> (af, 2u * k + 1u, tid, st, host_err, seq, 1u);
+                group_wait<2> (af, 2u * k + 1u, tid, st, host_err, seq, 1u, spin_limit);
             __syncthreads();
             // ---- B: rows [16 tile, 16 tile + 16)
 #pragma unroll
@@ -645,7 +665,7 @@ __global__ __launch_bounds__ (256, 2) void group256_conv_kernel (const float2* _
             for (int a = 1; a < 16; ++a)
                 v[a] = cmul (v[a], tw1[(a - 1) * 16 + hi]);
             fft_reg<16> (v);
-            group_wait<1> (bf, 2u * k + 1u, tid & 63, st, host_err, seq, 3u); // every member has read the first intermediate
+            group_wait<1> (bf, 2u * k + 1u, tid & 63, st, host_err, seq, 3u, spin_limit); // every member has read the first intermediate
 #pragma unroll
             for (int b = 0; b < 16; ++b)
                 slot[(size_t) tile * 4096u + b * 256 + tid] = cmulc (make_float2 (v[b].y, v[b].x), bwb[b]);
@@ -654,7 +674,7 @@ __global__ __launch_bounds__ (256, 2) void group256_conv_kernel (const float2* _
             if (tid == 0)
                 flag_store (&af[tile], 2u * k + 2u);
             if (tid < 64)
-                group_wait<2> (af, 2u * k + 2u, tid, st, host_err, seq, 4u);
+                group_wait<2> (af, 2u * k + 2u, tid, st, host_err, seq, 4u, spin_limit);
             __syncthreads();
             // ---- A': rows kb of the second intermediate for columns [16 tile, 16 tile + 16) -> y
 #pragma unroll

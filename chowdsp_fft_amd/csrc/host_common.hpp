@@ -89,6 +89,10 @@ inline Setup* as_setup (void* p)
     return (s != nullptr && s->magic == kMagic) ? s : nullptr;
 }
 
+// hipStreamSynchronize + the hand-off report of the one-launch two-pass forms (capi.cpp): what EVERY synchronous entry point
+// of the library uses to wait for a stream.  FFT_GPU_OK or FFT_GPU_ELAUNCH (reason recorded for fft_gpu_last_error).
+int sync_stream_checked (hipStream_t stream, const char* what);
+
 const DeviceTables* acquire_tables (int device, int N, int transform);
 // stage list + tables of the 2-D transform's column pass (rows-point FFTs of a tile of columns); nullptr if `rows` is not
 // 2-3-5-smooth or does not fit a column tile (tables.hpp kGeneralMaxFactor)

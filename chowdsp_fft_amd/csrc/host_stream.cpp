@@ -202,7 +202,10 @@ void release_range (HostRange& r)
 bool direct (const HostRange& r) { return r.hi > r.lo; }
 
 // host -> device copy of [src, src + bytes) of range r: the part inside the registered interior directly, a partial head /
-// tail page through its bounce page (each occurs at most once per call, so a bounce page is written once)
+// tail page through its bounce page.  Every byte of the head [base, lo) and of the tail [hi, base + bytes) has a place of its
+// OWN in the bounce page (offset = its distance from base resp. hi): with frames shorter than a page the tail can be split
+// between the last two chunks (N = 64 complex, batch = k * chunk_frames + 1, base = page + 16: chunk i - 1 owns 16 bytes of
+// it, chunk i 512), which run on different streams -- they must neither share bounce bytes nor a pending record.
 hipError_t copy_in (const HostRange& r, float* dst, const char* src, size_t bytes, hipStream_t st)
 {
     const char* end = src + bytes;
@@ -210,8 +213,9 @@ hipError_t copy_in (const HostRange& r, float* dst, const char* src, size_t byte
     if (src < r.lo)
     {
         const size_t n = (size_t) (std::min<const char*> (end, r.lo) - src);
-        std::memcpy (r.bounce_head, src, n);
-        const hipError_t e = hipMemcpyAsync (d, r.bounce_head, n, hipMemcpyHostToDevice, st);
+        char* bh = r.bounce_head + (src - r.base);
+        std::memcpy (bh, src, n);
+        const hipError_t e = hipMemcpyAsync (d, bh, n, hipMemcpyHostToDevice, st);
         if (e != hipSuccess)
             return e;
     }
@@ -227,8 +231,9 @@ hipError_t copy_in (const HostRange& r, float* dst, const char* src, size_t byte
     {
         const char* t = std::max<const char*> (src, r.hi);
         const size_t n = (size_t) (end - t);
-        std::memcpy (r.bounce_tail, t, n);
-        const hipError_t e = hipMemcpyAsync (d + (t - src), r.bounce_tail, n, hipMemcpyHostToDevice, st);
+        char* bt = r.bounce_tail + (t - r.hi);
+        std::memcpy (bt, t, n);
+        const hipError_t e = hipMemcpyAsync (d + (t - src), bt, n, hipMemcpyHostToDevice, st);
         if (e != hipSuccess)
             return e;
     }
@@ -249,10 +254,10 @@ hipError_t copy_out (const HostRange& r, char* dst, const float* src, size_t byt
     if (dst < r.lo)
     {
         const size_t n = (size_t) (std::min<char*> (end, r.lo) - dst);
-        const hipError_t e = hipMemcpyAsync (r.bounce_head, s, n, hipMemcpyDeviceToHost, st);
+        const hipError_t e = hipMemcpyAsync (r.bounce_head + (dst - r.base), s, n, hipMemcpyDeviceToHost, st);
         if (e != hipSuccess)
             return e;
-        pend[0] = Pending { dst, r.bounce_head, n };
+        pend[0] = Pending { r.base, r.bounce_head, (size_t) (r.lo - r.base) }; // the whole head, once (every byte of it gets written by some chunk)
     }
     char* a = std::max<char*> (dst, r.lo);
     char* b = std::min<char*> (end, r.hi);
@@ -266,10 +271,10 @@ hipError_t copy_out (const HostRange& r, char* dst, const float* src, size_t byt
     {
         char* t = std::max<char*> (dst, r.hi);
         const size_t n = (size_t) (end - t);
-        const hipError_t e = hipMemcpyAsync (r.bounce_tail, s + (t - dst), n, hipMemcpyDeviceToHost, st);
+        const hipError_t e = hipMemcpyAsync (r.bounce_tail + (t - r.hi), s + (t - dst), n, hipMemcpyDeviceToHost, st);
         if (e != hipSuccess)
             return e;
-        pend[1] = Pending { t, r.bounce_tail, n };
+        pend[1] = Pending { r.hi, r.bounce_tail, (size_t) (r.base + r.bytes - r.hi) }; // the whole tail, once
     }
     return hipSuccess;
 }
@@ -341,7 +346,7 @@ int fft_transform_host_batch (void* setup, const float* input, float* output, si
     const auto drain_slot = [&] (int k) -> bool {
         if (fly[k].bytes == 0)
             return true;
-        if (hipStreamSynchronize (g_pipe.st[k]) != hipSuccess)
+        if (sync_stream_checked (g_pipe.st[k], "fft_transform_host_batch: stream synchronisation") != FFT_GPU_OK)
             return false;
         std::memcpy (fly[k].dst, g_pipe.ring_out[k], fly[k].bytes);
         fly[k].bytes = 0;
@@ -360,8 +365,7 @@ int fft_transform_host_batch (void* setup, const float* input, float* output, si
         // the CPU writes, so slot k is drained (its stream waited for, its output handed to the caller) before it is refilled
         if ((ring_in || ring_out) && ! drain_slot (k))
         {
-            set_last_error ("fft_transform_host_batch: stream synchronisation failed");
-            rc = FFT_GPU_ELAUNCH;
+            rc = FFT_GPU_ELAUNCH; // (sync_stream_checked recorded the reason)
             break;
         }
         if (ring_in && frame_fits_ring)
@@ -400,11 +404,10 @@ int fft_transform_host_batch (void* setup, const float* input, float* output, si
     }
     for (int k = 0; k < 2; ++k)
     {
-        if (hipStreamSynchronize (g_pipe.st[k]) != hipSuccess && rc == FFT_GPU_OK)
-        {
-            set_last_error ("fft_transform_host_batch: stream synchronisation failed");
-            rc = FFT_GPU_ELAUNCH;
-        }
+        // (always both streams, also after a failure: nothing of this call may still be in flight when it returns)
+        const int src = sync_stream_checked (g_pipe.st[k], "fft_transform_host_batch: stream synchronisation");
+        if (src != FFT_GPU_OK && rc == FFT_GPU_OK)
+            rc = src;
         if (fly[k].bytes != 0 && rc == FFT_GPU_OK)
             std::memcpy (fly[k].dst, g_pipe.ring_out[k], fly[k].bytes);
         fly[k].bytes = 0;

@@ -446,6 +446,9 @@ constexpr size_t kGroupLds = (size_t) 16 * TileFrame<256>::stride * sizeof (floa
 // options "group_force_solo" (tests: every launch takes the fall-back mode) and "group_reg_polls" (how long a workgroup waits
 // for the grid to be complete before it decides for the fall-back mode; one poll is about a microsecond)
 std::atomic<int> g_group_force_solo { 0 }, g_group_reg_polls { 200 };
+// developer option "group_spin_limit": polls after which a hand-off wait gives up (0 = the built-in limit, a fraction of a
+// second).  Tests set 1: the waits DO run out, the launch reports it, the output is invalid -- the failure path end to end.
+std::atomic<int> g_group_spin_limit { 0 };
 unsigned group_grid (bool inverse)
 {
     auto k = inverse ? group256_kernel<true> : group256_kernel<false>;
@@ -463,9 +466,12 @@ void set_group_options (int force_solo, int reg_polls)
     if (reg_polls >= 0)
         g_group_reg_polls = reg_polls;
 }
+void set_group_spin_limit (int polls) { g_group_spin_limit = (polls > 0 && polls < 65536) ? polls : 0; }
+int get_group_spin_limit() { return g_group_spin_limit.load(); }
 void get_group_options (int& force_solo, int& reg_polls)
 {
-    force_solo = g_group_force_solo.load();
+    // (the kernels' `force_solo` argument: bit 0 the mode, bits 16.. the spin limit -- group_twopass_kernels.hpp group_spin_limit)
+    force_solo = g_group_force_solo.load() | (g_group_spin_limit.load() << 16);
     reg_polls = g_group_reg_polls.load();
 }
 int group_wg_per_cu_tenths() { return group_wg_per_cu_x10(); }
@@ -501,7 +507,7 @@ hipError_t launch_group_c2c (int n1, int n2, bool inverse, const float2* in, flo
     static const unsigned slots_flag = (std::getenv ("CHOWDSP_FFT_GROUP_SLOTS") != nullptr && std::atoi (std::getenv ("CHOWDSP_FFT_GROUP_SLOTS")) == 2) ? 1u : 0u;
     const int pf = pf_env >= 0 ? pf_env : (inverse ? 0 : 3);
     const unsigned two_slots = slots_flag | (pf == 1 ? 2u : (pf == 2 ? 6u : (pf == 3 ? 8u : 0u)));
-    unsigned force_solo = (unsigned) g_group_force_solo.load();
+    unsigned force_solo = (unsigned) g_group_force_solo.load() | ((unsigned) g_group_spin_limit.load() << 16);
     const unsigned reg_polls = (unsigned) g_group_reg_polls.load();
 #if CFFT_GROUP_EXPERIMENT
     static const unsigned dbg = std::getenv ("CHOWDSP_FFT_GROUP_DBG") != nullptr ? (unsigned) std::atoi (std::getenv ("CHOWDSP_FFT_GROUP_DBG")) : 0u;

@@ -90,6 +90,8 @@ bool groupfast_supported (int n1, int n2);
 size_t groupfast_workspace_bytes (int n1, int n2);
 hipError_t launch_groupfast_c2c (int n1, int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, void* state, unsigned* host_err, unsigned seq, size_t batch, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
 void get_group_options (int& force_solo, int& reg_polls);
+void set_group_spin_limit (int polls); // developer option: 0 = built-in limit
+int get_group_spin_limit();
 int group_wg_per_cu_tenths();
 unsigned group_conv_grid(); // workgroups of the fused-convolution form's launch (kernels_group_conv.hip)
 hipError_t launch_group_conv (const float2* in, const float2* H, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, void* state, unsigned* host_err, unsigned seq, float scaling, size_t batch, hipStream_t stream);

@@ -60,32 +60,14 @@ hipStream_t copy_stream (int src, int dst) // caller has `src` current
 }
 } // namespace
 
-#pragma GCC visibility push(default)
-extern "C"
+namespace
 {
-namespace chowdsp::fft
+using namespace chowdsp::fft;
+// One host thread per shard: a thread selects its plan's device, enqueues the shard (`enqueue (d, stream)`) on that device's
+// own stream and waits for it; the shards run concurrently.  Errors are collected per shard (last_error is thread local).
+template <class Enqueue>
+int run_shards (void* const* setups, int shards, const size_t* counts, const char* what, Enqueue&& enqueue)
 {
-int fft_gpu_shard_range (size_t total_frames, int shards, int rank, size_t* first, size_t* count)
-{
-    if (shards < 1 || rank < 0 || rank >= shards || first == nullptr || count == nullptr)
-        return FFT_GPU_EINVAL;
-    // blocks differ by at most one frame and cover [0, total) exactly once (= chowdsp_fft_amd/sharding.py::shard_range)
-    const size_t base = total_frames / (size_t) shards, extra = total_frames % (size_t) shards;
-    const size_t r = (size_t) rank;
-    *first = r * base + (r < extra ? r : extra);
-    *count = base + (r < extra ? 1 : 0);
-    return FFT_GPU_OK;
-}
-
-int fft_transform_batch_multi_gpu (void* const* setups, int shards, const float* const* inputs, float* const* outputs, const size_t* counts, fft_direction_t direction)
-{
-    if (setups == nullptr || inputs == nullptr || outputs == nullptr || counts == nullptr || shards < 1)
-        return FFT_GPU_EINVAL;
-    for (int d = 0; d < shards; ++d)
-        if (as_setup (setups[d]) == nullptr || (counts[d] != 0 && (inputs[d] == nullptr || outputs[d] == nullptr)))
-            return FFT_GPU_EINVAL;
-    // one host thread per shard: a thread selects its plan's device, enqueues the shard on that device's own stream and
-    // waits for it; the shards run concurrently.  Errors are collected per shard (last_error is thread local).
     std::vector<int> rc ((size_t) shards, FFT_GPU_OK);
     std::vector<std::string> msg ((size_t) shards);
     auto work = [&] (int d) {
@@ -105,12 +87,9 @@ int fft_transform_batch_multi_gpu (void* const* setups, int shards, const float*
             msg[(size_t) d] = "stream creation failed";
             return;
         }
-        int r = fft_transform_batch (setups[d], inputs[d], outputs[d], counts[d], direction, st);
-        if (r == FFT_GPU_OK && hipStreamSynchronize (st) != hipSuccess)
-        {
-            r = FFT_GPU_ELAUNCH;
-            set_last_error ("fft_transform_batch_multi_gpu: shard synchronisation failed");
-        }
+        int r = enqueue (d, st);
+        if (r == FFT_GPU_OK)
+            r = sync_stream_checked (st, what); // incl. the one-launch forms' hand-off report
         rc[(size_t) d] = r;
         if (r != FFT_GPU_OK)
             msg[(size_t) d] = last_error();
@@ -135,6 +114,48 @@ int fft_transform_batch_multi_gpu (void* const* setups, int shards, const float*
             return rc[(size_t) d];
         }
     return FFT_GPU_OK;
+}
+} // namespace
+
+#pragma GCC visibility push(default)
+extern "C"
+{
+namespace chowdsp::fft
+{
+int fft_gpu_shard_range (size_t total_frames, int shards, int rank, size_t* first, size_t* count)
+{
+    if (shards < 1 || rank < 0 || rank >= shards || first == nullptr || count == nullptr)
+        return FFT_GPU_EINVAL;
+    // blocks differ by at most one frame and cover [0, total) exactly once (= chowdsp_fft_amd/sharding.py::shard_range)
+    const size_t base = total_frames / (size_t) shards, extra = total_frames % (size_t) shards;
+    const size_t r = (size_t) rank;
+    *first = r * base + (r < extra ? r : extra);
+    *count = base + (r < extra ? 1 : 0);
+    return FFT_GPU_OK;
+}
+
+int fft_transform_batch_multi_gpu (void* const* setups, int shards, const float* const* inputs, float* const* outputs, const size_t* counts, fft_direction_t direction)
+{
+    if (setups == nullptr || inputs == nullptr || outputs == nullptr || counts == nullptr || shards < 1)
+        return FFT_GPU_EINVAL;
+    for (int d = 0; d < shards; ++d)
+        if (as_setup (setups[d]) == nullptr || (counts[d] != 0 && (inputs[d] == nullptr || outputs[d] == nullptr)))
+            return FFT_GPU_EINVAL;
+    return run_shards (setups, shards, counts, "fft_transform_batch_multi_gpu: shard synchronisation",
+                       [&] (int d, hipStream_t st) { return fft_transform_batch (setups[d], inputs[d], outputs[d], counts[d], direction, st); });
+}
+
+// BASELINE configs[3] at the C ABI: the fused forward -> x H x scaling -> backward of every shard on its own device, filter
+// spectrum replicated per device (reference call sequence test/test.cpp:161-166; plan / filter shareable chowdsp_fft.h:87-91)
+int fft_convolve_frames_batch_multi_gpu (void* const* setups, int shards, const float* const* x, const float* const* dft_filters, float* const* y, const size_t* counts, float scaling)
+{
+    if (setups == nullptr || x == nullptr || dft_filters == nullptr || y == nullptr || counts == nullptr || shards < 1)
+        return FFT_GPU_EINVAL;
+    for (int d = 0; d < shards; ++d)
+        if (as_setup (setups[d]) == nullptr || (counts[d] != 0 && (x[d] == nullptr || y[d] == nullptr || dft_filters[d] == nullptr)))
+            return FFT_GPU_EINVAL;
+    return run_shards (setups, shards, counts, "fft_convolve_frames_batch_multi_gpu: shard synchronisation",
+                       [&] (int d, hipStream_t st) { return fft_convolve_frames_batch (setups[d], x[d], dft_filters[d], y[d], scaling, counts[d], st); });
 }
 
 int fft_gather_multi_gpu (const float* const* shard_ptrs, const int* shard_devices, const size_t* shard_floats, int shards, float* const* dst_ptrs, const int* dst_devices, int ndst)

@@ -186,6 +186,13 @@ int fft_gpu_shard_range (size_t total_frames, int shards, int rank, size_t* firs
    each from its own host thread on that device's own stream, all at once.  Synchronous: every shard is complete on
    return.  Several shards may name the same device. */
 int fft_transform_batch_multi_gpu (void* const* setups, int shards, const float* const* inputs, float* const* outputs, const size_t* counts, fft_direction_t direction);
+/* `shards` x fft_convolve_frames_batch (BASELINE configs[3]: overlap-save frames sharded over the GPUs of a node): shard d on
+   the device of setups[d], y[d] = BACKWARD (FORWARD (x[d]) * dft_filters[d] * scaling) for counts[d] frames.  The filter spectrum
+   is REPLICATED: dft_filters[d] is a copy on shard d's device (one frame, fft_transform_unordered layout; the same pointer for
+   shards that share a device) -- plans and filters are immutable and replicable (reference chowdsp_fft.h:87-91), so nothing is
+   exchanged while convolving.  Same threading, streams and synchronous return as fft_transform_batch_multi_gpu; x[d] == y[d]
+   allowed.  Replaces the caller-side loop test/test.cpp:161-166 over a sharded batch. */
+int fft_convolve_frames_batch_multi_gpu (void* const* setups, int shards, const float* const* x, const float* const* dft_filters, float* const* y, const size_t* counts, float scaling);
 /* Collect result shards: shard s (shard_floats[s] floats on device shard_devices[s]) is copied behind the shards before
    it into EVERY non-NULL destination dst_ptrs[d] (a buffer of sum(shard_floats) floats on device dst_devices[d]) --
    an all-gather when every device is a destination, a gather-to-root when one is.  Each (source, destination) pair is

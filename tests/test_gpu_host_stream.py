@@ -111,3 +111,39 @@ def test_small_heap_blocks_next_to_pageable_copies(gpu, oracle):
             api.fft_destroy_setup(s)
             oracle.destroy_setup(so)
             del x, y, left, right, dl, dr, dx  # freed: the next round's arrays reuse the addresses
+
+
+@pytest.mark.parametrize("inplace", [False, True])
+def test_tail_page_shared_by_the_last_two_chunks(gpu, oracle, inplace):
+    """Frames shorter than a page (N = 64 complex: 512 B), batch = one pipeline chunk + 1 frame, buffer starting 16 bytes
+    into a page: the partial tail page (528 B) belongs to BOTH last chunks -- 16 bytes to the full chunk, 512 to the
+    one-frame chunk -- which run on different streams.  Each tail byte has its own place in the bounce page; round 3
+    put both pieces at offset 0 (the earlier chunk's input overwritten before its DMA ran, its output never delivered)."""
+    api = gpu[0]
+    n = 64
+    nf = 2 * n
+    chunk_frames = (32 << 20) // (nf * 4)
+    for batch in (chunk_frames + 1, 2 * chunk_frames + 3):
+        raw_in = np.zeros(batch * nf + 2048, np.float32)
+        off = (-(raw_in.ctypes.data) % 4096) // 4 + 4  # first float at page + 16 bytes
+        x = raw_in[off:off + batch * nf].reshape(batch, nf)
+        assert x.ctypes.data % 4096 == 16
+        x[:] = ol.uniform(batch * nf, 77).reshape(batch, nf)
+        x0 = x.copy()
+        if inplace:
+            y = x
+        else:
+            raw_out = np.full(batch * nf + 2048, -3.0, np.float32)
+            offo = (-(raw_out.ctypes.data) % 4096) // 4 + 4
+            y = raw_out[offo:offo + batch * nf].reshape(batch, nf)
+        s, so = api.fft_new_setup(n, api.FFT_COMPLEX), oracle.new_setup(n, COMPLEX)
+        api.fft_transform_host_batch(s, x, y, api.FFT_FORWARD)
+        idx = np.unique(np.concatenate([np.arange(0, 4), np.arange(chunk_frames - 3, chunk_frames + 2), np.arange(batch - 4, batch)]))
+        idx = idx[idx < batch]
+        assert_frames_close(y[idx], oracle.transform_batch(so, x0[idx], FORWARD), what="tail page split over two chunks")
+        # every frame: forward then backward in place returns N x
+        z = y.copy() if not inplace else y
+        api.fft_transform_host_batch(s, z, z, api.FFT_BACKWARD)
+        assert np.abs(z / n - x0).max() <= 2e-6
+        api.fft_destroy_setup(s)
+        oracle.destroy_setup(so)

@@ -131,3 +131,127 @@ def test_release_stream_resources(gpu):
     assert float(((y - ref).norm(dim=1) / ref.norm(dim=1)).max()) < 1e-6
     assert api.release_stream_resources(st) == 1
     api.fft_destroy_setup(s)
+
+
+def _oracle_conv_frames(oracle, so, xs, h, n):
+    hb = oracle.transform(so, h, FORWARD, False)
+    return np.stack([oracle.transform(so, oracle.convolve(so, oracle.transform(so, x, FORWARD, False), hb, np.zeros(n, np.float32), 1.0 / n),
+                                      ol.BACKWARD, False) for x in xs])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,tr,total,shards", [(4096, REAL, 1001, 3), (4096, REAL, 64, 8), (480, COMPLEX, 77, 2), (65536, COMPLEX, 9, 2)])
+def test_sharded_fused_convolution_small(gpu, oracle, n, tr, total, shards):
+    """fft_convolve_frames_batch_multi_gpu == the oracle's forward -> convolve -> backward sequence (reference test/test.cpp:161-166),
+    shard by shard, filter replicated per device, in place and out of place"""
+    api, torch, dev0 = gpu
+    from chowdsp_fft_amd import _lib
+
+    ndev = min(api.device_count(), 2)
+    devices = [d % ndev for d in range(shards)]
+    nf = 2 * n if tr == COMPLEX else n
+    x = ol.uniform(total * nf, 3 + n).reshape(total, nf)
+    h = ol.uniform(nf, 4 + n)
+    so = oracle.new_setup(n, tr)
+    pick = np.unique(np.concatenate([[0, total - 1], [api.shard_range(total, shards, r)[0] for r in range(shards)]]))
+    pick = pick[pick < total]
+    want = _oracle_conv_frames(oracle, so, x[pick], h, n)
+    setups, xs, ys, Hs, counts = [], [], [], [], []
+    Hdev = {}
+    for r in range(shards):
+        first, count = api.shard_range(total, shards, r)
+        d = devices[r]
+        assert _lib.lib().fft_gpu_set_device(d) == 0
+        s = api.fft_new_setup(n, tr)
+        setups.append(s)
+        td = torch.device("cuda", d)
+        if d not in Hdev:  # the filter spectrum, replicated: computed once per device
+            hd = torch.from_numpy(h.reshape(1, nf)).to(td)
+            Hdev[d] = torch.empty_like(hd)
+            api.fft_transform_unordered_batch(s, hd, Hdev[d], api.FFT_FORWARD)
+        xs.append(torch.from_numpy(x[first:first + count].copy()).to(td))
+        ys.append(torch.empty_like(xs[-1]))
+        Hs.append(Hdev[d])
+        counts.append(count)
+    assert _lib.lib().fft_gpu_set_device(0) == 0
+    for d in range(ndev):
+        torch.cuda.synchronize(d)
+    api.fft_convolve_frames_batch_multi_gpu(setups, xs, Hs, ys, counts, 1.0 / n)
+    got = np.concatenate([y.cpu().numpy() for y in ys])
+    assert_frames_close(got[pick], want, what="sharded fused convolution")
+    api.fft_convolve_frames_batch_multi_gpu(setups, xs, Hs, xs, counts, 1.0 / n)  # in place
+    got2 = np.concatenate([y.cpu().numpy() for y in xs])
+    assert np.array_equal(got, got2)
+    for s in setups:
+        api.fft_destroy_setup(s)
+    oracle.destroy_setup(so)
+
+
+@pytest.mark.gpu
+def test_config4_full_one_million_frames_folded(gpu, oracle):
+    """BASELINE configs[3] at its GLOBAL shape: 1 048 576 real N = 4096 overlap-save frames (16 GiB) as 8 shards
+    (fft_gpu_shard_range), fused convolution per shard through fft_convolve_frames_batch_multi_gpu, then fft_gather_multi_gpu.
+    On a one-GPU lease the 8 shards fold onto device 0 (the entry points allow it; a 288 GB MI355X holds the whole job);
+    with more devices they spread.  Frames {0, every shard boundary - 1 / + 0, last} == the oracle's pipeline; EVERY frame ==
+    the single-call fft_convolve_frames_batch of the whole batch (bit for bit: same kernel, frames are independent)."""
+    api, torch, dev0 = gpu
+    from chowdsp_fft_amd import _lib
+
+    n, total, shards = 4096, 1 << 20, 8
+    free, _ = torch.cuda.mem_get_info(0)
+    ndev = min(api.device_count(), shards)
+    if ndev == 1 and free < 40 * (1 << 30):
+        pytest.skip("needs 40 GiB of free device memory (16 GiB frames + 16 GiB gathered + scratch)")
+    if ndev > 1:
+        pytest.skip("folded form is for one device; the spread form is test_sharded_fused_convolution_small")
+    chunk = 65536  # frames per generator call: any frame's input can be regenerated from (seed, chunk)
+
+    def gen_chunk(c, out=None):
+        g = torch.Generator(device=dev0)
+        g.manual_seed(5000 + c)
+        r = torch.rand((chunk, n), device=dev0, generator=g)
+        r = r * 2 - 1
+        if out is not None:
+            out.copy_(r)
+        return r
+
+    def fill(buf):
+        for c in range(total // chunk):
+            gen_chunk(c, buf[c * chunk:(c + 1) * chunk])
+
+    x = torch.empty((total, n), device=dev0)
+    fill(x)
+    h = ol.uniform(n, 99)
+    s = api.fft_new_setup(n, api.FFT_REAL)
+    hd = torch.from_numpy(h.reshape(1, n)).to(dev0)
+    H = torch.empty_like(hd)
+    api.fft_transform_unordered_batch(s, hd, H, api.FFT_FORWARD)
+    setups = [api.fft_new_setup(n, api.FFT_REAL) for _ in range(shards)]  # replicated plans (one per shard)
+    ranges = [api.shard_range(total, shards, r) for r in range(shards)]
+    assert sum(c for _, c in ranges) == total and ranges[0][1] == 131072
+    xs = [x[f:f + c] for f, c in ranges]
+    torch.cuda.synchronize()
+    api.fft_convolve_frames_batch_multi_gpu(setups, xs, [H] * shards, xs, [c for _, c in ranges], 1.0 / n)  # in place, synchronous
+    dst = torch.empty((total, n), device=dev0)
+    torch.cuda.synchronize()
+    api.fft_gather_multi_gpu(xs, [0] * shards, [dst], [0])
+    # oracle pipeline on the boundary frames
+    pick = sorted({0, total - 1} | {f - 1 for f, _ in ranges[1:]} | {f for f, _ in ranges[1:]})
+    so = oracle.new_setup(n, REAL)
+    inputs = []
+    for i in pick:
+        inputs.append(gen_chunk(i // chunk)[i % chunk].cpu().numpy())
+    want = _oracle_conv_frames(oracle, so, inputs, h, n)
+    assert_frames_close(dst[pick].cpu().numpy(), want, what="1 M frames folded: shard boundaries")
+    oracle.destroy_setup(so)
+    # every frame against ONE call over the whole batch
+    fill(x)
+    api.fft_convolve_frames_batch(s, x, H, x, 1.0 / n)
+    torch.cuda.synchronize()
+    for c in range(total // chunk):
+        sl = slice(c * chunk, (c + 1) * chunk)
+        assert torch.equal(dst[sl], x[sl]), f"frames {sl} differ between the sharded and the single call"
+    for p in setups + [s]:
+        api.fft_destroy_setup(p)
+    del x, dst
+    torch.cuda.empty_cache()

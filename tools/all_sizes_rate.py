@@ -7,7 +7,9 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from chowdsp_fft_amd import api  # noqa: E402
+from _timing import measure, spread  # noqa: E402
 
 dev = torch.device("cuda:0")
 sizes = [(1 << lg, True) for lg in range(4, 22)] + [(1 << lg, False) for lg in range(5, 22)]
@@ -30,21 +32,15 @@ for n, cplx in sizes:
     x = torch.rand((batch, nf), device=dev) * 2 - 1
     y = torch.empty_like(x)
     z = torch.empty_like(x)
-    for _ in range(3):
+    def step():
         api.fft_transform_batch(s, x, y, api.FFT_FORWARD)
         api.fft_transform_batch(s, y, z, api.FFT_BACKWARD)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 8
-    e0.record()
-    for _ in range(reps):
-        api.fft_transform_batch(s, x, y, api.FFT_FORWARD)
-        api.fft_transform_batch(s, y, z, api.FFT_BACKWARD)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / (2 * reps)
+
+    # median of 5 repetitions of 10 forward + 10 backward launches after 0.3 s of the same calls untimed (tools/_timing.py)
+    ms2, lo, hi = measure(step, launches=10)
+    ms = ms2 / 2
     err = float((z[:4] / n - x[:4]).abs().max())
     gbs = batch * nf * 8 / ms / 1e6
-    print(f"{'c' if cplx else 'r'}{n:<8d} batch {batch:<9d} {ms:8.4f} ms/launch  {gbs:7.0f} GB/s  frac {gbs / 8000:5.3f}   round-trip err {err:.1e}")
+    print(f"{'c' if cplx else 'r'}{n:<8d} batch {batch:<9d} {ms:8.4f} ms/launch ({spread(ms2, lo, hi)})  {gbs:7.0f} GB/s  frac {gbs / 8000:5.3f}   round-trip err {err:.1e}")
     api.fft_destroy_setup(s)
     del x, y, z

@@ -8,7 +8,9 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from chowdsp_fft_amd import api  # noqa: E402
+from _timing import measure, spread  # noqa: E402
 
 dev = torch.device("cuda:0")
 opts = [a for a in sys.argv[1:] if "=" in a]
@@ -16,10 +18,7 @@ sys.argv = [a for a in sys.argv if "=" not in a]
 for o in opts:
     api.set_option(o.split("=")[0], int(o.split("=")[1]))
 sizes = sys.argv[1:] or ["c4096", "r8192", "c8192", "r16384", "c16384", "r32768", "c32768", "r65536"]
-_w = torch.rand((1 << 26,), device=dev)
-for _ in range(200):  # idle clocks: the first milliseconds run 10-25 % slow
-    _w.mul_(1.0001)
-torch.cuda.synchronize()
+# (per size: 0.3 s of the timed call itself untimed, then the median of 5 repetitions of 20 launches -- tools/_timing.py)
 for form, opt in (("one launch where fused", 1), ("three launches (fused_conv_split = fused_conv_generic = fused_conv_group = 0)", 0)):
     api.set_option("fused_conv_split", opt)
     api.set_option("fused_conv_generic", opt)
@@ -35,17 +34,7 @@ for form, opt in (("one launch where fused", 1), ("three launches (fused_conv_sp
         H = torch.empty_like(h)
         api.fft_transform_unordered_batch(s, h, H, api.FFT_FORWARD)
         y = torch.empty_like(x)
-        for _ in range(3):
-            api.fft_convolve_frames_batch(s, x, H, y, 1.0 / n)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 10
-        e0.record()
-        for _ in range(reps):
-            api.fft_convolve_frames_batch(s, x, H, y, 1.0 / n)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / reps
+        ms, lo, hi = measure(lambda: api.fft_convolve_frames_batch(s, x, H, y, 1.0 / n))
         nbytes = 2 * batch * nf * 4
-        print(f"{sz:>7s} batch={batch:<7d} {ms:8.4f} ms  {nbytes / ms / 1e6:7.0f} GB/s algorithmic  {nbytes / ms / 1e6 / 8000:.3f} of 8 TB/s")
+        print(f"{sz:>7s} batch={batch:<7d} {ms:8.4f} ms ({spread(ms, lo, hi)})  {nbytes / ms / 1e6:7.0f} GB/s algorithmic  {nbytes / ms / 1e6 / 8000:.3f} of 8 TB/s")
         api.fft_destroy_setup(s)

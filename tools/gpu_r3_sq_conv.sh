@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 3: SQ counters of the fused-convolution and engine kernels (none existed), next to the plain transforms of the same size
 REPO=$PWD
+mkdir -p gpurun_out/r3
 {
 echo "##### conv_real_n4096_b131072 (conv_frames_real_kernel_pf)"
 tools/prof_sq_cmd.sh r3/sq_conv_real4096 python3 $REPO/bench.py --steps 3 --warmup 1 --prewarm-seconds 0 --no-cpu-baseline --no-secondary --workload conv_real_n4096_b131072

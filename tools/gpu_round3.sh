@@ -33,8 +33,9 @@ find "$OUT/prof_stats" -name "*kernel_stats.csv" | head -1 | xargs -r cat > "$OU
 head -12 "$OUT/kernel_stats_bench_default.csv" | cut -c1-200
 echo "== PMC traffic of every bench workload"
 bash tools/pmc_refresh.sh "$TAG/pmc" "round 3, MI355X gpurun session $TAG (tools/gpu_round3.sh -> tools/pmc_refresh.sh)"
+PMC_RC=$?
 echo "== bench again: the traffic figures now belong to these sources"
-cp "$OUT/pmc/pmc_traffic.json" profiles/pmc_traffic.json
+if [ $PMC_RC -eq 0 ] && [ -s "$OUT/pmc/pmc_traffic.json" ]; then cp "$OUT/pmc/pmc_traffic.json" profiles/pmc_traffic.json; else echo "pmc_refresh failed (rc $PMC_RC): profiles/pmc_traffic.json NOT replaced"; fi
 timeout -k 10 600 python bench.py --steps 20 --warmup 3 > "$OUT/bench_default_with_traffic.json" 2> "$OUT/bench_default_with_traffic.err"
 python - "$OUT/bench_default_with_traffic.json" <<'PY'
 import json, sys

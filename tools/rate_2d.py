@@ -8,7 +8,9 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from chowdsp_fft_amd import api  # noqa: E402
+from _timing import measure, spread  # noqa: E402
 
 dev = torch.device("cuda:0")
 shapes = [(256, 256), (512, 512), (1024, 1024), (2048, 2048), (480, 640), (720, 1280), (1080, 1920), (144, 192), (600, 800)]
@@ -23,21 +25,14 @@ for rows, cols in shapes:
     x = torch.rand((batch, rows, 2 * cols), device=dev) * 2 - 1
     y = torch.empty_like(x)
     z = torch.empty_like(x)
-    for _ in range(2):
+    def step():
         api.fft_transform_2d_batch(s, rows, x, y, batch, api.FFT_FORWARD)
         api.fft_transform_2d_batch(s, rows, y, z, batch, api.FFT_BACKWARD)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 6
-    e0.record()
-    for _ in range(reps):
-        api.fft_transform_2d_batch(s, rows, x, y, batch, api.FFT_FORWARD)
-        api.fft_transform_2d_batch(s, rows, y, z, batch, api.FFT_BACKWARD)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / (2 * reps)
+
+    ms2, lo, hi = measure(step, launches=10)  # median of 5 repetitions of 10 forward + 10 backward calls (tools/_timing.py)
+    ms = ms2 / 2
     err = float((z[:1] / (rows * cols) - x[:1]).abs().max())
     gbs = batch * rows * cols * 16 / ms / 1e6
-    print(f"{rows:5d} x {cols:<5d} batch {batch:<6d} {ms:8.4f} ms/launch  {gbs:7.0f} GB/s  frac {gbs / 8000:5.3f}   round-trip err {err:.1e}")
+    print(f"{rows:5d} x {cols:<5d} batch {batch:<6d} {ms:8.4f} ms/launch ({spread(ms2, lo, hi)})  {gbs:7.0f} GB/s  frac {gbs / 8000:5.3f}   round-trip err {err:.1e}")
     api.fft_destroy_setup(s)
     del x, y, z
