@@ -135,7 +135,7 @@ def test_release_stream_resources(gpu):
 
 def _oracle_conv_frames(oracle, so, xs, h, n):
     hb = oracle.transform(so, h, FORWARD, False)
-    return np.stack([oracle.transform(so, oracle.convolve(so, oracle.transform(so, x, FORWARD, False), hb, np.zeros(n, np.float32), 1.0 / n),
+    return np.stack([oracle.transform(so, oracle.convolve(so, oracle.transform(so, x, FORWARD, False), hb, np.zeros(len(h), np.float32), 1.0 / n),
                                       ol.BACKWARD, False) for x in xs])
 
 
