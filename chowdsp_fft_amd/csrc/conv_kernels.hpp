@@ -184,6 +184,10 @@ __global__ __launch_bounds__ (256) void ols_extract_kernel (const float4* __rest
 #ifndef CFFT_CONV_PF_MIN_WAVES
 #define CFFT_CONV_PF_MIN_WAVES 1
 #endif
+// round 4: backward transforms of the fused kernels as the transposed network (1, default) or through a natural-order image (0)
+#ifndef CFFT_CONV_TRANSPOSED
+#define CFFT_CONV_TRANSPOSED 1
+#endif
 template <class P>
 __device__ __forceinline__ void conv_core (float2 (&v)[P::R], const TwiddleRegs<P>& tw, const float2* __restrict__ twtab, float2* __restrict__ lds, int t)
 {
@@ -224,6 +228,21 @@ __device__ __forceinline__ void conv_c2c_finish (float2 (&v)[P::R],
     }
     if constexpr (P::NS > 1)
         team_sync<P::T>();
+    // round 4: the backward transform as the TRANSPOSED network (stockham.hpp): it takes the spectrum where the forward
+    // transform left it -- no natural-order image pass, one LDS round trip and two barriers less per frame.  By A/B per
+    // plan (profiles/r04_conv_transposed_ab.txt; these kernels are bound by latency at two waves per SIMD, not by LDS
+    // traffic): N = 4096 +2.7 %, N = 1024 +1.6 %, N = 2048 -2.5 % (keeps the image pass); the others were not measured.
+    if constexpr (CFFT_CONV_TRANSPOSED && ! CFFT_CONV_STREAM_TW && (P::N == 4096 || P::N == 1024))
+    {
+        fft_core_transposed<P> (w, tw, lds, t);
+        if (! PREDICATED || active)
+        {
+#pragma unroll
+            for (int s = 0; s < P::R; ++s)
+                gstore (&dst[team_base + (unsigned) input_index<P> (t, s)], make_float2 (w[s].y, w[s].x));
+        }
+        return;
+    }
     lds_store_output_order<P> (w, lds, t);
     team_sync<P::T>();
     float2 u[P::R]; // fresh arrays: reusing the caller's `v` through the reference leaves it in scratch memory
@@ -452,6 +471,313 @@ __device__ __forceinline__ void conv_real_finish (float2 (&v)[P::R],
 #pragma unroll
         for (int s = 0; s < P::R; ++s)
             gstore (&dst[team_base + (unsigned) output_index<P> (t, s)], make_float2 (u[s].y, u[s].x));
+    }
+}
+
+// ---- round 4: the fused real convolution with the pair stage IN REGISTERS ---------------------------------------------
+// What the kernel above does between its two transforms -- spectrum to a natural-order image, pairs (k, M - k) read back,
+// split * H merge, pairs written, image read in input order: two LDS round trips and four barriers -- exists only because
+// a bin and its mirror bin sit in different work-items.  They need not: the last forward stage reads its operands from
+// LDS, so WHICH butterflies a work-item computes there is free.  With NB = M / r butterflies i (outputs k = i + NB b) the
+// mirror of (i, b) is (NB - i, r - 1 - b): give a work-item the butterflies i and NB - i (RealPairMap) and all its pairs
+// are its own registers, slot (q0, b) with slot (q1, r - 1 - b).  Two butterflies mirror into themselves (i = 0: b <-> r - b,
+// with the packed DC / Nyquist bin and bin M / 2 left over; i = NB / 2: b <-> r - 1 - b): they go to work-item 0, which
+// re-arranges its registers into the regular pattern with selects (first wave only) -- its pair twiddles and filter bins
+// are loaded for ITS bins, so the arithmetic needs no special case beyond the DC / Nyquist product (sse.cpp:1640-1644).
+// The backward transform is the transposed network (stockham.hpp), which starts from exactly this arrangement and shares
+// the forward twiddle registers.  Per frame: 4 LDS round trips and 8 barriers instead of 6 and 12.
+template <class P>
+struct RealPairMap
+{
+    template <class PP>
+    static __device__ __forceinline__ constexpr int index (int t, int q)
+    {
+        constexpr int NB = P::N / P::radix (P::NS - 1);
+        const int i = t + (q >> 1) * P::T;
+        if ((q & 1) == 0)
+            return i;
+        return i == 0 ? NB / 2 : NB - i;
+    }
+};
+template <class P>
+static constexpr bool kRealPairInRegs = P::NS >= 2 && ((P::R / P::radix (P::NS - 1)) % 2 == 0) && P::T >= 64;
+
+// bin index of operand A of pair (h, b) of work-item t (its partner is M - k; k == 0: the packed DC / Nyquist bin with M / 2)
+template <class P>
+__device__ __forceinline__ int real_pair_bin (int t, int h, int b)
+{
+    constexpr int r = P::radix (P::NS - 1), NB = P::N / r;
+    const int i = t + h * P::T;
+    if (i != 0)
+        return i + NB * b;
+    return b < r / 2 ? NB * b : NB / 2 + NB * (b - r / 2);
+}
+// The whole pair stage -- split, * H_k, * H_(M-k), * scaling, merge -- is ONE real-linear map of (Z_k, Z_(M-k)) whose
+// coefficients depend only on the filter, the pair twiddle and `scaling`, i.e. are the same for every frame:
+//     Z'_k     = c0.xy * A       + c0.zw * conj (X)        X = B (regular pair), X = A (the packed DC / Nyquist bin: real-linear in A alone)
+//     Z'_(M-k) = c1.xy * conj (A) + c1.zw * B
+// 16 multiply-adds per pair instead of about 40 (two half-butterflies, three complex products, four scalings), no filter
+// loads per frame.  The persistent work-item derives its 8 coefficient sets once per launch by pushing unit vectors
+// through the very functions the three-call sequence uses (real_split_pair, cmul, real_merge_pair, the real DC / Nyquist
+// products of sse.cpp:1640-1644) and keeps them in 64 VGPRs (the pair twiddles and the per-frame filter loads they
+// replace took 16 + the loads' staging registers).
+// CFFT_CONV_TP_MAP_LDS pairs of the P::R / 2 live in a private LDS area of the work-item instead ([j][t], conflict-free
+// 16-byte reads), for builds that need the registers (packed arithmetic)
+#ifndef CFFT_CONV_TP_MAP_LDS
+#define CFFT_CONV_TP_MAP_LDS 0
+#endif
+template <class P>
+struct RealPairMapRegs
+{
+    static constexpr int in_lds = CFFT_CONV_TP_MAP_LDS, in_regs = P::R / 2 - in_lds;
+    float4 c0[in_regs > 0 ? in_regs : 1], c1[in_regs > 0 ? in_regs : 1];
+    float4* spill; // this work-item's column of the LDS area: entry j at spill[j * stride]
+    static constexpr int stride = P::T; // (FPB == 1)
+    __device__ __forceinline__ float4 get0 (int p) const { return p < in_regs ? c0[p < in_regs ? p : 0] : spill[(2 * (p - in_regs)) * stride]; }
+    __device__ __forceinline__ float4 get1 (int p) const { return p < in_regs ? c1[p < in_regs ? p : 0] : spill[(2 * (p - in_regs) + 1) * stride]; }
+    __device__ __forceinline__ void set (int p, float4 a, float4 b)
+    {
+        if (p < in_regs)
+        {
+            c0[p < in_regs ? p : 0] = a;
+            c1[p < in_regs ? p : 0] = b;
+        }
+        else
+        {
+            spill[(2 * (p - in_regs)) * stride] = a;
+            spill[(2 * (p - in_regs) + 1) * stride] = b;
+        }
+    }
+};
+template <class P>
+__device__ __forceinline__ void real_pair_apply (float2 A, float2 Zp, float2 w, float2 fk, float2 fp, float scaling, bool dc, float2& zk, float2& zp)
+{
+    float2 Xk, Xp;
+    real_split_pair (A, Zp, w, Xk, Xp);
+    float2 Yk = cmul (Xk, fk), Yp = cmul (Xp, fp);
+    if (dc)
+    {
+        // packed DC / Nyquist: real products (reference :1640-1644); X[M/2] = conj(Z[M/2])
+        Yk = make_float2 ((A.x + A.y) * fk.x, (A.x - A.y) * fk.y);
+        Yp = cmul (make_float2 (Zp.x, -Zp.y), fp);
+    }
+    Yk = make_float2 (Yk.x * scaling, Yk.y * scaling);
+    Yp = make_float2 (Yp.x * scaling, Yp.y * scaling);
+    real_merge_pair (Yk, Yp, w, zk, zp);
+    if (dc)
+    {
+        zk = make_float2 (Yk.x + Yk.y, Yk.x - Yk.y);
+        zp = make_float2 (2.f * Yp.x, -2.f * Yp.y);
+    }
+}
+template <class P>
+__device__ __forceinline__ void load_real_pair_map (RealPairMapRegs<P>& m, const float2* __restrict__ H, const float2* __restrict__ wtab, float scaling, int t)
+{
+    constexpr int M = P::N, r = P::radix (P::NS - 1);
+#pragma unroll
+    for (int h = 0; h < P::R / r / 2; ++h)
+#pragma unroll
+        for (int b = 0; b < r; ++b)
+        {
+            // the table holds W_N^k for k <= M / 2 (N = 2 M); beyond: W_N^k = - conj (W_N^(M - k))
+            const int k = real_pair_bin<P> (t, h, b);
+            const float2 wt = wtab[k <= M / 2 ? k : M - k];
+            const float2 w = k <= M / 2 ? wt : make_float2 (-wt.x, wt.y);
+            const float2 fk = H[k], fp = H[k == 0 ? M / 2 : M - k];
+            const bool dc = k == 0;
+            float2 k10, p10, k01, p01, ki0, pi0;
+            real_pair_apply<P> (make_float2 (1.f, 0.f), make_float2 (0.f, 0.f), w, fk, fp, scaling, dc, k10, p10); // A = 1
+            real_pair_apply<P> (make_float2 (0.f, 0.f), make_float2 (1.f, 0.f), w, fk, fp, scaling, dc, k01, p01); // B = 1
+            real_pair_apply<P> (make_float2 (0.f, 1.f), make_float2 (0.f, 0.f), w, fk, fp, scaling, dc, ki0, pi0); // A = i (DC bin only)
+            // regular: Z'_k = M11 A + M12 conj B with M11 = k10, M12 = conj-free: B = 1 -> conj B = 1 -> M12 = k01;
+            //          Z'_p = conj (M21 A + M22 conj B): A = 1 -> conj M21 = p10; B = 1 -> conj M22 = p01
+            // DC bin:  Z'_0 = a A + b conj A: A = 1 -> a + b = k10; A = i -> i (a - b) = ki0  =>  a - b = -i ki0 = (ki0.y, -ki0.x)
+            const float2 amb = make_float2 (ki0.y, -ki0.x);
+            const float2 c_a = dc ? make_float2 (0.5f * (k10.x + amb.x), 0.5f * (k10.y + amb.y)) : k10;
+            const float2 c_b = dc ? make_float2 (0.5f * (k10.x - amb.x), 0.5f * (k10.y - amb.y)) : k01;
+            m.set (h * r + b, make_float4 (c_a.x, c_a.y, c_b.x, c_b.y), make_float4 (p10.x, p10.y, p01.x, p01.y));
+        }
+}
+
+template <class P, bool PREDICATED>
+__device__ __forceinline__ void conv_real_finish_tp (float2 (&v)[P::R],
+                                                     const TwiddleRegsL1<P>& tw, // last stage loaded with RealPairMap, stage 1 from its LDS table
+                                                     const RealPairMapRegs<P>& pm,
+                                                     float2* lds,
+                                                     float2* __restrict__ dst,
+                                                     unsigned team_base,
+                                                     int t,
+                                                     bool active,
+                                                     bool first_wave)
+{
+    constexpr int r = P::radix (P::NS - 1), HP = P::R / r / 2;
+    team_sync<P::T>();
+    fft_core<P, RealPairMap<P>> (v, tw, lds, t);
+    const bool t0 = t == 0;
+    float2 u[P::R]; // operands of the backward transform (a fresh array: reusing `v` through the reference leaves it in scratch memory)
+#pragma unroll
+    for (int h = 0; h < HP; ++h)
+    {
+        // butterfly i: slot b = bin i + NB b;   butterfly NB - i: slot r - 1 - b = bin M - (i + NB b)
+#define va(B) v[(2 * h) * r + (B)]
+#define vb(B) v[(2 * h + 1) * r + (B)]
+#define ua(B) u[(2 * h) * r + (B)]
+#define ub(B) u[(2 * h + 1) * r + (B)]
+        float2 A[r], Zp[r];
+#pragma unroll
+        for (int b = 0; b < r; ++b)
+        {
+            A[b] = va (b);
+            Zp[b] = vb (r - 1 - b);
+        }
+        if (h == 0 && first_wave)
+        {
+            // work-item 0: butterflies 0 and NB / 2, which mirror into themselves
+#pragma unroll
+            for (int b = r / 2; b < r; ++b)
+                A[b] = t0 ? vb (b - r / 2) : A[b];
+            Zp[0] = t0 ? va (r / 2) : Zp[0];
+#pragma unroll
+            for (int b = 1; b < r / 2; ++b)
+                Zp[b] = t0 ? va (r - b) : Zp[b];
+#pragma unroll
+            for (int b = r / 2; b < r; ++b)
+                Zp[b] = t0 ? vb (r - 1 - (b - r / 2)) : Zp[b];
+        }
+        float2 zk[r], zp[r];
+#pragma unroll
+        for (int b = 0; b < r; ++b)
+        {
+            const float4 c0 = pm.get0 (h * r + b), c1 = pm.get1 (h * r + b);
+            const float2 a = A[b], bb = Zp[b];
+            float2 x = bb;
+            if (h == 0 && b == 0 && first_wave)
+                x = t0 ? a : bb; // the packed DC / Nyquist bin maps onto itself
+            // Z'_k = c0.xy * a + c0.zw * conj (x)
+            zk[b].x = fmaf (c0.w, x.y, fmaf (c0.z, x.x, fmaf (-c0.y, a.y, c0.x * a.x)));
+            zk[b].y = fmaf (c0.w, x.x, fmaf (-c0.z, x.y, fmaf (c0.y, a.x, c0.x * a.y)));
+            // Z'_(M-k) = c1.xy * conj (a) + c1.zw * b
+            zp[b].x = fmaf (-c1.w, bb.y, fmaf (c1.z, bb.x, fmaf (c1.y, a.y, c1.x * a.x)));
+            zp[b].y = fmaf (c1.w, bb.x, fmaf (c1.z, bb.y, fmaf (c1.y, a.x, -c1.x * a.y)));
+        }
+        // back into the butterflies' slots, re <-> im swapped: operands of the backward transform
+#pragma unroll
+        for (int b = 0; b < r; ++b)
+        {
+            ua (b) = make_float2 (zk[b].y, zk[b].x);
+            ub (r - 1 - b) = make_float2 (zp[b].y, zp[b].x);
+        }
+        if (h == 0 && first_wave)
+        {
+            ua (r / 2) = t0 ? make_float2 (zp[0].y, zp[0].x) : ua (r / 2);
+#pragma unroll
+            for (int j = r / 2 + 1; j < r; ++j)
+                ua (j) = t0 ? make_float2 (zp[r - j].y, zp[r - j].x) : ua (j);
+#pragma unroll
+            for (int j = 0; j < r / 2; ++j)
+                ub (j) = t0 ? make_float2 (zk[j + r / 2].y, zk[j + r / 2].x) : ub (j);
+#pragma unroll
+            for (int j = r / 2; j < r; ++j)
+                ub (j) = t0 ? make_float2 (zp[(r - 1 - j) + r / 2].y, zp[(r - 1 - j) + r / 2].x) : ub (j);
+        }
+#undef va
+#undef vb
+#undef ua
+#undef ub
+    }
+    team_sync<P::T>(); // every work-item's last-stage reads of the image have completed
+    fft_core_transposed<P, RealPairMap<P>> (u, tw, lds, t);
+    if (! PREDICATED || active)
+    {
+#pragma unroll
+        for (int s = 0; s < P::R; ++s)
+            gstore (&dst[team_base + (unsigned) input_index<P> (t, s)], make_float2 (u[s].y, u[s].x));
+    }
+}
+
+// software-pipelined kernel around conv_real_finish_tp (same frame loop as conv_frames_real_kernel_pf)
+template <class P, int FPB>
+__global__ __launch_bounds__ (P::T* FPB, CFFT_CONV_PF_MIN_WAVES) void conv_frames_real_tp_kernel_pf (const float2* __restrict__ in,
+                                                                                                    const float2* __restrict__ H,
+                                                                                                    float2* __restrict__ out,
+                                                                                                    const float2* __restrict__ twtab,
+                                                                                                    const float2* __restrict__ wtab,
+                                                                                                    float scaling,
+                                                                                                    unsigned batch)
+{
+    extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
+    constexpr int M = P::N;
+    const int tid = threadIdx.x;
+    const int team = tid / P::T;
+    const int t = tid % P::T;
+    float2* lds = smem + team * LdsFrame<M>::floats2;
+    float2* l1 = smem + FPB * LdsFrame<M>::floats2; // stage-1 twiddle table, shared by the workgroup's teams
+    const bool first_wave = __builtin_amdgcn_readfirstlane (t) < 64; // wave-uniform: the wave that holds work-item 0 of its team
+
+    fill_l1_table<P, P::T * FPB> (l1, twtab, tid);
+    TwiddleRegsL1<P> tw;
+    load_twiddles<P, RealPairMap<P>> (tw, twtab, t, l1);
+    RealPairMapRegs<P> pm;
+    static_assert (FPB == 1 || RealPairMapRegs<P>::in_lds == 0, "the LDS part of the pair map is laid out for one team per workgroup");
+    pm.spill = reinterpret_cast<float4*> (l1 + (P::radix (1) - 1) * P::prod (1)) + t; // behind the stage-1 table (16-byte aligned: 240 float2)
+    load_real_pair_map<P> (pm, H, wtab, scaling, t);
+
+    const unsigned nfull = batch / FPB;
+    const unsigned team_base = (unsigned) team * M;
+    float nre[P::R], nim[P::R];
+    unsigned g = blockIdx.x;
+    if (g < nfull)
+    {
+        {
+            const float2* __restrict__ src = in + (size_t) g * (FPB * M);
+            float2 v[P::R];
+#pragma unroll
+            for (int s = 0; s < P::R; ++s)
+                v[s] = gload (&src[team_base + (unsigned) input_index<P> (t, s)]);
+            const unsigned gn = g + gridDim.x;
+            if (gn < nfull)
+            {
+                const float2* __restrict__ srcn = in + (size_t) gn * (FPB * M);
+#pragma unroll
+                for (int s = 0; s < P::R; ++s)
+                {
+                    const float2 x = gload (&srcn[team_base + (unsigned) input_index<P> (t, s)]);
+                    nre[s] = x.x;
+                    nim[s] = x.y;
+                }
+            }
+            conv_real_finish_tp<P, false> (v, tw, pm, lds, out + (size_t) g * (FPB * M), team_base, t, true, first_wave);
+        }
+        for (g += gridDim.x; g < nfull; g += gridDim.x)
+        {
+            float2 v[P::R];
+#pragma unroll
+            for (int s = 0; s < P::R; ++s)
+                v[s] = make_float2 (nre[s], nim[s]);
+            const unsigned gn = g + gridDim.x;
+            if (gn < nfull)
+            {
+                const float2* __restrict__ srcn = in + (size_t) gn * (FPB * M);
+#pragma unroll
+                for (int s = 0; s < P::R; ++s)
+                {
+                    const float2 x = gload (&srcn[team_base + (unsigned) input_index<P> (t, s)]);
+                    nre[s] = x.x;
+                    nim[s] = x.y;
+                }
+            }
+            conv_real_finish_tp<P, false> (v, tw, pm, lds, out + (size_t) g * (FPB * M), team_base, t, true, first_wave);
+        }
+    }
+    if (FPB > 1 && nfull * FPB < batch && blockIdx.x == nfull % gridDim.x)
+    {
+        const bool active = nfull * FPB + team < batch;
+        const float2* __restrict__ src = in + (size_t) nfull * (FPB * M);
+        float2 v[P::R];
+#pragma unroll
+        for (int s = 0; s < P::R; ++s)
+            v[s] = active ? gload (&src[team_base + (unsigned) input_index<P> (t, s)]) : make_float2 (0.f, 0.f);
+        conv_real_finish_tp<P, true> (v, tw, pm, lds, out + (size_t) nfull * (FPB * M), team_base, t, active, first_wave);
     }
 }
 

@@ -70,9 +70,22 @@ hipError_t launch_cf_real_m (const float2* in, const float2* H, float2* out, con
     constexpr bool use_pf = (CFFT_CONV_PREFETCH == 1) || (CFFT_CONV_PREFETCH == 2 && (M == 1024 || M == 4096 || (M == 2048 && CFFT_CONV_PF2048)));
     constexpr bool hregs = ! (use_pf && M == 2048);
     constexpr int threads = P::T * FPB;
-    constexpr size_t lds_bytes = G::lds_bytes / G::FPB * FPB; // no staging area for T >= 16
+#ifndef CFFT_CONV_REAL_TP
+#define CFFT_CONV_REAL_TP 1
+#endif
+    constexpr bool use_tp_decl = CFFT_CONV_REAL_TP && use_pf && kRealPairInRegs<P> && M == 2048 && ! CFFT_CONV_STREAM_TW;
+    constexpr size_t lds_bytes = G::lds_bytes / G::FPB * FPB // no staging area for T >= 16
+                                 + (use_tp_decl ? (size_t) (P::radix (1) - 1) * P::prod (1) * sizeof (float2) // + the stage-1 twiddle table of the round-4 kernel
+                                                      + (size_t) 2 * CFFT_CONV_TP_MAP_LDS * P::T * sizeof (float4) // + the part of the pair map kept in LDS
+                                                : 0);
+    // round 4 (CFFT_CONV_REAL_TP, default 1): pair stage in registers + transposed backward network for the plans whose last
+    // stage gives a work-item an even number of butterflies (M = 1024, 2048)
+    // (M = 1024, whose last radix-4 stage gives a work-item four butterflies, spills 144 bytes in this form: not taken)
+    constexpr bool use_tp = use_tp_decl;
     auto kernel = [] { // only the variant in use is instantiated
-        if constexpr (use_pf)
+        if constexpr (use_tp)
+            return &conv_frames_real_tp_kernel_pf<P, FPB>;
+        else if constexpr (use_pf)
             return &conv_frames_real_kernel_pf<P, FPB, hregs>;
         else
             return &conv_frames_real_kernel<P, FPB, hregs>;

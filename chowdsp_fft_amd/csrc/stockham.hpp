@@ -21,6 +21,8 @@
 #pragma once
 #include "butterflies.hpp"
 
+#include <type_traits>
+
 namespace cfft
 {
 // ---- compile-time plan -------------------------------------------------------------------------
@@ -81,6 +83,18 @@ __device__ __forceinline__ void team_sync()
     }
 }
 
+// Which butterfly of a stage a work-item's slot q computes.  PlainMap: i = t + T q (lane-contiguous: what the stages that
+// touch global memory need).  A stage that exchanges through LDS on both sides may use any bijection instead -- the fused
+// real convolution assigns its LAST stage so that a bin and its mirror bin end up in the same work-item (RealPairMap,
+// conv_kernels.hpp).  MapOf<P, S, MapLast> = MapLast for the last stage, PlainMap otherwise.
+struct PlainMap
+{
+    template <class P>
+    static __device__ __forceinline__ constexpr int index (int t, int q) { return t + P::T * q; }
+};
+template <class P, int S, class MapLast>
+using MapOf = std::conditional_t<S == P::NS - 1, MapLast, PlainMap>;
+
 // ---- twiddle registers -------------------------------------------------------------------------
 template <class P>
 struct TwiddleRegs
@@ -89,8 +103,38 @@ struct TwiddleRegs
     float2 w[(P::NS > 1 ? P::NS - 1 : 1)][P::R];
 };
 
+// The same with the twiddles of stage 1 read from an LDS table at their use instead of living in registers (round 4: the
+// fused real convolution trades these (r1 - 1) * Q1 register pairs for its resident pair-map coefficients).  Stage 1's
+// twiddles depend on k = i mod r0 only: a table of (r1 - 1) * r0 entries [a - 1][k] per workgroup, read as broadcasts.
+template <class P>
+struct TwiddleRegsL1
+{
+    const float2* l1; // (plans with at least three stages: stage 1 must not be the last one, whose assignment may be mapped)
+    float2 w[(P::NS > 1 ? P::NS - 1 : 1)][P::R]; // row 0 stays unused (never loaded: the optimiser drops it)
+};
 template <class P, int S>
-__device__ __forceinline__ void load_twiddles_stage (TwiddleRegs<P>& tw, const float2* __restrict__ table, int t)
+__device__ __forceinline__ float2 tw_get (const TwiddleRegs<P>& tw, int q, int a, int)
+{
+    return tw.w[S > 0 ? S - 1 : 0][q * (P::radix (S) - 1) + (a - 1)];
+}
+template <class P, int S>
+__device__ __forceinline__ float2 tw_get (const TwiddleRegsL1<P>& tw, int q, int a, int t)
+{
+    if constexpr (S == 1)
+        return tw.l1[(a - 1) * P::prod (1) + ((t + P::T * q) & (P::prod (1) - 1))];
+    else
+        return tw.w[S > 0 ? S - 1 : 0][q * (P::radix (S) - 1) + (a - 1)];
+}
+template <class P, int T_THREADS>
+__device__ __forceinline__ void fill_l1_table (float2* __restrict__ l1, const float2* __restrict__ table, int tid)
+{
+    constexpr int n = (P::radix (1) - 1) * P::prod (1);
+    for (int j = tid; j < n; j += T_THREADS)
+        l1[j] = table[P::tw_offset (1) + j];
+}
+
+template <class P, int S, class Map = PlainMap, class TW = TwiddleRegs<P>>
+__device__ __forceinline__ void load_twiddles_stage (TW& tw, const float2* __restrict__ table, int t)
 {
     constexpr int r = P::radix (S);
     constexpr int p = P::prod (S);
@@ -98,7 +142,7 @@ __device__ __forceinline__ void load_twiddles_stage (TwiddleRegs<P>& tw, const f
 #pragma unroll
     for (int q = 0; q < Q; ++q)
     {
-        const int i = t + P::T * q;
+        const int i = Map::template index<P> (t, q);
         const int k = i & (p - 1);
 #pragma unroll
         for (int a = 1; a < r; ++a)
@@ -117,12 +161,19 @@ __device__ __forceinline__ void load_twiddles_stage (TwiddleRegs<P>& tw, const f
     }
 }
 
-template <class P>
+template <class P, class MapLast = PlainMap>
+__device__ __forceinline__ void load_twiddles (TwiddleRegsL1<P>& tw, const float2* __restrict__ table, int t, const float2* l1)
+{
+    tw.l1 = l1;
+    if constexpr (P::NS > 2) load_twiddles_stage<P, 2, MapOf<P, 2, MapLast>> (tw, table, t);
+    if constexpr (P::NS > 3) load_twiddles_stage<P, 3, MapOf<P, 3, MapLast>> (tw, table, t);
+}
+template <class P, class MapLast = PlainMap>
 __device__ __forceinline__ void load_twiddles (TwiddleRegs<P>& tw, const float2* __restrict__ table, int t)
 {
-    if constexpr (P::NS > 1) load_twiddles_stage<P, 1> (tw, table, t);
-    if constexpr (P::NS > 2) load_twiddles_stage<P, 2> (tw, table, t);
-    if constexpr (P::NS > 3) load_twiddles_stage<P, 3> (tw, table, t);
+    if constexpr (P::NS > 1) load_twiddles_stage<P, 1, MapOf<P, 1, MapLast>> (tw, table, t);
+    if constexpr (P::NS > 2) load_twiddles_stage<P, 2, MapOf<P, 2, MapLast>> (tw, table, t);
+    if constexpr (P::NS > 3) load_twiddles_stage<P, 3, MapOf<P, 3, MapLast>> (tw, table, t);
 }
 
 // ---- one stage ---------------------------------------------------------------------------------
@@ -158,9 +209,34 @@ __device__ __forceinline__ void stage_compute (float2 (&v)[P::R], const TwiddleR
 {
     stage_compute_row<P, S> (v, tw.w[S > 0 ? S - 1 : 0]);
 }
+// ... with the twiddles through tw_get (registers, or stage 1 from its LDS table)
+template <class P, int S, class TW>
+__device__ __forceinline__ void stage_compute_tw (float2 (&v)[P::R], const TW& tw, int t)
+{
+    constexpr int r = P::radix (S);
+    constexpr int Q = P::R / r;
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+    {
+        float2 u[r];
+#pragma unroll
+        for (int a = 0; a < r; ++a)
+            u[a] = v[q * r + a];
+        if constexpr (S > 0)
+        {
+#pragma unroll
+            for (int a = 1; a < r; ++a)
+                u[a] = cmul (u[a], tw_get<P, S> (tw, q, a, t));
+        }
+        fft_reg<r> (u);
+#pragma unroll
+        for (int a = 0; a < r; ++a)
+            v[q * r + a] = u[a];
+    }
+}
 
 // scatter the outputs of stage S into the LDS image (Y[j + b*p])
-template <class P, int S>
+template <class P, int S, class Map = PlainMap>
 __device__ __forceinline__ void stage_write_lds (const float2 (&v)[P::R], float2* __restrict__ lds, int t)
 {
     constexpr int r = P::radix (S);
@@ -169,7 +245,7 @@ __device__ __forceinline__ void stage_write_lds (const float2 (&v)[P::R], float2
 #pragma unroll
     for (int q = 0; q < Q; ++q)
     {
-        const int i = t + P::T * q;
+        const int i = Map::template index<P> (t, q);
         const int k = i & (p - 1);
         const int j = (i - k) * r + k;
 #pragma unroll
@@ -179,7 +255,7 @@ __device__ __forceinline__ void stage_write_lds (const float2 (&v)[P::R], float2
 }
 
 // gather the inputs of stage S from the LDS image (X[i + a*N/r])
-template <class P, int S>
+template <class P, int S, class Map = PlainMap>
 __device__ __forceinline__ void stage_read_lds (float2 (&v)[P::R], const float2* __restrict__ lds, int t)
 {
     constexpr int r = P::radix (S);
@@ -188,10 +264,77 @@ __device__ __forceinline__ void stage_read_lds (float2 (&v)[P::R], const float2*
 #pragma unroll
     for (int q = 0; q < Q; ++q)
     {
-        const int i = t + P::T * q;
+        const int i = Map::template index<P> (t, q);
 #pragma unroll
         for (int a = 0; a < r; ++a)
             v[q * r + a] = lds[lds_phys (i + a * m)];
+    }
+}
+
+// ---- the TRANSPOSED network (round 4) ---------------------------------------------------------------------------
+// The DFT matrix is symmetric, so the transpose of the network above -- every stage run backwards: gather where it
+// scattered, DFT_r (symmetric itself), multiply by the SAME twiddles after the butterfly instead of before, scatter where
+// it gathered -- computes the same transform, but takes its operands in the forward network's OUTPUT arrangement (slot
+// q r + b of the last stage = index i_q + b N / r) and leaves its results in the forward network's INPUT arrangement
+// (input_index).  A kernel that runs a forward transform, works on the spectrum in registers and transforms back
+// (the fused convolutions) therefore needs no re-ordering pass through LDS between the two transforms, and both share
+// one set of twiddle registers.  Same LDS access patterns as the forward stages (mirrored), hence the same bank behaviour.
+template <class P, int S, class TW>
+__device__ __forceinline__ void stage_compute_t (float2 (&v)[P::R], const TW& tw, int t)
+{
+    constexpr int r = P::radix (S);
+    constexpr int Q = P::R / r;
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+    {
+        float2 u[r];
+#pragma unroll
+        for (int a = 0; a < r; ++a)
+            u[a] = v[q * r + a];
+        fft_reg<r> (u);
+        if constexpr (S > 0)
+        {
+#pragma unroll
+            for (int a = 1; a < r; ++a)
+                u[a] = cmul (u[a], tw_get<P, S> (tw, q, a, t));
+        }
+#pragma unroll
+        for (int a = 0; a < r; ++a)
+            v[q * r + a] = u[a];
+    }
+}
+// transposed stage S, output side: X'[i + a N / r] = v[q r + a]   (mirror of stage_read_lds)
+template <class P, int S, class Map = PlainMap>
+__device__ __forceinline__ void stage_write_lds_t (const float2 (&v)[P::R], float2* __restrict__ lds, int t)
+{
+    constexpr int r = P::radix (S);
+    constexpr int Q = P::R / r;
+    constexpr int m = P::N / r;
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+    {
+        const int i = Map::template index<P> (t, q);
+#pragma unroll
+        for (int a = 0; a < r; ++a)
+            lds[lds_phys (i + a * m)] = v[q * r + a];
+    }
+}
+// transposed stage S, input side: v[q r + b] = Y'[j + b p]   (mirror of stage_write_lds)
+template <class P, int S, class Map = PlainMap>
+__device__ __forceinline__ void stage_read_lds_t (float2 (&v)[P::R], const float2* __restrict__ lds, int t)
+{
+    constexpr int r = P::radix (S);
+    constexpr int p = P::prod (S);
+    constexpr int Q = P::R / r;
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+    {
+        const int i = Map::template index<P> (t, q);
+        const int k = i & (p - 1);
+        const int j = (i - k) * r + k;
+#pragma unroll
+        for (int b = 0; b < r; ++b)
+            v[q * r + b] = lds[lds_phys (j + b * p)];
     }
 }
 
@@ -280,32 +423,66 @@ __device__ __forceinline__ void stage_out_strided (float2* __restrict__ dst, uns
 
 // Stages 0..NS-1 on registers v (already loaded in input_index order); leaves the result in
 // output_index order.  `lds` is this team's private LDS image.
-template <class P>
-__device__ __forceinline__ void fft_core (float2 (&v)[P::R], const TwiddleRegs<P>& tw, float2* __restrict__ lds, int t)
+// MapLast: the butterfly assignment of the LAST stage (its twiddles must have been loaded with the same map); with
+// anything but PlainMap the result is in that map's arrangement instead of output_index order.
+template <class P, class MapLast = PlainMap, class TW = TwiddleRegs<P>>
+__device__ __forceinline__ void fft_core (float2 (&v)[P::R], const TW& tw, float2* __restrict__ lds, int t)
 {
-    stage_compute<P, 0> (v, tw);
+    stage_compute_tw<P, 0> (v, tw, t);
     if constexpr (P::NS > 1)
     {
         stage_write_lds<P, 0> (v, lds, t);
         team_sync<P::T>();
-        stage_read_lds<P, 1> (v, lds, t);
-        stage_compute<P, 1> (v, tw);
+        stage_read_lds<P, 1, MapOf<P, 1, MapLast>> (v, lds, t);
+        stage_compute_tw<P, 1> (v, tw, t);
     }
     if constexpr (P::NS > 2)
     {
         team_sync<P::T>();
         stage_write_lds<P, 1> (v, lds, t);
         team_sync<P::T>();
-        stage_read_lds<P, 2> (v, lds, t);
-        stage_compute<P, 2> (v, tw);
+        stage_read_lds<P, 2, MapOf<P, 2, MapLast>> (v, lds, t);
+        stage_compute_tw<P, 2> (v, tw, t);
     }
     if constexpr (P::NS > 3)
     {
         team_sync<P::T>();
         stage_write_lds<P, 2> (v, lds, t);
         team_sync<P::T>();
-        stage_read_lds<P, 3> (v, lds, t);
-        stage_compute<P, 3> (v, tw);
+        stage_read_lds<P, 3, MapOf<P, 3, MapLast>> (v, lds, t);
+        stage_compute_tw<P, 3> (v, tw, t);
+    }
+}
+
+// The transposed network: v in the arrangement fft_core<P, MapLast> leaves (output_index order for PlainMap), result in
+// input_index order.  The caller makes sure that every read of the image by the previous phase has completed (team_sync)
+// before calling -- the first thing this does with LDS is write.
+template <class P, class MapLast = PlainMap, class TW = TwiddleRegs<P>>
+__device__ __forceinline__ void fft_core_transposed (float2 (&v)[P::R], const TW& tw, float2* __restrict__ lds, int t)
+{
+    stage_compute_t<P, P::NS - 1> (v, tw, t);
+    if constexpr (P::NS > 3)
+    {
+        stage_write_lds_t<P, 3, MapOf<P, 3, MapLast>> (v, lds, t);
+        team_sync<P::T>();
+        stage_read_lds_t<P, 2> (v, lds, t);
+        stage_compute_t<P, 2> (v, tw, t);
+        team_sync<P::T>();
+    }
+    if constexpr (P::NS > 2)
+    {
+        stage_write_lds_t<P, 2, MapOf<P, 2, MapLast>> (v, lds, t);
+        team_sync<P::T>();
+        stage_read_lds_t<P, 1> (v, lds, t);
+        stage_compute_t<P, 1> (v, tw, t);
+        team_sync<P::T>();
+    }
+    if constexpr (P::NS > 1)
+    {
+        stage_write_lds_t<P, 1, MapOf<P, 1, MapLast>> (v, lds, t);
+        team_sync<P::T>();
+        stage_read_lds_t<P, 0> (v, lds, t);
+        stage_compute_t<P, 0> (v, tw, t);
     }
 }
 

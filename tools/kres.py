@@ -26,4 +26,4 @@ for line in txt.splitlines():
 for r in rows:
     n = re.sub(r"HIP_vector_type<float, 2u>", "float2", r["name"])
     n = re.sub(r"\(.*", "", n)
-    print(f"vgpr={r.get('VGPRs'):4d} sgpr={r.get('TotalSGPRs'):3d} scratch={r.get('ScratchSize'):4d} occ={r.get('Occupancy')} {n}")
+    print(f"vgpr={r.get('VGPRs'):4d} agpr={r.get('AGPRs', 0):3d} sgpr={r.get('TotalSGPRs'):3d} scratch={r.get('ScratchSize'):4d} occ={r.get('Occupancy')} {n}")
