@@ -119,14 +119,14 @@ __global__ __launch_bounds__ (256, 1) void groupfast_kernel (const float2* __res
                 BW[q * FA::R1 + b] = big_tw[(size_t) a_ * N2 + i_ + 32 * b];                        \
         }                                                                                           \
     }
-#define CFFT_GF_LOAD_A(V, SRC, TA)                                                                  \
+#define CFFT_GF_LOAD_A(V, SRC, TA, SWAP)                                                                  \
     {                                                                                               \
         const float2* __restrict__ s_ = (SRC) + ((unsigned) (TA) & 15u);                            \
         const unsigned m_ = (unsigned) (TA) >> 4;                                                   \
         _Pragma ("unroll") for (int a = 0; a < 32; ++a)                                             \
         {                                                                                           \
             const float2 x_ = gload (&s_[(size_t) (m_ + FA::Tn * a) * N1]);                         \
-            V[a] = INV ? make_float2 (x_.y, x_.x) : x_;                                             \
+            V[a] = (INV && (SWAP)) ? make_float2 (x_.y, x_.x) : x_;                                 \
         }                                                                                           \
     }
 #define CFFT_GF_STORE_OUT(V, DST, TB)                                                               \
@@ -157,7 +157,7 @@ __global__ __launch_bounds__ (256, 1) void groupfast_kernel (const float2* __res
         float2 nv[32];
         unsigned f = gg;
         if (f < batch)
-            CFFT_GF_LOAD_A (nv, in + (size_t) f * in_stride + a0, ta0)
+            CFFT_GF_LOAD_A (nv, in + (size_t) f * in_stride + a0, ta0, false)
         for (unsigned k = 0; f < batch; f += total, ++k)
         {
             int ta = ta0, tb = tb0;
@@ -166,7 +166,18 @@ __global__ __launch_bounds__ (256, 1) void groupfast_kernel (const float2* __res
             float2 v[32];
 #pragma unroll
             for (int a = 0; a < 32; ++a)
-                v[a] = nv[a];
+            {
+                if constexpr (INV)
+                {
+                    // the backward transform's re <-> im swap where the operands are CONSUMED, behind an opaque statement (at the
+                    // request it is an instruction that waits for the prefetch where it was issued: group_twopass_kernels.hpp)
+                    float2 x = nv[a];
+                    asm volatile ("" : "+v"(x.x), "+v"(x.y));
+                    v[a] = make_float2 (x.y, x.x);
+                }
+                else
+                    v[a] = nv[a];
+            }
             // ---- pass A
             fft_reg32<false> (v, wa);
             CFFT_PHASE_FENCE();
@@ -184,17 +195,42 @@ __global__ __launch_bounds__ (256, 1) void groupfast_kernel (const float2* __res
             const bool pre_here = fn < batch && (form == 2u || (form == 1u && tid0 >= 64));
             if (pre_here)
             {
-                CFFT_GF_LOAD_A (nv, in + (size_t) fn * in_stride + a0, ta)
+                CFFT_GF_LOAD_A (nv, in + (size_t) fn * in_stride + a0, ta, false)
                 asm volatile ("s_waitcnt vmcnt(32)" ::: "memory"); // all but the 32 prefetch loads: this wave's stores are in L2
             }
             else
                 asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+#if CFFT_GROUP_WAVE_FLAGS
+            // the hand-off by wave (group_twopass_kernels.hpp): word 4 member + wave, every wave polls all 4 M words itself,
+            // no workgroup barrier on either side
+            if ((tid0 & 63) == 0)
+                flag_store (&af[4u * member + ((unsigned) tid0 >> 6)], k + 1u);
+            {
+                unsigned n = 0;
+                for (;;)
+                {
+                    bool up = ld_relaxed (af + (tid0 & 63)) >= k + 1u;
+                    if (GF::M == 32)
+                        up = up && ld_relaxed (af + 64 + (tid0 & 63)) >= k + 1u;
+                    if (__all (up) != 0)
+                        break;
+                    __builtin_amdgcn_s_sleep (2);
+                    if (++n > spin_limit)
+                    {
+                        if ((tid0 & 63) == 0)
+                            group_fail (st, host_err, seq, 1u);
+                        break;
+                    }
+                }
+            }
+#else
             __syncthreads();
             if (tid0 == 0)
                 flag_store (&af[member], k + 1u);
             if (tid0 < 64)
                 group_wait_m<GF::M, 2> (af, k + 1u, tid0, st, host_err, seq, 1u, spin_limit);
             __syncthreads();
+#endif
             // ---- pass B: rows [kb0, kb0 + 16) of the slot
             {
                 const float2* __restrict__ src = slot + kb0 + ((unsigned) tb & 15u);
@@ -204,7 +240,7 @@ __global__ __launch_bounds__ (256, 1) void groupfast_kernel (const float2* __res
                     v[a] = gload_l2 (&src[(size_t) (mb + FB::Tn * a) * N2]);
             }
             if (fn < batch && ! pre_here)
-                CFFT_GF_LOAD_A (nv, in + (size_t) fn * in_stride + a0, ta)
+                CFFT_GF_LOAD_A (nv, in + (size_t) fn * in_stride + a0, ta, false)
             CFFT_PHASE_FENCE();
             fft_reg32<false> (v, wb[0]);
             CFFT_PHASE_FENCE();
@@ -235,7 +271,7 @@ __global__ __launch_bounds__ (256, 1) void groupfast_kernel (const float2* __res
         {
             const unsigned a0 = (round * (unsigned) GF::SA + (unsigned) sub_a) * 16u;
             float2 v[32], bw[32];
-            CFFT_GF_LOAD_A (v, in + (size_t) f * in_stride + a0, ta0)
+            CFFT_GF_LOAD_A (v, in + (size_t) f * in_stride + a0, ta0, true)
             CFFT_GF_LOAD_BW (bw, a0, ta0)
             fft_reg32<false> (v, wa);
             ft_exchange<FA, true> (v, plane_a, ta0);

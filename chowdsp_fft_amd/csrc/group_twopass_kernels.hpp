@@ -58,6 +58,13 @@
 #ifndef CFFT_GROUP_INV_CONJ
 #define CFFT_GROUP_INV_CONJ 0
 #endif
+// Hand-off flags per WAVE and no workgroup barrier around the hand-off (1) or per member behind two barriers (0, default).
+// Round-4 A/B (profiles/r04_group_two_pass.txt): the per-wave form is no faster at 8192 frames (0.483-0.485 against 0.488 of
+// 8 TB/s) and 5 % slower at 2048 (0.461 against 0.484); 2^17 / 2^18 0.393 / 0.377 against 0.395 / 0.385 -- four waves polling
+// 64 words each cost more than the two barriers they replace.
+#ifndef CFFT_GROUP_WAVE_FLAGS
+#define CFFT_GROUP_WAVE_FLAGS 0
+#endif
 
 namespace cfft
 {
@@ -78,8 +85,9 @@ struct GroupState
         unsigned count; // ranks drawn on this XCD
         unsigned pad[31];
     } xcc[kGroupMaxXcc];
-    // [xcc][group][member]: number of frames whose pass-A tile the member has stored (one 64-byte poll per group)
-    unsigned aflag[kGroupMaxXcc][kGroupMaxPerXcc][32];
+    // [xcc][group][member]: number of frames whose pass-A tile the member has stored (one 64-byte poll per group).
+    // group256_kernel (round 4): [4 member + wave] -- every WAVE publishes its own stores and polls all 64 words with one load
+    unsigned aflag[kGroupMaxXcc][kGroupMaxPerXcc][128]; // (groupfast_kernel with 32 members: 128 waves)
     // ... and whose pass-B tile it has loaded (lines of their own: they are written at another time than the aflags)
     unsigned bflag[kGroupMaxXcc][kGroupMaxPerXcc][32];
 #if CFFT_GROUP_EXPERIMENT
@@ -283,7 +291,7 @@ __global__ __launch_bounds__ (256, 2) void group256_kernel (const float2* __rest
         float nre[16], nim[16];
         unsigned f = gg;
         if (f < batch)
-            g256_load_a<INV> (nre, nim, in + (size_t) f * in_stride + tile * 16, t0, c0);
+            g256_load_a<false> (nre, nim, in + (size_t) f * in_stride + tile * 16, t0, c0);
 #if CFFT_GROUP_EXPERIMENT
         const bool stamping = (dbg & 32u) != 0 && gg == 0 && tile == 0;
 #endif
@@ -298,7 +306,21 @@ __global__ __launch_bounds__ (256, 2) void group256_kernel (const float2* __rest
             CFFT_GROUP_STAMP (1)
 #pragma unroll
             for (int s = 0; s < 16; ++s)
-                v[s] = make_float2 (nre[s], nim[s]);
+            {
+                if constexpr (INV)
+                {
+                    // the swap HERE, behind an opaque statement: written at the request (or written here without the statement --
+                    // the optimiser turns the 32 loop-carried scalars into 16 loop-carried pairs and builds the pairs at the
+                    // end of the previous iteration, i.e. right behind the loads) it is an instruction that reads the load's
+                    // result, so every wave waits for its prefetch where it issued it (vmcnt is one in-order counter: and for
+                    // everything requested before it).  That cost the backward instantiation 6-12 % in round 3.
+                    float a = nre[s], c = nim[s];
+                    asm volatile ("" : "+v"(a), "+v"(c));
+                    v[s] = CFFT_GROUP_INV_CONJ ? make_float2 (a, -c) : make_float2 (c, a);
+                }
+                else
+                    v[s] = make_float2 (nre[s], nim[s]);
+            }
             // ---- pass A: columns [16 tile, 16 tile + 16) of frame f
             fft256_two_stage_lds (v, tw1, i1, smem, c0, t0, c1, i1);
             float2* __restrict__ slot = slots + (size_t) (two_slots != 0 ? (k & 1u) : 0u) * N;
@@ -333,12 +355,37 @@ __global__ __launch_bounds__ (256, 2) void group256_kernel (const float2* __rest
             const bool pre_here = early && fn < batch && ! CFFT_GROUP_DBG (8u) && ! (w0late && tid < 64);
             if (pre_here)
             {
-                g256_load_a<INV> (nre, nim, in + (size_t) fn * in_stride + tile * 16, t0, c0);
+                g256_load_a<false> (nre, nim, in + (size_t) fn * in_stride + tile * 16, t0, c0);
                 asm volatile ("s_waitcnt vmcnt(16)" ::: "memory"); // all but the 16 prefetch loads: this wave's stores are in L2
             }
             else
                 asm volatile ("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's stores are in L2
             CFFT_GROUP_STAMP (4)
+#if CFFT_GROUP_WAVE_FLAGS
+            // Round 4: the hand-off by WAVE instead of by workgroup.  A wave's stores are acknowledged (the wait above): it
+            // publishes them itself -- word 4 tile + wave -- and polls the group's 64 words with ONE load, lane l word l.  No
+            // workgroup barrier on either side of the hand-off (it had two): a wave goes on as soon as the 64 producers of
+            // the frame have published, whatever its sister waves are doing.  Same protocol, same scopes, finer grain.
+            if ((tid & 63) == 0)
+                flag_store (&af[4u * tile + ((unsigned) tid >> 6)], k + 1u);
+            CFFT_GROUP_STAMP (5)
+            if (! CFFT_GROUP_DBG (1u))
+            {
+                unsigned n = 0;
+                while (__all (ld_relaxed (af + (tid & 63)) >= k + 1u) == 0)
+                {
+                    __builtin_amdgcn_s_sleep (2);
+                    if (++n > spin_limit)
+                    {
+                        if ((tid & 63) == 0)
+                            group_fail (st, host_err, seq, 1u);
+                        break;
+                    }
+                }
+            }
+            CFFT_GROUP_STAMP (6)
+            CFFT_GROUP_STAMP (7)
+#else
             __syncthreads();
             if (tid == 0)
                 flag_store (&af[tile], k + 1u);
@@ -360,6 +407,7 @@ __global__ __launch_bounds__ (256, 2) void group256_kernel (const float2* __rest
             CFFT_GROUP_STAMP (6)
             __syncthreads();
             CFFT_GROUP_STAMP (7)
+#endif
             // ---- pass B: rows [16 tile, 16 tile + 16) of the slot -> transposed store into frame f
             const float2* __restrict__ srcb = slot + tile * 256 + tid;
             if (! CFFT_GROUP_DBG (4u))
@@ -374,9 +422,9 @@ __global__ __launch_bounds__ (256, 2) void group256_kernel (const float2* __rest
             // `spread`: a quarter of them here, the others between the steps of the pass-B transform (its arithmetic and LDS
             // traffic then run while the memory pipeline drains, instead of behind one burst of 32 loads)
             if (pre_late && ! spread)
-                g256_load_a<INV> (nre, nim, nsrc, t0, c0);
+                g256_load_a<false> (nre, nim, nsrc, t0, c0);
             if (pre_late && spread)
-                g256_load_a_part<INV, 0> (nre, nim, nsrc, t0, c0);
+                g256_load_a_part<false, 0> (nre, nim, nsrc, t0, c0);
             CFFT_PHASE_FENCE();
             CFFT_GROUP_STAMP (8)
 #if CFFT_GROUP_EXPERIMENT
@@ -395,7 +443,7 @@ __global__ __launch_bounds__ (256, 2) void group256_kernel (const float2* __rest
             fft_reg<16> (v);
             CFFT_PHASE_FENCE();
             if (pre_late && spread)
-                g256_load_a_part<INV, 1> (nre, nim, nsrc, t0, c0);
+                g256_load_a_part<false, 1> (nre, nim, nsrc, t0, c0);
             CFFT_PHASE_FENCE();
             __syncthreads(); // the previous exchange's reads are finished; every wave's pass-B loads have returned
             if (tid == 0 && two_slots == 0)
@@ -405,7 +453,7 @@ __global__ __launch_bounds__ (256, 2) void group256_kernel (const float2* __rest
                 smem[kbl * kFS256 + 17 * tb + b] = v[b];
             CFFT_PHASE_FENCE();
             if (pre_late && spread)
-                g256_load_a_part<INV, 2> (nre, nim, nsrc, t0, c0);
+                g256_load_a_part<false, 2> (nre, nim, nsrc, t0, c0);
             CFFT_PHASE_FENCE();
             __syncthreads();
 #pragma unroll
@@ -413,7 +461,7 @@ __global__ __launch_bounds__ (256, 2) void group256_kernel (const float2* __rest
                 v[a] = smem[kbl * kFS256 + tb + 17 * a];
             CFFT_PHASE_FENCE();
             if (pre_late && spread)
-                g256_load_a_part<INV, 3> (nre, nim, nsrc, t0, c0);
+                g256_load_a_part<false, 3> (nre, nim, nsrc, t0, c0);
             CFFT_PHASE_FENCE();
 #pragma unroll
             for (int a = 1; a < 16; ++a)
