@@ -1085,18 +1085,7 @@ __device__ __forceinline__ void static_inplace_core (const GenericPlan& plan, co
     }
 }
 template <int N_> struct StaticInplacePlanFor { using type = void; };
-template <> struct StaticInplacePlanFor<4608> { using type = StaticPlan<4608, 9, 8, 8, 8>; };
-template <> struct StaticInplacePlanFor<9216> { using type = StaticPlan<9216, 12, 12, 8, 8>; };
-// round 3: the other long lengths the verdict named (5120, and 19200 = the longest frame of one image) + 12288
-template <> struct StaticInplacePlanFor<5120> { using type = StaticPlan<5120, 10, 8, 8, 8>; };
-template <> struct StaticInplacePlanFor<12288> { using type = StaticPlan<12288, 12, 16, 8, 8>; };
-template <> struct StaticInplacePlanFor<19200> { using type = StaticPlan<19200, 12, 10, 10, 16>; };
-// ... and the other lengths of 3 x 2^k and 5 x 2^k / 15 x 2^k between them (512- and 1024-thread forms, where the list pays)
-template <> struct StaticInplacePlanFor<6144> { using type = StaticPlan<6144, 12, 8, 8, 8>; };
-template <> struct StaticInplacePlanFor<7680> { using type = StaticPlan<7680, 12, 10, 8, 8>; };
-template <> struct StaticInplacePlanFor<10240> { using type = StaticPlan<10240, 10, 16, 8, 8>; };
-template <> struct StaticInplacePlanFor<15360> { using type = StaticPlan<15360, 12, 10, 16, 8>; };
-template <> struct StaticInplacePlanFor<18432> { using type = StaticPlan<18432, 12, 12, 16, 8>; };
+// (the lists: generic_static_inplace.hpp, generated from the planner for every length of this kernel)
 
 // same MODEs as generic_kernel; one frame per workgroup pass
 // 512 work-items: at most 128 VGPRs (4 waves per SIMD), so that two workgroups share a CU where their images fit

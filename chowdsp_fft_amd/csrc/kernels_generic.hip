@@ -174,30 +174,15 @@ hipError_t launch_generic_inplace (GenericPlan plan, const DeviceTables& t, cons
             const char* e = std::getenv ("CHOWDSP_FFT_GENERIC_STATIC");
             return e != nullptr && std::atoi (e) == 0;
         }();
-#define CFFT_TRY_STATIC_INPLACE(N_, B_)                                                                            \
-    if constexpr (BLOCK == B_)                                                                                     \
-    {                                                                                                              \
-        if (plan.n == N_ && ! static_off)                                                                          \
-        {                                                                                                          \
-            using SP = typename StaticInplacePlanFor<N_>::type;                                                    \
-            bool same = plan.ns == SP::ns;                                                                         \
-            for (int i = 0; same && i < SP::ns; ++i)                                                               \
-                same = plan.radix[i] == SP::radix (i);                                                             \
-            if (same)                                                                                              \
-                return launch_generic_inplace_tw<MODE, INV, BLOCK, true, SP> (plan, t, in, out, batch, stream);    \
-        }                                                                                                          \
-    }
-        CFFT_TRY_STATIC_INPLACE (4608, 256)
-        CFFT_TRY_STATIC_INPLACE (9216, 512)
-        CFFT_TRY_STATIC_INPLACE (5120, 256)
-        CFFT_TRY_STATIC_INPLACE (12288, 1024)
-        CFFT_TRY_STATIC_INPLACE (19200, 1024)
-        CFFT_TRY_STATIC_INPLACE (6144, 512)
-        CFFT_TRY_STATIC_INPLACE (7680, 512)
-        CFFT_TRY_STATIC_INPLACE (10240, 512)
-        CFFT_TRY_STATIC_INPLACE (15360, 1024)
-        CFFT_TRY_STATIC_INPLACE (18432, 1024)
-#undef CFFT_TRY_STATIC_INPLACE
+        if (! static_off)
+        {
+            // (generic_static_inplace.hpp: every length of this kernel has a list; four translation units)
+            hipError_t rc = hipSuccess;
+            const int mode_arg = MODE;
+            if (launch_static_inplace_a (mode_arg, INV, BLOCK, plan, t, in, out, batch, stream, rc) || launch_static_inplace_b (mode_arg, INV, BLOCK, plan, t, in, out, batch, stream, rc)
+                || launch_static_inplace_c (mode_arg, INV, BLOCK, plan, t, in, out, batch, stream, rc) || launch_static_inplace_d (mode_arg, INV, BLOCK, plan, t, in, out, batch, stream, rc))
+                return rc;
+        }
         if (table_granted)
             return launch_generic_inplace_tw<MODE, INV, BLOCK, true> (plan, t, in, out, batch, stream);
     }

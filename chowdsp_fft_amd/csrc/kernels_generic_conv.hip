@@ -1,5 +1,6 @@
 // Instantiation + launch of the fused convolution kernels for mixed-radix frames (generic_conv_kernels.hpp).
 #include "generic_conv_kernels.hpp"
+#include "generic_static_inplace.hpp"
 #include "launch_util.hpp"
 #include "tables.hpp"
 

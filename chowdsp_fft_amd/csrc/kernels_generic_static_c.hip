@@ -1,0 +1,4 @@
+// In-place mixed-radix kernels with compile-time stage lists, group C of generic_static_inplace.hpp (generic_static_inplace_impl.hpp).
+#define CFFT_SIP_GROUP CFFT_STATIC_INPLACE_C
+#define CFFT_SIP_ENTRY launch_static_inplace_c
+#include "generic_static_inplace_impl.hpp"

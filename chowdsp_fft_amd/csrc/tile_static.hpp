@@ -3,6 +3,7 @@
 // lengths) so that the 380-odd kernels build beside the others.
 #pragma once
 #include "generic_kernels.hpp"
+#include "host_common.hpp"
 
 #include <cstdlib>
 
@@ -73,6 +74,13 @@ inline ColumnFftFn pick_static_column (const GenericPlan& plan, int c, size_t ld
         return k;
     return pick_static_column_d (plan, c, lds_per_cu, inverse, launch);
 }
+// The in-place mixed-radix kernel with compile-time stage lists (generic_static_inplace.hpp, kernels_generic_static_{a,b,c,d}.hip):
+// true = the length is in the group, the list is the planner's, the launch was made (rc = its result)
+bool launch_static_inplace_a (int mode, bool inverse, int block, const GenericPlan& plan, const DeviceTables& t, const float2* in, float2* out, size_t batch, hipStream_t stream, hipError_t& rc);
+bool launch_static_inplace_b (int mode, bool inverse, int block, const GenericPlan& plan, const DeviceTables& t, const float2* in, float2* out, size_t batch, hipStream_t stream, hipError_t& rc);
+bool launch_static_inplace_c (int mode, bool inverse, int block, const GenericPlan& plan, const DeviceTables& t, const float2* in, float2* out, size_t batch, hipStream_t stream, hipError_t& rc);
+bool launch_static_inplace_d (int mode, bool inverse, int block, const GenericPlan& plan, const DeviceTables& t, const float2* in, float2* out, size_t batch, hipStream_t stream, hipError_t& rc);
+
 // PIPE variants of the tile kernels need an LDS copy of the n - 1 stage twiddles behind the two images: granted where that leaves
 // the workgroups per CU as they are (by LDS or by the CU's 32 waves, whichever binds).  CHOWDSP_FFT_TILE_PIPE (experiments): bit 0 =
 // pass A / the 2-D column pass, bit 1 = pass B; a set bit grants it wherever the copy fits at all, a clear one withholds it.

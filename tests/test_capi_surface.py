@@ -288,3 +288,31 @@ def test_round3_planner_rules_host_logic():
                     (20736, (144, 144)), (30000, (375, 80)), (1 << 22, (2048, 2048)), (245760, (1024, 240))):
         d = api.plan_describe(n, api.FFT_COMPLEX)
         assert d["passes"] == 2 and (d["n1"], d["n2"]) == want, (n, d)
+
+
+def test_generated_inplace_lists_are_the_planners():
+    """chowdsp_fft_amd/csrc/generic_static_inplace.hpp (tools/gen_static_inplace.py) covers EVERY 2-3-5-smooth multiple of 16 in
+    2048 < n <= 20000 that is not a power of two, each with the stage list the planner gives the length today (a list that
+    drifted would silently fall back to the run-time list at launch)."""
+    import re
+
+    from chowdsp_fft_amd import api
+
+    path = os.path.join(ROOT, "chowdsp_fft_amd", "csrc", "generic_static_inplace.hpp")
+    rows = {}
+    for m in re.finditer(r"X \(([0-9, ]+)\)", open(path).read()):
+        v = [int(t) for t in m.group(1).split(",")]
+        rows[v[0]] = (v[1], v[2:])
+    want = sorted(2 ** a * 3 ** b * 5 ** c for a in range(16) for b in range(10) for c in range(8)
+                  if 2048 < 2 ** a * 3 ** b * 5 ** c <= 20000 and (2 ** a * 3 ** b * 5 ** c) % 16 == 0 and not (b == 0 and c == 0))
+    assert sorted(rows) == want and len(want) == 52
+    for n, (block, radices) in rows.items():
+        d = api.plan_describe(n, api.FFT_COMPLEX)
+        assert d["complex_len"] == n and d["passes"] == 1
+        shown = d["radices"]
+        assert radices[:len(shown)] == shown, f"n = {n}: header {radices}, planner {shown}"
+        prod = 1
+        for r in radices:
+            prod *= r
+        assert prod == n
+        assert block == (256 if n <= 5120 else (512 if n <= 10240 else 1024))

@@ -347,3 +347,44 @@ def test_long_plans_many_tiles_per_workgroup(gpu, oracle, n):
         assert_frames_close(got[:5], _exact(src, n, COMPLEX, FORWARD if direction == api.FFT_FORWARD else BACKWARD), what=f"N={n} dir={direction} vs float64")
     api.fft_destroy_setup(s)
     oracle.destroy_setup(so)
+
+
+def _generated_inplace_lists():
+    """(n, work-items, radices) of chowdsp_fft_amd/csrc/generic_static_inplace.hpp (generated by tools/gen_static_inplace.py)"""
+    import os
+    import re
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "chowdsp_fft_amd", "csrc", "generic_static_inplace.hpp")
+    rows = []
+    for m in re.finditer(r"X \(([0-9, ]+)\)", open(path).read()):
+        v = [int(t) for t in m.group(1).split(",")]
+        rows.append((v[0], v[1], v[2:]))
+    return rows
+
+
+GENERATED_INPLACE = _generated_inplace_lists()
+
+
+@pytest.mark.parametrize("n,block,radices", GENERATED_INPLACE, ids=[str(r[0]) for r in GENERATED_INPLACE])
+def test_every_inplace_length_has_its_compile_time_list(gpu, oracle, n, block, radices):
+    """Round 4: every 2-3-5-smooth multiple of 16 in 2048 < n <= 20000 (52 lengths) runs generic_inplace_kernel with a
+    compile-time stage list.  One small batch per length, complex N = n and real N = 2 n (the same core), both
+    directions, against the oracle and the float64 transform."""
+    api = gpu[0]
+    assert int(np.prod(radices)) == n
+    for tr, size in ((COMPLEX, n), (REAL, 2 * n)):
+        s, so = api.fft_new_setup(size, tr), oracle.new_setup(size, tr)
+        assert s is not None and so is not None
+        nf = 2 * size if tr == COMPLEX else size
+        x = ol.uniform(3 * nf, 11 + n).reshape(3, nf)
+        got_f = _gpu(gpu, s, x, api.FFT_FORWARD)
+        exact_f = _exact(x, size, tr, FORWARD)
+        assert_frames_close(got_f, exact_f, what=f"N={size} fwd vs float64")
+        if not (tr == REAL and size % 25 == 0):  # (the reference's real forward transform is wrong for N % 25 == 0: see above)
+            assert_frames_close(got_f, oracle.transform_batch(so, x, FORWARD), what=f"N={size} fwd", maxabs_tol=MIXED_RADIX_MAXABS_TOL)
+        spec = exact_f.astype(np.float32)
+        got_b = _gpu(gpu, s, spec, api.FFT_BACKWARD)
+        assert_frames_close(got_b, oracle.transform_batch(so, spec, BACKWARD), what=f"N={size} bwd", maxabs_tol=MIXED_RADIX_MAXABS_TOL)
+        assert_frames_close(got_b, _exact(spec, size, tr, BACKWARD), what=f"N={size} bwd vs float64")
+        api.fft_destroy_setup(s)
+        oracle.destroy_setup(so)
