@@ -54,6 +54,28 @@ __device__ __forceinline__ float4 gload4 (const float4* p)
     return *p;
 #endif
 }
+// 16 bytes at an address that is only 8-byte aligned (two adjacent complex values that start at an odd index): the same
+// global_load_dwordx4 / global_store_dwordx4 -- the hardware asks for dword alignment -- through a type that says so
+typedef float v4f_native_a8 __attribute__ ((ext_vector_type (4), aligned (8)));
+__device__ __forceinline__ float4 gload4_a8 (const float2* p)
+{
+    const v4f_native_a8 v = __builtin_nontemporal_load (reinterpret_cast<const v4f_native_a8*> (p));
+    return make_float4 (v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float4 load4_a8 (const float2* p) // plain (cached) form: tables that stay in L2
+{
+    const v4f_native_a8 v = *reinterpret_cast<const v4f_native_a8*> (p);
+    return make_float4 (v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void gstore4_a8 (float2* p, float4 v)
+{
+    v4f_native_a8 n;
+    n.x = v.x;
+    n.y = v.y;
+    n.z = v.z;
+    n.w = v.w;
+    __builtin_nontemporal_store (n, reinterpret_cast<v4f_native_a8*> (p));
+}
 __device__ __forceinline__ void gstore4 (float4* p, float4 v)
 {
 #if CFFT_STREAM_NT

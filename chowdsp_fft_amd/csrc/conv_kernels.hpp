@@ -1162,8 +1162,17 @@ __global__ __launch_bounds__ (P::T* FPB) void ols_block_kernel (float2* buf0, //
         const float2* twp = twtab;
         const float2* wp = wtab;
         asm volatile ("" : "+s"(twp), "+s"(wp));
+        // Round 4: a work-item's pairs are ADJACENT bins -- k = 2 j + e, j = t + T q', e = 0 / 1 -- so that the delay line, the
+        // filter partitions and the new spectrum move 16 bytes per instruction (bins 2 j, 2 j + 1 and their mirrors M - 2 j - 1,
+        // M - 2 j): half the vector-memory instructions of the k = t + T q assignment, whose 8-byte loads were what this kernel
+        // was issue-bound on (profiles/r03_sq_counters_conv.txt: 4624 reads per wave, 55 % issue stalls).  The pair stage reads
+        // the forward spectrum from the LDS image, so the assignment is free.  j = 0 (work-item 0, q' = 0) is the odd one:
+        // bin 0 pairs with M / 2 (packed DC / Nyquist) and bin 1 with M - 1.
         PairTwiddles<P> pw;
-        load_pair_twiddles<P> (pw, wp, t);
+#pragma unroll
+        for (int q = 0; q < P::R / 2; ++q)
+            pw.w[q] = wp[2 * (t + P::T * (q >> 1)) + (q & 1)];
+        const bool j0 = t == 0; // (with q' == 0)
         float2 xk[P::R / 2], xp[P::R / 2]; // this block's spectrum, pairs (k, M - k)
         {
             TwiddleRegs<P> tw;
@@ -1198,32 +1207,70 @@ __global__ __launch_bounds__ (P::T* FPB) void ols_block_kernel (float2* buf0, //
         const unsigned fo = (unsigned) team * M, ho = (h_shared || ! active) ? 0u : (unsigned) team * M;
         const float2* __restrict__ hg = H + (h_shared ? (size_t) 0 : (size_t) g * (FPB * M));
         float2 yk[P::R / 2], yp[P::R / 2];
-#pragma unroll
-        for (int q = 0; q < P::R / 2; ++q)
+        // the filter bins of a partition / the delay-line bins of a slot, this work-item's pairs: [q] <-> bin k, its mirror
+#define CFFT_OLS_LOAD_PAIRS(BK, BP, BASE, OFF, LOAD4, LOAD4U, LOAD2)                                              \
+    {                                                                                                             \
+        _Pragma ("unroll") for (int qp = 0; qp < P::R / 4; ++qp)                                                  \
+        {                                                                                                         \
+            const unsigned j_ = (unsigned) (t + P::T * qp);                                                       \
+            const float4 a_ = LOAD4 (reinterpret_cast<const float4*> (&(BASE)[(OFF) + 2u * j_]));                 \
+            const unsigned mi_ = (qp == 0 && j0) ? (unsigned) (M - 2) : (unsigned) M - 2u * j_ - 1u;              \
+            const float4 m_ = LOAD4U (&(BASE)[(OFF) + mi_]);                                                      \
+            BK[2 * qp] = make_float2 (a_.x, a_.y);                                                                \
+            BK[2 * qp + 1] = make_float2 (a_.z, a_.w);                                                            \
+            BP[2 * qp] = make_float2 (m_.z, m_.w);     /* mirror of 2 j: M - 2 j (j = 0: replaced below) */       \
+            BP[2 * qp + 1] = make_float2 (m_.x, m_.y); /* mirror of 2 j + 1: M - 2 j - 1 */                       \
+            if (qp == 0)                                                                                          \
+            {                                                                                                     \
+                const float2 s_ = LOAD2 (&(BASE)[(OFF) + (unsigned) (M / 2)]); /* every work-item, one line */    \
+                BP[1] = j0 ? make_float2 (m_.z, m_.w) : BP[1];                 /* bin M - 1 */                    \
+                BP[0] = j0 ? s_ : BP[0];                                       /* bin M / 2 */                    \
+            }                                                                                                     \
+        }                                                                                                         \
+    }
+#define CFFT_OLS_PLAIN2(p) (*(p))
+#define CFFT_OLS_PLAIN4(p) (*(p))
         {
-            const int k = t + P::T * q;
-            const int kq = (k == 0 ? M / 2 : M - k);
-            const float2 A = lds[lds_phys (k)];
-            const float2 Zp = lds[lds_phys (kq)];
-            real_split_pair (A, Zp, pw.w[q], xk[q], xp[q]);
-            if (k == 0)
+            float2 bk0[P::R / 2], bp0[P::R / 2];
+            CFFT_OLS_LOAD_PAIRS (bk0, bp0, hg, ho, CFFT_OLS_PLAIN4, load4_a8, CFFT_OLS_PLAIN2)
+#pragma unroll
+            for (int q = 0; q < P::R / 2; ++q)
             {
-                xk[q] = make_float2 (A.x + A.y, A.x - A.y);
-                xp[q] = make_float2 (Zp.x, -Zp.y);
+                const int k = 2 * (t + P::T * (q >> 1)) + (q & 1);
+                const int kq = (k == 0 ? M / 2 : M - k);
+                const float2 A = lds[lds_phys (k)];
+                const float2 Zp = lds[lds_phys (kq)];
+                real_split_pair (A, Zp, pw.w[q], xk[q], xp[q]);
+                if (k == 0)
+                {
+                    xk[q] = make_float2 (A.x + A.y, A.x - A.y);
+                    xp[q] = make_float2 (Zp.x, -Zp.y);
+                }
+                // partition 0 straight from the registers
+                float2 mk = cmul (xk[q], bk0[q]);
+                if (k == 0)
+                    mk = make_float2 (xk[q].x * bk0[q].x, xk[q].y * bk0[q].y); // packed DC / Nyquist: real products
+                const float2 mp = cmul (xp[q], bp0[q]);
+                yk[q] = make_float2 (mk.x * scale, mk.y * scale);
+                yp[q] = make_float2 (mp.x * scale, mp.y * scale);
             }
             if (active)
             {
-                gstore (&slot[fo + (unsigned) k], xk[q]);
-                gstore (&slot[fo + (unsigned) kq], xp[q]);
+                // the new spectrum into its delay-line slot, 16 bytes per store (work-item 0's first group: bin M / 2 and bin M - 1 on their own)
+#pragma unroll
+                for (int qp = 0; qp < P::R / 4; ++qp)
+                {
+                    const unsigned j = (unsigned) (t + P::T * qp);
+                    gstore4 (reinterpret_cast<float4*> (&slot[fo + 2u * j]), make_float4 (xk[2 * qp].x, xk[2 * qp].y, xk[2 * qp + 1].x, xk[2 * qp + 1].y));
+                    if (qp == 0 && j0)
+                    {
+                        gstore (&slot[fo + (unsigned) (M / 2)], xp[0]);
+                        gstore (&slot[fo + (unsigned) (M - 1)], xp[1]);
+                    }
+                    else
+                        gstore4_a8 (&slot[fo + (unsigned) M - 2u * j - 1u], make_float4 (xp[2 * qp + 1].x, xp[2 * qp + 1].y, xp[2 * qp].x, xp[2 * qp].y));
+                }
             }
-            // partition 0 straight from the registers
-            const float2 bk = hg[ho + (unsigned) k], bp = hg[ho + (unsigned) kq];
-            float2 mk = cmul (xk[q], bk);
-            if (k == 0)
-                mk = make_float2 (xk[q].x * bk.x, xk[q].y * bk.y); // packed DC / Nyquist: real products
-            const float2 mp = cmul (xp[q], bp);
-            yk[q] = make_float2 (mk.x * scale, mk.y * scale);
-            yp[q] = make_float2 (mp.x * scale, mp.y * scale);
         }
         if (active)
         {
@@ -1235,20 +1282,12 @@ __global__ __launch_bounds__ (P::T* FPB) void ols_block_kernel (float2* buf0, //
                 const float2* __restrict__ fs = fg + (size_t) sl * slot_elems;
                 const float2* __restrict__ hs = hg + (size_t) p * hpart_elems;
                 float2 ak[P::R / 2], ap[P::R / 2], bk[P::R / 2], bp[P::R / 2];
+                CFFT_OLS_LOAD_PAIRS (ak, ap, fs, fo, gload4, gload4_a8, gload)
+                CFFT_OLS_LOAD_PAIRS (bk, bp, hs, ho, CFFT_OLS_PLAIN4, load4_a8, CFFT_OLS_PLAIN2)
 #pragma unroll
                 for (int q = 0; q < P::R / 2; ++q)
                 {
-                    const int k = t + P::T * q;
-                    const int kq = (k == 0 ? M / 2 : M - k);
-                    ak[q] = gload (&fs[fo + (unsigned) k]);
-                    ap[q] = gload (&fs[fo + (unsigned) kq]);
-                    bk[q] = hs[ho + (unsigned) k];
-                    bp[q] = hs[ho + (unsigned) kq];
-                }
-#pragma unroll
-                for (int q = 0; q < P::R / 2; ++q)
-                {
-                    const int k = t + P::T * q;
+                    const int k = 2 * (t + P::T * (q >> 1)) + (q & 1);
                     float2 mk = cmul (ak[q], bk[q]);
                     if (k == 0)
                         mk = make_float2 (ak[q].x * bk[q].x, ak[q].y * bk[q].y);
@@ -1268,7 +1307,7 @@ __global__ __launch_bounds__ (P::T* FPB) void ols_block_kernel (float2* buf0, //
 #pragma unroll
         for (int q = 0; q < P::R / 2; ++q)
         {
-            const int k = t + P::T * q;
+            const int k = 2 * (t + P::T * (q >> 1)) + (q & 1);
             real_merge_pair (yk[q], yp[q], pw.w[q], zk[q], zp[q]);
             if (k == 0)
             {
@@ -1280,7 +1319,7 @@ __global__ __launch_bounds__ (P::T* FPB) void ols_block_kernel (float2* buf0, //
 #pragma unroll
         for (int q = 0; q < P::R / 2; ++q)
         {
-            const int k = t + P::T * q;
+            const int k = 2 * (t + P::T * (q >> 1)) + (q & 1);
             lds[lds_phys (k)] = make_float2 (zk[q].y, zk[q].x);
             lds[lds_phys (k == 0 ? M / 2 : M - k)] = make_float2 (zp[q].y, zp[q].x);
         }
@@ -1302,6 +1341,9 @@ __global__ __launch_bounds__ (P::T* FPB) void ols_block_kernel (float2* buf0, //
         }
         team_sync<P::T>(); // the image is free for the next channel's forward transform
     }
+#undef CFFT_OLS_LOAD_PAIRS
+#undef CFFT_OLS_PLAIN2
+#undef CFFT_OLS_PLAIN4
     if (threadIdx.x == 0)
     {
         const unsigned arrived = atomicAdd (&state->done, 1u);
