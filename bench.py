@@ -54,7 +54,7 @@ WORKLOADS = {
 WORKLOAD_KERNELS = {
     "c2c_n4096_b65536_fwd_inv": ["c2c_kernel_pf"],
     "real_n1024_b262144_fwd_inv": ["r2c_kernel", "c2r_kernel"],
-    "conv_real_n4096_b131072": ["conv_frames_real_kernel"],
+    "conv_real_n4096_b131072": ["conv_frames_real_tp_kernel", "conv_frames_real_kernel"],
     "c2c_n65536_b8192_fwd_inv": ["group256_kernel"],
     "c2c_n65536_b8192_fwd_inv_two_launches": ["pass_a256_kernel", "pass_b256_kernel"],
     "c2c_n65536_b8192_fwd_inv_tickets": ["fused256_kernel"],
@@ -255,7 +255,7 @@ def run_workload(workload, args, world, rank, dev, frames_override=0, gather=Fal
         kernel = {
             "c2c_n4096_b65536_fwd_inv": "cfft::c2c_kernel_pf<Plan<4096,256,16,16,16>, 1, INV, false> (forward and backward instantiations)",
             "real_n1024_b262144_fwd_inv": "cfft::r2c_kernel<Plan<512,64,8,8,8>, 4, false> and cfft::c2r_kernel<Plan<512,64,8,8,8>, 4, false>",
-            "conv_real_n4096_b131072": "cfft::conv_frames_real_kernel_pf<Plan<2048,128,16,16,8>, 1, false>",
+            "conv_real_n4096_b131072": "cfft::conv_frames_real_tp_kernel_pf<Plan<2048,128,16,16,8>, 1> (pair stage in registers as one linear map, transposed backward network)",
             "c2c_n65536_b8192_fwd_inv": "cfft::group256_kernel<INV> (both passes in one launch, static groups of 16 workgroups per XCD)",
             "c2c_n65536_b8192_fwd_inv_two_launches": "cfft::pass_a256_kernel<INV> + cfft::pass_b256_kernel<INV> per 256-frame chunk (two passes over the frame)",
             "c2c_n65536_b8192_fwd_inv_tickets": "cfft::fused256_kernel<INV> (both passes in one launch, per-XCD ticket queues)",
