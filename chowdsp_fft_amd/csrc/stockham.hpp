@@ -423,12 +423,63 @@ __device__ __forceinline__ void stage_out_strided (float2* __restrict__ dst, uns
 
 // Stages 0..NS-1 on registers v (already loaded in input_index order); leaves the result in
 // output_index order.  `lds` is this team's private LDS image.
+// ---- the exchange of the two shortest plans inside the wavefront (round 4 A/B, CFFT_DPP_QUAD) -----------------------------
+// N = 16 (4 lanes x 4 points, 4 x 4) and N = 32 (4 lanes x 8 points, 8 x 4): the one exchange between the two stages is a
+// 4 x 4 transpose across the four lanes of a team -- lane i, slot a  <-  lane a, slot i -- and a team of four is a DPP quad.
+// Two rounds of v_mov_b32 dpp quad_perm (lane ^ 1, lane ^ 2) with selects instead of 4 (8) ds_write_b64 + 4 (8) ds_read_b64
+// and a wave-local barrier: the north star's "wavefront shuffle / DPP" for the cross-lane step.  Measured on MI355X
+// (profiles/r04_dpp_small_n_ab.txt, fwd + inv): complex N = 16 / 32 +0.9 / +1.0 %, real N = 32 +4.2 %, real N = 64 +0.2 %,
+// nothing slower: on (1); 0 = the LDS exchange.
+#ifndef CFFT_DPP_QUAD
+#define CFFT_DPP_QUAD 1
+#endif
+__device__ __forceinline__ float dpp_quad_xor1 (float x)
+{
+    return __int_as_float (__builtin_amdgcn_mov_dpp (__float_as_int (x), 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_quad_xor2 (float x)
+{
+    return __int_as_float (__builtin_amdgcn_mov_dpp (__float_as_int (x), 0x4E /* quad_perm:[2,3,0,1] */, 0xF, 0xF, true));
+}
+// w[a] (lane i of the quad)  <-  w[i] (lane a of the quad), a, i < 4
+__device__ __forceinline__ void quad_transpose4 (float2& w0, float2& w1, float2& w2, float2& w3, int lane)
+{
+    const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
+    {
+        const float2 s01 = b0 ? w0 : w1, s23 = b0 ? w2 : w3;
+        const float2 r01 = make_float2 (dpp_quad_xor1 (s01.x), dpp_quad_xor1 (s01.y)), r23 = make_float2 (dpp_quad_xor1 (s23.x), dpp_quad_xor1 (s23.y));
+        w0 = b0 ? r01 : w0;
+        w1 = b0 ? w1 : r01;
+        w2 = b0 ? r23 : w2;
+        w3 = b0 ? w3 : r23;
+    }
+    {
+        const float2 s02 = b1 ? w0 : w2, s13 = b1 ? w1 : w3;
+        const float2 r02 = make_float2 (dpp_quad_xor2 (s02.x), dpp_quad_xor2 (s02.y)), r13 = make_float2 (dpp_quad_xor2 (s13.x), dpp_quad_xor2 (s13.y));
+        w0 = b1 ? r02 : w0;
+        w2 = b1 ? w2 : r02;
+        w1 = b1 ? r13 : w1;
+        w3 = b1 ? w3 : r13;
+    }
+}
+template <class P>
+static constexpr bool kQuadExchange = CFFT_DPP_QUAD != 0 && P::T == 4 && P::NS == 2 && P::radix (1) == 4 && (P::N == 16 || P::N == 32);
+
 // MapLast: the butterfly assignment of the LAST stage (its twiddles must have been loaded with the same map); with
 // anything but PlainMap the result is in that map's arrangement instead of output_index order.
 template <class P, class MapLast = PlainMap, class TW = TwiddleRegs<P>>
 __device__ __forceinline__ void fft_core (float2 (&v)[P::R], const TW& tw, float2* __restrict__ lds, int t)
 {
     stage_compute_tw<P, 0> (v, tw, t);
+    if constexpr (kQuadExchange<P> && std::is_same<MapLast, PlainMap>::value)
+    {
+        // stage-0 output Y[r0 t' + b] = slot b of lane t'; stage-1 butterfly i = t + 4 q wants X[i + a N / 4] = slot t + 4 q of lane a
+#pragma unroll
+        for (int q = 0; q < P::R / 4; ++q)
+            quad_transpose4 (v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3], t);
+        stage_compute_tw<P, 1> (v, tw, t);
+        return;
+    }
     if constexpr (P::NS > 1)
     {
         stage_write_lds<P, 0> (v, lds, t);
