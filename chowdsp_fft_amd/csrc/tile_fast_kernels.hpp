@@ -79,6 +79,17 @@ __device__ __forceinline__ void fft_reg8_tw (float2 (&u)[8], const float2 (&w)[4
 // block b and b + 8 share an L2.  Item v of the persistent loop (v = blockIdx + k gridDim, gridDim a multiple of 8 on a full
 // chip) is mapped so that the items one XCD works through are CONSECUTIVE tiles: the rows whose mirrored halves straddle a
 // 128-byte line then share that line inside one L2 instead of fetching / writing it from two.
+// the mirrored halves' accesses: default cache policy (0), so that the two tiles that share a line meet in L2, or nontemporal (1, round 3)
+#ifndef CFFT_REAL4_MIRROR_NT
+#define CFFT_REAL4_MIRROR_NT 0
+#endif
+__device__ __forceinline__ void real4_mirror_store (float2* p, float2 v)
+{
+    if (CFFT_REAL4_MIRROR_NT)
+        gstore (p, v);
+    else
+        *p = v;
+}
 __device__ __forceinline__ size_t xcd_order (size_t v, size_t nwork)
 {
     const size_t per = (nwork + 7) / 8;
@@ -481,9 +492,9 @@ __global__ __launch_bounds__ (FastTile<R1_>::threads, FastTile<R1_>::min_waves) 
                     {
                         const size_t k = (size_t) (R1_ - 1 - ka) * n2 + (n2 - kb);
                         if constexpr (MULH)
-                            gstore (&dst[k], cmul (make_float2 (y.x, -y.y), make_float2 (H[k].x * scaling, H[k].y * scaling)));
+                            real4_mirror_store (&dst[k], cmul (make_float2 (y.x, -y.y), make_float2 (H[k].x * scaling, H[k].y * scaling)));
                         else
-                            gstore (&dst[k], make_float2 (y.x, -y.y));
+                            real4_mirror_store (&dst[k], make_float2 (y.x, -y.y));
                     }
                 }
         }
@@ -544,7 +555,11 @@ __global__ __launch_bounds__ (FastTile<R1_>::threads, FastTile<R1_>::min_waves) 
             {
                 const bool nyq = (FT::Tn * a == R1_ / 2) && first;
                 const size_t mi = nyq ? (size_t) 0 : (size_t) (R1_ - ka) * n2 - kbl;
-                const float2 p = gload (&src[mi]);
+                // (round 4) DEFAULT cache policy, not nontemporal: the 16 mirrored bins of a tile straddle two 128-byte lines, each
+                // of which the neighbouring tile -- same XCD, about the same time (xcd_order) -- needs too.  Nontemporal loads
+                // left nothing in L2 for it: FETCH_SIZE of this kernel was 1.4 x (R1 = 512) / 2.2 x (R1 = 1024) its input bytes
+                // (profiles/r04_real_four_step_traffic.txt).  CFFT_REAL4_MIRROR_NT=1 brings the old form back.
+                const float2 p = CFFT_REAL4_MIRROR_NT ? gload (&src[mi]) : src[mi];
                 x = make_float2 (nyq ? p.y : p.x, nyq ? 0.f : -p.y);
             }
             v[a] = make_float2 (x.y, x.x); // swapped: backward = swap . forward . swap
