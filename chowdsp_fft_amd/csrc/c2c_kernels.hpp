@@ -125,27 +125,61 @@ __global__ __launch_bounds__ (P::T* FPB) void c2c_kernel_pf (const float2* __res
     // loop carry the same queue shape (R loads, then R stores) and the loop-top wait is vmcnt(R), not vmcnt(0).
     // (The body is a macro, not a lambda: with a by-reference closure the INV instantiation keeps `v` in scratch.)
     float nre[P::R], nim[P::R]; // prefetch registers (re, im already swapped for INV)
+// CFFT_PF_AT (round-4 A/B, three-stage plans only): where the next frame's loads are issued -- 0 at the top of the frame
+// (default), 1 behind the first LDS exchange, 2 behind the second, 3 half and half.  A later request keeps fewer bytes in flight
+// per CU (the frame-shaped copy of tools/membench5.hip runs 5 % faster with half the bytes in flight).
+#ifndef CFFT_PF_AT
+#define CFFT_PF_AT 0
+#endif
+#define CFFT_PF_LOADS(LO, HI)                                                                                       \
+    if (gn_ < ngroups)                                                                                              \
+    {                                                                                                               \
+        const bool actn_ = gn_ * FPB + team < batch;                                                                \
+        const float2* __restrict__ srcn_ = in + (size_t) gn_ * FPB * in_stride;                                     \
+        if (FPB == 1 || actn_)                                                                                      \
+        {                                                                                                           \
+            _Pragma ("unroll") for (int s = (LO); s < (HI); ++s)                                                    \
+            {                                                                                                       \
+                const float2 x_ = gload (&srcn_[team_in + (unsigned) input_index<P> (t, s)]);                       \
+                nre[s] = INV ? x_.y : x_.x;                                                                         \
+                nim[s] = INV ? x_.x : x_.y;                                                                         \
+            }                                                                                                       \
+        }                                                                                                           \
+    }
 #define CFFT_PF_BODY(G, V)                                                                                          \
     {                                                                                                               \
         const bool active_ = (G) * FPB + team < batch;                                                              \
         float2* __restrict__ dst_ = out + (size_t) (G) * FPB * out_stride;                                          \
         const unsigned gn_ = (G) + gridDim.x;                                                                       \
-        if (gn_ < ngroups)                                                                                          \
+        constexpr int at_ = (P::NS == 3) ? CFFT_PF_AT : 0;                                                          \
+        if constexpr (at_ == 0)                                                                                     \
         {                                                                                                           \
-            const bool actn_ = gn_ * FPB + team < batch;                                                            \
-            const float2* __restrict__ srcn_ = in + (size_t) gn_ * FPB * in_stride;                                 \
-            if (FPB == 1 || actn_)                                                                                  \
-            {                                                                                                       \
-                _Pragma ("unroll") for (int s = 0; s < P::R; ++s)                                                   \
-                {                                                                                                   \
-                    const float2 x_ = gload (&srcn_[team_in + (unsigned) input_index<P> (t, s)]);                   \
-                    nre[s] = INV ? x_.y : x_.x;                                                                     \
-                    nim[s] = INV ? x_.x : x_.y;                                                                     \
-                }                                                                                                   \
-            }                                                                                                       \
+            CFFT_PF_LOADS (0, P::R)                                                                                 \
+            team_sync<P::T>();                                                                                      \
+            fft_core<P> (V, tw, lds, t);                                                                            \
         }                                                                                                           \
-        team_sync<P::T>();                                                                                          \
-        fft_core<P> (V, tw, lds, t);                                                                                \
+        else                                                                                                        \
+        {                                                                                                           \
+            team_sync<P::T>();                                                                                      \
+            stage_compute<P, 0> (V, tw);                                                                            \
+            stage_write_lds<P, 0> (V, lds, t);                                                                      \
+            team_sync<P::T>();                                                                                      \
+            if constexpr (at_ == 1)                                                                                 \
+                CFFT_PF_LOADS (0, P::R)                                                                             \
+            if constexpr (at_ == 3)                                                                                 \
+                CFFT_PF_LOADS (0, P::R / 2)                                                                         \
+            stage_read_lds<P, 1> (V, lds, t);                                                                       \
+            stage_compute<P, 1> (V, tw);                                                                            \
+            team_sync<P::T>();                                                                                      \
+            stage_write_lds<P, 1> (V, lds, t);                                                                      \
+            team_sync<P::T>();                                                                                      \
+            if constexpr (at_ == 2)                                                                                 \
+                CFFT_PF_LOADS (0, P::R)                                                                             \
+            if constexpr (at_ == 3)                                                                                 \
+                CFFT_PF_LOADS (P::R / 2, P::R)                                                                      \
+            stage_read_lds<P, 2> (V, lds, t);                                                                       \
+            stage_compute<P, 2> (V, tw);                                                                            \
+        }                                                                                                           \
         if (FPB == 1 || active_) /* FPB == 1: the store count per iteration is a compile-time constant */           \
         {                                                                                                           \
             _Pragma ("unroll") for (int s = 0; s < P::R; ++s)                                                       \
@@ -178,6 +212,7 @@ __global__ __launch_bounds__ (P::T* FPB) void c2c_kernel_pf (const float2* __res
         CFFT_PF_BODY (g, v)
     }
 #undef CFFT_PF_BODY
+#undef CFFT_PF_LOADS
 }
 
 // One frame per 1024-thread workgroup with streamed twiddles (fft_core_streamed): the N = 16384 plan, whose 128 KiB frame
