@@ -231,8 +231,9 @@ __device__ __forceinline__ void conv_c2c_finish (float2 (&v)[P::R],
     // round 4: the backward transform as the TRANSPOSED network (stockham.hpp): it takes the spectrum where the forward
     // transform left it -- no natural-order image pass, one LDS round trip and two barriers less per frame.  By A/B per
     // plan (profiles/r04_conv_transposed_ab.txt; these kernels are bound by latency at two waves per SIMD, not by LDS
-    // traffic): N = 4096 +2.7 %, N = 1024 +1.6 %, N = 2048 -2.5 % (keeps the image pass); the others were not measured.
-    if constexpr (CFFT_CONV_TRANSPOSED && ! CFFT_CONV_STREAM_TW && (P::N == 4096 || P::N == 1024))
+    // traffic): N = 4096 +2.7 %, 1024 +1.6 %, 512 +0.7 %, 256 +1.6 %, 32 +9 %, 16 +0.4 %; N = 2048 -2.5 / -3.3 %, 128 -2.1 %, 64 0
+    // (these three keep the image pass).  CFFT_CONV_TRANSPOSED = 2: every plan, 0: none.
+    if constexpr (CFFT_CONV_TRANSPOSED && ! CFFT_CONV_STREAM_TW && (CFFT_CONV_TRANSPOSED == 2 || (P::N != 2048 && P::N != 128 && P::N != 64)))
     {
         fft_core_transposed<P> (w, tw, lds, t);
         if (! PREDICATED || active)

@@ -31,6 +31,11 @@ WORK = {
     "cconv1024": (1024, 1, 262144, True),
     "cconv2048": (2048, 1, 131072, True),
     "cconv512": (512, 1, 524288, True),
+    "cconv256": (256, 1, 1048576, True),
+    "cconv128": (128, 1, 2097152, True),
+    "cconv64": (64, 1, 4194304, True),
+    "cconv32": (32, 1, 8388608, True),
+    "cconv16": (16, 1, 16777216, True),
     "c64": (64, 1, 4194304, False),
     "c256": (256, 1, 1048576, False),
     "c1024": (1024, 1, 262144, False),
