@@ -1,6 +1,7 @@
 // Instantiation + launch of the fused convolution kernels for mixed-radix frames (generic_conv_kernels.hpp).
 #include "generic_conv_kernels.hpp"
 #include "generic_static_inplace.hpp"
+#include "tile_static.hpp"
 #include "launch_util.hpp"
 #include "tables.hpp"
 
@@ -84,30 +85,16 @@ hipError_t launch_conv_inplace (GenericPlan plan, const DeviceTables& t, const f
     }
     // compile-time lists with or without the leading stages' tables in LDS (kernels_generic.hip: launch_generic_inplace)
     {
-#define CFFT_TRY_STATIC_INPLACE_CONV(N_, B_)                                                                       \
-    if constexpr (BLOCK == B_)                                                                                     \
-    {                                                                                                              \
-        if (plan.n == N_)                                                                                          \
-        {                                                                                                          \
-            using SP = typename StaticInplacePlanFor<N_>::type;                                                    \
-            bool same = plan.ns == SP::ns;                                                                         \
-            for (int i = 0; same && i < SP::ns; ++i)                                                               \
-                same = plan.radix[i] == SP::radix (i);                                                             \
-            if (same)                                                                                              \
-                return launch_conv_inplace_tw<REAL, BLOCK, true, SP> (plan, t, in, H, out, scaling, batch, stream); \
-        }                                                                                                          \
-    }
-        CFFT_TRY_STATIC_INPLACE_CONV (4608, 256)
-        CFFT_TRY_STATIC_INPLACE_CONV (9216, 512)
-        CFFT_TRY_STATIC_INPLACE_CONV (5120, 256)
-        CFFT_TRY_STATIC_INPLACE_CONV (12288, 1024)
-        CFFT_TRY_STATIC_INPLACE_CONV (19200, 1024)
-        CFFT_TRY_STATIC_INPLACE_CONV (6144, 512)
-        CFFT_TRY_STATIC_INPLACE_CONV (7680, 512)
-        CFFT_TRY_STATIC_INPLACE_CONV (10240, 512)
-        CFFT_TRY_STATIC_INPLACE_CONV (15360, 1024)
-        CFFT_TRY_STATIC_INPLACE_CONV (18432, 1024)
-#undef CFFT_TRY_STATIC_INPLACE_CONV
+        // (generic_static_inplace.hpp: every length of this kernel has a list; kernels_generic_conv_static_{a,b,c,d}.hip)
+        static const bool static_off = [] {
+            const char* e = std::getenv ("CHOWDSP_FFT_GENERIC_STATIC");
+            return e != nullptr && std::atoi (e) == 0;
+        }();
+        hipError_t rc = hipSuccess;
+        if (! static_off
+            && (launch_static_inplace_conv_a (REAL, BLOCK, plan, t, in, H, out, scaling, batch, stream, rc) || launch_static_inplace_conv_b (REAL, BLOCK, plan, t, in, H, out, scaling, batch, stream, rc)
+                || launch_static_inplace_conv_c (REAL, BLOCK, plan, t, in, H, out, scaling, batch, stream, rc) || launch_static_inplace_conv_d (REAL, BLOCK, plan, t, in, H, out, scaling, batch, stream, rc)))
+            return rc;
     }
     if (table_granted)
         return launch_conv_inplace_tw<REAL, BLOCK, true> (plan, t, in, H, out, scaling, batch, stream);

@@ -81,6 +81,12 @@ bool launch_static_inplace_b (int mode, bool inverse, int block, const GenericPl
 bool launch_static_inplace_c (int mode, bool inverse, int block, const GenericPlan& plan, const DeviceTables& t, const float2* in, float2* out, size_t batch, hipStream_t stream, hipError_t& rc);
 bool launch_static_inplace_d (int mode, bool inverse, int block, const GenericPlan& plan, const DeviceTables& t, const float2* in, float2* out, size_t batch, hipStream_t stream, hipError_t& rc);
 
+// ... and the fused convolution on the same lists (kernels_generic_conv_static_{a,b,c,d}.hip)
+bool launch_static_inplace_conv_a (bool real, int block, const GenericPlan& plan, const DeviceTables& t, const float2* in, const float2* H, float2* out, float scaling, size_t batch, hipStream_t stream, hipError_t& rc);
+bool launch_static_inplace_conv_b (bool real, int block, const GenericPlan& plan, const DeviceTables& t, const float2* in, const float2* H, float2* out, float scaling, size_t batch, hipStream_t stream, hipError_t& rc);
+bool launch_static_inplace_conv_c (bool real, int block, const GenericPlan& plan, const DeviceTables& t, const float2* in, const float2* H, float2* out, float scaling, size_t batch, hipStream_t stream, hipError_t& rc);
+bool launch_static_inplace_conv_d (bool real, int block, const GenericPlan& plan, const DeviceTables& t, const float2* in, const float2* H, float2* out, float scaling, size_t batch, hipStream_t stream, hipError_t& rc);
+
 // PIPE variants of the tile kernels need an LDS copy of the n - 1 stage twiddles behind the two images: granted where that leaves
 // the workgroups per CU as they are (by LDS or by the CU's 32 waves, whichever binds).  CHOWDSP_FFT_TILE_PIPE (experiments): bit 0 =
 // pass A / the 2-D column pass, bit 1 = pass B; a set bit grants it wherever the copy fits at all, a clear one withholds it.

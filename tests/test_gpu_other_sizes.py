@@ -388,3 +388,30 @@ def test_every_inplace_length_has_its_compile_time_list(gpu, oracle, n, block, r
         assert_frames_close(got_b, _exact(spec, size, tr, BACKWARD), what=f"N={size} bwd vs float64")
         api.fft_destroy_setup(s)
         oracle.destroy_setup(so)
+
+
+@pytest.mark.parametrize("n,block,radices", GENERATED_INPLACE, ids=[str(r[0]) for r in GENERATED_INPLACE])
+def test_fused_convolution_every_inplace_length(gpu, n, block, radices):
+    """fft_convolve_frames_batch on the in-place kernel's compile-time lists (round 4: every one of the 52 lengths, complex N = n
+    and real N = 2 n): ONE launch == the three-launch composition (which test_fused_convolution_mixed_radix pins to the oracle's
+    call sequence, test/test.cpp:161-166), in place == out of place."""
+    api, torch, dev = gpu
+    for tr, size in ((COMPLEX, n), (REAL, 2 * n)):
+        nf = 2 * size if tr == COMPLEX else size
+        s = api.fft_new_setup(size, tr)
+        x = torch.from_numpy(ol.uniform(5 * nf, 71 + n).reshape(5, nf)).to(dev)
+        h = torch.from_numpy(ol.uniform(nf, 72 + n).reshape(1, nf)).to(dev)
+        H = torch.empty_like(h)
+        api.fft_transform_unordered_batch(s, h, H, api.FFT_FORWARD)
+        one = torch.full_like(x, -3.0)
+        api.fft_convolve_frames_batch(s, x, H, one, 1.0 / size)
+        api.set_option("fused_conv_generic", 0)
+        three = torch.full_like(x, -5.0)
+        api.fft_convolve_frames_batch(s, x, H, three, 1.0 / size)
+        api.set_option("fused_conv_generic", 1)
+        inplace = x.clone()
+        api.fft_convolve_frames_batch(s, inplace, H, inplace, 1.0 / size)
+        torch.cuda.synchronize()
+        assert_frames_close(one.cpu().numpy(), three.cpu().numpy(), tol=3e-7, maxabs_tol=1e-6, what=f"N={size} one launch vs three launches")
+        assert torch.equal(inplace, one), "in place == out of place"
+        api.fft_destroy_setup(s)
