@@ -82,9 +82,11 @@ def committed_traffic(workload: str):
         cur_src, cur_lib = _buildinfo.source_sha256(), _buildinfo.lib_sha256()
         extra = {"traffic_source": tj.get("_taken_at"), "traffic_src_sha256": (tj.get("src_sha256") or "")[:16],
                  "timed_src_sha256": cur_src[:16], "traffic_lib_sha256_matches": tj.get("lib_sha256") == cur_lib}
-        # stale = taken on other sources, OR the shared object being timed is not the one that was profiled / is older than
-        # the sources (a stale build of the right sources' predecessor must not get a figure printed beside it either)
-        if tj.get("src_sha256") != cur_src or tj.get("lib_sha256") != cur_lib or not _buildinfo.lib_is_newer_than_sources():
+        # stale = taken on other sources, OR the shared object being timed is not the one that was profiled (a stale build of the
+        # right sources' predecessor must not get a figure printed beside it either; the pair of hashes says it all -- file
+        # times do not survive every way a tree gets copied to a GPU box, so they are reported, not used)
+        extra["lib_newer_than_sources"] = _buildinfo.lib_is_newer_than_sources()
+        if tj.get("src_sha256") != cur_src or tj.get("lib_sha256") != cur_lib:
             extra["traffic_stale"] = True
             return None, extra
         entry = (tj.get("workloads") or {}).get(workload)
