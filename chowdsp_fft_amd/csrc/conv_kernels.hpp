@@ -188,6 +188,10 @@ __global__ __launch_bounds__ (256) void ols_extract_kernel (const float4* __rest
 #ifndef CFFT_CONV_TRANSPOSED
 #define CFFT_CONV_TRANSPOSED 1
 #endif
+// fused convolution of narrow-team plans through the LDS staging area (1, round 4) or with direct global accesses (0)
+#ifndef CFFT_CONV_STAGED
+#define CFFT_CONV_STAGED 1
+#endif
 template <class P>
 __device__ __forceinline__ void conv_core (float2 (&v)[P::R], const TwiddleRegs<P>& tw, const float2* __restrict__ twtab, float2* __restrict__ lds, int t)
 {
@@ -204,7 +208,9 @@ __device__ __forceinline__ void conv_core (float2 (&v)[P::R], const TwiddleRegs<
 // ---- fused: y = BACKWARD( FORWARD(x) * H ) * scaling, one kernel, spectrum never leaves the CU -----
 // COMPLEX plan: P is the N point plan, H has N complex bins in canonical order.
 // The bins a work-item multiplies (its output_index positions) are the same for every frame: kept in VGPRs.
-template <class P, bool PREDICATED>
+// STAGED (narrow teams, round 4): `dst` is the workgroup's LDS staging area -- the result leaves through whole-workgroup 16-byte
+// copies like the plain transforms' (c2c_kernels.hpp), instead of 32-byte pieces per team and instruction
+template <class P, bool PREDICATED, bool STAGED = false>
 __device__ __forceinline__ void conv_c2c_finish (float2 (&v)[P::R],
                                                  const TwiddleRegs<P>& tw,
                                                  const float2 (&h)[P::R],
@@ -236,11 +242,16 @@ __device__ __forceinline__ void conv_c2c_finish (float2 (&v)[P::R],
     if constexpr (CFFT_CONV_TRANSPOSED && ! CFFT_CONV_STREAM_TW && (CFFT_CONV_TRANSPOSED == 2 || (P::N != 2048 && P::N != 128 && P::N != 64)))
     {
         fft_core_transposed<P> (w, tw, lds, t);
-        if (! PREDICATED || active)
+        if (STAGED || ! PREDICATED || active)
         {
 #pragma unroll
             for (int s = 0; s < P::R; ++s)
-                gstore (&dst[team_base + (unsigned) input_index<P> (t, s)], make_float2 (w[s].y, w[s].x));
+            {
+                if constexpr (STAGED)
+                    dst[team_base + (unsigned) input_index<P> (t, s)] = make_float2 (w[s].y, w[s].x);
+                else
+                    gstore (&dst[team_base + (unsigned) input_index<P> (t, s)], make_float2 (w[s].y, w[s].x));
+            }
         }
         return;
     }
@@ -250,11 +261,16 @@ __device__ __forceinline__ void conv_c2c_finish (float2 (&v)[P::R],
     lds_load_input_order<P> (u, lds, t);
     team_sync<P::T>();
     conv_core<P> (u, tw, twtab, lds, t);
-    if (! PREDICATED || active)
+    if (STAGED || ! PREDICATED || active)
     {
 #pragma unroll
         for (int s = 0; s < P::R; ++s)
-            gstore (&dst[team_base + (unsigned) output_index<P> (t, s)], make_float2 (u[s].y, u[s].x));
+        {
+            if constexpr (STAGED)
+                dst[team_base + (unsigned) output_index<P> (t, s)] = make_float2 (u[s].y, u[s].x);
+            else
+                gstore (&dst[team_base + (unsigned) output_index<P> (t, s)], make_float2 (u[s].y, u[s].x));
+        }
     }
 }
 
@@ -281,15 +297,36 @@ __global__ __launch_bounds__ (P::T* FPB) void conv_frames_c2c_kernel (const floa
 
     const unsigned ngroups = (batch + FPB - 1) / FPB;
     const unsigned team_base = (unsigned) team * P::N;
+    // Narrowest teams (T = 4: N = 16, 32): a team's instruction touches 32 bytes of its frame.  The workgroup's FPB frames are
+    // one contiguous block: they travel between HBM and an LDS staging area by whole-workgroup 16-byte copies, as in
+    // c2c_kernel (round 4, profiles/r04_conv_staged_small_ab.txt: complex N = 16 / 32 0.37 / 0.485 -> 0.62 / 0.66 of 8 TB/s, real N = 32 / 64 0.37 / 0.45 -> 0.62 / 0.61).
+    constexpr bool STAGED = (P::T < 8) && CFFT_CONV_STAGED; // (8-lane teams, N = 64: measured equal / 3 % slower staged)
+    float2* stage = smem + FPB * LdsFrame<P::N>::floats2;
     for (unsigned g = blockIdx.x; g < ngroups; g += gridDim.x)
     {
         const bool active = g * FPB + team < batch;
         const float2* __restrict__ src = in + (size_t) g * (FPB * P::N);
         float2 v[P::R];
+        if constexpr (STAGED)
+        {
+            const unsigned valid = min ((unsigned) FPB, batch - g * FPB) * P::N;
+            __syncthreads(); // the previous group's copy-out has read the staging area
+            stage_in<P::T * FPB, FPB * P::N> (src, stage, valid, tid);
+            __syncthreads();
 #pragma unroll
-        for (int s = 0; s < P::R; ++s)
-            v[s] = active ? gload (&src[team_base + (unsigned) input_index<P> (t, s)]) : make_float2 (0.f, 0.f);
-        conv_c2c_finish<P, true> (v, tw, h, lds, out + (size_t) g * (FPB * P::N), team_base, t, scaling, active, twtab);
+            for (int s = 0; s < P::R; ++s)
+                v[s] = stage[team_base + (unsigned) input_index<P> (t, s)];
+            conv_c2c_finish<P, true, true> (v, tw, h, lds, stage, team_base, t, scaling, active, twtab);
+            __syncthreads();
+            stage_out<P::T * FPB, FPB * P::N> (out + (size_t) g * (FPB * P::N), stage, valid, tid);
+        }
+        else
+        {
+#pragma unroll
+            for (int s = 0; s < P::R; ++s)
+                v[s] = active ? gload (&src[team_base + (unsigned) input_index<P> (t, s)]) : make_float2 (0.f, 0.f);
+            conv_c2c_finish<P, true> (v, tw, h, lds, out + (size_t) g * (FPB * P::N), team_base, t, scaling, active, twtab);
+        }
     }
 }
 
@@ -405,7 +442,7 @@ __device__ __forceinline__ void load_pair_filter (PairFilter<P, REGS>& h, const 
 }
 
 // everything after the frame is in registers: forward core, pair split * H merge, inverse core, store
-template <class P, bool PREDICATED, bool HREGS>
+template <class P, bool PREDICATED, bool HREGS, bool STAGED = false>
 __device__ __forceinline__ void conv_real_finish (float2 (&v)[P::R],
                                                   const TwiddleRegs<P>& tw,
                                                   const PairTwiddles<P>& pw,
@@ -467,11 +504,16 @@ __device__ __forceinline__ void conv_real_finish (float2 (&v)[P::R],
     lds_load_input_order<P> (u, lds, t);
     team_sync<P::T>();
     conv_core<P> (u, tw, twtab, lds, t);
-    if (!PREDICATED || active)
+    if (STAGED || ! PREDICATED || active)
     {
 #pragma unroll
         for (int s = 0; s < P::R; ++s)
-            gstore (&dst[team_base + (unsigned) output_index<P> (t, s)], make_float2 (u[s].y, u[s].x));
+        {
+            if constexpr (STAGED) // (conv_c2c_finish: the workgroup's LDS staging area)
+                dst[team_base + (unsigned) output_index<P> (t, s)] = make_float2 (u[s].y, u[s].x);
+            else
+                gstore (&dst[team_base + (unsigned) output_index<P> (t, s)], make_float2 (u[s].y, u[s].x));
+        }
     }
 }
 
@@ -807,15 +849,33 @@ __global__ __launch_bounds__ (P::T* FPB) void conv_frames_real_kernel (const flo
 
     const unsigned ngroups = (batch + FPB - 1) / FPB;
     const unsigned team_base = (unsigned) team * M;
+    constexpr bool STAGED = (P::T < 8) && CFFT_CONV_STAGED; // narrow teams: through the LDS staging area (conv_frames_c2c_kernel)
+    float2* stage = smem + FPB * LdsFrame<M>::floats2;
     for (unsigned g = blockIdx.x; g < ngroups; g += gridDim.x)
     {
         const bool active = g * FPB + team < batch;
         const float2* __restrict__ src = in + (size_t) g * (FPB * M);
         float2 v[P::R];
+        if constexpr (STAGED)
+        {
+            const unsigned valid = min ((unsigned) FPB, batch - g * FPB) * M;
+            __syncthreads();
+            stage_in<P::T * FPB, FPB * M> (src, stage, valid, tid);
+            __syncthreads();
 #pragma unroll
-        for (int s = 0; s < P::R; ++s)
-            v[s] = active ? gload (&src[team_base + (unsigned) input_index<P> (t, s)]) : make_float2 (0.f, 0.f);
-        conv_real_finish<P, true, HREGS> (v, tw, pw, h, lds, out + (size_t) g * (FPB * M), team_base, t, scaling, active, twtab);
+            for (int s = 0; s < P::R; ++s)
+                v[s] = stage[team_base + (unsigned) input_index<P> (t, s)];
+            conv_real_finish<P, true, HREGS, true> (v, tw, pw, h, lds, stage, team_base, t, scaling, active, twtab);
+            __syncthreads();
+            stage_out<P::T * FPB, FPB * M> (out + (size_t) g * (FPB * M), stage, valid, tid);
+        }
+        else
+        {
+#pragma unroll
+            for (int s = 0; s < P::R; ++s)
+                v[s] = active ? gload (&src[team_base + (unsigned) input_index<P> (t, s)]) : make_float2 (0.f, 0.f);
+            conv_real_finish<P, true, HREGS> (v, tw, pw, h, lds, out + (size_t) g * (FPB * M), team_base, t, scaling, active, twtab);
+        }
     }
 }
 

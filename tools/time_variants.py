@@ -25,6 +25,10 @@ WORK = {
     "c65536": (65536, 1, 8192, False),
     "conv4096": (4096, 0, 131072, True),
     "conv1024": (1024, 0, 524288, True),
+    "conv32": (32, 0, 16777216, True),
+    "conv64": (64, 0, 8388608, True),
+    "conv128": (128, 0, 4194304, True),
+    "conv256": (256, 0, 2097152, True),
     "conv2048": (2048, 0, 262144, True),
     "conv8192": (8192, 0, 65536, True),
     "cconv4096": (4096, 1, 65536, True),
