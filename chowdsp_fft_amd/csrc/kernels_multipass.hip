@@ -566,7 +566,11 @@ hipError_t groupfast_launch (bool inverse, const float2* in, float2* work, float
     const float2* tw_b = stage_tw + fast_tile_table_rows (N2) * 32; // n1 core (rows)
     int force_solo = 0, reg_polls = 200;
     get_group_options (force_solo, reg_polls);
-    static const unsigned form = std::getenv ("CHOWDSP_FFT_GROUPFAST_PREFETCH") != nullptr ? (unsigned) std::atoi (std::getenv ("CHOWDSP_FFT_GROUPFAST_PREFETCH")) : 0u;
+    // where the next frame's operands are requested (group_fast_kernels.hpp `form`).  Round 4, after the backward kernel stopped
+    // waiting for its prefetch at the request: 2^17 (two groups of 16 per XCD) 0.398 / 0.390 / 0.414 of 8 TB/s with 0 / 1 / 2,
+    // 2^18 (one group of 32) 0.385 / 0.371 / 0.371 -- in front of the hand-off for 2^17, behind the pass-B loads for 2^18
+    static const int form_env = std::getenv ("CHOWDSP_FFT_GROUPFAST_PREFETCH") != nullptr ? std::atoi (std::getenv ("CHOWDSP_FFT_GROUPFAST_PREFETCH")) : -1;
+    const unsigned form = form_env >= 0 ? (unsigned) form_env : (N2 == 256 ? 2u : 0u);
     hipLaunchKernelGGL (k, dim3 (grid), dim3 (256), GF::lds_bytes, stream, in, work, out, tw_a, tw_b, big_tw, (GroupState*) state, host_err, (unsigned) batch, in_stride, out_stride, seq, (unsigned) reg_polls, (unsigned) force_solo, form);
     return hipGetLastError();
 }
