@@ -171,6 +171,19 @@ size_t pair_chunk_divisor()
     return n;
 }
 
+// CHOWDSP_FFT_REAL4_CHUNK_DIV: the real four-step's chunks are this many times smaller than the complex two-pass plans' (round 4,
+// workspace sweep on MI355X: real N = 2^17 / 2^19 0.305 / 0.289 of 8 TB/s with 256 MiB of workspace, 0.314 / 0.297 with 128 -- a
+// real chunk's input and output are half the size of its workspace, so the smaller set stays in the Infinity Cache together)
+size_t real4_chunk_divisor()
+{
+    static const size_t n = [] {
+        const char* e = std::getenv ("CHOWDSP_FFT_REAL4_CHUNK_DIV");
+        const long v = e != nullptr ? std::atol (e) : 2;
+        return (size_t) (v >= 1 && v <= 16 ? v : 2);
+    }();
+    return n;
+}
+
 int lane_count()
 {
     static const int n = [] {
@@ -553,7 +566,7 @@ int big_real4_chunked (Setup* s, bool inverse, const float2* in, float2* out, si
     const int r1 = t->real4_r1, r2 = t->real4_r2;
     const size_t frame_bytes = workspace_frame_bytes (t, complex_len (s));
     const int want_lanes = lane_count();
-    size_t chunk = workspace_cap() / (size_t) want_lanes / frame_bytes;
+    size_t chunk = workspace_cap() / (size_t) want_lanes / frame_bytes / real4_chunk_divisor();
     if (chunk < 1)
         chunk = 1;
     if (chunk > batch)
@@ -1601,6 +1614,8 @@ size_t fft_gpu_workspace_bytes (void* setup, size_t batch)
     size_t chunk = workspace_cap() / (size_t) lane_count() / frame_bytes;
     if (s->transform == FFT_REAL && s->tables->real4_r1 == 0)
         chunk /= pair_chunk_divisor(); // the pair stage's operands share the cache with the two workspaces
+    if (s->transform == FFT_REAL && s->tables->real4_r1 != 0)
+        chunk /= real4_chunk_divisor(); // (big_real4_chunked)
     if (chunk < 1)
         chunk = 1;
     if (chunk > batch)
