@@ -85,3 +85,44 @@ def test_random_call_shapes(gpu, seed):
             fill = 123.0 if shape.endswith("inplace") else 321.0
             assert np.all(got[:, nf:] == fill), f"{what}: padding between frames was written"
         api.fft_destroy_setup(s)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_fused_convolutions(gpu, seed):
+    """fft_convolve_frames_batch over random supported sizes (every fused form: LDS-resident incl. the round-4 kernels -- pair
+    stage in registers, transposed backward network, staged narrow teams --, split-plane, mixed radix, two-pass), random batch
+    counts (ragged groups, fewer frames than resident workgroups), in place or not, against the float64 circular convolution
+    (the reference's forward -> convolve -> backward sequence, test/test.cpp:161-166, computes exactly that times N * scaling)."""
+    api, torch, dev = gpu
+    rng = np.random.RandomState(7000 + seed)
+    for _ in range(8):
+        tr = REAL if rng.rand() < 0.5 else COMPLEX
+        n = int(rng.choice([16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384] if rng.rand() < 0.75 else [96, 480, 768, 2400, 6000, 9216, 65536]))
+        if tr == REAL and (n % 32 != 0):
+            n *= 2
+        if not api.size_supported(n, tr):
+            continue
+        nf = 2 * n if tr == COMPLEX else n
+        batch = int(rng.choice([1, 2, 3, 7, 33, 130, 517])) if n <= 4096 else int(rng.choice([1, 2, 5]))
+        x = rng.uniform(-1, 1, (batch, nf)).astype(np.float32)
+        h = rng.uniform(-1, 1, (1, nf)).astype(np.float32)
+        if tr == COMPLEX:
+            xz = x[:, 0::2].astype(np.float64) + 1j * x[:, 1::2]
+            hz = h[:, 0::2].astype(np.float64) + 1j * h[:, 1::2]
+            yz = np.fft.ifft(np.fft.fft(xz, axis=1) * np.fft.fft(hz, axis=1), axis=1)
+            want = np.empty((batch, nf))
+            want[:, 0::2], want[:, 1::2] = yz.real, yz.imag
+        else:
+            want = np.fft.irfft(np.fft.rfft(x.astype(np.float64), axis=1) * np.fft.rfft(h.astype(np.float64), axis=1), n=n, axis=1)
+        s = api.fft_new_setup(n, tr)
+        xd, hd = torch.from_numpy(x).to(dev), torch.from_numpy(h).to(dev)
+        H = torch.empty_like(hd)
+        api.fft_transform_unordered_batch(s, hd, H, api.FFT_FORWARD)
+        inplace = rng.rand() < 0.5
+        yd = xd if inplace else torch.full_like(xd, 55.0)
+        api.fft_convolve_frames_batch(s, xd, H, yd, 1.0 / n)
+        api.stream_synchronize()
+        got = yd.cpu().numpy().astype(np.float64)
+        err = np.linalg.norm(got - want, axis=1) / np.maximum(np.linalg.norm(want, axis=1), 1e-30)
+        assert err.max() <= 1.5e-6, f"seed {seed}: N={n} {'real' if tr == REAL else 'complex'} batch={batch} inplace={inplace}: relative L2 {err.max():.3e}"
+        api.fft_destroy_setup(s)
