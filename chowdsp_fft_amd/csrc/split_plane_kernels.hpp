@@ -353,6 +353,12 @@ __device__ __forceinline__ void sp_core (float2 (&v)[32], const float2* __restri
 }
 
 // ---- complex ------------------------------------------------------------------------------------------------------
+// CFFT_SPLIT_PREFETCH (round 4): the first PF of the NEXT frame's 32 operands per work-item are requested before this frame's
+// transform and wait in registers (T = 1024, one workgroup per CU: its loads, cores and stores did not overlap at all; the
+// 128-register budget of four waves per SIMD has room for 16 of the 32).  0 = round 3's form.
+#ifndef CFFT_SPLIT_PREFETCH
+#define CFFT_SPLIT_PREFETCH 1
+#endif
 template <class G, bool INV>
 __global__ __launch_bounds__ (G::T) void c2c_split_kernel (const float2* __restrict__ in,
                                                             float2* __restrict__ out,
@@ -363,6 +369,18 @@ __global__ __launch_bounds__ (G::T) void c2c_split_kernel (const float2* __restr
 {
     extern __shared__ __attribute__ ((aligned (16))) float sp_plane[];
     const int t0 = threadIdx.x;
+    constexpr int PF = (CFFT_SPLIT_PREFETCH && G::T == 1024) ? 16 : 0;
+    float2 nx[PF > 0 ? PF : 1];
+    if constexpr (PF > 0)
+    {
+        if (blockIdx.x < batch)
+        {
+            const float2* __restrict__ src0 = in + (size_t) blockIdx.x * in_stride;
+#pragma unroll
+            for (int a = 0; a < PF; ++a)
+                nx[a] = gload (&src0[(unsigned) (t0 + G::T * a)]);
+        }
+    }
     for (unsigned g = blockIdx.x; g < batch; g += gridDim.x)
     {
         int t = t0;
@@ -371,10 +389,29 @@ __global__ __launch_bounds__ (G::T) void c2c_split_kernel (const float2* __restr
         float2* __restrict__ dst = out + (size_t) g * out_stride;
         float2 v[32];
 #pragma unroll
-        for (int a = 0; a < 32; ++a)
+        for (int a = PF; a < 32; ++a)
         {
             const float2 x = gload (&src[(unsigned) (t + G::T * a)]);
             v[a] = INV ? make_float2 (x.y, x.x) : x;
+        }
+        if constexpr (PF > 0)
+        {
+#pragma unroll
+            for (int a = 0; a < PF; ++a)
+            {
+                // (the swap at the consumer behind an opaque statement: built at the request it would wait for the prefetch there)
+                float2 x = nx[a];
+                asm volatile ("" : "+v"(x.x), "+v"(x.y));
+                v[a] = INV ? make_float2 (x.y, x.x) : x;
+            }
+            const unsigned gn = g + gridDim.x;
+            if (gn < batch)
+            {
+                const float2* __restrict__ srcn = in + (size_t) gn * in_stride;
+#pragma unroll
+                for (int a = 0; a < PF; ++a)
+                    nx[a] = gload (&srcn[(unsigned) (t + G::T * a)]);
+            }
         }
         sp_core<G> (v, tw, sp_plane, t);
         int ts = t0;
@@ -526,6 +563,24 @@ __global__ __launch_bounds__ (G::T) void c2r_split_kernel (const float2* __restr
     extern __shared__ __attribute__ ((aligned (16))) float sp_plane[];
     constexpr int M = G::N;
     const int t0 = threadIdx.x;
+    // round 4 (CFFT_SPLIT_PREFETCH, T = 1024, packed layout): the first round's sixteen operands of the NEXT frame wait in registers
+    constexpr bool PFC = CFFT_SPLIT_PREFETCH && G::T == 1024 && LAYOUT == 0;
+    constexpr int PFQ = 6; // pairs of the first round that are prefetched (all eight: 20 bytes of scratch)
+    float2 na[PFC ? PFQ : 1], nxp[PFC ? PFQ : 1];
+    if constexpr (PFC)
+    {
+        if (blockIdx.x < batch)
+        {
+            const float2* __restrict__ src0 = in + (size_t) blockIdx.x * in_stride;
+#pragma unroll
+            for (int q8 = 0; q8 < PFQ; ++q8)
+            {
+                const int k = t0 + G::T * q8;
+                na[q8] = gload (&src0[(unsigned) k]);
+                nxp[q8] = gload (&src0[(unsigned) (k == 0 ? M / 2 : M - k)]);
+            }
+        }
+    }
     for (unsigned g = blockIdx.x; g < batch; g += gridDim.x)
     {
         int t = t0;
@@ -542,13 +597,35 @@ __global__ __launch_bounds__ (G::T) void c2r_split_kernel (const float2* __restr
             for (int q8 = 0; q8 < 8; ++q8)
             {
                 const int k = t + G::T * (8 * h + q8);
-                a[q8] = gload (&src[(unsigned) k]);
-                xp[q8] = gload (&src[(unsigned) (k == 0 ? M / 2 : M - k)]);
+                if (PFC && h == 0 && q8 < PFQ)
+                {
+                    a[q8] = na[PFC ? q8 : 0];
+                    xp[q8] = nxp[PFC ? q8 : 0];
+                }
+                else
+                {
+                    a[q8] = gload (&src[(unsigned) k]);
+                    xp[q8] = gload (&src[(unsigned) (k == 0 ? M / 2 : M - k)]);
+                }
                 pw[q8] = wtab[k];
                 if constexpr (LAYOUT != 0)
                 {
                     if (k == 0)
                         a[q8].y = gload (&src[(unsigned) M]).x; // packed slot 0 = (X0.re, X_{N/2}.re)
+                }
+            }
+            if constexpr (PFC)
+            {
+                if (h == 1 && g + gridDim.x < batch) // behind this frame's second round of loads
+                {
+                    const float2* __restrict__ srcn = in + (size_t) (g + gridDim.x) * in_stride;
+#pragma unroll
+                    for (int q8 = 0; q8 < PFQ; ++q8)
+                    {
+                        const int k = t + G::T * q8;
+                        na[q8] = gload (&srcn[(unsigned) k]);
+                        nxp[q8] = gload (&srcn[(unsigned) (k == 0 ? M / 2 : M - k)]);
+                    }
                 }
             }
 #pragma unroll
