@@ -760,7 +760,7 @@ hipError_t launch_real_pair (bool forward, const float2* in, float2* out, const 
     DeviceInfo dev;
     if (! current_device_info (dev))
         return hipErrorNoDevice;
-    const size_t total = batch * ((size_t) (m / 2 + 255) / 256);
+    const size_t total = batch * ((size_t) (m / 4 + 255) / 256); // (two adjacent pairs per work-item)
     const unsigned grid = (unsigned) std::max<size_t> (1, std::min<size_t> (total, (size_t) dev.num_cus * 16));
     if (forward)
         hipLaunchKernelGGL (real_pair_kernel<true>, dim3 (grid), dim3 (256), 0, stream, in, out, real_tw, m, (unsigned) batch, in_stride, out_stride);
