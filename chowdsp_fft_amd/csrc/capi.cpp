@@ -307,6 +307,9 @@ std::atomic<int> g_fused_conv_generic { 1 };
 std::atomic<int> g_fused_conv_group { 1 };
 // "group_fast": N = 2^17 / 2^18 complex through the one-launch group form on the register-direct tiles (A/B against two launches)
 std::atomic<int> g_group_fast { 1 };
+// "group_real": real N = 131072 in one launch on the static groups, pair stage in registers (group_real_kernels.hpp; A/B against the
+// real four-step's two launches per chunk)
+std::atomic<int> g_group_real { 1 };
 bool split16384_enabled()
 {
     int v = g_split16384.load();
@@ -559,6 +562,36 @@ int big_c2c_chunked (Setup* s, int nc, bool inverse, const float2* in, float2* o
     return cf::FFT_GPU_OK;
 }
 
+// real N = 131072 in ONE launch on the static XCD groups (group_real_kernels.hpp): same conditions as the complex N = 65536 form
+bool group_real_applies (const Setup* s, size_t batch)
+{
+    return s->transform == cf::FFT_REAL && s->tables->group_core != nullptr && fused_form() == 2 && g_group_real.load() != 0 && batch >= fused_min_batch();
+}
+int group_real_transform (Setup* s, bool inverse, const float2* in, float2* out, size_t batch, hipStream_t stream, size_t is2, size_t os2)
+{
+    std::lock_guard<std::recursive_mutex> lock (g_ws_mutex);
+    Lanes* L = get_fused (s->device, stream, group_workspace_bytes());
+    if (L == nullptr)
+        return cf::FFT_GPU_ENOMEM;
+    if (*L->fused_err_host != 0)
+    {
+        // a bounded wait inside an EARLIER launch on this stream ran out (its output is not valid): say so now
+        const unsigned w = *L->fused_err_host;
+        *L->fused_err_host = 0;
+        set_last_error (fused_error_text (w).c_str());
+        return cf::FFT_GPU_ELAUNCH;
+    }
+    const unsigned seq = ++L->fused_seq;
+    const DeviceTables* core = s->tables->group_core;
+    const hipError_t e = launch_group_real (inverse, in, L->fused_ws, out, core->stage_twiddles, core->big_twiddles, s->tables->real_twiddles, L->fused_state, L->fused_err_host, seq, batch, stream, is2, os2);
+    if (e != hipSuccess)
+    {
+        set_last_error ("one-launch real two-pass kernel launch", e);
+        return cf::FFT_GPU_ELAUNCH;
+    }
+    return cf::FFT_GPU_OK;
+}
+
 // long real frames by the real four-step: the same chunked two-lane pipeline as big_c2c_chunked, two launches per chunk
 int big_real4_chunked (Setup* s, bool inverse, const float2* in, float2* out, size_t batch, hipStream_t stream, size_t is2, size_t os2, const float2* mul_h = nullptr, float mul_scale = 1.f)
 {
@@ -728,6 +761,8 @@ int run_transform (Setup* s, const float* in, float* out, size_t batch, cf::fft_
     hipError_t e = hipSuccess;
     if (t->huge_r > 0)
         return huge_transform (s, inverse, cin, cout, batch, stream, is2, os2);
+    if (group_real_applies (s, batch))
+        return group_real_transform (s, inverse, cin, cout, batch, stream, is2, os2);
     if (t->real4_r1 > 0)
         return big_real4_chunked (s, inverse, cin, cout, batch, stream, is2, os2);
     if (t->mixed_n2 > 0)
@@ -1531,6 +1566,8 @@ int fft_gpu_set_option (const char* name, long value)
         g_fused_conv_group = value != 0 ? 1 : 0;
     else if (std::strcmp (name, "group_fast") == 0)
         g_group_fast = value != 0 ? 1 : 0;
+    else if (std::strcmp (name, "group_real") == 0)
+        g_group_real = value != 0 ? 1 : 0;
     else
     {
         set_last_error ("fft_gpu_set_option: unknown option or value out of range");
@@ -1568,6 +1605,8 @@ long fft_gpu_get_option (const char* name)
         return g_fused_conv_group.load();
     if (std::strcmp (name, "group_fast") == 0)
         return g_group_fast.load();
+    if (std::strcmp (name, "group_real") == 0)
+        return g_group_real.load();
     return -1;
 }
 
@@ -1605,6 +1644,8 @@ size_t fft_gpu_workspace_bytes (void* setup, size_t batch)
     int n1 = 0, n2 = 0;
     if (s->tables->mixed_n2 == 0)
         split_large (complex_len (s), n1, n2);
+    if (group_real_applies (s, batch))
+        return group_workspace_bytes() + std::max (fused_state_bytes(), group_state_bytes());
     if (s->transform == FFT_COMPLEX && fused_enabled() && fused_supported (n1, n2) && batch >= fused_min_batch())
         return (fused_form() == 2 ? group_workspace_bytes() : fused_workspace_bytes (complex_len (s), fused_slots())) + std::max (fused_state_bytes(), group_state_bytes());
     // (the same conditions as big_c2c_chunked's register-direct group branch, N = 2^17 / 2^18)

@@ -139,6 +139,14 @@ const DeviceTables* acquire_tables (int device, int N, int transform)
                 return nullptr;
         }
     }
+    // real N = 131072 can run in one launch on the complex 65536-point plan's tables (group_real_kernels.hpp)
+    const DeviceTables* group_core = nullptr;
+    if (transform == 0 && N == 131072)
+    {
+        group_core = acquire_tables (device, 65536, 1);
+        if (group_core != nullptr && (group_core->fast_n1 != 0 || group_core->core_n != 0 || group_core->mixed_n2 != 0))
+            group_core = nullptr; // (CHOWDSP_FFT_FAST_TILES_65536 experiment: not the 256 x 256 block-ordered plan)
+    }
     std::lock_guard<std::mutex> lock (g_cache_mutex);
     const auto key = std::make_tuple (device, N, transform);
     auto it = g_tables.find (key);
@@ -180,6 +188,7 @@ const DeviceTables* acquire_tables (int device, int N, int transform)
     t->huge_shift = h.huge_shift;
     t->huge_plan_r = sub_r;
     t->huge_plan_c = sub_c;
+    t->group_core = group_core;
     t->huge_tw_lo = upload (h.huge_tw_lo);
     t->huge_tw_hi = upload (h.huge_tw_hi);
     t->stage_twiddles = upload (h.stage_twiddles);

@@ -55,6 +55,9 @@ struct DeviceTables
     // long real frames by the real four-step (N = real4_r1 * real4_r2), else 0
     int real4_r1 = 0, real4_r2 = 0;
     int real4_fast = 0; // ... on the register-direct tiles (tile_fast_kernels.hpp) instead of the LDS-staged ones
+    // real N = 131072: the 65536-point complex plan (256 x 256, block-ordered inter-pass twiddles) whose tables the one-launch group
+    // form of the REAL transform uses (group_real_kernels.hpp), else nullptr
+    const DeviceTables* group_core = nullptr;
     // general form (rows generic too): mixed_cb > 0, gen2_* = the n1-point row FFT's stage list
     int mixed_cb = 0;
     int gen2_ns = 0;

@@ -479,7 +479,7 @@ size_t group_state_bytes() { return sizeof (GroupState); }
 size_t group_workspace_bytes()
 {
     // GROUP mode addresses kGroupSlotsTotal slots; SOLO mode one per workgroup of the grid (the fused convolution: two)
-    const unsigned grid = std::max (std::max (group_grid (false), group_grid (true)), 2u * group_conv_grid());
+    const unsigned grid = std::max (std::max (std::max (group_grid (false), group_grid (true)), 2u * group_conv_grid()), std::max (group_real_grid (false), group_real_grid (true)));
     return (size_t) std::max<unsigned> (kGroupSlotsTotal, grid) * 65536u * sizeof (float2);
 }
 hipError_t launch_group_c2c (int n1, int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, void* state, unsigned* host_err, unsigned seq, size_t batch, hipStream_t stream, size_t in_stride, size_t out_stride)
