@@ -540,6 +540,8 @@ int big_c2c_chunked (Setup* s, int nc, bool inverse, const float2* in, float2* o
         }
         if (e == hipSuccess)
             e = mixed ? launch_mixed_big_c2c (*s->tables, inverse, cin, L->ws[k], out + f0 * os2, nb, lanes, st, cis, os2)
+                : s->tables->r2_n > 0
+                    ? launch_fast_r2_c2c (s->tables->r2_n, inverse, cin, L->ws[k], out + f0 * os2, s->tables->stage_twiddles, s->tables->big_twiddles, nb, lanes, st, cis, os2, mul_h, mul_scale)
                 : s->tables->fast_n1 > 0
                     ? launch_fast_c2c (n1, n2, inverse, cin, L->ws[k], out + f0 * os2, s->tables->stage_twiddles, s->tables->big_twiddles, nb, lanes, st, cis, os2, mul_h, mul_scale)
                     : launch_big_c2c (n1, n2, inverse, cin, L->ws[k], out + f0 * os2, s->tables->stage_twiddles, s->tables->big_twiddles, nb, lanes, st, cis, os2);
@@ -1818,7 +1820,7 @@ int fft_convolve_frames_batch (void* setup, const float* x, const float* dft_fil
         }
         return FFT_GPU_OK;
     }
-    if (s->transform == FFT_COMPLEX && t->fast_n1 > 0 && t->mixed_n2 == 0 && g_fused_conv_group.load() != 0)
+    if (s->transform == FFT_COMPLEX && (t->fast_n1 > 0 || t->r2_n > 0) && t->mixed_n2 == 0 && g_fused_conv_group.load() != 0)
     {
         // N = 2^17 ... 2^20 complex (register-direct two-pass tiles): the product rides on the forward transform's pass-B
         // stores, the backward transform follows in place -- four sweeps over the batch instead of five

@@ -174,6 +174,7 @@ const DeviceTables* acquire_tables (int device, int N, int transform)
     t->mixed_cb = h.mixed_cb;
     t->fast_n1 = h.fast_n1;
     t->fast_n2 = h.fast_n2;
+    t->r2_n = h.r2_n;
     t->real4_r1 = h.real4_r1;
     t->real4_r2 = h.real4_r2;
     t->real4_fast = h.real4_fast;

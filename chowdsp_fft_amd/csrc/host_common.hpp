@@ -52,6 +52,8 @@ struct DeviceTables
     int mixed_n1 = 0, mixed_n2 = 0, mixed_tw1_offset = 0, mixed_ca = 0;
     // N = 2^17 .. 2^20 complex by the register-direct passes (tile_fast_kernels.hpp): fast_n1 x fast_n2, else 0
     int fast_n1 = 0, fast_n2 = 0;
+    // 2^21 complex points: radix-2 around the r2_n x r2_n register-direct two-pass transform of the two half-length sub-frames, else 0
+    int r2_n = 0;
     // long real frames by the real four-step (N = real4_r1 * real4_r2), else 0
     int real4_r1 = 0, real4_r2 = 0;
     int real4_fast = 0; // ... on the register-direct tiles (tile_fast_kernels.hpp) instead of the LDS-staged ones

@@ -270,6 +270,62 @@ hipError_t launch_fast_c2c (int n1, int n2, bool inverse, const float2* in, floa
     return e;
 }
 
+namespace
+{
+template <int N2, bool INV>
+hipError_t fast_r2_pass_a (const float2* in, float2* work, const float2* tw2, const float2* big_tw, size_t batch, int div, hipStream_t stream, size_t in_stride)
+{
+    using FT = FastTile<N2>;
+    auto k = pass_a_fast_r2_kernel<N2, INV>;
+    unsigned grid = persistent_grid (k, FT::threads, FT::lds_bytes, batch * (size_t) (1024 / 16));
+    if (grid == 0)
+        return hipErrorNoDevice;
+    grid = std::max (1u, grid / (unsigned) div);
+    hipLaunchKernelGGL (k, dim3 (grid), dim3 (FT::threads), FT::lds_bytes, stream, reinterpret_cast<const float4*> (in), work, tw2, big_tw, 1024u, (unsigned) batch, in_stride / 2);
+    return hipGetLastError();
+}
+} // namespace
+
+// n2 = column length of the half-length sub-frames (256 / 512 / 1024); their rows are 1024 points
+hipError_t launch_fast_r2_c2c (int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, size_t batch, int grid_divisor, hipStream_t stream, size_t in_stride, size_t out_stride, const float2* mul_h, float mul_scale)
+{
+    if (mul_h != nullptr && inverse)
+        return hipErrorInvalidValue;
+    if (batch == 0)
+        return hipSuccess;
+    if (fast_tile_table_rows (n2) == 0 || batch > 0x7FFFFFFFull)
+        return hipErrorInvalidValue;
+    constexpr int kN1 = 1024;
+    using FB = FastTile<kN1>;
+    const size_t frame_len = (size_t) 2 * kN1 * (size_t) n2;
+    in_stride = in_stride ? in_stride : frame_len;
+    out_stride = out_stride ? out_stride : frame_len;
+    if ((in_stride & 1u) != 0)
+        return hipErrorInvalidValue; // (frames are read in 16-byte pairs; the C API only ever passes whole float2 counts of even length)
+    const float2* tw2 = stage_tw;                                     // column core
+    const float2* tw1 = stage_tw + fast_tile_table_rows (n2) * 32;    // row core
+    const float2* r2_tw = tw1 + fast_tile_table_rows (kN1) * 32;
+    hipError_t e = hipErrorInvalidValue;
+    if (inverse)
+    {
+        CFFT_DISPATCH_FAST (n2, e = (fast_r2_pass_a<N_, true> (in, work, tw2, big_tw, batch, grid_divisor, stream, in_stride)));
+    }
+    else
+    {
+        CFFT_DISPATCH_FAST (n2, e = (fast_r2_pass_a<N_, false> (in, work, tw2, big_tw, batch, grid_divisor, stream, in_stride)));
+    }
+    if (e != hipSuccess)
+        return e;
+    // (the product with a filter spectrum rides on the FORWARD transform's stores only: fft_convolve_frames_batch)
+    auto kb = inverse ? pass_b_fast_r2_kernel<kN1, true, false> : (mul_h != nullptr ? pass_b_fast_r2_kernel<kN1, false, true> : pass_b_fast_r2_kernel<kN1, false, false>);
+    unsigned grid = persistent_grid (kb, FB::threads, FB::lds_bytes, batch * (size_t) (n2 / 16));
+    if (grid == 0)
+        return hipErrorNoDevice;
+    grid = std::max (1u, grid / (unsigned) grid_divisor);
+    hipLaunchKernelGGL (kb, dim3 (grid), dim3 (FB::threads), FB::lds_bytes, stream, (const float2*) work, out, tw1, r2_tw, (unsigned) n2, (unsigned) batch, out_stride, mul_h, mul_scale);
+    return hipGetLastError();
+}
+
 // ---- long REAL frames: the four-step algorithm on the real data (multipass_kernels.hpp), two sweeps instead of three ----
 namespace
 {

@@ -172,6 +172,14 @@ bool split_real4 (int n_real, int& r1, int& r2)
     return true;
 }
 
+// not one of the power-of-two lengths that run as a radix-2 split around the register-direct two-pass tiles (2^min_log2 .. 2^21)
+static bool real_or_small_r2 (int nc, int min_log2)
+{
+    if (min_log2 < 19)
+        min_log2 = 19;
+    return ! (is_pow2 (nc) && nc <= (1 << 21) && nc >= (1 << min_log2));
+}
+
 bool split_general (int n_complex, int& n1, int& n2)
 {
     n1 = n2 = 0;
@@ -442,6 +450,45 @@ bool build_host_tables (int N, int transform, HostTables& out)
         for (long long i = 0; i < hi_len; ++i)
             out.huge_tw_hi.push_back (unit_root (i * lo_len, nc));
         return true;
+    }
+    {
+        // 2^21 complex points (round 4): one radix-2 decimation in time around the 1024 x 1024 register-direct two-pass transform of the two
+        // half-length sub-frames (tile_fast_kernels.hpp pass_*_fast_r2_kernel), unless CHOWDSP_FFT_FAST_TILES=0 / CHOWDSP_FFT_R2=0
+        const char* ev = std::getenv ("CHOWDSP_FFT_FAST_TILES");
+        const char* er = std::getenv ("CHOWDSP_FFT_R2");
+        // which powers of two take this form: 2^19 .. 2^21.  2^21 has no plain two-pass plan on these tiles (0.183 -> 0.325 of 8 TB/s);
+        // 2^20 / 2^19 gain 9 % / 3 % on their plain 1024 x 1024 / 1024 x 512 plans (half the inter-pass twiddle traffic, 16-byte loads:
+        // profiles/r04_radix2_wrap.txt); CHOWDSP_FFT_R2_MIN_LOG2 = 20 / 21 / 22 takes them back to the plain plans (A/B)
+        const char* em = std::getenv ("CHOWDSP_FFT_R2_MIN_LOG2");
+        // (real frames of 2^21 / 2^22 samples -- complex cores of 2^20 / 2^21 points, no real four-step plan -- take it in any case)
+        const int min_log2 = real ? 20 : (em != nullptr ? std::atoi (em) : 19);
+        if (! real_or_small_r2 (nc, min_log2) && ! (ev != nullptr && ev[0] == '0') && ! (er != nullptr && er[0] == '0'))
+        {
+            static const int a32[10] = { 1, 2, 3, 4, 5, 6, 7, 8, 16, 24 };
+            static const int a16[6] = { 1, 2, 3, 4, 8, 12 };
+            static const int a8[4] = { 1, 2, 3, 4 };
+            const int n1 = 1024, half = nc / 2, n2 = half / n1; // sub-frames of n1 x n2 points: n2-point columns, 1024-point rows
+            out.core_n = 0;
+            out.r2_n = n2;
+            for (int n : { n2, n1 })
+            {
+                const int* al = n == 1024 ? a32 : (n == 512 ? a16 : a8);
+                const int rows = n == 1024 ? 10 : (n == 512 ? 6 : 4);
+                for (int j = 0; j < rows; ++j)
+                    for (int k = 0; k < 32; ++k)
+                        out.stage_twiddles.push_back (unit_root ((long long) al[j] * k, n));
+            }
+            // the radix-2 twiddle W_N^k, k = n2 (ms + 32 b) + kb, factorised: W_N^kb (kb < n2), then W_2048^ms (ms < 32); W_64^b is a constant
+            for (int kb = 0; kb < n2; ++kb)
+                out.stage_twiddles.push_back (unit_root (kb, nc));
+            for (int ms = 0; ms < 32; ++ms)
+                out.stage_twiddles.push_back (unit_root (ms, 2 * n1));
+            out.big_twiddles.reserve ((size_t) half);
+            for (int a = 0; a < n1; ++a)
+                for (int kb = 0; kb < n2; ++kb)
+                    out.big_twiddles.push_back (unit_root ((long long) a * kb, half));
+            return true;
+        }
     }
     int gs1 = 0, gs2 = 0;
     if ((! is_pow2 (nc) && nc > kGenericMaxComplexLen && ! split_mixed (nc, gs1, gs2)) || (is_pow2 (nc) && nc > (1 << 20)))

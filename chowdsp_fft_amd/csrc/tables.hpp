@@ -27,6 +27,7 @@ struct HostTables
     std::vector<int> generic2_radix, generic2_tw_offset;
     int mixed_cb = 0;
     int fast_n1 = 0, fast_n2 = 0;   // complex 2^17 .. 2^20: register-direct passes (tile_fast_kernels.hpp)
+    int r2_n = 0;                   // complex 2^21: radix-2 around the r2_n x r2_n register-direct two-pass transform of the two half-length sub-frames
     int real4_r1 = 0, real4_r2 = 0; // long real frames: real four-step N = r1 * r2 (multipass_kernels.hpp)
     int real4_fast = 0;             // ... on the register-direct tiles (tile_fast_kernels.hpp)
     // frames beyond 2^21 complex points (split_huge): huge_r x huge_c, both factors transformed by plans of their own;

@@ -296,6 +296,171 @@ __global__ __launch_bounds__ (FastTile<N1>::threads, FastTile<N1>::min_waves) vo
 }
 
 // =====================================================================================================
+// N = 2^21 = 2 L, L = 1024 x 1024 (round 4): one radix-2 decimation in time AROUND the register-direct two-pass transform of
+// the two half-length sub-frames x_p[j] = x[2 j + p] -- no third sweep, no 2048-point tile (which these kernels cannot hold):
+//   pass A  one 16-byte load brings element j of BOTH sub-frames (adjacent in the frame: 256 contiguous bytes per half-wave row
+//           instead of 128); the two column tiles are transformed one after the other through the same LDS plane and stored as
+//           two consecutive intermediates W_p[a][kb] of L points;
+//   pass B  the row tiles of both intermediates -> E[k], O[k] in the same slots of one work-item, then
+//           X[k] = E[k] + W_N^k O[k],  X[k + L] = E[k] - W_N^k O[k]  -- two plain 128-byte runs per row, natural order.
+//           W_N^k for k = n2 (ms + 32 b) + kb:  (W_N^kb W_2048^ms) W_64^b = one table product per tile times a constant.
+// Before: 2048 x 1024 on the LDS-staged generic tiles, 0.18 of 8 TB/s.  Reference: the same radix-2 split is the first pass of
+// cfftf1_ps for any even N (simd/chowdsp_fft_impl_sse.cpp:372-432, passf2_ps :98-137).
+// =====================================================================================================
+// W_64^b = exp (-2 pi i b / 64), b < 32 (rounded from double)
+static __device__ const float kW64re[32] = { 1.0f, 0.9951847266721969f, 0.9807852804032304f, 0.9569403357322088f, 0.9238795325112867f, 0.881921264348355f, 0.8314696123025452f, 0.773010453362737f, 0.7071067811865476f, 0.6343932841636455f, 0.5555702330196023f, 0.4713967368259978f, 0.38268343236508984f, 0.29028467725446233f, 0.19509032201612833f, 0.09801714032956077f, 0.0f, -0.09801714032956065f, -0.1950903220161282f, -0.29028467725446216f, -0.3826834323650897f, -0.4713967368259977f, -0.555570233019602f, -0.6343932841636454f, -0.7071067811865475f, -0.773010453362737f, -0.8314696123025453f, -0.8819212643483549f, -0.9238795325112867f, -0.9569403357322088f, -0.9807852804032304f, -0.9951847266721968f };
+static __device__ const float kW64im[32] = { -0.0f, -0.0980171403295606f, -0.19509032201612825f, -0.29028467725446233f, -0.3826834323650898f, -0.47139673682599764f, -0.5555702330196022f, -0.6343932841636455f, -0.7071067811865475f, -0.773010453362737f, -0.8314696123025452f, -0.8819212643483549f, -0.9238795325112867f, -0.9569403357322089f, -0.9807852804032304f, -0.9951847266721968f, -1.0f, -0.9951847266721969f, -0.9807852804032304f, -0.9569403357322089f, -0.9238795325112867f, -0.881921264348355f, -0.8314696123025455f, -0.7730104533627371f, -0.7071067811865476f, -0.6343932841636455f, -0.5555702330196022f, -0.47139673682599786f, -0.3826834323650899f, -0.2902846772544624f, -0.1950903220161286f, -0.09801714032956083f };
+
+template <int N2, bool SWAP_IN>
+__global__ __launch_bounds__ (FastTile<N2>::threads, FastTile<N2>::min_waves) void pass_a_fast_r2_kernel (const float4* __restrict__ in, // the frame as L pairs (x[2 j], x[2 j + 1])
+                                                                              float2* __restrict__ work, // per frame: W_0[a][kb], W_1[a][kb]
+                                                                              const float2* __restrict__ stage_tw, // [rows][32] of the n2 core
+                                                                              const float2* __restrict__ big_tw,   // [a][kb] = W_L^{a kb}
+                                                                              unsigned n1,
+                                                                              unsigned batch,
+                                                                              size_t in_stride4)
+{
+    using FT = FastTile<N2>;
+    extern __shared__ __attribute__ ((aligned (16))) float ft_plane[];
+    const int tid0 = threadIdx.x;
+    float2 w[10];
+    ft_load_twiddles<FT> (w, stage_tw, tid0 & 31);
+    const unsigned tiles = n1 / 16;
+    const size_t sub_len = (size_t) n1 * N2;
+    const size_t nwork = (size_t) batch * tiles;
+    for (size_t wk = blockIdx.x; wk < nwork; wk += gridDim.x)
+    {
+        int tid = tid0;
+        CFFT_LAUNDER_INDEX (tid);
+        const unsigned f = (unsigned) (wk / tiles);
+        const unsigned a0 = (unsigned) (wk % tiles) * 16u;
+        const float4* __restrict__ src = in + (size_t) f * in_stride4 + a0 + (unsigned) (tid & 15);
+        const unsigned m = (unsigned) tid >> 4;
+        float2 v0[32], v1[32];
+#pragma unroll
+        for (int a = 0; a < 32; ++a)
+        {
+            const float4 q = gload4 (&src[(size_t) (m + FT::Tn * a) * n1]);
+            v0[a] = SWAP_IN ? make_float2 (q.y, q.x) : make_float2 (q.x, q.y);
+            v1[a] = SWAP_IN ? make_float2 (q.w, q.z) : make_float2 (q.z, q.w);
+        }
+        int ts = tid0;
+        CFFT_LAUNDER_INDEX (ts);
+        const unsigned i = (unsigned) ts & 31u;
+        // the inter-pass twiddles are the same for both sub-frames (same column a, same kb): loaded once, behind the first
+        // sub-frame's arithmetic
+        float2 bt[32];
+#define CFFT_R2_PASS_A(V, P)                                                                                              \
+    {                                                                                                                     \
+        CFFT_PHASE_FENCE();                                                                                               \
+        fft_reg32<false> (V, w);                                                                                          \
+        CFFT_PHASE_FENCE();                                                                                               \
+        ft_exchange<FT, true> (V, ft_plane, tid);                                                                         \
+        CFFT_PHASE_FENCE();                                                                                               \
+        if ((P) == 0)                                                                                                     \
+        {                                                                                                                 \
+            _Pragma ("unroll") for (int q = 0; q < FT::Q; ++q)                                                            \
+            {                                                                                                             \
+                const unsigned a = a0 + ((unsigned) ts >> 5) + (unsigned) (FT::Tn / 2) * q;                               \
+                const float2* __restrict__ twp = big_tw + (size_t) a * N2 + i;                                            \
+                _Pragma ("unroll") for (int b = 0; b < FT::R1; ++b)                                                       \
+                    bt[q * FT::R1 + b] = twp[32 * b];                                                                     \
+            }                                                                                                             \
+        }                                                                                                                 \
+        CFFT_PHASE_FENCE();                                                                                               \
+        ft_stage1_all<FT> (V, w, w, w, w);                                                                                \
+        CFFT_PHASE_FENCE();                                                                                               \
+        _Pragma ("unroll") for (int q = 0; q < FT::Q; ++q)                                                                \
+        {                                                                                                                 \
+            const unsigned a = a0 + ((unsigned) ts >> 5) + (unsigned) (FT::Tn / 2) * q;                                   \
+            float2* __restrict__ dst = work + ((size_t) f * 2 + (P)) * sub_len + (size_t) a * N2 + i;                     \
+            _Pragma ("unroll") for (int b = 0; b < FT::R1; ++b)                                                           \
+                dst[32 * b] = cmul (V[q * FT::R1 + b], bt[q * FT::R1 + b]); /* plain store: the workspace should stay cached */ \
+        }                                                                                                                 \
+    }
+        CFFT_R2_PASS_A (v0, 0)
+        CFFT_R2_PASS_A (v1, 1)
+#undef CFFT_R2_PASS_A
+    }
+}
+
+// MULH (fft_convolve_frames_batch, forward transform only): every bin times H[bin] * scaling on its way out, as in pass_b_fast_kernel
+template <int N1, bool SWAP_OUT, bool MULH = false>
+__global__ __launch_bounds__ (FastTile<N1>::threads, FastTile<N1>::min_waves) void pass_b_fast_r2_kernel (const float2* __restrict__ work,
+                                                                              float2* __restrict__ out,
+                                                                              const float2* __restrict__ stage_tw, // [rows][32] of the n1 core
+                                                                              const float2* __restrict__ r2_tw,    // W_N^kb, kb < n2; then W_(2 N1)^j, j < 32
+                                                                              unsigned n2,
+                                                                              unsigned batch,
+                                                                              size_t out_stride,
+                                                                              const float2* __restrict__ H = nullptr,
+                                                                              float scaling = 1.f)
+{
+    using FT = FastTile<N1>;
+    static_assert (N1 == 1024 && FT::Q == 1 && FT::Tn == 32, "the radix-2 twiddle is factorised for 1024-point rows: W_N^(n2 (ms + 32 b)) = W_2048^ms W_64^b");
+    extern __shared__ __attribute__ ((aligned (16))) float ft_plane[];
+    const int tid0 = threadIdx.x;
+    float2 w[10];
+    ft_load_twiddles<FT> (w, stage_tw, tid0 >> 4); // butterfly index i = member
+    const float2 wms = r2_tw[n2 + ((unsigned) tid0 >> 4)]; // W_2048^ms
+    const unsigned tiles = n2 / 16;
+    const size_t sub_len = (size_t) N1 * n2;
+    const size_t nwork = (size_t) batch * tiles;
+    for (size_t wk = blockIdx.x; wk < nwork; wk += gridDim.x)
+    {
+        int tid = tid0;
+        CFFT_LAUNDER_INDEX (tid);
+        const unsigned f = (unsigned) (wk / tiles);
+        const unsigned kb0 = (unsigned) (wk % tiles) * 16u;
+        const unsigned m = (unsigned) tid >> 4;
+        const float2* __restrict__ src = work + (size_t) f * 2 * sub_len + kb0 + (unsigned) (tid & 15);
+        float2 v0[32], v1[32];
+#pragma unroll
+        for (int a = 0; a < 32; ++a)
+            v0[a] = src[(size_t) (m + FT::Tn * a) * n2];
+#pragma unroll
+        for (int a = 0; a < 32; ++a)
+            v1[a] = src[sub_len + (size_t) (m + FT::Tn * a) * n2];
+        const float2 wkb = r2_tw[kb0 + ((unsigned) tid & 15u)]; // W_N^kb
+        CFFT_PHASE_FENCE();
+        fft_reg32<false> (v0, w);
+        CFFT_PHASE_FENCE();
+        ft_exchange<FT, false> (v0, ft_plane, tid);
+        CFFT_PHASE_FENCE();
+        ft_stage1_all<FT> (v0, w, w, w, w);
+        CFFT_PHASE_FENCE();
+        fft_reg32<false> (v1, w);
+        CFFT_PHASE_FENCE();
+        ft_exchange<FT, false> (v1, ft_plane, tid);
+        CFFT_PHASE_FENCE();
+        ft_stage1_all<FT> (v1, w, w, w, w);
+        CFFT_PHASE_FENCE();
+        int ts = tid0;
+        CFFT_LAUNDER_INDEX (ts);
+        float2* __restrict__ dst = out + (size_t) f * out_stride + kb0 + ((unsigned) ts & 15u);
+        const unsigned ms = (unsigned) ts >> 4;
+        const float2 wbase = cmul (wkb, wms); // W_N^(kb + n2 ms)
+#pragma unroll
+        for (int b = 0; b < 32; ++b)
+        {
+            const float2 wk2 = cmul (wbase, make_float2 (kW64re[b], kW64im[b])); // W_N^k, k = n2 (ms + 32 b) + kb
+            const float2 o = cmul (v1[b], wk2);
+            float2 x0 = make_float2 (v0[b].x + o.x, v0[b].y + o.y), x1 = make_float2 (v0[b].x - o.x, v0[b].y - o.y);
+            if constexpr (MULH)
+            {
+                const float2* __restrict__ hp = &H[(size_t) (ms + 32 * b) * n2 + kb0 + ((unsigned) ts & 15u)];
+                const float2 h0 = hp[0], h1 = hp[sub_len];
+                x0 = cmul (x0, make_float2 (h0.x * scaling, h0.y * scaling));
+                x1 = cmul (x1, make_float2 (h1.x * scaling, h1.y * scaling));
+            }
+            float2* __restrict__ d = &dst[(size_t) (ms + 32 * b) * n2];
+            gstore (d, SWAP_OUT ? make_float2 (x0.y, x0.x) : x0);
+            gstore (d + sub_len, SWAP_OUT ? make_float2 (x1.y, x1.x) : x1);
+        }
+    }
+}
+
+// =====================================================================================================
 // Long REAL frames (N = R1 x R2 = 2^17 .. 2^20 samples) on the same register-direct tiles: the real four-step of
 // multipass_kernels.hpp (pairs of real columns as complex columns, separation, rows kb <= R2/2 only, packed spectrum
 // written directly) with the column / row transforms done as above.
