@@ -1417,6 +1417,20 @@ int fft_gpu_plan_describe (int N, fft_transform_t transform, int desc[8])
         return FFT_GPU_OK;
     }
     int n1 = 0, n2 = 0;
+    if ((nc >= (1 << 19) && nc <= (1 << 21) && transform == FFT_COMPLEX) || (nc >= (1 << 20) && nc <= (1 << 21)))
+    {
+        // 2^19 .. 2^21 complex points (and the complex cores of real 2^21 / 2^22): one radix-2 split around the register-direct two-pass
+        // transform of the two half-length sub-frames -- reported as rows of 2 x 1024 points, columns of nc / 2048 points; CHOWDSP_FFT_R2 / CHOWDSP_FFT_R2_MIN_LOG2 (A/B switches, tables.cpp) are not reflected here
+        desc[0] = nc;
+        desc[1] = 2;
+        desc[2] = 2048;
+        desc[3] = nc / 2048;
+        desc[4] = 32; // (as for every two-pass plan: the radices of the n2-point column core)
+        desc[5] = nc / 2048 / 32;
+        desc[6] = 0;
+        desc[7] = 0;
+        return FFT_GPU_OK;
+    }
     if (nc > (1 << 20))
     {
         // powers of two beyond 2^20: the general two-pass form
