@@ -95,6 +95,20 @@ __global__ __launch_bounds__ (P::T* FPB) void c2c_kernel (const float2* __restri
     }
 }
 
+// CFFT_C2C_XCD_ORDER (round-4 A/B): 1 = the frames one XCD works through are CONSECUTIVE in memory (workgroups are dealt round-robin
+// over the 8 XCDs, so loop index g belongs to XCD g % 8: XCD x owns ngroups / 8 consecutive groups) instead of every XCD striding
+// through the whole batch -- fewer pages and DRAM rows shared between XCDs.  Any bijection is correct.
+#ifndef CFFT_C2C_XCD_ORDER
+#define CFFT_C2C_XCD_ORDER 0
+#endif
+__device__ __forceinline__ unsigned c2c_group_map (unsigned g, unsigned ngroups)
+{
+    if (! CFFT_C2C_XCD_ORDER)
+        return g;
+    const unsigned q = ngroups / 8u, r = ngroups % 8u, x = g % 8u;
+    return x * q + (x < r ? x : r) + g / 8u;
+}
+
 // Software-pipelined variant: the loads of the NEXT frame are issued before the current frame is computed and
 // stored.  Besides hiding the load latency behind this frame's arithmetic, it puts the loads AHEAD of the
 // stores in the wave's in-order vmcnt queue, so waiting for them (s_waitcnt vmcnt(R)) no longer has to wait
@@ -134,8 +148,9 @@ __global__ __launch_bounds__ (P::T* FPB) void c2c_kernel_pf (const float2* __res
 #define CFFT_PF_LOADS(LO, HI)                                                                                       \
     if (gn_ < ngroups)                                                                                              \
     {                                                                                                               \
-        const bool actn_ = gn_ * FPB + team < batch;                                                                \
-        const float2* __restrict__ srcn_ = in + (size_t) gn_ * FPB * in_stride;                                     \
+        const unsigned gnm_ = c2c_group_map (gn_, ngroups);                                                         \
+        const bool actn_ = gnm_ * FPB + team < batch;                                                               \
+        const float2* __restrict__ srcn_ = in + (size_t) gnm_ * FPB * in_stride;                                    \
         if (FPB == 1 || actn_)                                                                                      \
         {                                                                                                           \
             _Pragma ("unroll") for (int s = (LO); s < (HI); ++s)                                                    \
@@ -148,8 +163,9 @@ __global__ __launch_bounds__ (P::T* FPB) void c2c_kernel_pf (const float2* __res
     }
 #define CFFT_PF_BODY(G, V)                                                                                          \
     {                                                                                                               \
-        const bool active_ = (G) * FPB + team < batch;                                                              \
-        float2* __restrict__ dst_ = out + (size_t) (G) * FPB * out_stride;                                          \
+        const unsigned gm_ = c2c_group_map ((G), ngroups);                                                          \
+        const bool active_ = gm_ * FPB + team < batch;                                                              \
+        float2* __restrict__ dst_ = out + (size_t) gm_ * FPB * out_stride;                                          \
         const unsigned gn_ = (G) + gridDim.x;                                                                       \
         constexpr int at_ = (P::NS == 3) ? CFFT_PF_AT : 0;                                                          \
         if constexpr (at_ == 0)                                                                                     \
@@ -192,8 +208,9 @@ __global__ __launch_bounds__ (P::T* FPB) void c2c_kernel_pf (const float2* __res
     if (g >= ngroups)
         return;
     {
-        const bool act0 = g * FPB + team < batch;
-        const float2* __restrict__ src0 = in + (size_t) g * FPB * in_stride;
+        const unsigned g0 = c2c_group_map (g, ngroups);
+        const bool act0 = g0 * FPB + team < batch;
+        const float2* __restrict__ src0 = in + (size_t) g0 * FPB * in_stride;
         float2 v[P::R];
 #pragma unroll
         for (int s = 0; s < P::R; ++s)
