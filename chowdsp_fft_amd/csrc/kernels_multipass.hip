@@ -182,6 +182,10 @@ template <int N_>
 constexpr auto pass_b_real_fast_plain = pass_b_real_fast_kernel<N_, false>;
 template <int N_>
 constexpr auto pass_b_real_fast_mulh = pass_b_real_fast_kernel<N_, true>;
+template <int N_>
+constexpr auto pass_a_real_fast_one = pass_a_real_fast_kernel<N_, 1>;
+template <int N_>
+constexpr auto pass_a_real_fast_two = pass_a_real_fast_kernel<N_, 2>;
 
 // long REAL frames on the register-direct tiles: N = r1 x r2 samples, r1, r2 in {256, 512, 1024}
 hipError_t launch_real4_fast (int r1, int r2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, size_t batch, int grid_divisor, hipStream_t stream, size_t in_stride, size_t out_stride, const float2* mul_h, float mul_scale)
@@ -202,11 +206,15 @@ hipError_t launch_real4_fast (int r1, int r2, bool inverse, const float2* in, fl
     const int n1c = r1 / 2;
     const unsigned div = (unsigned) grid_divisor;
     const size_t tiles_a = (size_t) (n1c / 16), tiles_b = (size_t) ((r2 / 2 + 16) / 16);
-#define CFFT_REAL4_FAST_LAUNCH(KERNEL, NN, TILES, ...)                                                              \
+    // CHOWDSP_FFT_REAL4_FRAMES = 2 (A/B): two frames per work item of the forward column pass, which then share every inter-pass twiddle
+    // load (columns of up to 512 points; the 1024-point form needs more than 256 registers).  Measured no gain -- r2^18 0.310 against
+    // 0.317, r2^19 0.287 against 0.291 of 8 TB/s (profiles/r04_radix2_wrap.txt): the doubled registers halve the workgroups per CU.
+    static const bool two_frames = std::getenv ("CHOWDSP_FFT_REAL4_FRAMES") != nullptr && std::atoi (std::getenv ("CHOWDSP_FFT_REAL4_FRAMES")) == 2;
+#define CFFT_REAL4_FAST_LAUNCH(KERNEL, NN, TILES, ...) /* TILES: work items of the launch */                                                              \
     {                                                                                                               \
         using FT = FastTile<NN>;                                                                                    \
         auto k_ = KERNEL<NN>;                                                                                       \
-        unsigned grid_ = persistent_grid (k_, FT::threads, FT::lds_bytes, batch * (TILES));                         \
+        unsigned grid_ = persistent_grid (k_, FT::threads, FT::lds_bytes, (size_t) (TILES));                        \
         if (grid_ == 0)                                                                                             \
             return hipErrorNoDevice;                                                                                \
         grid_ = std::max (1u, grid_ / div);                                                                         \
@@ -216,24 +224,24 @@ hipError_t launch_real4_fast (int r1, int r2, bool inverse, const float2* in, fl
     hipError_t e = hipErrorInvalidValue;
     if (! inverse)
     {
-        CFFT_DISPATCH_FAST (r2, CFFT_REAL4_FAST_LAUNCH (pass_a_real_fast_kernel, N_, tiles_a, in, work, tw2, big_fwd, (unsigned) n1c, (unsigned) batch, in_stride));
+        CFFT_DISPATCH_FAST (r2, if (two_frames && N_ <= 512) { CFFT_REAL4_FAST_LAUNCH (pass_a_real_fast_two, N_, ((batch + 1) / 2) * tiles_a, in, work, tw2, big_fwd, (unsigned) n1c, (unsigned) batch, in_stride) } else { CFFT_REAL4_FAST_LAUNCH (pass_a_real_fast_one, N_, batch * tiles_a, in, work, tw2, big_fwd, (unsigned) n1c, (unsigned) batch, in_stride) });
         if (e != hipSuccess)
             return e;
         if (mul_h != nullptr) // the product with a packed filter spectrum rides on the stores (fft_convolve_frames_batch)
         {
-            CFFT_DISPATCH_FAST (r1, CFFT_REAL4_FAST_LAUNCH (pass_b_real_fast_mulh, N_, tiles_b, (const float2*) work, out, tw1, (unsigned) r2, (unsigned) batch, out_stride, mul_h, mul_scale));
+            CFFT_DISPATCH_FAST (r1, CFFT_REAL4_FAST_LAUNCH (pass_b_real_fast_mulh, N_, batch * tiles_b, (const float2*) work, out, tw1, (unsigned) r2, (unsigned) batch, out_stride, mul_h, mul_scale));
         }
         else
         {
-            CFFT_DISPATCH_FAST (r1, CFFT_REAL4_FAST_LAUNCH (pass_b_real_fast_plain, N_, tiles_b, (const float2*) work, out, tw1, (unsigned) r2, (unsigned) batch, out_stride, (const float2*) nullptr, 1.f));
+            CFFT_DISPATCH_FAST (r1, CFFT_REAL4_FAST_LAUNCH (pass_b_real_fast_plain, N_, batch * tiles_b, (const float2*) work, out, tw1, (unsigned) r2, (unsigned) batch, out_stride, (const float2*) nullptr, 1.f));
         }
     }
     else
     {
-        CFFT_DISPATCH_FAST (r1, CFFT_REAL4_FAST_LAUNCH (pass_b_real_inv_fast_kernel, N_, tiles_b, in, work, tw1, big_inv, (unsigned) r2, (unsigned) batch, in_stride));
+        CFFT_DISPATCH_FAST (r1, CFFT_REAL4_FAST_LAUNCH (pass_b_real_inv_fast_kernel, N_, batch * tiles_b, in, work, tw1, big_inv, (unsigned) r2, (unsigned) batch, in_stride));
         if (e != hipSuccess)
             return e;
-        CFFT_DISPATCH_FAST (r2, CFFT_REAL4_FAST_LAUNCH (pass_a_real_inv_fast_kernel, N_, tiles_a, (const float2*) work, out, tw2, (unsigned) n1c, (unsigned) batch, out_stride));
+        CFFT_DISPATCH_FAST (r2, CFFT_REAL4_FAST_LAUNCH (pass_a_real_inv_fast_kernel, N_, batch * tiles_a, (const float2*) work, out, tw2, (unsigned) n1c, (unsigned) batch, out_stride));
     }
 #undef CFFT_REAL4_FAST_LAUNCH
     return e;
