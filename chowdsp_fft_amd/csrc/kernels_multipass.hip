@@ -295,9 +295,11 @@ hipError_t fast_r2_pass_a (const float2* in, float2* work, const float2* tw2, co
 } // namespace
 
 // n2 = column length of the half-length sub-frames (256 / 512 / 1024); their rows are 1024 points
-hipError_t launch_fast_r2_c2c (int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, size_t batch, int grid_divisor, hipStream_t stream, size_t in_stride, size_t out_stride, const float2* mul_h, float mul_scale)
+hipError_t launch_fast_r2_c2c (int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, size_t batch, int grid_divisor, hipStream_t stream, size_t in_stride, size_t out_stride, const float2* mul_h, float mul_scale, const float2* pair_tw)
 {
-    if (mul_h != nullptr && inverse)
+    if ((mul_h != nullptr || pair_tw != nullptr) && inverse)
+        return hipErrorInvalidValue;
+    if (mul_h != nullptr && pair_tw != nullptr)
         return hipErrorInvalidValue;
     if (batch == 0)
         return hipSuccess;
@@ -324,6 +326,17 @@ hipError_t launch_fast_r2_c2c (int n2, bool inverse, const float2* in, float2* w
     }
     if (e != hipSuccess)
         return e;
+    if (pair_tw != nullptr)
+    {
+        // REAL forward transform: pass B forms the packed spectrum itself (pair stage in registers)
+        auto kr = pass_b_fast_r2_real_kernel<kN1>;
+        unsigned gridr = persistent_grid (kr, FB::threads, FB::lds_bytes, batch * (size_t) (n2 / 16));
+        if (gridr == 0)
+            return hipErrorNoDevice;
+        gridr = std::max (1u, gridr / (unsigned) grid_divisor);
+        hipLaunchKernelGGL (kr, dim3 (gridr), dim3 (FB::threads), FB::lds_bytes, stream, (const float2*) work, out, tw1, r2_tw, pair_tw, (unsigned) n2, (unsigned) batch, out_stride);
+        return hipGetLastError();
+    }
     // (the product with a filter spectrum rides on the FORWARD transform's stores only: fft_convolve_frames_batch)
     auto kb = inverse ? pass_b_fast_r2_kernel<kN1, true, false> : (mul_h != nullptr ? pass_b_fast_r2_kernel<kN1, false, true> : pass_b_fast_r2_kernel<kN1, false, false>);
     unsigned grid = persistent_grid (kb, FB::threads, FB::lds_bytes, batch * (size_t) (n2 / 16));
