@@ -310,9 +310,6 @@ std::atomic<int> g_group_fast { 1 };
 // "group_real": real N = 131072 in one launch on the static groups, pair stage in registers (group_real_kernels.hpp; A/B against the
 // real four-step's two launches per chunk)
 std::atomic<int> g_group_real { 1 };
-// "r2_real_pair": real frames of 2^21 / 2^22 samples (complex cores on the radix-2 plans): the forward transform's pair stage in the
-// registers of pass B (tile_fast_kernels.hpp pass_b_fast_r2_real_kernel) instead of a stand-alone sweep
-std::atomic<int> g_r2_real_pair { 1 };
 bool split16384_enabled()
 {
     int v = g_split16384.load();
@@ -501,8 +498,6 @@ int big_c2c_chunked (Setup* s, int nc, bool inverse, const float2* in, float2* o
         }
         return cf::FFT_GPU_OK;
     }
-    // real forward transform on the radix-2 plans: pass B forms the packed spectrum itself (option "r2_real_pair"; 0 = stand-alone pair stage)
-    const bool pair_in_pass_b = pair > 0 && ! mixed && s->tables->r2_n > 0 && mul_h == nullptr && g_r2_real_pair.load() != 0;
     const size_t frame_bytes = workspace_frame_bytes (s->tables, nc);
     const int want_lanes = lane_count();
     // the cap covers BOTH workspaces, so that they fit the Infinity Cache together
@@ -546,12 +541,11 @@ int big_c2c_chunked (Setup* s, int nc, bool inverse, const float2* in, float2* o
         if (e == hipSuccess)
             e = mixed ? launch_mixed_big_c2c (*s->tables, inverse, cin, L->ws[k], out + f0 * os2, nb, lanes, st, cis, os2)
                 : s->tables->r2_n > 0
-                    ? launch_fast_r2_c2c (s->tables->r2_n, inverse, cin, L->ws[k], out + f0 * os2, s->tables->stage_twiddles, s->tables->big_twiddles, nb, lanes, st, cis, os2, mul_h, mul_scale,
-                                          pair_in_pass_b ? s->tables->real_twiddles : nullptr)
+                    ? launch_fast_r2_c2c (s->tables->r2_n, inverse, cin, L->ws[k], out + f0 * os2, s->tables->stage_twiddles, s->tables->big_twiddles, nb, lanes, st, cis, os2, mul_h, mul_scale)
                 : s->tables->fast_n1 > 0
                     ? launch_fast_c2c (n1, n2, inverse, cin, L->ws[k], out + f0 * os2, s->tables->stage_twiddles, s->tables->big_twiddles, nb, lanes, st, cis, os2, mul_h, mul_scale)
                     : launch_big_c2c (n1, n2, inverse, cin, L->ws[k], out + f0 * os2, s->tables->stage_twiddles, s->tables->big_twiddles, nb, lanes, st, cis, os2);
-        if (e == hipSuccess && pair > 0 && ! pair_in_pass_b)
+        if (e == hipSuccess && pair > 0)
             e = launch_real_pair (true, out + f0 * os2, out + f0 * os2, s->tables->real_twiddles, (unsigned) nc, nb, st, os2, os2);
         if (e != hipSuccess)
         {
@@ -1590,8 +1584,6 @@ int fft_gpu_set_option (const char* name, long value)
         g_group_fast = value != 0 ? 1 : 0;
     else if (std::strcmp (name, "group_real") == 0)
         g_group_real = value != 0 ? 1 : 0;
-    else if (std::strcmp (name, "r2_real_pair") == 0)
-        g_r2_real_pair = value != 0 ? 1 : 0;
     else
     {
         set_last_error ("fft_gpu_set_option: unknown option or value out of range");
@@ -1631,8 +1623,6 @@ long fft_gpu_get_option (const char* name)
         return g_group_fast.load();
     if (std::strcmp (name, "group_real") == 0)
         return g_group_real.load();
-    if (std::strcmp (name, "r2_real_pair") == 0)
-        return g_r2_real_pair.load();
     return -1;
 }
 

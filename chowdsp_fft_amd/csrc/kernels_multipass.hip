@@ -182,10 +182,7 @@ template <int N_>
 constexpr auto pass_b_real_fast_plain = pass_b_real_fast_kernel<N_, false>;
 template <int N_>
 constexpr auto pass_b_real_fast_mulh = pass_b_real_fast_kernel<N_, true>;
-template <int N_>
-constexpr auto pass_a_real_fast_one = pass_a_real_fast_kernel<N_, 1>;
-template <int N_>
-constexpr auto pass_a_real_fast_two = pass_a_real_fast_kernel<N_, 2>;
+
 
 // long REAL frames on the register-direct tiles: N = r1 x r2 samples, r1, r2 in {256, 512, 1024}
 hipError_t launch_real4_fast (int r1, int r2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, size_t batch, int grid_divisor, hipStream_t stream, size_t in_stride, size_t out_stride, const float2* mul_h, float mul_scale)
@@ -206,10 +203,6 @@ hipError_t launch_real4_fast (int r1, int r2, bool inverse, const float2* in, fl
     const int n1c = r1 / 2;
     const unsigned div = (unsigned) grid_divisor;
     const size_t tiles_a = (size_t) (n1c / 16), tiles_b = (size_t) ((r2 / 2 + 16) / 16);
-    // CHOWDSP_FFT_REAL4_FRAMES = 2 (A/B): two frames per work item of the forward column pass, which then share every inter-pass twiddle
-    // load (columns of up to 512 points; the 1024-point form needs more than 256 registers).  Measured no gain -- r2^18 0.310 against
-    // 0.317, r2^19 0.287 against 0.291 of 8 TB/s (profiles/r04_radix2_wrap.txt): the doubled registers halve the workgroups per CU.
-    static const bool two_frames = std::getenv ("CHOWDSP_FFT_REAL4_FRAMES") != nullptr && std::atoi (std::getenv ("CHOWDSP_FFT_REAL4_FRAMES")) == 2;
 #define CFFT_REAL4_FAST_LAUNCH(KERNEL, NN, TILES, ...) /* TILES: work items of the launch */                                                              \
     {                                                                                                               \
         using FT = FastTile<NN>;                                                                                    \
@@ -224,7 +217,7 @@ hipError_t launch_real4_fast (int r1, int r2, bool inverse, const float2* in, fl
     hipError_t e = hipErrorInvalidValue;
     if (! inverse)
     {
-        CFFT_DISPATCH_FAST (r2, if (two_frames && N_ <= 512) { CFFT_REAL4_FAST_LAUNCH (pass_a_real_fast_two, N_, ((batch + 1) / 2) * tiles_a, in, work, tw2, big_fwd, (unsigned) n1c, (unsigned) batch, in_stride) } else { CFFT_REAL4_FAST_LAUNCH (pass_a_real_fast_one, N_, batch * tiles_a, in, work, tw2, big_fwd, (unsigned) n1c, (unsigned) batch, in_stride) });
+        CFFT_DISPATCH_FAST (r2, CFFT_REAL4_FAST_LAUNCH (pass_a_real_fast_kernel, N_, batch * tiles_a, in, work, tw2, big_fwd, (unsigned) n1c, (unsigned) batch, in_stride));
         if (e != hipSuccess)
             return e;
         if (mul_h != nullptr) // the product with a packed filter spectrum rides on the stores (fft_convolve_frames_batch)
@@ -295,11 +288,9 @@ hipError_t fast_r2_pass_a (const float2* in, float2* work, const float2* tw2, co
 } // namespace
 
 // n2 = column length of the half-length sub-frames (256 / 512 / 1024); their rows are 1024 points
-hipError_t launch_fast_r2_c2c (int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, size_t batch, int grid_divisor, hipStream_t stream, size_t in_stride, size_t out_stride, const float2* mul_h, float mul_scale, const float2* pair_tw)
+hipError_t launch_fast_r2_c2c (int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, size_t batch, int grid_divisor, hipStream_t stream, size_t in_stride, size_t out_stride, const float2* mul_h, float mul_scale)
 {
-    if ((mul_h != nullptr || pair_tw != nullptr) && inverse)
-        return hipErrorInvalidValue;
-    if (mul_h != nullptr && pair_tw != nullptr)
+    if (mul_h != nullptr && inverse)
         return hipErrorInvalidValue;
     if (batch == 0)
         return hipSuccess;
@@ -326,17 +317,6 @@ hipError_t launch_fast_r2_c2c (int n2, bool inverse, const float2* in, float2* w
     }
     if (e != hipSuccess)
         return e;
-    if (pair_tw != nullptr)
-    {
-        // REAL forward transform: pass B forms the packed spectrum itself (pair stage in registers)
-        auto kr = pass_b_fast_r2_real_kernel<kN1>;
-        unsigned gridr = persistent_grid (kr, FB::threads, FB::lds_bytes, batch * (size_t) (n2 / 16));
-        if (gridr == 0)
-            return hipErrorNoDevice;
-        gridr = std::max (1u, gridr / (unsigned) grid_divisor);
-        hipLaunchKernelGGL (kr, dim3 (gridr), dim3 (FB::threads), FB::lds_bytes, stream, (const float2*) work, out, tw1, r2_tw, pair_tw, (unsigned) n2, (unsigned) batch, out_stride);
-        return hipGetLastError();
-    }
     // (the product with a filter spectrum rides on the FORWARD transform's stores only: fft_convolve_frames_batch)
     auto kb = inverse ? pass_b_fast_r2_kernel<kN1, true, false> : (mul_h != nullptr ? pass_b_fast_r2_kernel<kN1, false, true> : pass_b_fast_r2_kernel<kN1, false, false>);
     unsigned grid = persistent_grid (kb, FB::threads, FB::lds_bytes, batch * (size_t) (n2 / 16));

@@ -97,9 +97,8 @@ unsigned group_conv_grid(); // workgroups of the fused-convolution form's launch
 hipError_t launch_group_conv (const float2* in, const float2* H, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, void* state, unsigned* host_err, unsigned seq, float scaling, size_t batch, hipStream_t stream);
 // 2^19 .. 2^21 complex points: radix-2 decimation in time around the 1024 x n2 register-direct passes of the two half-length sub-frames
 // (tile_fast_kernels.hpp); stage_tw = the two cores' rows, then W_N^kb (kb < n2), then W_2048^ms (ms < 32); big_tw = W_(N/2)^(a kb);
-// mul_h (forward only): every bin times mul_h[bin] * mul_scale; pair_tw (forward only, real frames of 2 N samples): W_(2N)^k of the real plan --
-// pass B then writes the packed real spectrum itself (pair stage in registers)
-hipError_t launch_fast_r2_c2c (int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, size_t batch, int grid_divisor, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0, const float2* mul_h = nullptr, float mul_scale = 1.f, const float2* pair_tw = nullptr);
+// mul_h (forward only): every bin times mul_h[bin] * mul_scale
+hipError_t launch_fast_r2_c2c (int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, size_t batch, int grid_divisor, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0, const float2* mul_h = nullptr, float mul_scale = 1.f);
 // real N = 131072 on the same groups, pair stage in registers (group_real_kernels.hpp, kernels_group_real.hip): stage_tw / big_tw of
 // the 65536-point complex plan, real_tw = W_131072^k of the real plan
 unsigned group_real_grid (bool inverse);

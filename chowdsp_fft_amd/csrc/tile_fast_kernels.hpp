@@ -146,13 +146,12 @@ __device__ __forceinline__ void ft_stage1_all (float2 (&v)[32], const float2 (&w
 // Stage-1 role: SWAPPED (pass A): butterfly i = tid & 31 of the columns cc_q = (tid >> 5) + (Tn / 2) q;
 //               plain   (pass B): butterflies i_q = m + Tn q of team c.   v[q R1 + a] = X[i + 32 a].
 // Addresses: team image at c S; write phys (32 m + b) = 33 m + b; read phys (i + 32 a) = i + 33 a  (i < 32).
-// read_member (plain role only; default: the work-item's own member index): the stage-1 butterfly index the work-item takes over
 template <class FT, bool SWAPPED>
-__device__ __forceinline__ void ft_exchange (float2 (&v)[32], float* __restrict__ plane, int tid, int read_member = -1)
+__device__ __forceinline__ void ft_exchange (float2 (&v)[32], float* __restrict__ plane, int tid)
 {
     const int c = tid & 15, m = tid >> 4;
     float* __restrict__ wp = plane + c * FT::S + 33 * m;
-    const float* __restrict__ rp = SWAPPED ? plane + (tid >> 5) * FT::S + (tid & 31) : plane + c * FT::S + (read_member >= 0 ? read_member : m);
+    const float* __restrict__ rp = SWAPPED ? plane + (tid >> 5) * FT::S + (tid & 31) : plane + c * FT::S + m;
     constexpr int rq = SWAPPED ? (FT::Tn / 2) * FT::S : FT::Tn; // distance between a work-item's butterflies q
     __syncthreads(); // the previous tile's reads of the plane are finished
 #pragma unroll
@@ -461,168 +460,6 @@ __global__ __launch_bounds__ (FastTile<N1>::threads, FastTile<N1>::min_waves) vo
     }
 }
 
-// ---- REAL frames of N = 2 M samples on these plans (M = 2^20 / 2^21 complex points; round 4): the forward transform's pass B with the real
-// pair stage IN REGISTERS, as group_real_kernels.hpp does it for N = 131072.  After the radix-2 combine a work-item holds X[k] and X[k + L]
-// (L = M / 2) for k = n2 (i + 32 b) + kb; the pair stage needs X[M - k] = the UPPER output at sub-index L - k = n2 (1023 - i - 32 b) + (n2 - kb)
-// and X[M - k - L] = the lower one there.  So a tile is dealt as EIGHT rows kb = 8 t + 1 + j and their mirrors n2 - kb, the work-items of a
-// mirrored row take their stage-1 butterflies in reversed order (31 - i), and both partners sit in slot 31 - b of the lane 8 further on in
-// the same 16-lane row: one DPP row rotation per component.  Rows 0 and n2 / 2 pair with themselves across work-items: they replace the one
-// duplicate of that dealing in the last tile and go through the (then idle) LDS plane.  Pair twiddle W_N^k = (W_N^kb W_4096^i) W_128^b
-// (times -i for the upper half).  The packed spectrum leaves in 64-byte runs (default cache policy: a neighbour tile completes the line).
-// W_128^b = exp (-2 pi i b / 128), b < 32 (rounded from double)
-static __device__ const float kW128re[32] = { 1.0f, 0.9987954562051724f, 0.9951847266721969f, 0.989176509964781f, 0.9807852804032304f, 0.970031253194544f, 0.9569403357322088f, 0.9415440651830208f, 0.9238795325112867f, 0.9039892931234433f, 0.881921264348355f, 0.8577286100002721f, 0.8314696123025452f, 0.8032075314806449f, 0.773010453362737f, 0.7409511253549591f, 0.7071067811865476f, 0.6715589548470183f, 0.6343932841636455f, 0.5956993044924335f, 0.5555702330196023f, 0.5141027441932217f, 0.4713967368259978f, 0.4275550934302822f, 0.38268343236508984f, 0.33688985339222005f, 0.29028467725446233f, 0.24298017990326398f, 0.19509032201612833f, 0.14673047445536175f, 0.09801714032956077f, 0.049067674327418126f };
-static __device__ const float kW128im[32] = { -0.0f, -0.049067674327418015f, -0.0980171403295606f, -0.14673047445536175f, -0.19509032201612825f, -0.24298017990326387f, -0.29028467725446233f, -0.33688985339222005f, -0.3826834323650898f, -0.4275550934302821f, -0.47139673682599764f, -0.5141027441932217f, -0.5555702330196022f, -0.5956993044924334f, -0.6343932841636455f, -0.6715589548470183f, -0.7071067811865475f, -0.7409511253549591f, -0.773010453362737f, -0.8032075314806448f, -0.8314696123025452f, -0.8577286100002721f, -0.8819212643483549f, -0.9039892931234433f, -0.9238795325112867f, -0.9415440651830208f, -0.9569403357322089f, -0.970031253194544f, -0.9807852804032304f, -0.989176509964781f, -0.9951847266721968f, -0.9987954562051724f };
-__device__ __forceinline__ float r2r_ror8 (float x)
-{
-    return __int_as_float (__builtin_amdgcn_mov_dpp (__float_as_int (x), 0x128 /* row_ror:8 */, 0xF, 0xF, true));
-}
-// X[k] of the packed real spectrum from Z[k], Z[M - k] and wh = W_N^k / 2
-__device__ __forceinline__ float2 r2r_split (float2 A, float2 Zp, float2 wh)
-{
-    const float sx = A.x + Zp.x, sy = A.y - Zp.y;
-    const float dx = A.x - Zp.x, dy = A.y + Zp.y;
-    return make_float2 (fmaf (0.5f, sx, fmaf (dx, wh.y, dy * wh.x)), fmaf (0.5f, sy, fmaf (dy, wh.y, -dx * wh.x)));
-}
-
-template <int N1>
-__global__ __launch_bounds__ (FastTile<N1>::threads, FastTile<N1>::min_waves) void pass_b_fast_r2_real_kernel (const float2* __restrict__ work,
-                                                                                   float2* __restrict__ out, // packed spectrum, M float2 per frame
-                                                                                   const float2* __restrict__ stage_tw, // [rows][32] of the n1 core
-                                                                                   const float2* __restrict__ r2_tw,    // W_M^kb, kb < n2; then W_(2 N1)^j, j < 32
-                                                                                   const float2* __restrict__ rtw,      // W_N^k, k <= N / 4 (the real plan's pair table)
-                                                                                   unsigned n2,
-                                                                                   unsigned batch,
-                                                                                   size_t out_stride)
-{
-    using FT = FastTile<N1>;
-    static_assert (N1 == 1024 && FT::Q == 1 && FT::Tn == 32, "1024-point rows (see pass_b_fast_r2_kernel)");
-    extern __shared__ __attribute__ ((aligned (16))) float ft_plane[];
-    const int tid0 = threadIdx.x;
-    const unsigned tiles = n2 / 16;
-    const size_t sub_len = (size_t) N1 * n2;
-    const size_t nwork = (size_t) batch * tiles;
-    const size_t nloop = ((nwork + 7) / 8) * 8;
-    for (size_t wv = blockIdx.x; wv < nloop; wv += gridDim.x)
-    {
-        // XCD-aware order (xcd_order above): neighbouring tiles, which complete each other's 128-byte lines of the packed spectrum, run on
-        // ONE XCD at about the same time, so that the halves meet in its L2
-        const size_t wk = xcd_order (wv, nwork);
-        if (wk >= nwork)
-            continue;
-        int tid = tid0;
-        CFFT_LAUNDER_INDEX (tid);
-        const unsigned f = (unsigned) (wk / tiles);
-        const unsigned t = (unsigned) (wk % tiles);
-        const bool last = t + 1u == tiles; // (uniform) the tile that also holds the two self-paired rows
-        const int c = tid & 15;
-        const unsigned m = (unsigned) tid >> 4;
-        const bool row0 = last && c == 15;
-        const unsigned kb = row0 ? 0u : (c < 8 ? 8u * t + 1u + (unsigned) c : n2 - 8u * t - (unsigned) (c - 7));
-        const bool rev = c >= 8 && ! row0;
-        const unsigned mr = rev ? 31u - m : m; // stage-1 butterfly index of this work-item
-        float2 w[10];
-        ft_load_twiddles<FT> (w, stage_tw, (int) mr);
-        // (a uniform base and ONE 32-bit offset per work-item -- a frame pair is 2^21 points at most --, the row steps uniform: with per-lane
-        // 64-bit pointers the 64 loads' addresses alone overflowed the register file)
-        const float2* __restrict__ src = work + (size_t) f * 2 * sub_len;
-        const unsigned off0 = kb + m * n2, step = 32u * n2, sub32 = (unsigned) sub_len;
-        float2 v0[32], v1[32];
-#pragma unroll
-        for (int a = 0; a < 32; ++a)
-            v0[a] = src[off0 + step * (unsigned) a];
-#pragma unroll
-        for (int a = 0; a < 32; ++a)
-            v1[a] = src[sub32 + off0 + step * (unsigned) a];
-        CFFT_PHASE_FENCE();
-        fft_reg32<false> (v0, w);
-        CFFT_PHASE_FENCE();
-        ft_exchange<FT, false> (v0, ft_plane, tid, (int) mr);
-        CFFT_PHASE_FENCE();
-        ft_stage1_all<FT> (v0, w, w, w, w);
-        CFFT_PHASE_FENCE();
-        // (requested here: behind the second sub-frame's transform, with the first one's results parked, every register counts)
-        const float2 wkb = r2_tw[kb], wms = r2_tw[n2 + mr];
-        const float2 pk = rtw[kb], pm = rtw[(size_t) n2 * mr]; // W_N^kb, W_N^(n2 mr) = W_4096^mr
-        CFFT_PHASE_FENCE();
-        fft_reg32<false> (v1, w);
-        CFFT_PHASE_FENCE();
-        ft_exchange<FT, false> (v1, ft_plane, tid, (int) mr);
-        CFFT_PHASE_FENCE();
-        ft_stage1_all<FT> (v1, w, w, w, w);
-        CFFT_PHASE_FENCE();
-        // the radix-2 combine, in place: v0[b] = X[k], v1[b] = X[k + L], k = n2 (mr + 32 b) + kb
-        const float2 wbase = cmul (wkb, wms);
-#pragma unroll
-        for (int b = 0; b < 32; ++b)
-        {
-            const float2 o = cmul (v1[b], cmul (wbase, make_float2 (kW64re[b], kW64im[b])));
-            const float2 e = v0[b];
-            v0[b] = make_float2 (e.x + o.x, e.y + o.y);
-            v1[b] = make_float2 (e.x - o.x, e.y - o.y);
-        }
-        CFFT_PHASE_FENCE();
-        float2* __restrict__ dst = out + (size_t) f * out_stride + (size_t) mr * n2 + kb;
-        const float2 ph = cmul (pk, make_float2 (0.5f * pm.x, 0.5f * pm.y)); // W_N^(kb + n2 mr) / 2
-        const bool self = last && (c == 7 || c == 15);
-#pragma unroll
-        for (int b = 0; b < 32; ++b)
-        {
-            const float2 p1 = make_float2 (r2r_ror8 (v1[31 - b].x), r2r_ror8 (v1[31 - b].y)); // X[M - k]
-            const float2 p0 = make_float2 (r2r_ror8 (v0[31 - b].x), r2r_ror8 (v0[31 - b].y)); // X[M - k - L]
-            const float2 wl = cmul (ph, make_float2 (kW128re[b], kW128im[b]));
-            const float2 lo = r2r_split (v0[b], p1, wl);
-            const float2 hi = r2r_split (v1[b], p0, make_float2 (wl.y, -wl.x)); // W_N^(k + L) = -i W_N^k
-            if (! self)
-            {
-                dst[(size_t) (32 * b) * n2] = lo;
-                dst[sub_len + (size_t) (32 * b) * n2] = hi;
-            }
-            if ((b & 3) == 3)
-                CFFT_PHASE_FENCE();
-        }
-        if (last)
-        {
-            // rows n2 / 2 (lane 7) and 0 (lane 15): their partners sit in other work-items of the same row -- through the plane, by [row][half][ka]
-            float2* __restrict__ spec = reinterpret_cast<float2*> (ft_plane);
-            __syncthreads(); // everybody's stage-1 reads of the plane are finished
-            if (self)
-            {
-                float2* __restrict__ sp = spec + (c == 15 ? 2048 : 0) + mr;
-#pragma unroll
-                for (int b = 0; b < 32; ++b)
-                {
-                    sp[32 * b] = v0[b];
-                    sp[1024 + 32 * b] = v1[b];
-                }
-            }
-            __syncthreads();
-            if (self)
-            {
-                const float2* __restrict__ sp = spec + (c == 15 ? 2048 : 0);
-#pragma unroll
-                for (int b = 0; b < 32; ++b)
-                {
-                    const unsigned ka = mr + 32u * (unsigned) b;
-                    // row n2 / 2: sub-index L - k = n2 (1023 - ka) + n2 / 2;  row 0: n2 (1024 - ka)  (ka = 0: bins 0 and L, below)
-                    const unsigned kp = c == 7 ? 1023u - ka : (1024u - ka) & 1023u;
-                    const float2 p1 = sp[1024 + kp], p0 = sp[kp];
-                    const float2 wl = cmul (ph, make_float2 (kW128re[b], kW128im[b]));
-                    float2 lo = r2r_split (v0[b], p1, wl);
-                    float2 hi = r2r_split (v1[b], p0, make_float2 (wl.y, -wl.x));
-                    if (c == 15 && ka == 0u)
-                    {
-                        lo = make_float2 (v0[0].x + v0[0].y, v0[0].x - v0[0].y); // packed slot 0: X[0] and X[N / 2]
-                        hi = make_float2 (v1[0].x, -v1[0].y);                     // bin M / 2 pairs with itself: conj
-                    }
-                    dst[(size_t) (32 * b) * n2] = lo;
-                    dst[sub_len + (size_t) (32 * b) * n2] = hi;
-                }
-            }
-            // (the next tile's exchange starts with a barrier of its own)
-        }
-    }
-}
-
 // =====================================================================================================
 // Long REAL frames (N = R1 x R2 = 2^17 .. 2^20 samples) on the same register-direct tiles: the real four-step of
 // multipass_kernels.hpp (pairs of real columns as complex columns, separation, rows kb <= R2/2 only, packed spectrum
@@ -633,10 +470,9 @@ __global__ __launch_bounds__ (FastTile<N1>::threads, FastTile<N1>::min_waves) vo
 // The partner Z_c[R2 - kb] of the separation sits in the SAME 32-lane group as Z_c[kb] after the re-mapping (butterfly index
 // 32 - i, slot R1c - 1 - b): one ds_bpermute per component, no LDS traffic, no barrier.
 // =====================================================================================================
-// FR (round 4): frames per work item.  The inter-pass twiddles depend on the tile's columns only, so FR = 2 frames taken through the
-// same tile position share every twiddle load (the radix-2 plans of 2^19 .. 2^21 gained 17 % from exactly that): twice the operands in
-// registers, half the table traffic per frame.
-template <int N2, int FR = 1>
+// (Round-4 A/B, not kept: TWO frames per work item sharing every inter-pass twiddle load, as the radix-2 plans do with their two sub-frames --
+// twice the registers, half the workgroups per CU, no gain: profiles/r04_radix2_wrap.txt section 5.)
+template <int N2>
 __global__ __launch_bounds__ (FastTile<N2>::threads, FastTile<N2>::min_waves) void pass_a_real_fast_kernel (const float2* __restrict__ in, // real frame as N/2 float2
                                                                                                        float2* __restrict__ work, // Wf[a][kb]
                                                                                                        const float2* __restrict__ stage_tw,
@@ -653,35 +489,25 @@ __global__ __launch_bounds__ (FastTile<N2>::threads, FastTile<N2>::min_waves) vo
     ft_load_twiddles<FT> (w, stage_tw, tid0 & 31);
     const unsigned tiles = n1c / 16;
     const size_t ws_len = (size_t) (2 * n1c) * NRp;
-    const size_t nwork = (size_t) ((batch + FR - 1) / FR) * tiles;
+    const size_t nwork = (size_t) batch * tiles;
     for (size_t wk = blockIdx.x; wk < nwork; wk += gridDim.x)
     {
         int tid = tid0;
         CFFT_LAUNDER_INDEX (tid);
-        const unsigned f = (unsigned) (wk / tiles) * (unsigned) FR;
+        const unsigned f = (unsigned) (wk / tiles);
         const unsigned a0 = (unsigned) (wk % tiles) * 16u;
-        const bool second = FR > 1 && f + 1u < batch; // (uniform) the item's second frame exists
         const float2* __restrict__ src = in + (size_t) f * in_stride + a0 + (unsigned) (tid & 15);
         const unsigned m = (unsigned) tid >> 4;
-        float2 v[FR][32];
+        float2 v[32];
 #pragma unroll
-        for (int fr = 0; fr < FR; ++fr)
-            if (fr == 0 || second)
-            {
-#pragma unroll
-                for (int a = 0; a < 32; ++a)
-                    v[fr][a] = gload (&src[(size_t) fr * in_stride + (size_t) (m + FT::Tn * a) * n1c]);
-            }
-#pragma unroll
-        for (int fr = 0; fr < FR; ++fr)
-        {
-            CFFT_PHASE_FENCE();
-            fft_reg32<false> (v[fr], w);
-            CFFT_PHASE_FENCE();
-            ft_exchange<FT, true> (v[fr], ft_plane, tid);
-            CFFT_PHASE_FENCE();
-            ft_stage1_all<FT> (v[fr], w, w, w, w);
-        }
+        for (int a = 0; a < 32; ++a)
+            v[a] = gload (&src[(size_t) (m + FT::Tn * a) * n1c]);
+        CFFT_PHASE_FENCE();
+        fft_reg32<false> (v, w);
+        CFFT_PHASE_FENCE();
+        ft_exchange<FT, true> (v, ft_plane, tid);
+        CFFT_PHASE_FENCE();
+        ft_stage1_all<FT> (v, w, w, w, w);
         CFFT_PHASE_FENCE();
         int ts = tid0;
         CFFT_LAUNDER_INDEX (ts);
@@ -728,23 +554,19 @@ __global__ __launch_bounds__ (FastTile<N2>::threads, FastTile<N2>::min_waves) vo
                 {
                     const int q = st / NB, b = st % NB;
                     const size_t row_e = (size_t) (2 * (cc0 + (unsigned) (FT::Tn / 2) * q)) * NRp + i, row_o = row_e + NRp;
-#pragma unroll
-                    for (int fr = 0; fr < FR; ++fr)
+                    // kb = i + 32 b <= R2 / 2: b < R1c / 2 for every lane, b = R1c / 2 for i = 0 only
+                    const float2 zk = v[q * FT::R1 + (b % FT::R1)];
+                    const float2 own = v[q * FT::R1 + ((FT::R1 - b) % FT::R1)];         // lane 0: Z[R2 - 32 b] is its own slot R1c - b
+                    const float2 oth = v[q * FT::R1 + ((2 * FT::R1 - 1 - b) % FT::R1)]; // others: slot R1c - 1 - b of lane 32 - i
+                    float2 zm = make_float2 (__shfl (oth.x, partner, 32), __shfl (oth.y, partner, 32));
+                    if (i == 0)
+                        zm = own;
+                    if (b < FT::R1 / 2 || i == 0)
                     {
-                        // kb = i + 32 b <= R2 / 2: b < R1c / 2 for every lane, b = R1c / 2 for i = 0 only
-                        const float2 zk = v[fr][q * FT::R1 + (b % FT::R1)];
-                        const float2 own = v[fr][q * FT::R1 + ((FT::R1 - b) % FT::R1)];         // lane 0: Z[R2 - 32 b] is its own slot R1c - b
-                        const float2 oth = v[fr][q * FT::R1 + ((2 * FT::R1 - 1 - b) % FT::R1)]; // others: slot R1c - 1 - b of lane 32 - i
-                        float2 zm = make_float2 (__shfl (oth.x, partner, 32), __shfl (oth.y, partner, 32));
-                        if (i == 0)
-                            zm = own;
-                        if ((b < FT::R1 / 2 || i == 0) && (fr == 0 || second))
-                        {
-                            const float2 ce = make_float2 (0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
-                            const float2 co = make_float2 (0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));
-                            dst[(size_t) fr * ws_len + row_e + 32 * b] = cmul (ce, te[g & 1][c]);
-                            dst[(size_t) fr * ws_len + row_o + 32 * b] = cmul (co, to[g & 1][c]);
-                        }
+                        const float2 ce = make_float2 (0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+                        const float2 co = make_float2 (0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));
+                        dst[row_e + 32 * b] = cmul (ce, te[g & 1][c]);
+                        dst[row_o + 32 * b] = cmul (co, to[g & 1][c]);
                     }
                 }
             }

@@ -56,39 +56,6 @@ def test_real_frames_on_these_cores(gpu, oracle, lg):
     oracle.destroy_setup(so)
 
 
-def test_real_forward_pair_stage_in_pass_b_equals_the_stand_alone_stage(gpu):
-    """real 2^21: the forward transform's pair stage in the registers of pass B (rows dealt 8 + 8 mirrored, partner by a DPP row rotation,
-    rows 0 and n2 / 2 through the LDS plane; option r2_real_pair, default on) against the stand-alone pair sweep: every bin of 3 frames, and
-    the special bins against a float64 FFT"""
-    api, torch, dev = gpu
-    n = 1 << 21
-    assert api.get_option("r2_real_pair") == 1
-    s = api.fft_new_setup(n, api.FFT_REAL)
-    rng = np.random.default_rng(5)
-    x = rng.uniform(-1, 1, (3, n)).astype(np.float32)
-    fused = _gpu(gpu, s, x, api.FFT_FORWARD)
-    api.set_option("r2_real_pair", 0)
-    try:
-        plain = _gpu(gpu, s, x, api.FFT_FORWARD)
-    finally:
-        api.set_option("r2_real_pair", 1)
-    assert_frames_close(fused, plain, tol=3e-7, maxabs_tol=2e-6, what="pair stage in pass B vs stand-alone")
-    ref = np.fft.rfft(x.astype(np.float64), axis=1)
-    scale = np.sqrt(np.mean(np.abs(ref) ** 2))
-    assert np.max(np.abs(fused[:, 0] - ref[:, 0].real)) / scale < 2e-6 and np.max(np.abs(fused[:, 1] - ref[:, n // 2].real)) / scale < 2e-6
-    z = fused[:, 2:].reshape(3, -1, 2)
-    z = z[..., 0] + 1j * z[..., 1]
-    err = np.abs(z - ref[:, 1:n // 2]) / scale
-    k = np.arange(1, n // 2)
-    m = n // 2
-    n2 = m // 2048
-    for kb in (0, 1, n2 // 2 - 1, n2 // 2, n2 // 2 + 1, n2 - 1):
-        assert np.max(err[:, (k % n2) == kb]) < 2e-6, f"row kb = {kb}"
-    assert np.max(err[:, [m // 2 - 2, m // 2 - 1, m // 2, m // 4 - 1, 3 * m // 4 - 1]]) < 2e-6  # bins M/2 - 1, M/2, M/2 + 1, M/4, 3M/4
-    assert np.max(err) < 2e-6
-    api.fft_destroy_setup(s)
-
-
 def test_in_place_and_strided(gpu, oracle):
     api, torch, dev = gpu
     n, batch, pad = 1 << 21, 3, 32
