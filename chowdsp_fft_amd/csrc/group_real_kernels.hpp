@@ -192,9 +192,8 @@ __device__ __forceinline__ void gr_inv_load_a (float (&re)[16], float (&im)[16],
     }
 }
 // ... pair stage (merge) + swap for the backward transform + complex pass A into the slot
-template <class Wait>
 __device__ __forceinline__ void gr_inv_pass_a (const float (&re)[16], const float (&im)[16], unsigned t, float2 wthr, const float2 (&bw)[16], float2* __restrict__ slot, size_t base,
-                                               float2* __restrict__ smem, const float2* __restrict__ tw1, float2 (*spec)[256], int tid, Wait wait_slot_free)
+                                               float2* __restrict__ smem, const float2* __restrict__ tw1, float2 (*spec)[256], int tid)
 {
     const int l = tid & 15, m = tid >> 4;
     const int mr = gr_reversed (t, l) ? 15 - m : m;
@@ -254,7 +253,6 @@ __device__ __forceinline__ void gr_inv_pass_a (const float (&re)[16], const floa
     for (int a = 1; a < 16; ++a)
         v[a] = cmul (v[a], tw1[(a - 1) * 16 + l]);
     fft_reg<16> (v);
-    wait_slot_free(); // (GROUP mode: every member has read the previous frame out of the slot)
     gr_slot_store (v, bw, slot, base);
 }
 // slot position of the pass-A results of stage-1 role (column gr_index (t, m), butterfly l): base + 256 b
@@ -376,11 +374,10 @@ __global__ __launch_bounds__ (256, 2) void group256_real_kernel (const float2* _
                     va[s] = make_float2 (nre[s], nim[s]);
                 fft256_two_stage_lds (va, tw1, l, smem, l, m, m, l);
             }
-            // every member has read frame k - 1 out of the slot (each wave looks for itself: no barrier needed), waited for right before
-            // this frame's stores into it
-            auto wait_slot_free = [&] () __attribute__ ((always_inline)) {
-                if (k == 0)
-                    return;
+            if (k != 0)
+            {
+                // every member has read frame k - 1 out of the slot (each wave looks for itself: no barrier needed; the backward
+                // transform waits in front of its whole pass A, whose last step stores -- the flags are normally up long before)
                 unsigned n = 0;
                 while (! flags_reached (bf, k, tid & 63))
                 {
@@ -392,14 +389,11 @@ __global__ __launch_bounds__ (256, 2) void group256_real_kernel (const float2* _
                         break;
                     }
                 }
-            };
-            if constexpr (INV)
-                gr_inv_pass_a (nre, nim, tile, wthr, bw, slot, base_a, smem, tw1, spec, tid, wait_slot_free);
-            else
-            {
-                wait_slot_free();
-                gr_slot_store (va, bw, slot, base_a);
             }
+            if constexpr (INV)
+                gr_inv_pass_a (nre, nim, tile, wthr, bw, slot, base_a, smem, tw1, spec, tid);
+            else
+                gr_slot_store (va, bw, slot, base_a);
             asm volatile ("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's stores are in L2
             __syncthreads();
             if (tid == 0)
@@ -498,7 +492,7 @@ __global__ __launch_bounds__ (256, 2) void group256_real_kernel (const float2* _
             if constexpr (INV)
             {
                 gr_inv_load_a<4> (re, im, in + (size_t) f * in_stride, t, tid);
-                gr_inv_pass_a (re, im, t, gr_pair_twiddle (rtw, t, l, m), bw, slot, base_a, smem, tw1, spec, tid, [] () __attribute__ ((always_inline)) {});
+                gr_inv_pass_a (re, im, t, gr_pair_twiddle (rtw, t, l, m), bw, slot, base_a, smem, tw1, spec, tid);
             }
             else
             {
