@@ -569,7 +569,7 @@ bool group_real_applies (const Setup* s, size_t batch)
 {
     return s->transform == cf::FFT_REAL && s->tables->group_core != nullptr && fused_form() == 2 && g_group_real.load() != 0 && batch >= fused_min_batch();
 }
-int group_real_transform (Setup* s, bool inverse, const float2* in, float2* out, size_t batch, hipStream_t stream, size_t is2, size_t os2)
+int group_real_transform (Setup* s, bool inverse, const float2* in, float2* out, size_t batch, hipStream_t stream, size_t is2, size_t os2, const float2* mul_h = nullptr, float mul_scale = 1.f)
 {
     std::lock_guard<std::recursive_mutex> lock (g_ws_mutex);
     Lanes* L = get_fused (s->device, stream, group_workspace_bytes());
@@ -585,7 +585,7 @@ int group_real_transform (Setup* s, bool inverse, const float2* in, float2* out,
     }
     const unsigned seq = ++L->fused_seq;
     const DeviceTables* core = s->tables->group_core;
-    const hipError_t e = launch_group_real (inverse, in, L->fused_ws, out, core->stage_twiddles, core->big_twiddles, s->tables->real_twiddles, L->fused_state, L->fused_err_host, seq, batch, stream, is2, os2);
+    const hipError_t e = launch_group_real (inverse, in, L->fused_ws, out, core->stage_twiddles, core->big_twiddles, s->tables->real_twiddles, L->fused_state, L->fused_err_host, seq, batch, stream, is2, os2, mul_h, mul_scale);
     if (e != hipSuccess)
     {
         set_last_error ("one-launch real two-pass kernel launch", e);
@@ -1839,6 +1839,15 @@ int fft_convolve_frames_batch (void* setup, const float* x, const float* dft_fil
         // N = 2^17 ... 2^20 complex (register-direct two-pass tiles): the product rides on the forward transform's pass-B
         // stores, the backward transform follows in place -- four sweeps over the batch instead of five
         const int rc = big_c2c_chunked (s, nc, false, (const float2*) x, (float2*) y, batch, (hipStream_t) stream, (size_t) nc, (size_t) nc, 0, (const float2*) dft_filter, scaling);
+        if (rc != FFT_GPU_OK)
+            return rc;
+        return run_transform (s, y, y, batch, FFT_BACKWARD, (hipStream_t) stream);
+    }
+    if (group_real_applies (s, batch) && g_fused_conv_group.load() != 0)
+    {
+        // real N = 131072 on the static groups: the product on the forward kernel's stores (pair stage and product in registers), the backward
+        // transform in place -- two launches
+        const int rc = group_real_transform (s, false, (const float2*) x, (float2*) y, batch, (hipStream_t) stream, (size_t) nc, (size_t) nc, (const float2*) dft_filter, scaling);
         if (rc != FFT_GPU_OK)
             return rc;
         return run_transform (s, y, y, batch, FFT_BACKWARD, (hipStream_t) stream);

@@ -98,9 +98,17 @@ __device__ __forceinline__ float2 gr_pair_twiddle (const float2* __restrict__ rt
 }
 
 // FORWARD pass B of tile t: rows gr_index (t, l) of the slot (already in v) -> Z -> pair stage -> packed spectrum of frame `dstf`
-template <class Hook>
+// MULH (fft_convolve_frames_batch): every packed bin times H[bin] * scaling on its way out (bin 0 = DC / Nyquist: two real products,
+// reference simd/chowdsp_fft_impl_sse.cpp:1640-1644); the 16 filter bins of a work-item are requested behind the exchange, ahead of the
+// last butterflies
+#ifndef CFFT_GR_HGROUP
+#define CFFT_GR_HGROUP 4
+#endif
+constexpr int kGrHGroup = CFFT_GR_HGROUP;
+template <bool MULH, class Hook>
 __device__ __forceinline__ void gr_fwd_pass_b (float2 (&v)[16], unsigned t, float2 wthr, float2* __restrict__ dstf, unsigned* bflag, unsigned bval, Hook hook,
-                                               float2* __restrict__ smem, const float2* __restrict__ tw1, float2 (*spec)[256], int tid)
+                                               float2* __restrict__ smem, const float2* __restrict__ tw1, float2 (*spec)[256], int tid,
+                                               const float2* __restrict__ H = nullptr, float scaling = 1.f)
 {
     const int l = tid & 15, m = tid >> 4;
     const unsigned kb = gr_index (t, l);
@@ -121,6 +129,15 @@ __device__ __forceinline__ void gr_fwd_pass_b (float2 (&v)[16], unsigned t, floa
     for (int a = 0; a < 16; ++a)
         v[a] = smem[l * kFS256 + mr + 17 * a];
     hook (3);
+    // (a few filter bins at a time, one group ahead of its products: all 16 at once cost 156 bytes of scratch)
+    float2 h[MULH ? 16 : 1];
+    const float2* __restrict__ hp = H + kb + 256u * (unsigned) mr;
+    if constexpr (MULH)
+    {
+#pragma unroll
+        for (int b = 0; b < kGrHGroup; ++b)
+            h[b] = hp[4096 * b];
+    }
 #pragma unroll
     for (int a = 1; a < 16; ++a)
         v[a] = cmul (v[a], tw1[(a - 1) * 16 + mr]);
@@ -132,34 +149,73 @@ __device__ __forceinline__ void gr_fwd_pass_b (float2 (&v)[16], unsigned t, floa
 #pragma unroll
         for (int b = 0; b < 16; ++b)
         {
+            if constexpr (MULH)
+            {
+                if (b % kGrHGroup == 0 && b + kGrHGroup < 16)
+                {
+                    // (an opaque copy of the pointer: the loads are requested HERE, not lifted to the top of the pass and held)
+                    const float2* hq = hp;
+                    asm volatile ("" : "+v"(hq));
+#pragma unroll
+                    for (int c = kGrHGroup; c < 2 * kGrHGroup; ++c)
+                        h[b + c] = hq[4096 * (b + c)];
+                    CFFT_PHASE_FENCE();
+                }
+            }
             const float2 zp = make_float2 (dpp_row_ror8 (v[15 - b].x), dpp_row_ror8 (v[15 - b].y));
             const float2 w = cmul (wloc, make_float2 (kW32re[b], kW32im[b]));
-            gr_packed_store (&dst[4096 * b], gr_split (v[b], zp, w));
+            float2 x = gr_split (v[b], zp, w);
+            if constexpr (MULH)
+                x = cmul (x, make_float2 (h[b].x * scaling, h[b].y * scaling));
+            gr_packed_store (&dst[4096 * b], x);
             if (CFFT_GR_FENCE > 0 && (b % (CFFT_GR_FENCE > 0 ? CFFT_GR_FENCE : 1)) == CFFT_GR_FENCE - 1)
                 CFFT_PHASE_FENCE();
         }
     }
     else
     {
+        // (an opaque copy of the member index: the 2 x 16 LDS addresses of this branch are then formed here, per frame, by the one member that
+        // needs them -- lifted out of the frame loop they were held in 20-odd registers by every member for the whole launch)
+        int mrl = mr;
+        CFFT_LAUNDER_INDEX (mrl);
         const bool self = (l == 7 || l == 15);
         if (self)
         {
 #pragma unroll
             for (int b = 0; b < 16; ++b)
-                spec[l == 15 ? 1 : 0][mr + 16 * b] = v[b];
+                spec[l == 15 ? 1 : 0][mrl + 16 * b] = v[b];
         }
         __syncthreads();
 #pragma unroll
         for (int b = 0; b < 16; ++b)
         {
+            if constexpr (MULH)
+            {
+                if (b % kGrHGroup == 0 && b + kGrHGroup < 16)
+                {
+                    // (an opaque copy of the pointer: the loads are requested HERE, not lifted to the top of the pass and held)
+                    const float2* hq = hp;
+                    asm volatile ("" : "+v"(hq));
+#pragma unroll
+                    for (int c = kGrHGroup; c < 2 * kGrHGroup; ++c)
+                        h[b + c] = hq[4096 * (b + c)];
+                    CFFT_PHASE_FENCE();
+                }
+            }
             float2 zp = make_float2 (dpp_row_ror8 (v[15 - b].x), dpp_row_ror8 (v[15 - b].y));
-            const int ka = mr + 16 * b;
+            const int ka = mrl + 16 * b;
             if (self)
                 zp = (l == 7) ? spec[0][255 - ka] : spec[1][(256 - ka) & 255];
             const float2 w = cmul (wloc, make_float2 (kW32re[b], kW32im[b]));
             float2 x = gr_split (v[b], zp, w);
+            if constexpr (MULH)
+                x = cmul (x, make_float2 (h[b].x * scaling, h[b].y * scaling));
             if (b == 0 && l == 15 && m == 0)
+            {
                 x = make_float2 (v[0].x + v[0].y, v[0].x - v[0].y); // packed slot 0: X[0] and X[N/2]
+                if constexpr (MULH)
+                    x = make_float2 (x.x * h[0].x * scaling, x.y * h[0].y * scaling); // ... two real products
+            }
             gr_packed_store (&dst[4096 * b], x);
         }
     }
@@ -217,19 +273,21 @@ __device__ __forceinline__ void gr_inv_pass_a (const float (&re)[16], const floa
     }
     else
     {
+        int mrl = mr; // (opaque: see gr_fwd_pass_b)
+        CFFT_LAUNDER_INDEX (mrl);
         const bool self = (l == 7 || l == 15);
         if (self)
         {
 #pragma unroll
             for (int s = 0; s < 16; ++s)
-                spec[l == 15 ? 1 : 0][mr + 16 * s] = make_float2 (re[s], im[s]);
+                spec[l == 15 ? 1 : 0][mrl + 16 * s] = make_float2 (re[s], im[s]);
         }
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < 16; ++s)
         {
             float2 xp = make_float2 (dpp_row_ror8 (re[15 - s]), dpp_row_ror8 (im[15 - s]));
-            const int row = mr + 16 * s;
+            const int row = mrl + 16 * s;
             if (self)
                 xp = (l == 7) ? spec[0][255 - row] : spec[1][(256 - row) & 255];
             const float2 w = cmul (wloc, make_float2 (kW32re[s], kW32im[s]));
@@ -302,7 +360,7 @@ struct GrNoHook
     __device__ __forceinline__ void operator() (int) const {}
 };
 
-template <bool INV>
+template <bool INV, bool MULH = false>
 __global__ __launch_bounds__ (256, 2) void group256_real_kernel (const float2* __restrict__ in,  // forward: the real frame as 65536 float2; backward: the packed spectrum
                                                              float2* __restrict__ work, // max (kGroupSlotsTotal, gridDim.x) slots of 65536 float2
                                                              float2* __restrict__ out,
@@ -317,14 +375,17 @@ __global__ __launch_bounds__ (256, 2) void group256_real_kernel (const float2* _
                                                              unsigned seq,
                                                              unsigned reg_polls,
                                                              unsigned force_solo,
-                                                             unsigned form) // bit 3: the next frame's operands a quarter at a time between the steps of pass B (else: one burst behind the pass-B loads)
+                                                             unsigned form, // bit 3: the next frame's operands a quarter at a time between the steps of pass B (else: one burst behind the pass-B loads)
+                                                             const float2* __restrict__ H = nullptr, // MULH (forward only): packed filter spectrum
+                                                             float scaling = 1.f)
 {
+    static_assert (! (INV && MULH), "the product rides on the forward transform's stores");
     extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
     __shared__ unsigned info[8];
     __shared__ float2 tw1[15 * 16];  // stage-1 twiddles of Plan256: [a - 1][k]
     __shared__ float2 spec[2][256];  // member 15: the two self-paired rows / columns (128, 0) by their natural index
     constexpr unsigned N = 65536;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, tid_k = tid;
     const int l = tid & 15, m = tid >> 4; // lanes run along the 16 strided indices of a tile; m = team member / butterfly
     const bool spread = (form & 8u) != 0;
     const unsigned spin_limit = group_spin_limit (force_solo);
@@ -462,7 +523,7 @@ __global__ __launch_bounds__ (256, 2) void group256_real_kernel (const float2* _
             if constexpr (INV)
                 gr_inv_pass_b (v, tile, out + (size_t) f * out_stride, &bf[tile], k + 1u, hook, smem, tw1, tid);
             else
-                gr_fwd_pass_b (v, tile, wthr, out + (size_t) f * out_stride, &bf[tile], k + 1u, hook, smem, tw1, spec, tid);
+                gr_fwd_pass_b<MULH> (v, tile, wthr, out + (size_t) f * out_stride, &bf[tile], k + 1u, hook, smem, tw1, spec, tid, H, scaling);
 #undef CFFT_GR_PART
         }
         return;
@@ -510,6 +571,11 @@ __global__ __launch_bounds__ (256, 2) void group256_real_kernel (const float2* _
 #pragma unroll 1
         for (unsigned t = 0; t < 16; ++t)
         {
+            // (per tile: nothing derived from the work-item index is lifted out of this loop and held across it -- the fall-back mode has no
+            // registers to spare next to the product's filter bins)
+            int tid = tid_k;
+            CFFT_LAUNDER_INDEX (tid);
+            const int l = tid & 15, m = tid >> 4;
             float2 v[16];
             if constexpr (INV)
             {
@@ -522,7 +588,7 @@ __global__ __launch_bounds__ (256, 2) void group256_real_kernel (const float2* _
             else
             {
                 gr_fwd_load_b (v, slot, t, tid);
-                gr_fwd_pass_b (v, t, gr_pair_twiddle (rtw, t, l, m), out + (size_t) f * out_stride, nullptr, 0u, GrNoHook(), smem, tw1, spec, tid);
+                gr_fwd_pass_b<MULH> (v, t, gr_pair_twiddle (rtw, t, l, m), out + (size_t) f * out_stride, nullptr, 0u, GrNoHook(), smem, tw1, spec, tid, H, scaling);
             }
         }
     }

@@ -16,7 +16,7 @@ constexpr size_t kGroupRealLds = (size_t) 16 * TileFrame<256>::stride * sizeof (
 
 unsigned group_real_grid (bool inverse)
 {
-    auto k = inverse ? group256_real_kernel<true> : group256_real_kernel<false>;
+    auto k = inverse ? group256_real_kernel<true, false> : group256_real_kernel<false, true>; // (the forward kernel with the product: the larger one)
     DeviceInfo dev;
     if (! current_device_info (dev))
         return 0;
@@ -25,11 +25,11 @@ unsigned group_real_grid (bool inverse)
 }
 
 // real N = 131072: forward (real frame -> packed spectrum) or backward, one launch; strides in float2 (0 = 65536)
-hipError_t launch_group_real (bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, const float2* real_tw, void* state, unsigned* host_err, unsigned seq, size_t batch, hipStream_t stream, size_t in_stride, size_t out_stride)
+hipError_t launch_group_real (bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, const float2* real_tw, void* state, unsigned* host_err, unsigned seq, size_t batch, hipStream_t stream, size_t in_stride, size_t out_stride, const float2* mul_h, float mul_scale)
 {
     if (batch == 0)
         return hipSuccess;
-    if (batch >= 0x7FFFFFFFull)
+    if (batch >= 0x7FFFFFFFull || (mul_h != nullptr && inverse))
         return hipErrorInvalidValue;
     in_stride = in_stride ? in_stride : 65536;
     out_stride = out_stride ? out_stride : 65536;
@@ -45,8 +45,9 @@ hipError_t launch_group_real (bool inverse, const float2* in, float2* work, floa
     // behind the pass-B loads (CHOWDSP_FFT_GROUP_PREFETCH, as for the complex kernel)
     static const int pf_env = std::getenv ("CHOWDSP_FFT_GROUP_PREFETCH") != nullptr ? std::atoi (std::getenv ("CHOWDSP_FFT_GROUP_PREFETCH")) : -1;
     const unsigned form = (pf_env >= 0 ? pf_env : 3) == 3 ? 8u : 0u;
-    auto k = inverse ? group256_real_kernel<true> : group256_real_kernel<false>;
-    hipLaunchKernelGGL (k, dim3 (grid), dim3 (256), kGroupRealLds, stream, in, work, out, stage_tw, big_tw, real_tw, (GroupState*) state, host_err, (unsigned) batch, in_stride, out_stride, seq, (unsigned) reg_polls, (unsigned) force_solo, form);
+    // (the product with a packed filter spectrum rides on the FORWARD transform's stores: fft_convolve_frames_batch)
+    auto k = inverse ? group256_real_kernel<true, false> : (mul_h != nullptr ? group256_real_kernel<false, true> : group256_real_kernel<false, false>);
+    hipLaunchKernelGGL (k, dim3 (grid), dim3 (256), kGroupRealLds, stream, in, work, out, stage_tw, big_tw, real_tw, (GroupState*) state, host_err, (unsigned) batch, in_stride, out_stride, seq, (unsigned) reg_polls, (unsigned) force_solo, form, mul_h, mul_scale);
     return hipGetLastError();
 }
 } // namespace cfft::host

@@ -102,7 +102,7 @@ hipError_t launch_fast_r2_c2c (int n2, bool inverse, const float2* in, float2* w
 // real N = 131072 on the same groups, pair stage in registers (group_real_kernels.hpp, kernels_group_real.hip): stage_tw / big_tw of
 // the 65536-point complex plan, real_tw = W_131072^k of the real plan
 unsigned group_real_grid (bool inverse);
-hipError_t launch_group_real (bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, const float2* real_tw, void* state, unsigned* host_err, unsigned seq, size_t batch, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
+hipError_t launch_group_real (bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, const float2* real_tw, void* state, unsigned* host_err, unsigned seq, size_t batch, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0, const float2* mul_h = nullptr, float mul_scale = 1.f);
 hipError_t launch_group_c2c (int n1, int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, void* state, unsigned* host_err, unsigned seq, size_t batch, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
 // long mixed-radix frames (t.mixed_n2 > 0): generic column pass + power-of-two row pass, in -> work -> out
 hipError_t launch_mixed_big_c2c (const DeviceTables& t, bool inverse, const float2* in, float2* work, float2* out, size_t batch, int grid_divisor, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);

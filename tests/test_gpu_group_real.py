@@ -153,3 +153,38 @@ def test_handoff_failure_is_reported(gpu):
     api.stream_synchronize()
     assert torch.equal(y, good)
     api.fft_destroy_setup(s)
+
+
+@pytest.mark.parametrize("batch", [1, 33, 70])
+def test_fused_convolution_on_the_groups(gpu, real_groups, batch):
+    """fft_convolve_frames_batch of real N = 131072: the product rides on the forward group kernel's stores (pair stage and product in
+    registers, DC / Nyquist as two real products -- reference simd/chowdsp_fft_impl_sse.cpp:1640-1644), the backward transform follows in
+    place: == the composition of the three public calls == the float64 circular convolution, in GROUP mode and in the fall-back mode"""
+    api, torch, dev = gpu
+    rng = np.random.RandomState(910 + batch)
+    x = rng.uniform(-1, 1, (batch, N)).astype(np.float32)
+    h = rng.uniform(-1, 1, (1, N)).astype(np.float32)
+    want = np.fft.irfft(np.fft.rfft(x.astype(np.float64), axis=1) * np.fft.rfft(h.astype(np.float64), axis=1), n=N, axis=1)
+    s = api.fft_new_setup(N, api.FFT_REAL)
+    xd, hd = torch.from_numpy(x).to(dev), torch.from_numpy(h).to(dev)
+    H = torch.empty_like(hd)
+    api.fft_transform_unordered_batch(s, hd, H, api.FFT_FORWARD)
+    one = torch.full_like(xd, 3.0)
+    api.fft_convolve_frames_batch(s, xd, H, one, 1.0 / N)
+    api.stream_synchronize()
+    api.set_option("fused_conv_group", 0)
+    try:
+        three = torch.full_like(xd, 5.0)
+        api.fft_convolve_frames_batch(s, xd, H, three, 1.0 / N)
+        api.stream_synchronize()
+    finally:
+        api.set_option("fused_conv_group", 1)
+    inplace = xd.clone()
+    api.fft_convolve_frames_batch(s, inplace, H, inplace, 1.0 / N)
+    api.stream_synchronize()
+    got = one.cpu().numpy().astype(np.float64)
+    err = np.linalg.norm(got - want, axis=1) / np.linalg.norm(want, axis=1)
+    assert err.max() <= 1.5e-6, f"relative L2 {err.max():.3e}"
+    assert_frames_close(one.cpu().numpy(), three.cpu().numpy(), tol=4e-7, maxabs_tol=2e-6, what="product on the group kernel's stores vs composition")
+    assert np.array_equal(inplace.cpu().numpy(), one.cpu().numpy()), "in place == out of place"
+    api.fft_destroy_setup(s)
