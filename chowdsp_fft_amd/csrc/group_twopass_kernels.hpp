@@ -66,6 +66,10 @@
 #define CFFT_GROUP_WAVE_FLAGS 0
 #endif
 
+// workgroups per CU the compiler has to leave room for (2: 256 VGPRs; 3: 168)
+#ifndef CFFT_GROUP_MIN_WG
+#define CFFT_GROUP_MIN_WG 2
+#endif
 namespace cfft
 {
 constexpr int kGroupMaxXcc = 16;      // HW_REG_XCC_ID is a 4-bit field
@@ -233,7 +237,7 @@ __device__ __forceinline__ void fft256_two_stage_lds (float2 (&v)[16], const flo
 }
 
 template <bool INV>
-__global__ __launch_bounds__ (256, 2) void group256_kernel (const float2* __restrict__ in,
+__global__ __launch_bounds__ (256, CFFT_GROUP_MIN_WG) void group256_kernel (const float2* __restrict__ in,
                                                         float2* __restrict__ work, // max (kGroupSlotsTotal, gridDim.x) slots of 65536 float2
                                                         float2* __restrict__ out,
                                                         const float2* __restrict__ stage_tw,
