@@ -131,7 +131,7 @@ __device__ __forceinline__ void gr_fwd_pass_b (float2 (&v)[16], unsigned t, floa
     hook (3);
     // (a few filter bins at a time, one group ahead of its products: all 16 at once cost 156 bytes of scratch)
     float2 h[MULH ? 16 : 1];
-    const float2* __restrict__ hp = H + kb + 256u * (unsigned) mr;
+    const float2* __restrict__ hp = MULH ? H + kb + 256u * (unsigned) mr : nullptr;
     if constexpr (MULH)
     {
 #pragma unroll
