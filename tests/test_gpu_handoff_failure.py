@@ -280,3 +280,51 @@ def test_groupfast_handoff_stress_uneven_load(gpu, short_fuse, n, batch):
         api.set_option("group_fast", 1)
         api.fft_destroy_setup(s)
         api.fft_destroy_setup(s4)
+
+
+def test_real_group_handoff_stress_uneven_load(gpu, short_fuse):
+    """the same for the REAL one-launch form (N = 131072 on the N = 65536 groups, group_real_kernels.hpp: pair stage in registers, the
+    packed side in 64-byte runs that neighbours of a group complete in L2): 2048 frames (1 GiB), 30 launches alternating forward / backward
+    beside a second stream's uneven load; every frame within 3e-7 of the real four-step's result and every launch bit-identical to the first
+    of its direction (a stale or torn hand-off would differ from launch to launch)"""
+    api, torch, dev = gpu
+    n, batch = 1 << 17, 2048
+    g = torch.Generator(device=dev)
+    g.manual_seed(4244)
+    x = torch.rand((batch, n), device=dev, generator=g) * 2 - 1
+    s = api.fft_new_setup(n, api.FFT_REAL)
+    s4 = api.fft_new_setup(4096, api.FFT_COMPLEX)
+    want = {}
+    api.set_option("group_real", 0)
+    for d in (api.FFT_FORWARD, api.FFT_BACKWARD):
+        want[d] = torch.empty_like(x)
+        api.fft_transform_batch(s, x, want[d], d)
+    torch.cuda.synchronize()
+    api.set_option("group_real", 1)
+    api.set_option("group_reg_polls", 5000)
+    side, main = torch.cuda.Stream(), torch.cuda.Stream()
+    frames = torch.rand((8192, 8192), device=dev)
+    scratch = torch.empty_like(frames)
+    small = torch.rand((1 << 16,), device=dev)
+    y = torch.empty_like(x)
+    first = {}
+    torch.cuda.synchronize()
+    try:
+        for launch in range(30):
+            d = api.FFT_FORWARD if launch % 2 == 0 else api.FFT_BACKWARD
+            _side_load(api, torch, side, s4, frames, scratch, small, 10)
+            y.fill_(-1.0)
+            main.wait_stream(torch.cuda.current_stream())
+            api.fft_transform_batch(s, x, y, d, stream=main)
+            api.stream_synchronize(main)
+            rel = (y - want[d]).norm(dim=1) / want[d].norm(dim=1)
+            assert float(rel.max()) <= 3e-7, f"launch {launch}: frame {int(rel.argmax())} off by {float(rel.max()):.2e}"
+            if d not in first:
+                first[d] = y.clone()
+            else:
+                assert torch.equal(y, first[d]), f"launch {launch} differs from the first launch of its direction in {int((y != first[d]).sum())} words"
+            side.synchronize()
+    finally:
+        api.set_option("group_real", 1)
+        api.fft_destroy_setup(s)
+        api.fft_destroy_setup(s4)
