@@ -101,8 +101,13 @@ __global__ __launch_bounds__ (P::T* FPB) void c2c_kernel (const float2* __restri
 #ifndef CFFT_C2C_XCD_ORDER
 #define CFFT_C2C_XCD_ORDER 0
 #endif
+#ifndef CFFT_C2C_XOR
+#define CFFT_C2C_XOR 0
+#endif
 __device__ __forceinline__ unsigned c2c_group_map (unsigned g, unsigned ngroups)
 {
+    if (CFFT_C2C_XOR != 0 && (ngroups % 8u) == 0) // (experiment: which frame residue mod 8 an XCD works on)
+        return g ^ (unsigned) CFFT_C2C_XOR;
     if (! CFFT_C2C_XCD_ORDER)
         return g;
     const unsigned q = ngroups / 8u, r = ngroups % 8u, x = g % 8u;

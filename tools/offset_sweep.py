@@ -18,7 +18,8 @@ nf = 2 * n if cplx else n
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 s = api.fft_new_setup(n, api.FFT_COMPLEX if cplx else api.FFT_REAL)
 elems = batch * nf
-for pad in (0, 256, 4096, 65536, 1 << 20, (1 << 20) + 4096, (16 << 20) + 65536, (64 << 20) + 256):
+pads = [int(p) for p in os.environ["OFFSET_SWEEP_PADS"].split(",")] if os.environ.get("OFFSET_SWEEP_PADS") else [0, 256, 4096, 65536, 1 << 20, (1 << 20) + 4096, (16 << 20) + 65536, (64 << 20) + 256]
+for pad in pads:
     padf = pad // 4
     pool = torch.empty(3 * elems + 2 * padf + 1024, device=dev)
     base = (-(pool.data_ptr() // 4)) % 64  # 256-byte aligned start
