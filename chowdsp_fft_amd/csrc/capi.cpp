@@ -310,6 +310,9 @@ std::atomic<int> g_group_fast { 1 };
 // "group_real": real N = 131072 in one launch on the static groups, pair stage in registers (group_real_kernels.hpp; A/B against the
 // real four-step's two launches per chunk)
 std::atomic<int> g_group_real { 1 };
+// "huge_columns": frames beyond 2^21 complex points as strided columns (2-D column kernel, twiddle at its stores) x contiguous rows + ONE
+// transpose (round 4) instead of the plans of two factors between three transposes (0)
+std::atomic<int> g_huge_columns { 1 };
 bool split16384_enabled()
 {
     int v = g_split16384.load();
@@ -697,6 +700,33 @@ int huge_transform (Setup* s, bool inverse, const float2* in, float2* out, size_
             // packed spectrum -> Z (pair stage), then the complex backward transform of Z in place
             e = launch_real_pair (false, x, y, t->real_twiddles, (unsigned) nc, 1, stream, is2, os2);
             x = y;
+        }
+        if (t->huge2_r > 0 && g_huge_columns.load() != 0)
+        {
+            // round 4: columns x rows.  The huge2_r-point column transforms run on the frame where it lies (strided tiles of the 2-D column
+            // kernel) and multiply by W_N^(k col) on their way into the workspace; the huge2_c-point rows are then contiguous (one batched call, in
+            // place); ONE transpose brings X[kr + R kc] from [kr][kc] into natural order -- three sweeps + the row plan's instead of five
+            const unsigned R2 = (unsigned) t->huge2_r, C2 = (unsigned) t->huge2_c;
+            Setup plan_c2 { kMagic, (int) C2, (int) cf::FFT_COMPLEX, s->device, nullptr, t->huge2_plan_c };
+            if (e == hipSuccess)
+                e = launch_column_fft (inverse, (int) R2, (int) C2, *t->huge2_cols, W, 1, stream, x, t->huge_tw_lo, t->huge_tw_hi, (unsigned) t->huge_shift);
+            if (e != hipSuccess)
+            {
+                set_last_error ("kernel launch (frame beyond 2^21 points, column pass)", e);
+                return cf::FFT_GPU_ELAUNCH;
+            }
+            const int rc2 = run_transform (&plan_c2, (const float*) W, (float*) W, R2, dir, stream, 0, 0);
+            if (rc2 != cf::FFT_GPU_OK)
+                return rc2;
+            e = launch_transpose (W, y, R2, C2, 0, nullptr, nullptr, 0, stream);
+            if (e == hipSuccess && real && ! inverse)
+                e = launch_real_pair (true, y, y, t->real_twiddles, (unsigned) nc, 1, stream, os2, os2);
+            if (e != hipSuccess)
+            {
+                set_last_error ("kernel launch (frame beyond 2^21 points)", e);
+                return cf::FFT_GPU_ELAUNCH;
+            }
+            continue;
         }
         float2* A = (x != y) ? y : W; // first intermediate; the second one is the other buffer
         float2* B = (A == y) ? W : y;
@@ -1584,6 +1614,8 @@ int fft_gpu_set_option (const char* name, long value)
         g_group_fast = value != 0 ? 1 : 0;
     else if (std::strcmp (name, "group_real") == 0)
         g_group_real = value != 0 ? 1 : 0;
+    else if (std::strcmp (name, "huge_columns") == 0)
+        g_huge_columns = value != 0 ? 1 : 0;
     else
     {
         set_last_error ("fft_gpu_set_option: unknown option or value out of range");
@@ -1623,6 +1655,8 @@ long fft_gpu_get_option (const char* name)
         return g_group_fast.load();
     if (std::strcmp (name, "group_real") == 0)
         return g_group_real.load();
+    if (std::strcmp (name, "huge_columns") == 0)
+        return g_huge_columns.load();
     return -1;
 }
 
@@ -1654,7 +1688,14 @@ size_t fft_gpu_workspace_bytes (void* setup, size_t batch)
         // one frame for the transposes + what the two factors' plans cache for their batches of huge_c / huge_r frames
         Setup plan_r { kMagic, s->tables->huge_r, (int) FFT_COMPLEX, s->device, nullptr, s->tables->huge_plan_r };
         Setup plan_c { kMagic, s->tables->huge_c, (int) FFT_COMPLEX, s->device, nullptr, s->tables->huge_plan_c };
-        return (size_t) complex_len (s) * sizeof (float2) + std::max (fft_gpu_workspace_bytes (&plan_r, (size_t) s->tables->huge_c), fft_gpu_workspace_bytes (&plan_c, (size_t) s->tables->huge_r));
+        size_t inner = std::max (fft_gpu_workspace_bytes (&plan_r, (size_t) s->tables->huge_c), fft_gpu_workspace_bytes (&plan_c, (size_t) s->tables->huge_r));
+        if (s->tables->huge2_r > 0)
+        {
+            // (the columns x rows form: its rows' plan for a batch of huge2_r frames)
+            Setup plan_c2 { kMagic, s->tables->huge2_c, (int) FFT_COMPLEX, s->device, nullptr, s->tables->huge2_plan_c };
+            inner = std::max (inner, fft_gpu_workspace_bytes (&plan_c2, (size_t) s->tables->huge2_r));
+        }
+        return (size_t) complex_len (s) * sizeof (float2) + inner;
     }
     const size_t frame_bytes = workspace_frame_bytes (s->tables, complex_len (s));
     int n1 = 0, n2 = 0;

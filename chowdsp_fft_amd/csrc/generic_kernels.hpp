@@ -1563,14 +1563,22 @@ __global__ __launch_bounds__ (BLOCK) void pass_b_generic_kernel (const float2* _
 // twiddle, and stored back where it came from.  cols need not be a multiple of C.
 // PIPE / SP: as in pass_a_generic_kernel (the next tile requested across the stages, stage twiddles in LDS; compile-time list).
 template <bool SWAP, int C, int BLOCK, bool PIPE = false, class SP = void, bool INPLACE = false>
-__global__ __launch_bounds__ (BLOCK, PIPE ? 4 : 1) void column_fft_kernel (float2* __restrict__ data,
+__global__ __launch_bounds__ (BLOCK, PIPE ? 4 : 1) void column_fft_kernel (float2* data, // (no __restrict__: the source below may be this array)
                                                           const float2* __restrict__ twtab,
                                                           GenericPlan plan, // n = rows, frames = C
                                                           unsigned cols,
                                                           unsigned batch,
                                                           size_t array_stride, // float2 between consecutive arrays
-                                                          unsigned lfs)
+                                                          unsigned lfs,
+                                                          // round 4 (frames beyond 2^22 points as columns x rows, capi.cpp huge_transform): the arrays are read from
+                                                          // `src_arg` (nullptr: in place) and every result is multiplied by W_N^(k col), N = rows * cols, formed from the
+                                                          // two-level table W_N^j = tw_hi[j >> tw_shift] * tw_lo[j & mask] (nullptr: no twiddle)
+                                                          const float2* src_arg,
+                                                          const float2* __restrict__ tw_lo,
+                                                          const float2* __restrict__ tw_hi,
+                                                          unsigned tw_shift)
 {
+    const float2* srcdata = src_arg != nullptr ? src_arg : data;
     extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
     const int tid0 = threadIdx.x;
     constexpr bool STATIC = ! std::is_void<SP>::value;
@@ -1598,7 +1606,7 @@ __global__ __launch_bounds__ (BLOCK, PIPE ? 4 : 1) void column_fft_kernel (float
         const size_t w = tile_xcd_order<1> (v, nwork);
         const unsigned f = (unsigned) (w / tiles), tile = (unsigned) (w % tiles);
         const int valid = (int) min ((unsigned) C, cols - tile * C);
-        const float2* __restrict__ src = data + (size_t) f * array_stride + (size_t) tile * C;
+        const float2* src = srcdata + (size_t) f * array_stride + (size_t) tile * C;
         const auto slot = [&] (int u) {
             const int e = min (tid + u * BLOCK, total - 1);
             const int c = min (e % C, valid - 1), j = e / C;
@@ -1631,7 +1639,8 @@ __global__ __launch_bounds__ (BLOCK, PIPE ? 4 : 1) void column_fft_kernel (float
         const unsigned f = (unsigned) (w / tiles);
         const unsigned tile = (unsigned) (w % tiles);
         const int valid = (int) min ((unsigned) C, cols - tile * C);
-        float2* __restrict__ base = data + (size_t) f * array_stride + (size_t) tile * C;
+        float2* base = data + (size_t) f * array_stride + (size_t) tile * C;
+        const float2* sbase = srcdata + (size_t) f * array_stride + (size_t) tile * C;
         __syncthreads(); // previous tile fully stored
         if constexpr (PIPE)
         {
@@ -1652,7 +1661,7 @@ __global__ __launch_bounds__ (BLOCK, PIPE ? 4 : 1) void column_fft_kernel (float
             {
                 const int e = min (e0 + u * BLOCK, total - 1);
                 const int c = min (e % C, valid - 1), j = e / C;
-                x[u] = gload (&base[(size_t) j * cols + c]);
+                x[u] = gload (&sbase[(size_t) j * cols + c]);
             }
 #pragma unroll
             for (int u = 0; u < kTileLoadsInFlight; ++u)
@@ -1681,14 +1690,36 @@ __global__ __launch_bounds__ (BLOCK, PIPE ? 4 : 1) void column_fft_kernel (float
         }
         else
             res = generic_core<BLOCK, false, false, false> (plan, twtab, bufA, bufB, nullptr, nullptr, C, tid, lfs);
-#pragma unroll 4
-        for (int e = tid; e < total; e += BLOCK)
+        if (tw_lo == nullptr)
         {
-            const int c = e % C, k = e / C;
-            if (c < valid)
+#pragma unroll 4
+            for (int e = tid; e < total; e += BLOCK)
             {
-                const float2 y = res[c * lfs + k];
-                gstore (&base[(size_t) k * cols + c], SWAP ? make_float2 (y.y, y.x) : y);
+                const int c = e % C, k = e / C;
+                if (c < valid)
+                {
+                    const float2 y = res[c * lfs + k];
+                    gstore (&base[(size_t) k * cols + c], SWAP ? make_float2 (y.y, y.x) : y);
+                }
+            }
+        }
+        else
+        {
+            // ... times W_N^(k col): the forward twiddle in BOTH directions -- the backward transform is this forward algorithm on
+            // swapped data, and the swap back happens behind the product
+            const unsigned col0 = tile * C;
+            const unsigned mask = (1u << tw_shift) - 1u;
+#pragma unroll 2
+            for (int e = tid; e < total; e += BLOCK)
+            {
+                const int c = e % C, k = e / C;
+                if (c < valid)
+                {
+                    const unsigned jj = (unsigned) k * (col0 + (unsigned) c); // < N <= 2^27
+                    const float2 w = cmul (tw_lo[jj & mask], tw_hi[jj >> tw_shift]);
+                    const float2 y = cmul (res[c * lfs + k], w);
+                    gstore (&base[(size_t) k * cols + c], SWAP ? make_float2 (y.y, y.x) : y);
+                }
             }
         }
     }

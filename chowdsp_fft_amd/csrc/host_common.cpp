@@ -139,6 +139,19 @@ const DeviceTables* acquire_tables (int device, int N, int transform)
                 return nullptr;
         }
     }
+    // ... and, where the frame splits into columns the 2-D column kernel takes, that plan too (capi.cpp huge_transform prefers it)
+    const DeviceTables *cols2 = nullptr, *plan2_c = nullptr;
+    int h2r = 0, h2c = 0;
+    {
+        const int nc = (transform == 0) ? N / 2 : N;
+        if (sub_r != nullptr && split_huge_columns (nc, h2r, h2c))
+        {
+            cols2 = acquire_column_tables (device, h2r);
+            plan2_c = acquire_tables (device, h2c, 1);
+            if (cols2 == nullptr || plan2_c == nullptr)
+                cols2 = plan2_c = nullptr;
+        }
+    }
     // real N = 131072 can run in one launch on the complex 65536-point plan's tables (group_real_kernels.hpp)
     const DeviceTables* group_core = nullptr;
     if (transform == 0 && N == 131072)
@@ -189,6 +202,13 @@ const DeviceTables* acquire_tables (int device, int N, int transform)
     t->huge_shift = h.huge_shift;
     t->huge_plan_r = sub_r;
     t->huge_plan_c = sub_c;
+    if (cols2 != nullptr)
+    {
+        t->huge2_r = h2r;
+        t->huge2_c = h2c;
+        t->huge2_cols = cols2;
+        t->huge2_plan_c = plan2_c;
+    }
     t->group_core = group_core;
     t->huge_tw_lo = upload (h.huge_tw_lo);
     t->huge_tw_hi = upload (h.huge_tw_hi);

@@ -72,6 +72,10 @@ struct DeviceTables
     const DeviceTables* huge_plan_c = nullptr;
     float2* huge_tw_lo = nullptr;
     float2* huge_tw_hi = nullptr;
+    // ... the same frames as huge2_r-point COLUMNS (the 2-D column kernel, twiddle at its stores) x huge2_c-point rows + one transpose (round 4), else 0
+    int huge2_r = 0, huge2_c = 0;
+    const DeviceTables* huge2_cols = nullptr;   // column tables of huge2_r (acquire_column_tables)
+    const DeviceTables* huge2_plan_c = nullptr; // complex plan of huge2_c
 };
 
 // The plan header.  Lives either in a block we allocated (fft_new_setup) or in caller memory

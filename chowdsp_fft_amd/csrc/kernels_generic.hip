@@ -275,7 +275,7 @@ ColumnFftFn pick_column (int c, int block, bool inverse, bool pipe)
 }
 } // namespace
 
-hipError_t launch_column_fft (bool inverse, int rows, int cols, const DeviceTables& t, float2* data, size_t batch, hipStream_t stream)
+hipError_t launch_column_fft (bool inverse, int rows, int cols, const DeviceTables& t, float2* data, size_t batch, hipStream_t stream, const float2* src, const float2* tw_lo, const float2* tw_hi, unsigned tw_shift)
 {
     if (batch == 0)
         return hipSuccess;
@@ -323,7 +323,7 @@ hipError_t launch_column_fft (bool inverse, int rows, int cols, const DeviceTabl
     const unsigned grid = persistent_grid (k, block, lds, batch * (size_t) ((cols + c - 1) / c));
     if (grid == 0)
         return hipErrorNoDevice;
-    hipLaunchKernelGGL (k, dim3 (grid), dim3 (block), lds, stream, data, (const float2*) t.stage_twiddles, plan, (unsigned) cols, (unsigned) batch, (size_t) rows * (size_t) cols, lfs);
+    hipLaunchKernelGGL (k, dim3 (grid), dim3 (block), lds, stream, data, (const float2*) t.stage_twiddles, plan, (unsigned) cols, (unsigned) batch, (size_t) rows * (size_t) cols, lfs, src, tw_lo, tw_hi, tw_shift);
     return hipGetLastError();
 }
 } // namespace cfft::host

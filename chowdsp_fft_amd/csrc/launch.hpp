@@ -117,7 +117,8 @@ hipError_t launch_generic_conv (bool real, int nc, const DeviceTables& t, const 
 
 // column pass of the 2-D transform (row f4): rows-point FFTs along the columns of `batch` row-major [rows][cols] complex arrays,
 // in place; `t` = acquire_column_tables (device, rows)
-hipError_t launch_column_fft (bool inverse, int rows, int cols, const DeviceTables& t, float2* data, size_t batch, hipStream_t stream);
+// src (nullptr: in place): where the arrays are read from; tw_lo / tw_hi / tw_shift (nullptr: none): every result times W_(rows cols)^(k col)
+hipError_t launch_column_fft (bool inverse, int rows, int cols, const DeviceTables& t, float2* data, size_t batch, hipStream_t stream, const float2* src = nullptr, const float2* tw_lo = nullptr, const float2* tw_hi = nullptr, unsigned tw_shift = 0);
 
 // layout conversions of the JUCE-engine adapter (kernels_layout.hip); data = batch frames of 2*m float2
 // real transform with the JUCE engine's layout fused into the pair stage, in place on frames of 4 m floats; hipErrorNotSupported

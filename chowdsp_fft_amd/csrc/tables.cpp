@@ -255,6 +255,29 @@ bool split_huge (int n_complex, int& r, int& c)
     return false;
 }
 
+bool split_huge_columns (int n_complex, int& r, int& c)
+{
+    r = c = 0;
+    if (! runs_as_huge (n_complex) || n_complex > kMaxHugeComplexLen)
+        return false;
+    // CHOWDSP_FFT_HUGE_COLS_MAX (A/B): the longest column length tried.  Default 640: the lengths the column kernel takes 16 columns (whole 128-byte
+    // lines) at a time -- measured c2^23 / c2^24 / c3*2^21 / c2^27: 0.164 / 0.156 / 0.151 / 0.137 of 8 TB/s against 0.141 / 0.137 / 0.118 / 0.119 with
+    // 2048-point columns (8-column tiles: 64-byte runs), 0.134 / 0.142 / 0.126 / 0.130 with 1024, 0.147 / 0.145 / 0.117 / 0.137 with 256
+    static const int dmax = [] { const char* e = std::getenv ("CHOWDSP_FFT_HUGE_COLS_MAX"); const int v = e != nullptr ? std::atoi (e) : 0; return (v >= 256 && v <= 2048) ? v : 640; }();
+    for (int d = dmax - dmax % 16; d >= 256; d -= 16)
+    {
+        if (n_complex % d != 0 || ! is_235_smooth (d))
+            continue;
+        const long long e = n_complex / d;
+        if (e % 16 != 0 || e > kMaxComplexLen || runs_as_huge ((int) e) || ! size_supported ((int) e, 1))
+            continue;
+        r = d;
+        c = (int) e;
+        return true;
+    }
+    return false;
+}
+
 bool size_supported (int N, int transform)
 {
     // the reference needs N % 16 == 0 (complex) / N % 32 == 0 (real) on its SSE path

@@ -151,6 +151,9 @@ static constexpr int kMaxComplexLen = 1 << 21;
 // frame).  false if no such pair of factors exists (then the size is not supported).
 static constexpr int kMaxHugeComplexLen = 1 << 27;
 bool split_huge (int n_complex, int& r, int& c);
+// ... as columns x rows (round 4): r = the largest column length the 2-D column kernel takes (a multiple of 16, at most 2048) that divides n_complex
+// with c = n_complex / r an accepted complex length of at most 2^21 points that is not huge itself.  false if there is none.
+bool split_huge_columns (int n_complex, int& r, int& c);
 // ... except the lengths up to 2^22 that are the product of two static tile lengths (at most 2048 points each, tables below): those
 // stay two-pass plans of the general form (2^22 = 2048 x 2048, 2304000 = 2048 x 1125: two sweeps instead of five)
 static constexpr int kMaxStaticTwoPassLen = 1 << 22;

@@ -11,7 +11,7 @@ namespace cfft::host
 {
 using PassAGenericFn = void (*) (const float2*, float2*, const float2*, const float2*, GenericPlan, unsigned, unsigned, size_t, unsigned, size_t);
 using PassBGenericFn = void (*) (const float2*, float2*, const float2*, GenericPlan, unsigned, unsigned, unsigned, size_t, unsigned, size_t);
-using ColumnFftFn = void (*) (float2*, const float2*, GenericPlan, unsigned, unsigned, size_t, unsigned); // the 2-D transforms' column pass
+using ColumnFftFn = void (*) (float2*, const float2*, GenericPlan, unsigned, unsigned, size_t, unsigned, const float2*, const float2*, const float2*, unsigned); // the 2-D transforms' column pass
 // nullptr: no compile-time list for this (plan, tile width) in the group, or its LDS does not fit the device.  Otherwise `launch`
 // holds what the kernel was instantiated for.
 struct StaticTileLaunch

@@ -300,6 +300,35 @@ def test_frames_beyond_2_21(gpu, oracle, n, tr):
     oracle.destroy_setup(so)
 
 
+@pytest.mark.parametrize("n,tr", [(1 << 23, COMPLEX), (3 << 21, COMPLEX), (5 << 21, REAL)])
+def test_frames_beyond_2_21_columns_form_equals_the_transposes_form(gpu, n, tr):
+    """round 4: such frames run as strided COLUMNS (the 2-D column kernel, inter-pass twiddle at its stores) x contiguous rows + one transpose
+    (option huge_columns, default on) instead of two plans between three transposes: same transform, both directions, in place and not"""
+    api, torch, dev = gpu
+    assert api.get_option("huge_columns") == 1
+    nf = 2 * n if tr == COMPLEX else n
+    s = api.fft_new_setup(n, tr)
+    g = torch.Generator(device=dev)
+    g.manual_seed(n % 997)
+    x = torch.rand((2, nf), device=dev, generator=g) * 2 - 1
+    for direction in (api.FFT_FORWARD, api.FFT_BACKWARD):
+        new = torch.full_like(x, -2.0)
+        api.fft_transform_batch(s, x, new, direction)
+        inplace = x.clone()
+        api.fft_transform_batch(s, inplace, inplace, direction)
+        api.set_option("huge_columns", 0)
+        try:
+            old = torch.full_like(x, -3.0)
+            api.fft_transform_batch(s, x, old, direction)
+            torch.cuda.synchronize()
+        finally:
+            api.set_option("huge_columns", 1)
+        rel = (new - old).norm(dim=1) / old.norm(dim=1)
+        assert float(rel.max()) <= 4e-7, f"N={n} direction {direction}: {float(rel.max()):.2e}"
+        assert torch.equal(inplace, new), "in place == out of place"
+    api.fft_destroy_setup(s)
+
+
 # The tile kernels of the long plans with a compile-time stage list (kernels_tile_static_{a,b,c}.hip): for every static length the
 # shortest frame that runs it as the column pass and the shortest that runs it as the row pass (generated from
 # fft_gpu_plan_describe over the products of two static lengths).  The workgroups are persistent and request their NEXT tile
