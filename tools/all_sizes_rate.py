@@ -18,6 +18,8 @@ sizes += [(n, True) for n in (96, 192, 384, 480, 640, 768, 9216)] + [(n, False) 
 sizes += [(n, True) for n in (1536, 1920, 5120, 19200, 20736, 46080, 245760)] + [(n, False) for n in (1920, 3840, 18432, 41472)]
 # round 3: more of the long plans (run-time factors, 48 kHz seconds, factors beyond 639 points, two-pass beyond 2^21)
 sizes += [(n, True) for n in (34992, 48000, 655360, 1327104, 1 << 22)] + [(n, False) for n in (96000,)]
+# round 4: frames beyond 2^22 complex points (strided columns x contiguous rows + one transpose)
+sizes += [(n, True) for n in (1 << 23, 3 << 21, 1 << 24)] + [(n, False) for n in (1 << 24,)]
 if len(sys.argv) > 1:  # subset: "c480,c768,r9216"; further arguments: library options, "split8192=1"
     sizes = [(int(t[1:]), t[0] == "c") for t in sys.argv[1].split(",")]
 for opt in sys.argv[2:]:
