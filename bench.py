@@ -304,6 +304,11 @@ def main() -> int:
                          "clocks (measured: the first ~3 ms after idle run 10-25 %% slower); the timed region is still exactly K steps")
     ap.add_argument("--gather", action="store_true", help="(default when N > 1) time the final all-gather of results over xGMI, reported separately")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the final all-gather")
+    ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl",
+                    help="N > 1: process-group backend.  nccl (= RCCL over xGMI) is what a multi-GPU node runs; gloo rehearses the "
+                         "same branch on ONE GPU box (ranks share the devices that exist, collectives move host copies)")
+    ap.add_argument("--secondary-frames-per-gpu", type=int, default=0,
+                    help="override the batch of every secondary workload (rehearsals only: a reduced batch is not a bench result)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -352,10 +357,16 @@ def main() -> int:
     if not torch.cuda.is_available():
         sys.stderr.write("[bench] no GPU visible: the HIP path cannot run (there is no CPU fallback)\n")
         return 3
+    if args.dist_backend == "gloo":
+        # rehearsal: more ranks than devices is fine, the ranks then share the devices that exist
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     do_gather = world > 1 and not args.no_gather
     line = run_workload(args.workload, args, world, rank, dev, frames_override=args.frames_per_gpu, gather=do_gather)
@@ -367,7 +378,8 @@ def main() -> int:
     if args.workload == DEFAULT_WORKLOAD and not args.no_secondary:
         for name in SECONDARY_WORKLOADS:
             # N > 1: BASELINE configs[3] (1M overlap-save frames over 8 GPUs = 131072 per GPU) gets a gather of its own
-            sec = run_workload(name, args, world, rank, dev, gather=(do_gather and name == MULTI_GPU_CONV_WORKLOAD))
+            sec = run_workload(name, args, world, rank, dev, frames_override=args.secondary_frames_per_gpu,
+                               gather=(do_gather and name == MULTI_GPU_CONV_WORKLOAD))
             if isinstance(sec, int):
                 return sec
             if rank == 0:
@@ -385,6 +397,9 @@ def main() -> int:
         rank_desc = sharding.describe_ranks(desc)
         if rank == 0:
             line.update(sharding.multi_gpu_fields(world, rank_desc, line.pop("gather_xgmi", None), multi_extra))
+            line["dist_backend"] = args.dist_backend
+            if args.dist_backend != "nccl":
+                line["rehearsal"] = "gloo process group: ranks may share a device and the gather moves host copies -- not a scaling measurement"
     if rank == 0:
         if secondary:
             line["secondary"] = secondary

@@ -45,6 +45,8 @@ PROTOTYPES = {
     "fft_gpu_set_option": (_i, [C.c_char_p, C.c_long]),
     "fft_gpu_get_option": (C.c_long, [C.c_char_p]),
     "fft_gpu_release_stream_resources": (_i, [_vp]),
+    "fft_gpu_trim_tables": (_sz, [_i]),
+    "fft_gpu_table_cache_info": (_i, [_i, C.POINTER(C.c_size_t)]),
     "fft_gpu_defer_begin": (_i, []),
     "fft_gpu_defer_flush": (_i, []),
     "fft_gpu_size_supported": (_i, [_i, _i]),

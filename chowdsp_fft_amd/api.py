@@ -308,6 +308,20 @@ def release_stream_resources(stream=None) -> int:
     return int(_lib.lib().fft_gpu_release_stream_resources(_stream_handle(stream)))
 
 
+def trim_tables(device: int = -1) -> int:
+    """fft_gpu_trim_tables: free the device tables no plan references any more; returns the bytes given back"""
+    return int(_lib.lib().fft_gpu_trim_tables(int(device)))
+
+
+def table_cache_info(device: int = -1) -> dict:
+    """fft_gpu_table_cache_info: {entries, bytes, idle_entries, idle_bytes} of the device-table cache"""
+    import ctypes as C
+
+    info = (C.c_size_t * 4)()
+    _check(_lib.lib().fft_gpu_table_cache_info(int(device), info), "fft_gpu_table_cache_info")
+    return {"entries": int(info[0]), "bytes": int(info[1]), "idle_entries": int(info[2]), "idle_bytes": int(info[3])}
+
+
 def set_option(name: str, value: int) -> None:
     """fft_gpu_set_option: run-time knobs of the library (chowdsp_fft_gpu.h)"""
     _check(_lib.lib().fft_gpu_set_option(name.encode(), int(value)), f"fft_gpu_set_option({name})")

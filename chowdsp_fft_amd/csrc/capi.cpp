@@ -925,6 +925,16 @@ int deferred_flush()
     calls.swap (q.calls);
     const size_t total = q.floats;
     q.floats = 0;
+    // every path out of here gives the recorded calls' table references back
+    struct ReleaseRecorded
+    {
+        const std::vector<DeferredCall>& calls;
+        ~ReleaseRecorded()
+        {
+            for (const DeferredCall& c : calls)
+                release_tables (c.plan.tables);
+        }
+    } release_recorded { calls };
     // groups of calls that share plan (same tables = same device, length and transform) and direction, in order of first appearance
     const auto same_group = [] (const DeferredCall& a, const DeferredCall& b) { return a.plan.tables == b.plan.tables && a.dir == b.dir; };
     std::vector<size_t> groups; // index of each group's first call
@@ -1050,6 +1060,7 @@ bool deferred_record (Setup* s, const float* input, float* output, cf::fft_direc
     }
     if (q.floats + nf > kDeferredMaxFloats)
         deferred_flush_implicit();
+    retain_tables (s->tables); // given back when the flush has run the call (deferred_flush)
     q.calls.push_back (DeferredCall { *s, input, output, (int) direction });
     q.floats += nf;
     return true;
@@ -1264,9 +1275,15 @@ void fft_destroy_setup (void* setup)
     Setup* s = as_setup (setup);
     if (s == nullptr)
         return;
-    // calls recorded by fft_gpu_defer_begin() regions hold the plan by value (DeferredCall): nothing to flush here
+    // calls recorded by fft_gpu_defer_begin() regions hold the plan by value and a table reference of their own (DeferredCall):
+    // nothing to flush here
     void* block = s->owned_block;
+    const DeviceTables* tables = s->tables;
     s->magic = 0;
+    s->tables = nullptr;
+    // the plan's reference to its device tables (the reference frees everything the setup owns here, sse.cpp:79-82); the last
+    // one makes them idle: kept while the idle set fits the cache limit, freed by fft_gpu_trim_tables (host_common.cpp)
+    release_tables (tables);
     if (block != nullptr)
         aligned_free (block);
 }
@@ -1565,6 +1582,8 @@ int fft_gpu_release_stream_resources (void* stream)
         it = g_lanes.erase (it);
         ++released;
     }
+    // "give the memory back": the device tables of plans that have all been destroyed go too (fft_gpu_trim_tables)
+    (void) trim_tables (-1);
     if (pending_error != 0)
     {
         set_last_error (fused_error_text (pending_error).c_str());
@@ -1616,6 +1635,8 @@ int fft_gpu_set_option (const char* name, long value)
         g_group_real = value != 0 ? 1 : 0;
     else if (std::strcmp (name, "huge_columns") == 0)
         g_huge_columns = value != 0 ? 1 : 0;
+    else if (std::strcmp (name, "table_cache_mib") == 0 && value >= 0 && value <= (1 << 20))
+        set_table_cache_limit ((size_t) value << 20); // device tables of destroyed plans kept for re-use: at most this much
     else
     {
         set_last_error ("fft_gpu_set_option: unknown option or value out of range");
@@ -1657,7 +1678,26 @@ long fft_gpu_get_option (const char* name)
         return g_group_real.load();
     if (std::strcmp (name, "huge_columns") == 0)
         return g_huge_columns.load();
+    if (std::strcmp (name, "table_cache_mib") == 0)
+        return (long) (table_cache_limit() >> 20);
     return -1;
+}
+
+size_t fft_gpu_trim_tables (int device)
+{
+    return trim_tables (device);
+}
+
+int fft_gpu_table_cache_info (int device, size_t info[4])
+{
+    if (info == nullptr)
+        return FFT_GPU_EINVAL;
+    const TableCacheStats st = table_cache_stats (device);
+    info[0] = st.entries;
+    info[1] = st.bytes;
+    info[2] = st.idle_entries;
+    info[3] = st.idle_bytes;
+    return FFT_GPU_OK;
 }
 
 int fft_gpu_setup_size (void* setup)
@@ -1779,6 +1819,13 @@ int fft_transform_2d_batch (void* setup, int rows, const float* input, float* ou
         set_last_error ("fft_transform_2d_batch: the number of rows must be 2^a 3^b 5^c and at most 2559");
         return FFT_GPU_EINVAL;
     }
+    // the call's own reference to the column tables goes back on every path (idle tables stay cached; freeing them waits for
+    // the device, so the column pass launched below is never left reading freed memory)
+    struct ReleaseColumns
+    {
+        const DeviceTables* t;
+        ~ReleaseColumns() { release_tables (t); }
+    } release_columns { ct };
     const int rc = run_transform (s, input, output, batch * (size_t) rows, direction, (hipStream_t) stream);
     if (rc != FFT_GPU_OK || rows == 1)
         return rc;

@@ -102,10 +102,30 @@ inline Setup* as_setup (void* p)
 // of the library uses to wait for a stream.  FFT_GPU_OK or FFT_GPU_ELAUNCH (reason recorded for fft_gpu_last_error).
 int sync_stream_checked (hipStream_t stream, const char* what);
 
+// ---- the device-table cache (host_common.cpp) -------------------------------------------------------------------------
+// Every plan holds ONE counted reference to the tables of its (device, N, transform), taken by acquire_tables and given back by
+// release_tables (fft_destroy_setup; the reference frees everything a setup owns there, simd/chowdsp_fft_impl_sse.cpp:79-82).
+// Tables nobody references any more are IDLE: they stay cached, least recently released first out, while the idle set fits
+// table_cache_limit() bytes of device memory (default 64 MiB; 0 = freed at the last release), and trim_tables() frees all of
+// them.  Composite plans (frames beyond 2^21 points, real N = 131072, the 2-D column pass) reference the tables of their
+// parts; those references go when the composite entry is freed.  hipFree waits for the device, so a kernel still reading a
+// table when it is released completes first.
 const DeviceTables* acquire_tables (int device, int N, int transform);
 // stage list + tables of the 2-D transform's column pass (rows-point FFTs of a tile of columns); nullptr if `rows` is not
-// 2-3-5-smooth or does not fit a column tile (tables.hpp kGeneralMaxFactor)
+// 2-3-5-smooth or does not fit a column tile (tables.hpp kGeneralMaxFactor).  Counted like acquire_tables.
 const DeviceTables* acquire_column_tables (int device, int rows);
+void retain_tables (const DeviceTables* t);  // one more reference to tables the caller already holds (recorded deferred calls)
+void release_tables (const DeviceTables* t); // nullptr and unknown pointers are ignored
+// frees the idle tables of `device` (-1: every device); returns the bytes of device memory given back
+size_t trim_tables (int device);
+void set_table_cache_limit (size_t bytes);
+size_t table_cache_limit();
+struct TableCacheStats
+{
+    size_t entries = 0, idle_entries = 0;  // (device, N, transform) sets cached / of them unreferenced
+    size_t bytes = 0, idle_bytes = 0;      // device memory they hold
+};
+TableCacheStats table_cache_stats (int device); // -1: every device
 // RAII: run on the device the plan's tables live on, whatever device the calling thread has current
 struct DeviceGuard
 {

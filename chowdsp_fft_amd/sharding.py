@@ -21,6 +21,14 @@ def shard_range(total_frames: int, world_size: int, rank: int) -> Tuple[int, int
     return start, base + (1 if rank < extra else 0)
 
 
+def _host_backend() -> bool:
+    """True when the process group moves host memory only (gloo: the CPU tests, and the one-box rehearsal of bench.py's
+    N > 1 branch): device tensors are then staged through the host around every collective."""
+    import torch.distributed as dist
+
+    return dist.get_backend() == "gloo"
+
+
 def max_over_ranks(value: float, device=None) -> float:
     """MAX all-reduce of a scalar (elapsed time): the job is as slow as its slowest rank."""
     import torch
@@ -28,6 +36,8 @@ def max_over_ranks(value: float, device=None) -> float:
 
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return float(value)
+    if _host_backend():
+        device = None
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
@@ -39,6 +49,8 @@ def sum_over_ranks(value: float, device=None) -> float:
 
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return float(value)
+    if _host_backend():
+        device = None
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
@@ -55,6 +67,8 @@ def gather_frames(local, total_frames: int):
     world, rank = dist.get_world_size(), dist.get_rank()
     counts = [shard_range(total_frames, world, r)[1] for r in range(world)]
     assert local.shape[0] == counts[rank]
+    if _host_backend() and local.device.type != "cpu":
+        local = local.cpu()  # gloo rehearsal on a GPU box: the collective runs on host copies (RCCL gathers device memory)
     width = max(counts)
     if local.shape[0] != width:
         pad = torch.zeros((width - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)

@@ -61,6 +61,18 @@ const char* fft_gpu_last_error (void);
    a hipGraph makes the call fail with FFT_GPU_ENOMEM (run the same call once outside the capture first). */
 int fft_gpu_release_stream_resources (void* stream);
 
+/* Device tables (twiddles, stage lists) are shared by every plan of one (device, N, transform) and counted: each plan holds
+   one reference from fft_new_setup / fft_new_setup_preallocated until fft_destroy_setup (the reference frees everything a
+   setup owns there).  Tables without a plan stay cached for the next fft_new_setup of the same size while the idle set fits
+   option "table_cache_mib" (default 64; 0 = freed with their last plan), oldest out first.
+   fft_gpu_trim_tables frees every idle table of `device` (-1: all devices) and returns the bytes of device memory given
+   back; fft_gpu_release_stream_resources calls it too.  A plan made by fft_new_setup_preallocated whose owner follows the
+   reference's rule (no fft_destroy_setup) keeps its tables pinned; calling fft_destroy_setup on it before freeing the
+   caller's block is allowed here and drops the reference.
+   fft_gpu_table_cache_info: info[0..3] = { table sets cached, their bytes, idle sets, idle bytes } for `device` (-1: all). */
+size_t fft_gpu_trim_tables (int device);
+int fft_gpu_table_cache_info (int device, size_t info[4]);
+
 /* Run-time options (process-wide; initial values come from the environment variables named in INTEGRATION.md):
      "fused_two_pass"   which form runs two-pass sizes that have a one-launch form (N = 65536, 2^17, 2^18 complex), batches of at
                         least "fused_min_batch" frames:  2 (default) one launch, static groups of 16 workgroups per XCD, the
@@ -93,6 +105,7 @@ int fft_gpu_release_stream_resources (void* stream);
                         launches instead of one launch on the static groups of "fused_two_pass" = 2 (A/B switch; default 1)
      "conv_wave2048"    1: fft_convolve_frames_batch of 2048-point cores by one wavefront per frame; 12-14 % slower than
                         the workgroup plan, default 0
+     "table_cache_mib"  device memory (MiB) that tables of destroyed plans may keep for re-use (default 64; 0 = none)
    Returns 0, or FFT_GPU_EINVAL for an unknown name / a value out of range. */
 int fft_gpu_set_option (const char* name, long value);
 /* Current value of an option ("fused_two_pass", "fused_min_batch", "fused_lag", "fused_slots", "split16384", "split8192",
