@@ -264,6 +264,11 @@ __global__ __launch_bounds__ (256, CFFT_GROUP_MIN_WG) void group256_kernel (cons
     const int kbl = tid & 15, tb = tid >> 4;
     const unsigned two_slots = form & 1u;
     const bool early = (form & 2u) != 0, w0late = (form & 4u) != 0, spread = (form & 8u) != 0;
+#if CFFT_GROUP_WAVE_FLAGS
+    const bool incr = false;
+#else
+    const bool incr = (form & 16u) != 0;
+#endif
     const unsigned spin_limit = group_spin_limit (force_solo);
 #if CFFT_GROUP_EXPERIMENT
     const unsigned dbg = (force_solo >> 8) & 255u;
@@ -394,7 +399,38 @@ __global__ __launch_bounds__ (256, CFFT_GROUP_MIN_WG) void group256_kernel (cons
             if (tid == 0)
                 flag_store (&af[tile], k + 1u);
             CFFT_GROUP_STAMP (5)
-            if (tid < 64 && ! CFFT_GROUP_DBG (1u))
+            const float2* __restrict__ srcb_i = slot + tile * 256 + tid;
+            if (incr)
+            {
+                // Round 5 (form bit 4): the hand-off member by member.  Block s of this member's pass-B tile is member s's pass-A
+                // tile, so its load depends on member s's flag alone: every wave polls the group's 16 flags for itself (one 64-byte
+                // line, lane l word l & 15) and requests the blocks of the members that have published, until it has all 16 -- the
+                // slowest member then delays one sixteenth of the tile instead of all of it.  (Vector memory operations return in
+                // issue order, so a poll issued behind block loads comes back behind them: the loop cannot spin faster than the L2.)
+                unsigned done = 0, n = 0;
+                while (done != 0xFFFFu)
+                {
+                    const unsigned fl = ld_relaxed (af + (tid & 15));
+                    const unsigned ready = (unsigned) __ballot (fl >= k + 1u) & 0xFFFFu;
+                    const unsigned fresh = ready & ~done;
+#pragma unroll
+                    for (int s = 0; s < 16; ++s)
+                        if ((fresh >> s) & 1u)
+                            v[s] = gload_l2 (&srcb_i[s * 16 * 256]);
+                    done |= fresh;
+                    if (fresh == 0)
+                    {
+                        __builtin_amdgcn_s_sleep (1);
+                        if (++n > spin_limit)
+                        {
+                            if ((tid & 63) == 0)
+                                group_fail (st, host_err, seq, 1u);
+                            break;
+                        }
+                    }
+                }
+            }
+            else if (tid < 64 && ! CFFT_GROUP_DBG (1u))
             {
                 unsigned n = 0;
                 while (! flags_reached (af, k + 1u, tid))
@@ -409,12 +445,13 @@ __global__ __launch_bounds__ (256, CFFT_GROUP_MIN_WG) void group256_kernel (cons
                 }
             }
             CFFT_GROUP_STAMP (6)
-            __syncthreads();
+            if (! incr)
+                __syncthreads();
             CFFT_GROUP_STAMP (7)
 #endif
             // ---- pass B: rows [16 tile, 16 tile + 16) of the slot -> transposed store into frame f
             const float2* __restrict__ srcb = slot + tile * 256 + tid;
-            if (! CFFT_GROUP_DBG (4u))
+            if (! CFFT_GROUP_DBG (4u) && ! incr)
             {
 #pragma unroll
                 for (int s = 0; s < 16; ++s)

@@ -563,7 +563,9 @@ hipError_t launch_group_c2c (int n1, int n2, bool inverse, const float2* in, flo
     static const int pf_env = std::getenv ("CHOWDSP_FFT_GROUP_PREFETCH") != nullptr ? std::atoi (std::getenv ("CHOWDSP_FFT_GROUP_PREFETCH")) : -1;
     static const unsigned slots_flag = (std::getenv ("CHOWDSP_FFT_GROUP_SLOTS") != nullptr && std::atoi (std::getenv ("CHOWDSP_FFT_GROUP_SLOTS")) == 2) ? 1u : 0u;
     const int pf = pf_env >= 0 ? pf_env : 3; // (round 4: the backward instantiation no longer waits for its prefetch at the request, so it takes the spread form too)
-    const unsigned two_slots = slots_flag | (pf == 1 ? 2u : (pf == 2 ? 6u : (pf == 3 ? 8u : 0u)));
+    // round 5 A/B: CHOWDSP_FFT_GROUP_INCR = 1: the hand-off member by member (every wave requests a producer's block as that producer's flag comes up)
+    static const unsigned incr_flag = (std::getenv ("CHOWDSP_FFT_GROUP_INCR") != nullptr && std::atoi (std::getenv ("CHOWDSP_FFT_GROUP_INCR")) != 0) ? 16u : 0u;
+    const unsigned two_slots = slots_flag | incr_flag | (pf == 1 ? 2u : (pf == 2 ? 6u : (pf == 3 ? 8u : 0u)));
     unsigned force_solo = (unsigned) g_group_force_solo.load() | ((unsigned) g_group_spin_limit.load() << 16);
     const unsigned reg_polls = (unsigned) g_group_reg_polls.load();
 #if CFFT_GROUP_EXPERIMENT
