@@ -35,6 +35,10 @@ __global__ __launch_bounds__ (P::T* FPB) void c2c_kernel (const float2* __restri
     const unsigned team_in = (unsigned) team * in_stride, team_out = (unsigned) team * out_stride;
     constexpr bool STAGED = (P::T < 16);
     float2* stage = smem + FPB * LdsFrame<P::N>::floats2; // staging area (STAGED only): FPB frames, natural order
+    StagePrefetch<P::T * FPB, FPB * P::N, P::N> ahead; // (STAGED only) the next group's operands, requested a group ahead
+    if constexpr (STAGED && kStagedPrefetch<P::N, false>)
+        if (blockIdx.x < ngroups)
+            ahead.fetch (in + (size_t) blockIdx.x * FPB * in_stride, in_stride, min ((unsigned) FPB, batch - blockIdx.x * FPB) * P::N, tid);
     for (unsigned g = blockIdx.x; g < ngroups; g += gridDim.x)
     {
         const bool active = g * FPB + team < batch; // uniform per team
@@ -47,7 +51,15 @@ __global__ __launch_bounds__ (P::T* FPB) void c2c_kernel (const float2* __restri
         if constexpr (STAGED)
         {
             __syncthreads(); // previous group's copy-out has read the staging area
-            stage_in_strided<P::T * FPB, FPB * P::N, P::N> (src, in_stride, stage, valid, tid);
+            if constexpr (kStagedPrefetch<P::N, false>)
+            {
+                ahead.put (stage, tid);
+                const unsigned gn = g + gridDim.x;
+                if (gn < ngroups)
+                    ahead.fetch (in + (size_t) gn * FPB * in_stride, in_stride, min ((unsigned) FPB, batch - gn * FPB) * P::N, tid);
+            }
+            else
+                stage_in_strided<P::T * FPB, FPB * P::N, P::N> (src, in_stride, stage, valid, tid);
             __syncthreads();
 #pragma unroll
             for (int s = 0; s < P::R; ++s)

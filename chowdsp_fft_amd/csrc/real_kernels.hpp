@@ -114,6 +114,10 @@ __global__ __launch_bounds__ (P::T* FPB) void r2c_kernel (const float2* __restri
     const unsigned team_in = (unsigned) team * in_stride, team_out = (unsigned) team * out_stride; // in global memory
     constexpr bool STAGED = (P::T <= CFFT_REAL_STAGED_MAX_T); // narrow teams: whole-workgroup coalesced copies through LDS (plans.hpp)
     float2* stage = smem + FPB * LdsFrame<M>::floats2;
+    StagePrefetch<P::T * FPB, FPB * M, M> ahead; // (STAGED only) the next group's operands, requested a group ahead (stockham.hpp)
+    if constexpr (STAGED && kStagedPrefetch<M, true>)
+        if (blockIdx.x < ngroups)
+            ahead.fetch (in + (size_t) blockIdx.x * FPB * in_stride, in_stride, min ((unsigned) FPB, batch - blockIdx.x * FPB) * M, tid);
     for (unsigned g = blockIdx.x; g < ngroups; g += gridDim.x)
     {
         const bool active = g * FPB + team < batch;
@@ -125,7 +129,15 @@ __global__ __launch_bounds__ (P::T* FPB) void r2c_kernel (const float2* __restri
         if constexpr (STAGED)
         {
             __syncthreads();
-            stage_in_strided<P::T * FPB, FPB * M, M> (src, in_stride, stage, valid, tid);
+            if constexpr (kStagedPrefetch<M, true>)
+            {
+                ahead.put (stage, tid);
+                const unsigned gn = g + gridDim.x;
+                if (gn < ngroups)
+                    ahead.fetch (in + (size_t) gn * FPB * in_stride, in_stride, min ((unsigned) FPB, batch - gn * FPB) * M, tid);
+            }
+            else
+                stage_in_strided<P::T * FPB, FPB * M, M> (src, in_stride, stage, valid, tid);
             __syncthreads();
 #pragma unroll
             for (int s = 0; s < P::R; ++s)
@@ -412,6 +424,10 @@ __global__ __launch_bounds__ (P::T* FPB, (P::N == 512 && CFFT_C2R512_WAVES5) ? 5
     const unsigned team_in = (unsigned) team * in_stride, team_out = (unsigned) team * out_stride; // in global memory
     constexpr bool STAGED = (P::T <= CFFT_REAL_STAGED_MAX_T); // narrow teams: whole-workgroup coalesced copies through LDS (plans.hpp)
     float2* stage = smem + FPB * LdsFrame<M>::floats2;
+    StagePrefetch<P::T * FPB, FPB * M, M> ahead; // (STAGED only) the next group's operands, requested a group ahead (stockham.hpp)
+    if constexpr (STAGED && kStagedPrefetch<M, true>)
+        if (blockIdx.x < ngroups)
+            ahead.fetch (in + (size_t) blockIdx.x * FPB * in_stride, in_stride, min ((unsigned) FPB, batch - blockIdx.x * FPB) * M, tid);
     for (unsigned g = blockIdx.x; g < ngroups; g += gridDim.x)
     {
         const bool active = g * FPB + team < batch;
@@ -421,7 +437,15 @@ __global__ __launch_bounds__ (P::T* FPB, (P::N == 512 && CFFT_C2R512_WAVES5) ? 5
         if constexpr (STAGED)
         {
             __syncthreads();
-            stage_in_strided<P::T * FPB, FPB * M, M> (src, in_stride, stage, valid, tid);
+            if constexpr (kStagedPrefetch<M, true>)
+            {
+                ahead.put (stage, tid);
+                const unsigned gn = g + gridDim.x;
+                if (gn < ngroups)
+                    ahead.fetch (in + (size_t) gn * FPB * in_stride, in_stride, min ((unsigned) FPB, batch - gn * FPB) * M, tid);
+            }
+            else
+                stage_in_strided<P::T * FPB, FPB * M, M> (src, in_stride, stage, valid, tid);
             __syncthreads();
         }
 

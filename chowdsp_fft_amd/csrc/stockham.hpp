@@ -421,6 +421,55 @@ __device__ __forceinline__ void stage_out_strided (float2* __restrict__ dst, uns
     }
 }
 
+// ---- round 5: the staged copy-in one group AHEAD --------------------------------------------------------------------------
+// The staged kernels ran copy-in -> barrier -> stages -> barrier -> copy-out per group: while a workgroup computes it has nothing
+// in flight, and the narrow plans (complex N <= 64, real N <= 512) sat at a plain copy's rate (0.64-0.66 of 8 TB/s) next to 0.70-0.74
+// for their neighbours with direct accesses.  Here the NEXT group's 16-byte loads are issued into registers (K = ELEMS / 2 / THREADS
+// float4 per work-item, 2-4 for these plans) right after this group's operands have been put into the staging area, fly during
+// the stages and the copy-out, and are written to LDS at the top of the next iteration.  Same accesses, same barriers.
+// Per plan, from same-box A/B (profiles/r05_staged_prefetch_ab.txt, 512 MiB batches, two rounds): complex N = 32 +2.5 %, real N = 64 / 128 /
+// 256 / 512 +4.8 / +2.7 / +2.8 / +1.6 %; complex N = 16 / 64 and real N = 32 lose 1-2.5 % (their groups are 8-16 KiB: the extra
+// registers and the second wait cost more than the latency they hide) and keep the plain copy-in.
+// CFFT_STAGED_PREFETCH: 2 (default) = that selection, 1 = every staged plan, 0 = none.
+#ifndef CFFT_STAGED_PREFETCH
+#define CFFT_STAGED_PREFETCH 2
+#endif
+template <int N, bool REAL>
+static constexpr bool kStagedPrefetch = CFFT_STAGED_PREFETCH == 1 || (CFFT_STAGED_PREFETCH == 2 && (REAL ? N >= 32 : N == 32)); // N: the plan's complex length
+template <int THREADS, int ELEMS, int N>
+struct StagePrefetch
+{
+    static constexpr int K = (ELEMS / 2 + THREADS - 1) / THREADS;
+    float4 r[K];
+    __device__ __forceinline__ void fetch (const float2* __restrict__ src, unsigned stride, unsigned valid, int tid)
+    {
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+        {
+            const unsigned e = (unsigned) tid + (unsigned) j * THREADS;
+            const unsigned e2 = 2u * e;
+            if (stride == (unsigned) N)
+                r[j] = (e < (unsigned) (ELEMS / 2) && e2 < valid) ? gload4 (reinterpret_cast<const float4*> (src) + e) : make_float4 (0.f, 0.f, 0.f, 0.f);
+            else
+            {
+                const unsigned f = e2 / (unsigned) N, o = e2 % (unsigned) N;
+                r[j] = (e < (unsigned) (ELEMS / 2) && e2 < valid) ? gload4 (reinterpret_cast<const float4*> (src + (size_t) f * stride + o)) : make_float4 (0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+    __device__ __forceinline__ void put (float2* __restrict__ stage, int tid) const
+    {
+        float4* __restrict__ d4 = reinterpret_cast<float4*> (stage);
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+        {
+            const unsigned e = (unsigned) tid + (unsigned) j * THREADS;
+            if (e < (unsigned) (ELEMS / 2))
+                d4[e] = r[j];
+        }
+    }
+};
+
 // Stages 0..NS-1 on registers v (already loaded in input_index order); leaves the result in
 // output_index order.  `lds` is this team's private LDS image.
 // ---- the exchange of the two shortest plans inside the wavefront (round 4 A/B, CFFT_DPP_QUAD) -----------------------------
