@@ -477,7 +477,7 @@ int big_c2c_chunked (Setup* s, int nc, bool inverse, const float2* in, float2* o
         }
         return cf::FFT_GPU_OK;
     }
-    if (! mixed && pair == 0 && mul_h == nullptr && fused_form() == 2 && s->tables->fast_n1 > 0 && groupfast_supported (n1, n2) && g_group_fast.load() != 0
+    if (! mixed && pair == 0 && mul_h == nullptr && fused_form() == 2 && s->tables->fast_n1 > 0 && groupfast_supported (n1, n2) && g_group_fast.load() != 0 && get_group_handoff() == 0
         && batch >= std::max<size_t> (1, fused_min_batch() / 4))
     {
         // N = 2^17 / 2^18 on the register-direct tiles: one launch, static groups, one workgroup per CU (group_fast_kernels.hpp)
@@ -1635,6 +1635,8 @@ int fft_gpu_set_option (const char* name, long value)
         g_group_real = value != 0 ? 1 : 0;
     else if (std::strcmp (name, "huge_columns") == 0)
         g_huge_columns = value != 0 ? 1 : 0;
+    else if (std::strcmp (name, "group_handoff") == 0 && (value == 0 || value == 1))
+        set_group_handoff ((int) value); // 1: the hand-off form the CDNA4 guide lists, for the one-launch forms that offer it (chowdsp_fft_gpu.h)
     else if (std::strcmp (name, "table_cache_mib") == 0 && value >= 0 && value <= (1 << 20))
         set_table_cache_limit ((size_t) value << 20); // device tables of destroyed plans kept for re-use: at most this much
     else
@@ -1680,6 +1682,8 @@ long fft_gpu_get_option (const char* name)
         return g_huge_columns.load();
     if (std::strcmp (name, "table_cache_mib") == 0)
         return (long) (table_cache_limit() >> 20);
+    if (std::strcmp (name, "group_handoff") == 0)
+        return get_group_handoff();
     return -1;
 }
 
@@ -1746,7 +1750,7 @@ size_t fft_gpu_workspace_bytes (void* setup, size_t batch)
     if (s->transform == FFT_COMPLEX && fused_enabled() && fused_supported (n1, n2) && batch >= fused_min_batch())
         return (fused_form() == 2 ? group_workspace_bytes() : fused_workspace_bytes (complex_len (s), fused_slots())) + std::max (fused_state_bytes(), group_state_bytes());
     // (the same conditions as big_c2c_chunked's register-direct group branch, N = 2^17 / 2^18)
-    if (s->transform == FFT_COMPLEX && s->tables->mixed_n2 == 0 && fused_form() == 2 && s->tables->fast_n1 > 0 && groupfast_supported (n1, n2) && g_group_fast.load() != 0
+    if (s->transform == FFT_COMPLEX && s->tables->mixed_n2 == 0 && fused_form() == 2 && s->tables->fast_n1 > 0 && groupfast_supported (n1, n2) && g_group_fast.load() != 0 && get_group_handoff() == 0
         && batch >= std::max<size_t> (1, fused_min_batch() / 4))
         return groupfast_workspace_bytes (n1, n2) + std::max (fused_state_bytes(), group_state_bytes());
     size_t chunk = workspace_cap() / (size_t) lane_count() / frame_bytes;
@@ -1899,7 +1903,7 @@ int fft_convolve_frames_batch (void* setup, const float* x, const float* dft_fil
         }
         return FFT_GPU_OK;
     }
-    if (s->transform == FFT_COMPLEX && nc == 65536 && t->fast_n1 == 0 && t->mixed_n2 == 0 && fused_form() == 2 && batch >= fused_min_batch() && g_fused_conv_group.load() != 0)
+    if (s->transform == FFT_COMPLEX && nc == 65536 && t->fast_n1 == 0 && t->mixed_n2 == 0 && fused_form() == 2 && batch >= fused_min_batch() && g_fused_conv_group.load() != 0 && get_group_handoff() == 0)
     {
         // N = 65536 complex: both transforms and the product in ONE launch on the static groups (group_twopass_kernels.hpp)
         std::lock_guard<std::recursive_mutex> lock (g_ws_mutex);

@@ -297,6 +297,24 @@ __device__ __forceinline__ void flag_store (unsigned* p, unsigned v)
     __hip_atomic_store (p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // a plain store, kept from being merged or reordered by the compiler
 }
 
+// ---- the hand-off in the form the CDNA4 guide LISTS (option "group_handoff" = 1; MI355X_MICROARCH.md, "Hand-offs measured with sc1 loads in
+// place of the acquire", first row): every store of the handed-off bytes `sc1` (write-through: the line leaves this XCD's L2), every storing
+// wave's s_waitcnt vmcnt(0), the workgroup's barrier, ONE lane's `sc1` flag store; the consumer's `sc1` poll, a barrier, `sc1` loads; one
+// workgroup per CU.  The default (fast) form differs in three cells: plain payload and flag stores (the lines STAY in the L2 the same-XCD
+// consumers read them from) and two workgroups per CU.  `wt` is uniform over the launch.
+__device__ __forceinline__ void flag_store_as (unsigned* p, unsigned v, bool wt)
+{
+    if (wt)
+        __hip_atomic_store (p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // global_store_dword ... sc1
+    else
+        flag_store (p, v);
+}
+__device__ __forceinline__ void slot_store_wt (float2* p, float2 v)
+{
+    const unsigned long long w = (unsigned long long) __float_as_uint (v.x) | ((unsigned long long) __float_as_uint (v.y) << 32);
+    __hip_atomic_store (reinterpret_cast<unsigned long long*> (p), w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // global_store_dwordx2 ... sc1
+}
+
 template <bool INV>
 __global__ __launch_bounds__ (256) void fused256_kernel (const float2* __restrict__ in,
                                                         float2* __restrict__ work, // [kFusedMaxXcc][slots][65536]

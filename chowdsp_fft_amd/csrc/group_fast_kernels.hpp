@@ -84,7 +84,7 @@ __global__ __launch_bounds__ (256, 1) void groupfast_kernel (const float2* __res
     float* __restrict__ plane_a = gf_plane + (size_t) sub_a * GF::plane_a;
     float* __restrict__ plane_b = gf_plane + (size_t) sub_b * GF::plane_b;
     const unsigned spin_limit = group_spin_limit (force_solo);
-    force_solo &= 255u;
+    force_solo &= 1u; // (bit 1, the listed hand-off form, is not offered by this kernel: capi.cpp runs two launches instead)
     if (tid0 == 0)
         group_register (st, info, reg_polls, force_solo, (unsigned) GF::M);
     __syncthreads();

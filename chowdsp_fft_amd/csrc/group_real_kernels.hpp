@@ -83,8 +83,16 @@ __device__ __forceinline__ float2 gr_merge (float2 A, float2 Xp, float2 w)
 
 // ---- the building blocks, for member / tile t of one frame (l = tid & 15: lane along the tile's 16 strided indices, m = tid >> 4) ----
 // the pass-A results (times the inter-pass twiddles) into the slot, 16 x 16 block order
-__device__ __forceinline__ void gr_slot_store (const float2 (&v)[16], const float2 (&bw)[16], float2* __restrict__ slot, size_t base)
+__device__ __forceinline__ void gr_slot_store (const float2 (&v)[16], const float2 (&bw)[16], float2* __restrict__ slot, size_t base, bool wt = false)
 {
+    if (wt)
+    {
+        // option "group_handoff" = 1: sc1 stores (written through), the listed hand-off form (fused_twopass_kernels.hpp flag_store_as)
+#pragma unroll
+        for (int b = 0; b < 16; ++b)
+            slot_store_wt (&slot[base + b * 256], cmul (v[b], bw[b]));
+        return;
+    }
 #pragma unroll
     for (int b = 0; b < 16; ++b)
         slot[base + b * 256] = cmul (v[b], bw[b]); // plain store: stays in this XCD's L2
@@ -108,7 +116,7 @@ constexpr int kGrHGroup = CFFT_GR_HGROUP;
 template <bool MULH, class Hook>
 __device__ __forceinline__ void gr_fwd_pass_b (float2 (&v)[16], unsigned t, float2 wthr, float2* __restrict__ dstf, unsigned* bflag, unsigned bval, Hook hook,
                                                float2* __restrict__ smem, const float2* __restrict__ tw1, float2 (*spec)[256], int tid,
-                                               const float2* __restrict__ H = nullptr, float scaling = 1.f)
+                                               const float2* __restrict__ H = nullptr, float scaling = 1.f, bool wt = false)
 {
     const int l = tid & 15, m = tid >> 4;
     const unsigned kb = gr_index (t, l);
@@ -119,7 +127,7 @@ __device__ __forceinline__ void gr_fwd_pass_b (float2 (&v)[16], unsigned t, floa
     hook (1);
     __syncthreads(); // the previous exchange's reads are finished; every wave's pass-B loads have returned
     if (tid == 0 && bflag != nullptr)
-        flag_store (bflag, bval);
+        flag_store_as (bflag, bval, wt);
 #pragma unroll
     for (int b = 0; b < 16; ++b)
         smem[l * kFS256 + 17 * m + b] = v[b];
@@ -249,7 +257,7 @@ __device__ __forceinline__ void gr_inv_load_a (float (&re)[16], float (&im)[16],
 }
 // ... pair stage (merge) + swap for the backward transform + complex pass A into the slot
 __device__ __forceinline__ void gr_inv_pass_a (const float (&re)[16], const float (&im)[16], unsigned t, float2 wthr, const float2 (&bw)[16], float2* __restrict__ slot, size_t base,
-                                               float2* __restrict__ smem, const float2* __restrict__ tw1, float2 (*spec)[256], int tid)
+                                               float2* __restrict__ smem, const float2* __restrict__ tw1, float2 (*spec)[256], int tid, bool wt = false)
 {
     const int l = tid & 15, m = tid >> 4;
     const int mr = gr_reversed (t, l) ? 15 - m : m;
@@ -311,7 +319,7 @@ __device__ __forceinline__ void gr_inv_pass_a (const float (&re)[16], const floa
     for (int a = 1; a < 16; ++a)
         v[a] = cmul (v[a], tw1[(a - 1) * 16 + l]);
     fft_reg<16> (v);
-    gr_slot_store (v, bw, slot, base);
+    gr_slot_store (v, bw, slot, base, wt);
 }
 // slot position of the pass-A results of stage-1 role (column gr_index (t, m), butterfly l): base + 256 b
 __device__ __forceinline__ size_t gr_inv_base_a (unsigned t, int tid)
@@ -323,14 +331,14 @@ __device__ __forceinline__ size_t gr_inv_base_a (unsigned t, int tid)
 // BACKWARD pass B (complex, rows [16 t, 16 t + 16) of the slot, already in v) with the re <-> im swap on the way out
 template <class Hook>
 __device__ __forceinline__ void gr_inv_pass_b (float2 (&v)[16], unsigned t, float2* __restrict__ dstf, unsigned* bflag, unsigned bval, Hook hook,
-                                               float2* __restrict__ smem, const float2* __restrict__ tw1, int tid)
+                                               float2* __restrict__ smem, const float2* __restrict__ tw1, int tid, bool wt = false)
 {
     const int l = tid & 15, m = tid >> 4;
     fft_reg<16> (v);
     hook (1);
     __syncthreads();
     if (tid == 0 && bflag != nullptr)
-        flag_store (bflag, bval);
+        flag_store_as (bflag, bval, wt);
 #pragma unroll
     for (int b = 0; b < 16; ++b)
         smem[l * kFS256 + 17 * m + b] = v[b];
@@ -389,7 +397,8 @@ __global__ __launch_bounds__ (256, 2) void group256_real_kernel (const float2* _
     const int l = tid & 15, m = tid >> 4; // lanes run along the 16 strided indices of a tile; m = team member / butterfly
     const bool spread = (form & 8u) != 0;
     const unsigned spin_limit = group_spin_limit (force_solo);
-    force_solo &= 255u;
+    const bool wt = (force_solo & 2u) != 0; // option "group_handoff" = 1: the listed hand-off form (fused_twopass_kernels.hpp flag_store_as)
+    force_solo &= 1u;
 
     if (tid < 240)
         tw1[tid] = stage_tw[Plan256::tw_offset (1) + tid];
@@ -452,13 +461,13 @@ __global__ __launch_bounds__ (256, 2) void group256_real_kernel (const float2* _
                 }
             }
             if constexpr (INV)
-                gr_inv_pass_a (nre, nim, tile, wthr, bw, slot, base_a, smem, tw1, spec, tid);
+                gr_inv_pass_a (nre, nim, tile, wthr, bw, slot, base_a, smem, tw1, spec, tid, wt);
             else
-                gr_slot_store (va, bw, slot, base_a);
+                gr_slot_store (va, bw, slot, base_a, wt);
             asm volatile ("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's stores are in L2
             __syncthreads();
             if (tid == 0)
-                flag_store (&af[tile], k + 1u);
+                flag_store_as (&af[tile], k + 1u, wt);
             if (tid < 64)
             {
                 unsigned n = 0;
@@ -521,9 +530,9 @@ __global__ __launch_bounds__ (256, 2) void group256_real_kernel (const float2* _
                 CFFT_PHASE_FENCE();
             };
             if constexpr (INV)
-                gr_inv_pass_b (v, tile, out + (size_t) f * out_stride, &bf[tile], k + 1u, hook, smem, tw1, tid);
+                gr_inv_pass_b (v, tile, out + (size_t) f * out_stride, &bf[tile], k + 1u, hook, smem, tw1, tid, wt);
             else
-                gr_fwd_pass_b<MULH> (v, tile, wthr, out + (size_t) f * out_stride, &bf[tile], k + 1u, hook, smem, tw1, spec, tid, H, scaling);
+                gr_fwd_pass_b<MULH> (v, tile, wthr, out + (size_t) f * out_stride, &bf[tile], k + 1u, hook, smem, tw1, spec, tid, H, scaling, wt);
 #undef CFFT_GR_PART
         }
         return;

@@ -273,7 +273,8 @@ __global__ __launch_bounds__ (256, CFFT_GROUP_MIN_WG) void group256_kernel (cons
 #if CFFT_GROUP_EXPERIMENT
     const unsigned dbg = (force_solo >> 8) & 255u;
 #endif
-    force_solo &= 255u;
+    const bool wt = (force_solo & 2u) != 0; // option "group_handoff" = 1: the listed hand-off form (fused_twopass_kernels.hpp flag_store_as)
+    force_solo &= 1u;
 
     if (tid < 240)
         tw1[tid] = stage_tw[Plan256::tw_offset (1) + tid];
@@ -351,9 +352,18 @@ __global__ __launch_bounds__ (256, CFFT_GROUP_MIN_WG) void group256_kernel (cons
             }
             if (! CFFT_GROUP_DBG (2u))
             {
+                if (wt)
+                {
 #pragma unroll
-                for (int b = 0; b < 16; ++b)
-                    slot[base_a + b * 256] = cmul (v[b], bw[b]); // plain store: stays in this XCD's L2
+                    for (int b = 0; b < 16; ++b)
+                        slot_store_wt (&slot[base_a + b * 256], cmul (v[b], bw[b])); // sc1: written through
+                }
+                else
+                {
+#pragma unroll
+                    for (int b = 0; b < 16; ++b)
+                        slot[base_a + b * 256] = cmul (v[b], bw[b]); // plain store: stays in this XCD's L2
+                }
             }
             CFFT_GROUP_STAMP (3)
             // The next frame's pass-A operands.  `early`: requested HERE, in front of the hand-off: the wait for the rest of the
@@ -397,7 +407,7 @@ __global__ __launch_bounds__ (256, CFFT_GROUP_MIN_WG) void group256_kernel (cons
 #else
             __syncthreads();
             if (tid == 0)
-                flag_store (&af[tile], k + 1u);
+                flag_store_as (&af[tile], k + 1u, wt);
             CFFT_GROUP_STAMP (5)
             const float2* __restrict__ srcb_i = slot + tile * 256 + tid;
             if (incr)
@@ -488,7 +498,7 @@ __global__ __launch_bounds__ (256, CFFT_GROUP_MIN_WG) void group256_kernel (cons
             CFFT_PHASE_FENCE();
             __syncthreads(); // the previous exchange's reads are finished; every wave's pass-B loads have returned
             if (tid == 0 && two_slots == 0)
-                flag_store (&bf[tile], k + 1u);
+                flag_store_as (&bf[tile], k + 1u, wt);
 #pragma unroll
             for (int b = 0; b < 16; ++b)
                 smem[kbl * kFS256 + 17 * tb + b] = v[b];
@@ -611,7 +621,7 @@ __global__ __launch_bounds__ (256, 2) void group256_conv_kernel (const float2* _
     const int tid = threadIdx.x;
     const int lo = tid & 15, hi = tid >> 4;
     const unsigned spin_limit = group_spin_limit (force_solo);
-    force_solo &= 255u;
+    force_solo &= 1u; // (bit 1, the listed hand-off form, is not offered by this kernel: capi.cpp runs three launches instead)
     if (tid < 240)
         tw1[tid] = stage_tw[Plan256::tw_offset (1) + tid];
     if (tid == 0)

@@ -16,11 +16,20 @@ constexpr size_t kGroupRealLds = (size_t) 16 * TileFrame<256>::stride * sizeof (
 
 unsigned group_real_grid (bool inverse)
 {
-    auto k = inverse ? group256_real_kernel<true, false> : group256_real_kernel<false, true>; // (the forward kernel with the product: the larger one)
+    // every workgroup of the grid must be resident at once: forward launches take either instantiation (with / without the product), so the
+    // grid is sized for the one with the LOWER occupancy (register allocation is not monotonic in what a kernel does)
+    auto k = inverse ? group256_real_kernel<true, false> : group256_real_kernel<false, true>;
     DeviceInfo dev;
     if (! current_device_info (dev))
         return 0;
-    const int per_cu_x10 = std::min (group_wg_per_cu_tenths(), 10 * blocks_per_cu_cached ((const void*) k, 256, kGroupRealLds));
+    if (! inverse)
+    {
+        const int plain = blocks_per_cu_cached ((const void*) group256_real_kernel<false, false>, 256, group_lds_bytes (kGroupRealLds));
+        const int mulh = blocks_per_cu_cached ((const void*) k, 256, group_lds_bytes (kGroupRealLds));
+        const int per_cu_x10 = std::min (get_group_handoff() != 0 ? 10 : group_wg_per_cu_tenths(), 10 * std::min (plain, mulh));
+        return (unsigned) (dev.num_cus * std::max (per_cu_x10, 0) / 10);
+    }
+    const int per_cu_x10 = std::min (get_group_handoff() != 0 ? 10 : group_wg_per_cu_tenths(), 10 * blocks_per_cu_cached ((const void*) k, 256, group_lds_bytes (kGroupRealLds)));
     return (unsigned) (dev.num_cus * std::max (per_cu_x10, 0) / 10);
 }
 
@@ -47,7 +56,8 @@ hipError_t launch_group_real (bool inverse, const float2* in, float2* work, floa
     const unsigned form = (pf_env >= 0 ? pf_env : 3) == 3 ? 8u : 0u;
     // (the product with a packed filter spectrum rides on the FORWARD transform's stores: fft_convolve_frames_batch)
     auto k = inverse ? group256_real_kernel<true, false> : (mul_h != nullptr ? group256_real_kernel<false, true> : group256_real_kernel<false, false>);
-    hipLaunchKernelGGL (k, dim3 (grid), dim3 (256), kGroupRealLds, stream, in, work, out, stage_tw, big_tw, real_tw, (GroupState*) state, host_err, (unsigned) batch, in_stride, out_stride, seq, (unsigned) reg_polls, (unsigned) force_solo, form, mul_h, mul_scale);
+    (void) blocks_per_cu_cached ((const void*) k, 256, group_lds_bytes (kGroupRealLds)); // (raises the launched instantiation's dynamic-LDS cap where the listed form asks for 84 KiB)
+    hipLaunchKernelGGL (k, dim3 (grid), dim3 (256), group_lds_bytes (kGroupRealLds), stream, in, work, out, stage_tw, big_tw, real_tw, (GroupState*) state, host_err, (unsigned) batch, in_stride, out_stride, seq, (unsigned) reg_polls, (unsigned) force_solo, form, mul_h, mul_scale);
     return hipGetLastError();
 }
 } // namespace cfft::host

@@ -506,16 +506,28 @@ std::atomic<int> g_group_force_solo { 0 }, g_group_reg_polls { 200 };
 // developer option "group_spin_limit": polls after which a hand-off wait gives up (0 = the built-in limit, a fraction of a
 // second).  Tests set 1: the waits DO run out, the launch reports it, the output is invalid -- the failure path end to end.
 std::atomic<int> g_group_spin_limit { 0 };
+// option "group_handoff": 0 (default) the fast hand-off (plain payload and flag stores, two workgroups per CU), 1 the form the CDNA4
+// guide lists (sc1 payload and flag stores, ONE workgroup per CU: fused_twopass_kernels.hpp flag_store_as).  One workgroup per CU is
+// enforced, not hoped for: the launch asks for more than half of the CU's LDS.
+std::atomic<int> g_group_handoff { 0 };
 unsigned group_grid (bool inverse)
 {
     auto k = inverse ? group256_kernel<true> : group256_kernel<false>;
     DeviceInfo dev;
     if (! current_device_info (dev))
         return 0;
-    const int per_cu_x10 = std::min (group_wg_per_cu_x10(), 10 * blocks_per_cu_cached ((const void*) k, 256, kGroupLds));
+    const bool listed = g_group_handoff.load() != 0;
+    const int per_cu_x10 = std::min (listed ? 10 : group_wg_per_cu_x10(), 10 * blocks_per_cu_cached ((const void*) k, 256, group_lds_bytes (kGroupLds)));
     return (unsigned) (dev.num_cus * std::max (per_cu_x10, 0) / 10);
 }
 } // namespace
+void set_group_handoff (int listed) { g_group_handoff = listed != 0 ? 1 : 0; }
+int get_group_handoff() { return g_group_handoff.load(); }
+size_t group_lds_bytes (size_t kernel_lds)
+{
+    // the listed form: more than half of the CU's 160 KiB, so that a second workgroup cannot become resident on the CU
+    return g_group_handoff.load() != 0 ? std::max<size_t> (kernel_lds, (size_t) 84 * 1024) : kernel_lds;
+}
 void set_group_options (int force_solo, int reg_polls)
 {
     if (force_solo >= 0)
@@ -527,8 +539,8 @@ void set_group_spin_limit (int polls) { g_group_spin_limit = (polls > 0 && polls
 int get_group_spin_limit() { return g_group_spin_limit.load(); }
 void get_group_options (int& force_solo, int& reg_polls)
 {
-    // (the kernels' `force_solo` argument: bit 0 the mode, bits 16.. the spin limit -- group_twopass_kernels.hpp group_spin_limit)
-    force_solo = g_group_force_solo.load() | (g_group_spin_limit.load() << 16);
+    // (the kernels' `force_solo` argument: bit 0 the mode, bit 1 the listed hand-off form, bits 16.. the spin limit -- group_twopass_kernels.hpp group_spin_limit)
+    force_solo = g_group_force_solo.load() | (g_group_handoff.load() != 0 ? 2 : 0) | (g_group_spin_limit.load() << 16);
     reg_polls = g_group_reg_polls.load();
 }
 int group_wg_per_cu_tenths() { return group_wg_per_cu_x10(); }
@@ -566,13 +578,13 @@ hipError_t launch_group_c2c (int n1, int n2, bool inverse, const float2* in, flo
     // round 5 A/B: CHOWDSP_FFT_GROUP_INCR = 1: the hand-off member by member (every wave requests a producer's block as that producer's flag comes up)
     static const unsigned incr_flag = (std::getenv ("CHOWDSP_FFT_GROUP_INCR") != nullptr && std::atoi (std::getenv ("CHOWDSP_FFT_GROUP_INCR")) != 0) ? 16u : 0u;
     const unsigned two_slots = slots_flag | incr_flag | (pf == 1 ? 2u : (pf == 2 ? 6u : (pf == 3 ? 8u : 0u)));
-    unsigned force_solo = (unsigned) g_group_force_solo.load() | ((unsigned) g_group_spin_limit.load() << 16);
+    unsigned force_solo = (unsigned) g_group_force_solo.load() | (g_group_handoff.load() != 0 ? 2u : 0u) | ((unsigned) g_group_spin_limit.load() << 16);
     const unsigned reg_polls = (unsigned) g_group_reg_polls.load();
 #if CFFT_GROUP_EXPERIMENT
     static const unsigned dbg = std::getenv ("CHOWDSP_FFT_GROUP_DBG") != nullptr ? (unsigned) std::atoi (std::getenv ("CHOWDSP_FFT_GROUP_DBG")) : 0u;
     force_solo |= dbg << 8;
 #endif
-    hipLaunchKernelGGL (k, dim3 (grid), dim3 (256), kGroupLds, stream, in, work, out, stage_tw, big_tw, (GroupState*) state, host_err, (unsigned) batch, in_stride, out_stride, seq, reg_polls, force_solo, two_slots);
+    hipLaunchKernelGGL (k, dim3 (grid), dim3 (256), group_lds_bytes (kGroupLds), stream, in, work, out, stage_tw, big_tw, (GroupState*) state, host_err, (unsigned) batch, in_stride, out_stride, seq, reg_polls, force_solo, two_slots);
     e = hipGetLastError();
     static const bool debug = std::getenv ("CHOWDSP_FFT_FUSED_DEBUG") != nullptr;
     if (debug && e == hipSuccess)

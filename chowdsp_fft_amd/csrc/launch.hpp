@@ -90,6 +90,11 @@ bool groupfast_supported (int n1, int n2);
 size_t groupfast_workspace_bytes (int n1, int n2);
 hipError_t launch_groupfast_c2c (int n1, int n2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, void* state, unsigned* host_err, unsigned seq, size_t batch, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
 void get_group_options (int& force_solo, int& reg_polls);
+// option "group_handoff": 1 = the hand-off form the CDNA4 guide lists (sc1 payload and flag stores, one workgroup per CU) for the
+// one-launch forms that offer it (complex N = 65536, real N = 131072); group_lds_bytes: the dynamic LDS such a launch asks for
+void set_group_handoff (int listed);
+int get_group_handoff();
+size_t group_lds_bytes (size_t kernel_lds);
 void set_group_spin_limit (int polls); // developer option: 0 = built-in limit
 int get_group_spin_limit();
 int group_wg_per_cu_tenths();

@@ -199,10 +199,13 @@ def _side_load(api, torch, side, s4, frames, scratch, small, rounds):
                 api.fft_transform_batch(s4, frames, scratch, api.FFT_FORWARD, stream=side)
 
 
-def test_group_handoff_stress_every_word_uneven_load(gpu, short_fuse):
+@pytest.mark.parametrize("handoff", [0, 1])
+def test_group_handoff_stress_every_word_uneven_load(gpu, short_fuse, handoff):
     """N = 65536, 2048 frames (1 GiB), 50 launches beside a second stream's uneven load: every output word == the two-launch
-    form's (bit for bit: the same arithmetic in the same order)."""
+    form's (bit for bit: the same arithmetic in the same order).  Both hand-off forms: the fast one (option group_handoff = 0)
+    and the one the CDNA4 guide lists (1: sc1 stores, one workgroup per CU)."""
     api, torch, dev = gpu
+    api.set_option("group_handoff", handoff)
     batch = 2048
     g = torch.Generator(device=dev)
     g.manual_seed(4242)
@@ -235,6 +238,7 @@ def test_group_handoff_stress_every_word_uneven_load(gpu, short_fuse):
             side.synchronize()
     finally:
         api.set_option("fused_two_pass", 2)
+        api.set_option("group_handoff", 0)
         api.fft_destroy_setup(s)
         api.fft_destroy_setup(s4)
 
