@@ -324,6 +324,16 @@ bool split16384_enabled()
     }
     return v != 0;
 }
+// CHOWDSP_FFT_DEVELOPER=1 unlocks the options that can make a launch produce invalid output on purpose ("group_spin_limit"): they are
+// process-wide, and a production host must not be able to reach them through the public fft_gpu_set_option by accident
+bool developer_options()
+{
+    static const bool on = [] {
+        const char* e = std::getenv ("CHOWDSP_FFT_DEVELOPER");
+        return e != nullptr && e[0] == '1';
+    }();
+    return on;
+}
 bool fused_enabled() { return fused_options().enabled.load() != 0; }
 int fused_form() { return (int) fused_options().enabled.load(); } // 1 = ticket queues, 2 = static groups
 size_t fused_min_batch() { return (size_t) fused_options().min_batch.load(); }
@@ -339,10 +349,15 @@ std::string fused_error_text (unsigned word)
 // Takes the report (the word is cleared).  0 = no.
 unsigned take_fused_error (hipStream_t stream)
 {
+    // the report of THIS device's lane only: the same stream handle (the null stream above all) names a different queue on every
+    // device, and a synchronisation on device B must neither take nor clear what a launch on device A has reported
+    int device = -1;
+    if (hipGetDevice (&device) != hipSuccess)
+        device = -1;
     std::lock_guard<std::recursive_mutex> lock (g_ws_mutex);
     unsigned word = 0;
     for (auto& kv : g_lanes)
-        if (kv.first.second == stream && kv.second.fused_err_host != nullptr && *kv.second.fused_err_host != 0)
+        if (kv.first.second == stream && (device < 0 || kv.first.first == device) && kv.second.fused_err_host != nullptr && *kv.second.fused_err_host != 0)
         {
             if (word == 0)
                 word = *kv.second.fused_err_host;
@@ -1409,6 +1424,15 @@ int fft_gpu_plan_describe (int N, fft_transform_t transform, int desc[8])
         desc[2] = q1;
         desc[3] = q2;
         desc[4] = desc[5] = desc[6] = desc[7] = 0;
+        // what executes by default (option "huge_columns" = 1) where the frame splits that way: h2r-point strided COLUMNS (the 2-D column
+        // kernel, twiddle at its stores) x h2c-point contiguous rows + ONE transpose -- reported in desc[4], desc[5] (0, 0: only the
+        // three-transposes form above exists for this length)
+        int h2r = 0, h2c = 0;
+        if (g_huge_columns.load() != 0 && cfft::host::split_huge_columns (nc, h2r, h2c))
+        {
+            desc[4] = h2r;
+            desc[5] = h2c;
+        }
         return FFT_GPU_OK;
     }
     if (transform == FFT_REAL && split_real4 (N, q1, q2))
@@ -1613,8 +1637,8 @@ int fft_gpu_set_option (const char* name, long value)
         set_group_options (value != 0 ? 1 : 0, -1);
     else if (std::strcmp (name, "group_reg_polls") == 0 && value >= 0 && value <= 1000000)
         set_group_options (-1, (int) value);
-    else if (std::strcmp (name, "group_spin_limit") == 0 && value >= 0 && value < 65536)
-        set_group_spin_limit ((int) value); // developer option: tests force the hand-off waits to run out (1); 0 = built-in limit
+    else if (std::strcmp (name, "group_spin_limit") == 0 && value >= 0 && value < 65536 && (value == 0 || developer_options()))
+        set_group_spin_limit ((int) value); // developer option (CHOWDSP_FFT_DEVELOPER=1): tests force the hand-off waits to run out (1); 0 = built-in limit
     else if (std::strcmp (name, "wave4096") == 0)
         set_wave4096 (value != 0);
     else if (std::strcmp (name, "split16384") == 0)

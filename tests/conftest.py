@@ -15,6 +15,10 @@ for p in (ROOT, HERE):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# the developer options of the library ("group_spin_limit": hand-off waits that DO run out, for the failure-path tests) are locked
+# unless this is set before the library reads it (capi.cpp developer_options)
+os.environ.setdefault("CHOWDSP_FFT_DEVELOPER", "1")
+
 import oracle_lib  # noqa: E402
 
 # parity bound of the north star: results match the reference SSE path within 1e-6 relative fp32,

@@ -94,6 +94,15 @@ def test_size_rule_host_logic():
             continue
         d = api.plan_describe(n, api.FFT_COMPLEX)
         assert d["passes"] == 3 and d["n1"] * d["n2"] == n and max(d["n1"], d["n2"]) <= 1 << 21 and d["n1"] % 16 == 0 and d["n2"] % 16 == 0, (n, d)
+        # what executes by default (option huge_columns = 1): strided columns x contiguous rows + one transpose, reported in the radix slots
+        if d["radices"]:
+            cols, rows = d["radices"]
+            assert cols * rows == n and cols <= 2559 and rows <= 1 << 21 and rows % 16 == 0, (n, d)
+    for n in (1 << 23, 3 << 21, 1 << 27):
+        assert len(api.plan_describe(n, api.FFT_COMPLEX)["radices"]) == 2, n
+    api.set_option("huge_columns", 0)
+    assert api.plan_describe(1 << 23, api.FFT_COMPLEX)["radices"] == []
+    api.set_option("huge_columns", 1)
     assert api.size_supported(1 << 25, api.FFT_REAL) and not api.size_supported(1 << 26, api.FFT_REAL)
     # ... except, up to 2^22, the products of two tile lengths with compile-time stage lists (at most 2048 points each): two passes
     for n, pair in ((1 << 22, (2048, 2048)), (2304000, (1440, 1600)), (3 << 20, (1536, 2048)), (2560000, (1600, 1600))):
@@ -317,3 +326,22 @@ def test_generated_inplace_lists_are_the_planners():
             prod *= r
         assert prod == n
         assert block == (256 if n <= 5120 else (512 if n <= 10240 else 1024))
+
+
+def test_developer_options_are_locked_without_the_environment_switch():
+    """"group_spin_limit" can make every one-launch transform of the process time out on purpose: only reachable with
+    CHOWDSP_FFT_DEVELOPER=1 (the test suite sets it, tests/conftest.py); resetting it to 0 is always allowed"""
+    import subprocess
+    import sys
+
+    code = ("from chowdsp_fft_amd import api\n"
+            "api.set_option('group_spin_limit', 0)\n"
+            "try:\n"
+            "    api.set_option('group_spin_limit', 1)\n"
+            "    print('accepted')\n"
+            "except api.FFTError:\n"
+            "    print('refused')\n")
+    for dev, want in (("0", "refused"), ("1", "accepted")):
+        env = dict(os.environ, CHOWDSP_FFT_DEVELOPER=dev)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+        assert r.returncode == 0 and r.stdout.strip().endswith(want), (dev, r.stdout, r.stderr[-500:])
