@@ -40,7 +40,7 @@ WORKLOADS = {
     # the same configuration through the other two forms (option fused_two_pass): two launches per chunk (round 1), and the
     # ticket-queue one-launch form (round 2)
     "c2c_n65536_b8192_fwd_inv_two_launches": (65536, "complex", 8192, "BASELINE configs[4] as two launches per 256-frame chunk (fused_two_pass = 0)"),
-    "c2c_n65536_b8192_fwd_inv_tickets": (65536, "complex", 8192, "BASELINE configs[4] through the ticket-queue one-launch form (fused_two_pass = 1)"),
+    "c2c_n65536_b8192_fwd_inv_tickets": (65536, "complex", 8192, "BASELINE configs[4] through the superseded ticket-queue one-launch form (fused_two_pass = 1; EXPERIMENTS=1 builds only)"),
     "conv_real_n4096_b131072": (4096, "real", 131072, "BASELINE configs[3] per-GPU share: fused fwd->mul->inv frames, N=4096 real, 131072 frames per GPU"),
     # a mixed-radix size from the reference's "Other sizes" list (9216 = 2^10 * 3^2), generic kernel
     "c2c_n9216_b16384_fwd_inv": (9216, "complex", 16384, "mixed-radix N=9216 fp32 complex fwd+inv (generic kernel), batch=16384 per GPU"),
@@ -164,6 +164,9 @@ def run_workload(workload, args, world, rank, dev, frames_override=0, gather=Fal
     if workload.endswith("_two_launches"):
         api.set_option("fused_two_pass", 0)
     elif workload.endswith("_tickets"):
+        if api.get_option("experiments") != 1:
+            sys.stderr.write("[bench] the ticket-queue form needs a library built with EXPERIMENTS=1\n")
+            return 4
         api.set_option("fused_two_pass", 1)
     setup = api.fft_new_setup(n, tr)
     if setup is None:

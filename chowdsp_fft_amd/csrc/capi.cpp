@@ -1621,6 +1621,15 @@ int fft_gpu_set_option (const char* name, long value)
     if (name == nullptr)
         return FFT_GPU_EINVAL;
     FusedOptions& o = fused_options();
+    // the superseded forms exist in EXPERIMENTS=1 builds only (launch.hpp CFFT_EXPERIMENTS): their options are refused otherwise
+    const bool experiment_option = std::strcmp (name, "wave4096") == 0 || std::strcmp (name, "split8192") == 0 || std::strcmp (name, "conv_wave2048") == 0
+                                   || std::strcmp (name, "fused_lag") == 0 || std::strcmp (name, "fused_slots") == 0
+                                   || (std::strcmp (name, "fused_two_pass") == 0 && value == 1);
+    if (experiment_option && ! CFFT_EXPERIMENTS)
+    {
+        set_last_error ("fft_gpu_set_option: this option selects a superseded form that only a library built with EXPERIMENTS=1 contains");
+        return FFT_GPU_EINVAL;
+    }
     if (std::strcmp (name, "fused_two_pass") == 0 && value >= 0 && value <= 2)
         o.enabled = value;
     else if (std::strcmp (name, "fused_min_batch") == 0 && value >= 1)
@@ -1676,6 +1685,8 @@ long fft_gpu_get_option (const char* name)
     if (name == nullptr)
         return -1;
     FusedOptions& o = fused_options();
+    if (std::strcmp (name, "experiments") == 0)
+        return CFFT_EXPERIMENTS ? 1 : 0; // 1: the library carries the superseded forms (built with EXPERIMENTS=1)
     if (std::strcmp (name, "fused_two_pass") == 0)
         return o.enabled.load();
     if (std::strcmp (name, "fused_min_batch") == 0)

@@ -58,6 +58,7 @@ hipError_t launch_c2c_n (const float2* in, float2* out, const float2* tw, size_t
 }
 } // namespace
 
+#if CFFT_EXPERIMENTS
 std::atomic<int> g_wave4096 { -1 };
 bool wave4096_enabled()
 {
@@ -86,6 +87,9 @@ hipError_t launch_c2c_wave4096 (const float2* in, float2* out, const float2* sta
 }
 
 void set_wave4096 (bool on) { g_wave4096 = on ? 1 : 0; }
+#else
+void set_wave4096 (bool) {}
+#endif
 
 hipError_t launch_c2c (int n, bool inverse, const float2* in, float2* out, const float2* stage_tw, size_t batch, hipStream_t stream, size_t in_stride, size_t out_stride)
 {
@@ -96,9 +100,11 @@ hipError_t launch_c2c (int n, bool inverse, const float2* in, float2* out, const
     // one wavefront per 4096-point frame instead of the 256-work-item workgroup plan (option "wave4096" /
     // CHOWDSP_FFT_WAVE4096=1): measured at the same rate (5.76 vs 5.80 TB/s, profiles/r02_wave4096.txt), kept as the
     // alternative form; packed and strided batches alike
+#if CFFT_EXPERIMENTS
     if (n == 4096 && wave4096_enabled())
         return inverse ? launch_c2c_wave4096<true> (in, out, stage_tw, batch, stream, (unsigned) in_stride, (unsigned) out_stride)
                        : launch_c2c_wave4096<false> (in, out, stage_tw, batch, stream, (unsigned) in_stride, (unsigned) out_stride);
+#endif
     if (inverse)
     {
         CFFT_DISPATCH_CORE_N (n, return (launch_c2c_n<N_, true> (in, out, stage_tw, batch, stream, (unsigned) in_stride, (unsigned) out_stride)));

@@ -436,6 +436,10 @@ hipError_t launch_fused_c2c (int n1, int n2, bool inverse, const float2* in, flo
         return hipSuccess;
     if (! fused_supported (n1, n2) || batch >= 0x7FFFFFFFull || lag < 1 || slots <= lag || slots > kFusedMaxSlots)
         return hipErrorInvalidValue;
+#if ! CFFT_EXPERIMENTS
+    (void) in; (void) work; (void) out; (void) stage_tw; (void) big_tw; (void) state; (void) host_err; (void) seq; (void) stream; (void) in_stride; (void) out_stride;
+    return hipErrorNotSupported; // the ticket-queue form is an EXPERIMENTS=1 build's (launch.hpp)
+#else
     const size_t frame_len = (size_t) n1 * (size_t) n2;
     in_stride = in_stride ? in_stride : frame_len;
     out_stride = out_stride ? out_stride : frame_len;
@@ -483,6 +487,7 @@ hipError_t launch_fused_c2c (int n1, int n2, bool inverse, const float2* in, flo
         }
     }
     return e;
+#endif
 }
 
 // ---- the same, by static groups of workgroups per XCD (group_twopass_kernels.hpp) ---------------------------------------

@@ -113,8 +113,10 @@ hipError_t launch_c2c_split (int n, bool inverse, const float2* in, float2* out,
         return c2c_split<SplitGeom<1024>> (inverse, in, out, tw, batch, stream, in_stride, out_stride);
     if (n == SplitGeom<512>::N)
         return c2c_split<SplitGeom<512>> (inverse, in, out, tw, batch, stream, in_stride, out_stride);
+#if CFFT_EXPERIMENTS // option "split8192": the plain 8192-point transforms on the split-plane geometry
     if (n == SplitGeom<256>::N)
         return c2c_split<SplitGeom<256>> (inverse, in, out, tw, batch, stream, in_stride, out_stride);
+#endif
     return hipErrorInvalidValue;
 }
 
@@ -126,8 +128,10 @@ hipError_t launch_real_split (int m, bool forward, const float2* in, float2* out
         return real_split<SplitGeom<1024>> (forward, in, out, tw, real_tw, batch, stream, in_stride, out_stride);
     if (m == SplitGeom<512>::N)
         return real_split<SplitGeom<512>> (forward, in, out, tw, real_tw, batch, stream, in_stride, out_stride);
+#if CFFT_EXPERIMENTS // option "split8192": the plain 8192-point transforms on the split-plane geometry
     if (m == SplitGeom<256>::N)
         return real_split<SplitGeom<256>> (forward, in, out, tw, real_tw, batch, stream, in_stride, out_stride);
+#endif
     return hipErrorInvalidValue;
 }
 
@@ -152,8 +156,10 @@ hipError_t launch_conv_frames_split (int n, bool real, const float2* in, const f
         return conv_frames_split<SplitGeom<512>> (real, in, H, out, tw, real_tw, scaling, batch, stream);
     if (n == SplitGeom<256>::N)
         return conv_frames_split<SplitGeom<256>> (real, in, H, out, tw, real_tw, scaling, batch, stream);
-    if (n == SplitGeom<64>::N)
+#if CFFT_EXPERIMENTS
+    if (n == SplitGeom<64>::N) // option "conv_wave2048": one wavefront per 2048-point frame
         return conv_frames_split<SplitGeom<64>> (real, in, H, out, tw, real_tw, scaling, batch, stream);
+#endif
     return hipErrorInvalidValue;
 }
 } // namespace cfft::host

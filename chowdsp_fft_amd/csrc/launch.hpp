@@ -16,6 +16,13 @@ static constexpr size_t kMaxFrameStride = (size_t) 1 << 24;
 // batched complex FFT, interleaved in/out, in may equal out
 hipError_t launch_c2c (int n, bool inverse, const float2* in, float2* out, const float2* stage_tw, size_t batch, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
 
+// CFFT_EXPERIMENTS (make EXPERIMENTS=1): superseded forms kept for A/B runs -- the ticket-queue one-launch form of N = 65536 (option
+// "fused_two_pass" = 1, with "fused_lag" / "fused_slots"), one wavefront per 4096-point frame ("wave4096"), the split-plane geometry for
+// plain 8192-point transforms ("split8192"), one wavefront per 2048-point fused-convolution frame ("conv_wave2048").  The shipped
+// library carries ONE form per size: without the flag those kernels are not instantiated and their options are refused.
+#ifndef CFFT_EXPERIMENTS
+#define CFFT_EXPERIMENTS 0
+#endif
 void set_wave4096 (bool on); // N = 4096 complex: one wavefront per frame (wave_kernels.hpp) instead of the workgroup plan
 
 // batched real FFT of N = 2*m real points through the m-point core (m = 16..4096)

@@ -27,13 +27,17 @@ def _form_now(api):
 @pytest.fixture(params=["tickets", "groups", "groups-solo"])
 def fused_on(gpu, request):
     api = gpu[0]
+    experiments = api.get_option("experiments") == 1
+    if request.param == "tickets" and not experiments:
+        pytest.skip("the ticket-queue form is a superseded form: only libraries built with EXPERIMENTS=1 contain it")
     default, default_min = _form_now(api), int(api.get_option("fused_min_batch"))
     api.set_option("fused_two_pass", FORM[request.param.split("-")[0]])
     api.set_option("group_force_solo", 1 if request.param.endswith("solo") else 0)
     api.set_option("fused_min_batch", 1)
     yield api
     api.set_option("fused_min_batch", default_min)
-    api.set_option("fused_lag", 4)
+    if experiments:
+        api.set_option("fused_lag", 4)
     api.set_option("group_force_solo", 0)
     api.set_option("fused_two_pass", default)
 
@@ -56,7 +60,8 @@ def test_fused_vs_oracle_and_two_launch(gpu, oracle, fused_on, batch, lag):
     api = fused_on
     if _form_now(api) == 2 and lag != 4:
         pytest.skip("the group form has no lag")
-    api.set_option("fused_lag", lag)
+    if _form_now(api) == 1:
+        api.set_option("fused_lag", lag)
     s, so = api.fft_new_setup(N, api.FFT_COMPLEX), oracle.new_setup(N, COMPLEX)
     x = ol.uniform(batch * 2 * N, 900 + batch).reshape(batch, 2 * N)
     nref = min(batch, 3)
@@ -121,6 +126,12 @@ def test_set_option_rejects_nonsense(gpu):
         api.set_option("no_such_option", 1)
     with pytest.raises(api.FFTError):
         api.set_option("fused_lag", 99)
+    if api.get_option("experiments") != 1:
+        # the shipped library carries one form per size: the superseded forms' options are refused
+        for name, value in (("fused_two_pass", 1), ("wave4096", 1), ("split8192", 1), ("conv_wave2048", 1), ("fused_lag", 4)):
+            with pytest.raises(api.FFTError):
+                api.set_option(name, value)
+        assert api.get_option("fused_two_pass") == 2
 
 
 @pytest.mark.parametrize("solo", [0, 1])

@@ -388,6 +388,8 @@ def test_two_streams_share_one_setup(gpu, oracle):
 
 def test_wave_per_frame_form_of_n4096(gpu, oracle):
     """option "wave4096": one wavefront per 4096-point frame (csrc/wave_kernels.hpp) -- same results as the workgroup plan"""
+    if gpu[0].get_option("experiments") != 1:
+        pytest.skip("a superseded form: only libraries built with EXPERIMENTS=1 contain it")
     api, torch, dev = gpu
     n, batch = 4096, 37
     s, so = api.fft_new_setup(n, api.FFT_COMPLEX), oracle.new_setup(n, COMPLEX)
@@ -419,6 +421,8 @@ def test_split_plane_form_of_n8192(gpu, oracle, tr):
     """option "split8192": the 8192-point core (N = 8192 complex, real N = 16384) through the 256-work-item split-plane
     kernels (csrc/split_plane_kernels.hpp, 32 x 32 x 8) -- same results as the interleaved-image plan; the fused
     convolution of these sizes always runs on them"""
+    if gpu[0].get_option("experiments") != 1:
+        pytest.skip("a superseded form: only libraries built with EXPERIMENTS=1 contain it")
     api, torch, dev = gpu
     n = 8192 if tr == COMPLEX else 16384
     nf, batch = _frame(n, tr), 11
@@ -449,6 +453,8 @@ def test_split_plane_form_of_n8192(gpu, oracle, tr):
 def test_wave_per_frame_fused_convolution(gpu, oracle, n, tr):
     """option "conv_wave2048": fft_convolve_frames_batch of 2048-point cores by one wavefront per frame
     (csrc/split_plane_kernels.hpp, SplitGeom<64>) -- same results as the workgroup plan and the oracle's pipeline"""
+    if gpu[0].get_option("experiments") != 1:
+        pytest.skip("a superseded form: only libraries built with EXPERIMENTS=1 contain it")
     api, torch, dev = gpu
     nf, batch = _frame(n, tr), 37
     x = ol.uniform(batch * nf, 91 + n).reshape(batch, nf)

@@ -6,7 +6,7 @@ TAG=${1:-pmc}; NOTE=${2:-"tools/pmc_refresh.sh"}
 REPO=$PWD; OUT=$REPO/gpurun_out/$TAG; mkdir -p "$OUT"
 export TMPDIR=/tmp
 STEPS=3; WARMUP=1
-for W in c2c_n4096_b65536_fwd_inv real_n1024_b262144_fwd_inv conv_real_n4096_b131072 c2c_n65536_b8192_fwd_inv c2c_n65536_b8192_fwd_inv_two_launches c2c_n65536_b8192_fwd_inv_tickets; do
+for W in c2c_n4096_b65536_fwd_inv real_n1024_b262144_fwd_inv conv_real_n4096_b131072 c2c_n65536_b8192_fwd_inv c2c_n65536_b8192_fwd_inv_two_launches; do
   for C in FETCH_SIZE WRITE_SIZE; do
     cd /tmp
     timeout -k 10 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/$W/prof_pmc_$C" -- python3 "$REPO/bench.py" --steps $STEPS --warmup $WARMUP --prewarm-seconds 0 --no-cpu-baseline --no-secondary --workload $W > "$OUT/${W}_$C.log" 2>&1 || { echo "pmc pass failed: $W $C"; tail -5 "$OUT/${W}_$C.log"; exit 1; }
