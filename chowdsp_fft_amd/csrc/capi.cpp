@@ -642,7 +642,9 @@ int big_real4_chunked (Setup* s, bool inverse, const float2* in, float2* out, si
         const size_t nb = (batch - f0 < chunk) ? batch - f0 : chunk;
         const int k = (lanes == 2) ? (int) (i & 1) : 0;
         const hipStream_t st = (lanes == 2) ? L->lane[k] : stream;
-        const hipError_t e = t->real4_fast
+        const hipError_t e = t->real4_generic
+                                 ? launch_real4_generic (*t, inverse, in + f0 * is2, L->ws[k], out + f0 * os2, nb, lanes, st, is2, os2)
+                             : t->real4_fast
                                  ? launch_real4_fast (r1, r2, inverse, in + f0 * is2, L->ws[k], out + f0 * os2, t->stage_twiddles, t->big_twiddles, nb, lanes, st, is2, os2, mul_h, mul_scale)
                                  : launch_real4 (r1, r2, inverse, in + f0 * is2, L->ws[k], out + f0 * os2, t->stage_twiddles, t->big_twiddles, nb, lanes, st, is2, os2);
         if (e != hipSuccess)
@@ -1435,6 +1437,16 @@ int fft_gpu_plan_describe (int N, fft_transform_t transform, int desc[8])
         }
         return FFT_GPU_OK;
     }
+    if (transform == FFT_REAL && cfft::host::split_real4_generic (N, q1, q2))
+    {
+        // long mixed-radix real frame: the real four-step with run-time stage lists for both cores, N = q1 x q2 (rows x columns)
+        desc[0] = nc;
+        desc[1] = 2;
+        desc[2] = q1;
+        desc[3] = q2;
+        desc[4] = desc[5] = desc[6] = desc[7] = 0;
+        return FFT_GPU_OK;
+    }
     if (transform == FFT_REAL && split_real4 (N, q1, q2))
     {
         // long real frame: the four-step algorithm on the N real samples themselves, N = q1 x q2 (rows x columns)
@@ -1668,6 +1680,8 @@ int fft_gpu_set_option (const char* name, long value)
         g_group_real = value != 0 ? 1 : 0;
     else if (std::strcmp (name, "huge_columns") == 0)
         g_huge_columns = value != 0 ? 1 : 0;
+    else if (std::strcmp (name, "real4_generic") == 0 && (value == 0 || value == 1))
+        cfft::host::set_real4_generic ((int) value); // plans MADE from now on: long mixed-radix real frames by the real four-step with generic cores
     else if (std::strcmp (name, "group_handoff") == 0 && (value == 0 || value == 1))
         set_group_handoff ((int) value); // 1: the hand-off form the CDNA4 guide lists, for the one-launch forms that offer it (chowdsp_fft_gpu.h)
     else if (std::strcmp (name, "table_cache_mib") == 0 && value >= 0 && value <= (1 << 20))
@@ -1719,6 +1733,8 @@ long fft_gpu_get_option (const char* name)
         return (long) (table_cache_limit() >> 20);
     if (std::strcmp (name, "group_handoff") == 0)
         return get_group_handoff();
+    if (std::strcmp (name, "real4_generic") == 0)
+        return cfft::host::get_real4_generic();
     return -1;
 }
 

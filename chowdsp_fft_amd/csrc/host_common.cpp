@@ -278,7 +278,9 @@ const DeviceTables* acquire_column_tables (int device, int rows)
 
 const DeviceTables* acquire_tables (int device, int N, int transform)
 {
-    const TableKey key = std::make_tuple (device, N, transform);
+    // (a real plan made while option "real4_generic" is on is a different plan of the same length: a key of its own)
+    int g1 = 0, g2 = 0;
+    const TableKey key = std::make_tuple (device, N, (transform == 0 && split_real4_generic (N, g1, g2)) ? 16 : transform);
     {
         std::lock_guard<std::mutex> lock (g_cache_mutex);
         if (const DeviceTables* hit = lookup_ref_locked (key))
@@ -372,6 +374,7 @@ const DeviceTables* acquire_tables (int device, int N, int transform)
     t->real4_r1 = h.real4_r1;
     t->real4_r2 = h.real4_r2;
     t->real4_fast = h.real4_fast;
+    t->real4_generic = h.real4_generic;
     t->gen2_ns = (int) h.generic2_radix.size();
     for (int i = 0; i < t->gen2_ns; ++i)
     {

@@ -57,6 +57,7 @@ struct DeviceTables
     // long real frames by the real four-step (N = real4_r1 * real4_r2), else 0
     int real4_r1 = 0, real4_r2 = 0;
     int real4_fast = 0; // ... on the register-direct tiles (tile_fast_kernels.hpp) instead of the LDS-staged ones
+    int real4_generic = 0; // ... mixed-radix: gen_* = the r2-point column core's stage list, gen2_* = the r1-point row core's (real4_generic_kernels.hpp)
     // real N = 131072: the 65536-point complex plan (256 x 256, block-ordered inter-pass twiddles) whose tables the one-launch group
     // form of the REAL transform uses (group_real_kernels.hpp), else nullptr
     const DeviceTables* group_core = nullptr;

@@ -1,0 +1,101 @@
+// Instantiation + launch of the real four-step with generic cores (real4_generic_kernels.hpp): long mixed-radix REAL frames in two
+// sweeps.  A translation unit of its own (builds in parallel with the other long-plan kernels).
+#include "launch_util.hpp"
+#include "real4_generic_kernels.hpp"
+#include "tables.hpp"
+
+namespace cfft::host
+{
+namespace
+{
+GenericPlan make_plan (int n, int ns, const int* radix, const int* tw_offset)
+{
+    GenericPlan plan {};
+    plan.n = n;
+    plan.ns = ns;
+    plan.frames = kReal4GTile;
+    plan.in_stride = plan.out_stride = (unsigned) n;
+    for (int i = 0; i < ns; ++i)
+    {
+        plan.radix[i] = radix[i];
+        plan.tw_offset[i] = tw_offset[i];
+    }
+    return plan;
+}
+// two images of 16 frames of n + 1 points (the + 1 spreads the lanes that walk across frames over the banks)
+size_t tile_lds (int n, unsigned& lfs)
+{
+    lfs = (unsigned) n + 1u;
+    return (size_t) 2 * kReal4GTile * lfs * sizeof (float2);
+}
+template <class K>
+unsigned tile_grid (K kernel, int block, size_t lds, size_t work, int divisor)
+{
+    const unsigned grid = persistent_grid (kernel, block, lds, work);
+    return grid == 0 ? 0u : std::max (1u, grid / (unsigned) std::max (divisor, 1));
+}
+} // namespace
+
+// real N = r1 x r2 (tables.cpp split_real4_generic); in / out: the real frame resp. its packed spectrum, both as N/2 float2;
+// work: real4_workspace_frame_len (r1, r2) float2 per frame
+hipError_t launch_real4_generic (const DeviceTables& t, bool inverse, const float2* in, float2* work, float2* out, size_t batch, int grid_divisor, hipStream_t stream, size_t in_stride, size_t out_stride)
+{
+    if (batch == 0)
+        return hipSuccess;
+    const int r1 = t.real4_r1, r2 = t.real4_r2;
+    if (batch > 0x7FFFFFFFull || t.real4_generic == 0 || r1 < 32 || (r1 % 32) != 0 || r2 < 2 || (r2 & 1) != 0 || t.gen_ns < 1 || t.gen2_ns < 1
+        || t.gen_ns > kGenericMaxStages || t.gen2_ns > kGenericMaxStages)
+        return hipErrorInvalidValue;
+    DeviceInfo dev;
+    if (! current_device_info (dev))
+        return hipErrorNoDevice;
+    const size_t m = (size_t) r1 * (size_t) r2 / 2; // float2 per frame on the caller's side
+    in_stride = in_stride ? in_stride : m;
+    out_stride = out_stride ? out_stride : m;
+    const size_t ws_len = real4_workspace_frame_len (r1, r2);
+    const GenericPlan plan_c = make_plan (r2, t.gen_ns, t.gen_radix, t.gen_tw_offset);    // columns
+    const GenericPlan plan_r = make_plan (r1, t.gen2_ns, t.gen2_radix, t.gen2_tw_offset); // rows
+    unsigned lfs_c = 0, lfs_r = 0;
+    const size_t lds_c = tile_lds (r2, lfs_c), lds_r = tile_lds (r1, lfs_r);
+    if (lds_c > dev.lds_per_cu || lds_r > dev.lds_per_cu)
+        return hipErrorInvalidValue;
+    const int block_c = generic_tile_block (lds_c, dev.lds_per_cu), block_r = generic_tile_block (lds_r, dev.lds_per_cu);
+    const int n1c = r1 / 2;
+    const size_t col_tiles = (size_t) (n1c / kReal4GTile), row_tiles = ((size_t) r2 / 2 + 1 + kReal4GTile - 1) / kReal4GTile;
+    const float2* tw = t.stage_twiddles;
+    const float2* big = t.big_twiddles;
+#define CFFT_R4G_LAUNCH(KERNEL, BLOCKV, LDS, WORK, ...)                                                        \
+    {                                                                                                          \
+        hipError_t e_ = hipSuccess;                                                                            \
+        if ((BLOCKV) == 1024)                                                                                  \
+        {                                                                                                      \
+            const unsigned g_ = tile_grid (KERNEL<1024>, 1024, LDS, WORK, grid_divisor);                       \
+            if (g_ == 0)                                                                                       \
+                return hipErrorNoDevice;                                                                       \
+            hipLaunchKernelGGL (KERNEL<1024>, dim3 (g_), dim3 (1024), LDS, stream, __VA_ARGS__);               \
+        }                                                                                                      \
+        else                                                                                                   \
+        {                                                                                                      \
+            const unsigned g_ = tile_grid (KERNEL<256>, 256, LDS, WORK, grid_divisor);                         \
+            if (g_ == 0)                                                                                       \
+                return hipErrorNoDevice;                                                                       \
+            hipLaunchKernelGGL (KERNEL<256>, dim3 (g_), dim3 (256), LDS, stream, __VA_ARGS__);                 \
+        }                                                                                                      \
+        e_ = hipGetLastError();                                                                                \
+        if (e_ != hipSuccess)                                                                                  \
+            return e_;                                                                                         \
+    }
+    if (! inverse)
+    {
+        CFFT_R4G_LAUNCH (real4g_pass_a_kernel, block_c, lds_c, batch * col_tiles, in, work, tw, big, plan_c, (unsigned) n1c, (unsigned) batch, in_stride, lfs_c, ws_len);
+        CFFT_R4G_LAUNCH (real4g_pass_b_kernel, block_r, lds_r, batch * row_tiles, (const float2*) work, out, tw, plan_r, (unsigned) r2, (unsigned) batch, out_stride, lfs_r, ws_len);
+    }
+    else
+    {
+        CFFT_R4G_LAUNCH (real4g_pass_b_inv_kernel, block_r, lds_r, batch * row_tiles, in, work, tw, big, plan_r, (unsigned) r2, (unsigned) batch, in_stride, lfs_r, ws_len);
+        CFFT_R4G_LAUNCH (real4g_pass_a_inv_kernel, block_c, lds_c, batch * col_tiles, (const float2*) work, out, tw, plan_c, (unsigned) n1c, (unsigned) batch, out_stride, lfs_c, ws_len);
+    }
+#undef CFFT_R4G_LAUNCH
+    return hipSuccess;
+}
+} // namespace cfft::host

@@ -1,5 +1,7 @@
 // Twiddle-table construction (host, double precision, rounded once to fp32).
 #include "tables.hpp"
+
+#include <atomic>
 #include <algorithm>
 #include <functional>
 #include "plans.hpp"
@@ -170,6 +172,58 @@ bool split_real4 (int n_real, int& r1, int& r2)
     r2 = 1 << (lg / 2);        // column length
     r1 = 1 << (lg - lg / 2);   // row length
     return true;
+}
+
+// option "real4_generic" (initial value: CHOWDSP_FFT_REAL4_GENERIC=1): read when a plan is MADE (the device-table cache keeps plans of
+// either kind apart, host_common.cpp).  Off by default: the form is correct but not yet as fast as the three sweeps it replaces
+// (profiles/r05_real4_generic.txt).
+static std::atomic<int> g_real4_generic { -1 };
+void set_real4_generic (int on) { g_real4_generic = on != 0 ? 1 : 0; }
+int get_real4_generic()
+{
+    int v = g_real4_generic.load();
+    if (v < 0)
+    {
+        const char* e = std::getenv ("CHOWDSP_FFT_REAL4_GENERIC");
+        v = (e != nullptr && e[0] == '1') ? 1 : 0;
+        g_real4_generic = v;
+    }
+    return v;
+}
+
+bool split_real4_generic (int n_real, int& r1, int& r2)
+{
+    r1 = r2 = 0;
+    const bool off = get_real4_generic() == 0;
+    constexpr int kOnePassMaxComplex = 20000; // (= kGenericMaxComplexLen below: shorter frames stay on chip)
+    if (off || n_real <= 2 * kOnePassMaxComplex || is_pow2 (n_real) || (n_real % 64) != 0)
+        return false;
+    const auto smooth = [] (int v) {
+        for (int q : { 2, 3, 5 })
+            while (v % q == 0)
+                v /= q;
+        return v == 1;
+    };
+    if (! smooth (n_real))
+        return false;
+    // the split nearest to square (both passes then work on tiles of similar size); r1 = 32 j
+    double best = 1e30;
+    for (int a = 32; a <= 639; a += 32)
+    {
+        if (n_real % a != 0 || ! smooth (a))
+            continue;
+        const int b = n_real / a;
+        if (b > 639 || b < 16 || (b & 1) != 0)
+            continue;
+        const double score = a > b ? (double) a / b : (double) b / a;
+        if (score < best)
+        {
+            best = score;
+            r1 = a;
+            r2 = b;
+        }
+    }
+    return r1 != 0;
 }
 
 // not one of the power-of-two lengths that run as a radix-2 split around the register-direct two-pass tiles (2^min_log2 .. 2^21)
@@ -510,6 +564,41 @@ bool build_host_tables (int N, int transform, HostTables& out)
             for (int a = 0; a < n1; ++a)
                 for (int kb = 0; kb < n2; ++kb)
                     out.big_twiddles.push_back (unit_root ((long long) a * kb, half));
+            return true;
+        }
+    }
+    {
+        int g1 = 0, g2 = 0;
+        if (real && split_real4_generic (N, g1, g2))
+        {
+            // long mixed-radix REAL frame: the four-step algorithm on the real data with run-time stage lists for both cores
+            // (real4_generic_kernels.hpp).  Stage tables of the r2-point column core, then of the r1-point row core; W_N^{a kb} in the
+            // workspace's order [column tile tA][kb <= r2 / 2][32], a = 32 tA + al (the layout of the power-of-two form's LDS-staged tiles)
+            out.core_n = 0;
+            out.real4_r1 = g1;
+            out.real4_r2 = g2;
+            out.real4_generic = 1;
+            const auto add_list = [&out] (int n, int frames, std::vector<int>& radix, std::vector<int>& offs) {
+                generic_radices (n, radix, frames);
+                int p = 1;
+                for (int r : radix)
+                {
+                    offs.push_back ((int) out.stage_twiddles.size());
+                    for (int a = 1; a < r; ++a)
+                        for (int k = 0; k < p; ++k)
+                            out.stage_twiddles.push_back (unit_root ((long long) a * k, (long long) p * r));
+                    p *= r;
+                }
+                return p == n && radix.size() <= 10;
+            };
+            if (! add_list (g2, 16, out.generic_radix, out.generic_tw_offset) || ! add_list (g1, 16, out.generic2_radix, out.generic2_tw_offset))
+                return false;
+            const int nr = g2 / 2 + 1;
+            out.big_twiddles.reserve ((size_t) g1 * nr);
+            for (int ta = 0; ta < g1 / 32; ++ta)
+                for (int kb = 0; kb < nr; ++kb)
+                    for (int al = 0; al < 32; ++al)
+                        out.big_twiddles.push_back (unit_root ((long long) (ta * 32 + al) * kb, N));
             return true;
         }
     }

@@ -30,6 +30,8 @@ struct HostTables
     int r2_n = 0;                   // complex 2^21: radix-2 around the r2_n x r2_n register-direct two-pass transform of the two half-length sub-frames
     int real4_r1 = 0, real4_r2 = 0; // long real frames: real four-step N = r1 * r2 (multipass_kernels.hpp)
     int real4_fast = 0;             // ... on the register-direct tiles (tile_fast_kernels.hpp)
+    int real4_generic = 0;          // ... long MIXED-RADIX real frames: both cores by the run-time stage lists (real4_generic_kernels.hpp);
+                                    //     generic_* = the r2-point column core, generic2_* = the r1-point row core
     // frames beyond 2^21 complex points (split_huge): huge_r x huge_c, both factors transformed by plans of their own;
     // W_N^j = huge_tw_hi[j >> huge_shift] * huge_tw_lo[j & ((1 << huge_shift) - 1)]
     int huge_r = 0, huge_c = 0, huge_shift = 0;
@@ -45,6 +47,13 @@ bool build_column_tables (int rows, HostTables& out);
 
 // Real N = 2^17 .. 2^20: the real four-step split N = r1 * r2 (r1 >= r2, both in 256..1024); false for any other N.
 bool split_real4 (int n_real, int& r1, int& r2);
+// Long real frames that are not a power of two (complex length beyond the one-pass kernels): N = r1 x r2 for the real four-step with
+// generic cores -- r1 a multiple of 32 (tiles of 16 complex = 32 real columns), r2 even, both 2^a 3^b 5^c and at most 639 points (two
+// LDS images of 16 frames of r + 1 points).  false where no such split exists (the frame then runs as a complex two-pass transform of
+// N / 2 points + the stand-alone pair stage, three sweeps) -- and while option "real4_generic" is 0 (the default: set_real4_generic).
+bool split_real4_generic (int n_real, int& r1, int& r2);
+void set_real4_generic (int on);
+int get_real4_generic();
 
 // Size policy shared with the C API.
 bool size_supported (int N, int transform);
