@@ -1680,7 +1680,7 @@ int fft_gpu_set_option (const char* name, long value)
         g_group_real = value != 0 ? 1 : 0;
     else if (std::strcmp (name, "huge_columns") == 0)
         g_huge_columns = value != 0 ? 1 : 0;
-    else if (std::strcmp (name, "real4_generic") == 0 && (value == 0 || value == 1))
+    else if (std::strcmp (name, "real4_generic") == 0 && value >= 0 && value <= 2)
         cfft::host::set_real4_generic ((int) value); // plans MADE from now on: long mixed-radix real frames by the real four-step with generic cores
     else if (std::strcmp (name, "group_handoff") == 0 && (value == 0 || value == 1))
         set_group_handoff ((int) value); // 1: the hand-off form the CDNA4 guide lists, for the one-launch forms that offer it (chowdsp_fft_gpu.h)

@@ -280,7 +280,7 @@ const DeviceTables* acquire_tables (int device, int N, int transform)
 {
     // (a real plan made while option "real4_generic" is on is a different plan of the same length: a key of its own)
     int g1 = 0, g2 = 0;
-    const TableKey key = std::make_tuple (device, N, (transform == 0 && split_real4_generic (N, g1, g2)) ? 16 : transform);
+    const TableKey key = std::make_tuple (device, N, (transform == 0 && split_real4_generic (N, g1, g2)) ? 16 + get_real4_generic() : transform);
     {
         std::lock_guard<std::mutex> lock (g_cache_mutex);
         if (const DeviceTables* hit = lookup_ref_locked (key))

@@ -1,8 +1,10 @@
 // Instantiation + launch of the real four-step with generic cores (real4_generic_kernels.hpp): long mixed-radix REAL frames in two
 // sweeps.  A translation unit of its own (builds in parallel with the other long-plan kernels).
 #include "launch_util.hpp"
-#include "real4_generic_kernels.hpp"
+#include "real4_static.hpp"
 #include "tables.hpp"
+
+#include <cstdlib>
 
 namespace cfft::host
 {
@@ -23,10 +25,11 @@ GenericPlan make_plan (int n, int ns, const int* radix, const int* tw_offset)
     return plan;
 }
 // two images of 16 frames of n + 1 points (the + 1 spreads the lanes that walk across frames over the banks)
+// ... and the stage twiddles' LDS copy behind them (n - 1 entries)
 size_t tile_lds (int n, unsigned& lfs)
 {
     lfs = (unsigned) n + 1u;
-    return (size_t) 2 * kReal4GTile * lfs * sizeof (float2);
+    return ((size_t) 2 * kReal4GTile * lfs + (size_t) (n - 1)) * sizeof (float2);
 }
 template <class K>
 unsigned tile_grid (K kernel, int block, size_t lds, size_t work, int divisor)
@@ -60,42 +63,101 @@ hipError_t launch_real4_generic (const DeviceTables& t, bool inverse, const floa
     if (lds_c > dev.lds_per_cu || lds_r > dev.lds_per_cu)
         return hipErrorInvalidValue;
     const int block_c = generic_tile_block (lds_c, dev.lds_per_cu), block_r = generic_tile_block (lds_r, dev.lds_per_cu);
+
     const int n1c = r1 / 2;
     const size_t col_tiles = (size_t) (n1c / kReal4GTile), row_tiles = ((size_t) r2 / 2 + 1 + kReal4GTile - 1) / kReal4GTile;
     const float2* tw = t.stage_twiddles;
     const float2* big = t.big_twiddles;
-#define CFFT_R4G_LAUNCH(KERNEL, BLOCKV, LDS, WORK, ...)                                                        \
+    // request registers per work-item: the fewest of 4 / 6 / 8 / 10 that hold a tile (fewer registers, more workgroups per CU)
+    // (the column kernels also move 16 (r2 / 2 + 1) float4 -- the rows kept -- through SLOTS / 2 registers: 32 float2 more than the tile)
+    const auto slots_for = [] (int n, int block, int extra) {
+        const int need = (kReal4GTile * n + extra + block - 1) / block;
+        return need <= 4 ? 4 : (need <= 6 ? 6 : (need <= 8 ? 8 : (need <= 10 ? 10 : 0)));
+    };
+    const int slots_c = slots_for (r2, block_c, 32), slots_r = slots_for (r1, block_r, 0);
+    if (slots_c == 0 || slots_r == 0)
+        return hipErrorInvalidValue;
+#define CFFT_R4G_LAUNCH_BS(KERNEL, B_, S_, LDS, WORK, ...)                                                     \
     {                                                                                                          \
-        hipError_t e_ = hipSuccess;                                                                            \
+        const unsigned g_ = tile_grid (KERNEL<B_, S_>, B_, LDS, WORK, grid_divisor);                           \
+        if (g_ == 0)                                                                                           \
+            return hipErrorNoDevice;                                                                           \
+        hipLaunchKernelGGL ((KERNEL<B_, S_>), dim3 (g_), dim3 (B_), LDS, stream, __VA_ARGS__);                 \
+    }
+#define CFFT_R4G_LAUNCH_B(KERNEL, B_, SLOTSV, LDS, WORK, ...)                                                  \
+    switch (SLOTSV)                                                                                            \
+    {                                                                                                          \
+        case 4: CFFT_R4G_LAUNCH_BS (KERNEL, B_, 4, LDS, WORK, __VA_ARGS__) break;                              \
+        case 6: CFFT_R4G_LAUNCH_BS (KERNEL, B_, 6, LDS, WORK, __VA_ARGS__) break;                              \
+        case 8: CFFT_R4G_LAUNCH_BS (KERNEL, B_, 8, LDS, WORK, __VA_ARGS__) break;                              \
+        default: CFFT_R4G_LAUNCH_BS (KERNEL, B_, 10, LDS, WORK, __VA_ARGS__) break;                            \
+    }
+#define CFFT_R4G_LAUNCH(KERNEL, BLOCKV, SLOTSV, LDS, WORK, ...)                                                \
+    {                                                                                                          \
         if ((BLOCKV) == 1024)                                                                                  \
-        {                                                                                                      \
-            const unsigned g_ = tile_grid (KERNEL<1024>, 1024, LDS, WORK, grid_divisor);                       \
-            if (g_ == 0)                                                                                       \
-                return hipErrorNoDevice;                                                                       \
-            hipLaunchKernelGGL (KERNEL<1024>, dim3 (g_), dim3 (1024), LDS, stream, __VA_ARGS__);               \
-        }                                                                                                      \
+            CFFT_R4G_LAUNCH_B (KERNEL, 1024, SLOTSV, LDS, WORK, __VA_ARGS__)                                   \
         else                                                                                                   \
-        {                                                                                                      \
-            const unsigned g_ = tile_grid (KERNEL<256>, 256, LDS, WORK, grid_divisor);                         \
-            if (g_ == 0)                                                                                       \
-                return hipErrorNoDevice;                                                                       \
-            hipLaunchKernelGGL (KERNEL<256>, dim3 (g_), dim3 (256), LDS, stream, __VA_ARGS__);                 \
-        }                                                                                                      \
-        e_ = hipGetLastError();                                                                                \
+            CFFT_R4G_LAUNCH_B (KERNEL, 256, SLOTSV, LDS, WORK, __VA_ARGS__)                                    \
+        const hipError_t e_ = hipGetLastError();                                                               \
         if (e_ != hipSuccess)                                                                                  \
             return e_;                                                                                         \
     }
+    // a compile-time stage list for the length (kernels_real4_static_*.hip) brings its own geometry; else the run-time list
+    const bool runtime_lists_only = t.real4_generic == 2; // (a plan made under option "real4_generic" = 2)
+    const auto static_off = [runtime_lists_only] { static const bool off = [] { const char* e = std::getenv ("CHOWDSP_FFT_TILE_STATIC"); return e != nullptr && std::atoi (e) == 0; }(); return off || runtime_lists_only; };
+#define CFFT_R4G_PICK(NAME, PLAN, OUT)                                                         \
+    if (! static_off())                                                                        \
+    {                                                                                          \
+        if ((OUT = pick_real4_##NAME##_a (PLAN, dev.lds_per_cu, sl)) == nullptr)               \
+            if ((OUT = pick_real4_##NAME##_b (PLAN, dev.lds_per_cu, sl)) == nullptr)           \
+                OUT = pick_real4_##NAME##_c (PLAN, dev.lds_per_cu, sl);                        \
+    }
+#define CFFT_R4G_STATIC_LAUNCH(FN, WORK, ...)                                                  \
+    {                                                                                          \
+        const unsigned g_ = tile_grid (FN, sl.block, sl.lds_bytes, WORK, grid_divisor);        \
+        if (g_ == 0)                                                                           \
+            return hipErrorNoDevice;                                                           \
+        hipLaunchKernelGGL (FN, dim3 (g_), dim3 (sl.block), sl.lds_bytes, stream, __VA_ARGS__); \
+        const hipError_t e_ = hipGetLastError();                                               \
+        if (e_ != hipSuccess)                                                                  \
+            return e_;                                                                         \
+    }
+    Real4GLaunch sl {};
     if (! inverse)
     {
-        CFFT_R4G_LAUNCH (real4g_pass_a_kernel, block_c, lds_c, batch * col_tiles, in, work, tw, big, plan_c, (unsigned) n1c, (unsigned) batch, in_stride, lfs_c, ws_len);
-        CFFT_R4G_LAUNCH (real4g_pass_b_kernel, block_r, lds_r, batch * row_tiles, (const float2*) work, out, tw, plan_r, (unsigned) r2, (unsigned) batch, out_stride, lfs_r, ws_len);
+        Real4GTwFn ka = nullptr;
+        CFFT_R4G_PICK (cols_fwd, plan_c, ka)
+        if (ka != nullptr)
+            CFFT_R4G_STATIC_LAUNCH (ka, batch * col_tiles, in, work, tw, big, plan_c, (unsigned) n1c, (unsigned) batch, in_stride, sl.lfs, ws_len)
+        else
+            CFFT_R4G_LAUNCH (real4g_pass_a_kernel, block_c, slots_c, lds_c, batch * col_tiles, in, work, tw, big, plan_c, (unsigned) n1c, (unsigned) batch, in_stride, lfs_c, ws_len);
+        Real4GFn kb = nullptr;
+        CFFT_R4G_PICK (rows_fwd, plan_r, kb)
+        if (kb != nullptr)
+            CFFT_R4G_STATIC_LAUNCH (kb, batch * row_tiles, (const float2*) work, out, tw, plan_r, (unsigned) r2, (unsigned) batch, out_stride, sl.lfs, ws_len)
+        else
+            CFFT_R4G_LAUNCH (real4g_pass_b_kernel, block_r, slots_r, lds_r, batch * row_tiles, (const float2*) work, out, tw, plan_r, (unsigned) r2, (unsigned) batch, out_stride, lfs_r, ws_len);
     }
     else
     {
-        CFFT_R4G_LAUNCH (real4g_pass_b_inv_kernel, block_r, lds_r, batch * row_tiles, in, work, tw, big, plan_r, (unsigned) r2, (unsigned) batch, in_stride, lfs_r, ws_len);
-        CFFT_R4G_LAUNCH (real4g_pass_a_inv_kernel, block_c, lds_c, batch * col_tiles, (const float2*) work, out, tw, plan_c, (unsigned) n1c, (unsigned) batch, out_stride, lfs_c, ws_len);
+        Real4GTwFn kb = nullptr;
+        CFFT_R4G_PICK (rows_inv, plan_r, kb)
+        if (kb != nullptr)
+            CFFT_R4G_STATIC_LAUNCH (kb, batch * row_tiles, in, work, tw, big, plan_r, (unsigned) r2, (unsigned) batch, in_stride, sl.lfs, ws_len)
+        else
+            CFFT_R4G_LAUNCH (real4g_pass_b_inv_kernel, block_r, slots_r, lds_r, batch * row_tiles, in, work, tw, big, plan_r, (unsigned) r2, (unsigned) batch, in_stride, lfs_r, ws_len);
+        Real4GFn ka = nullptr;
+        CFFT_R4G_PICK (cols_inv, plan_c, ka)
+        if (ka != nullptr)
+            CFFT_R4G_STATIC_LAUNCH (ka, batch * col_tiles, (const float2*) work, out, tw, plan_c, (unsigned) n1c, (unsigned) batch, out_stride, sl.lfs, ws_len)
+        else
+            CFFT_R4G_LAUNCH (real4g_pass_a_inv_kernel, block_c, slots_c, lds_c, batch * col_tiles, (const float2*) work, out, tw, plan_c, (unsigned) n1c, (unsigned) batch, out_stride, lfs_c, ws_len);
     }
+#undef CFFT_R4G_PICK
+#undef CFFT_R4G_STATIC_LAUNCH
 #undef CFFT_R4G_LAUNCH
+#undef CFFT_R4G_LAUNCH_B
+#undef CFFT_R4G_LAUNCH_BS
     return hipSuccess;
 }
 } // namespace cfft::host

@@ -21,10 +21,35 @@
 
 namespace cfft
 {
-constexpr int kReal4GTile = 16;   // complex columns (pass A) / rows (pass B) per tile
-constexpr int kReal4GLoads = 4;   // loads in flight per work-item while a tile is brought in
+constexpr int kReal4GTile = 16; // complex columns (pass A) / rows (pass B) per tile
+// Operands of a tile per work-item: 16 frames of at most 639 points on 1024 work-items (or of at most 159 on 256: generic_tile_block).
+// The whole NEXT tile is requested into these registers as soon as this tile's operands have been committed to the image; they fly
+// during the stages and the stores (the tile kernels of round 3 were parked on memory for 65-80 % of their wave cycles without that).
+// vmcnt is one in-order counter, so nothing between the request and the end of the stages may wait on a younger load: the stage
+// twiddles are read from an LDS copy behind the images, and a tile's inter-pass twiddles are all loaded BEFORE its stores (a load
+// issued behind stores waits for them too).  Slots beyond the tile re-read its last element (a test around a load makes the compiler
+// wait for every load before the next).
+constexpr int kReal4GSlots = 10; // (the most: SLOTS below is the launcher's pick of 4, 6, 8 or 10 -- the fewest that hold a tile of this plan)
 
-template <int BLOCK>
+// the stages of one tile: the run-time list, or (SP) the compile-time list of this length (radix switch, stage loop and divisions fold away)
+template <int BLOCK, class SP>
+__device__ __forceinline__ const float2* r4g_core (const GenericPlan& plan, const float2* twl, float2* a, float2* b, int frames, int tid, unsigned lfs)
+{
+    if constexpr (std::is_void<SP>::value)
+        return generic_core<BLOCK, false, false, false> (plan, twl, a, b, nullptr, nullptr, frames, tid, lfs, plan.tw_offset[0]);
+    else
+        return static_core<SP, BLOCK, false, false, false, 0, false, SP::n + 1> (twl, a, b, nullptr, nullptr, frames, tid, 0u, 0u);
+}
+
+template <int BLOCK, int SLOTS, class T, class ADDR>
+__device__ __forceinline__ void r4g_request (T (&pre)[SLOTS], int total, int tid, ADDR addr)
+{
+#pragma unroll
+    for (int u = 0; u < SLOTS; ++u)
+        pre[u] = *addr (min (tid + u * BLOCK, total - 1));
+}
+
+template <int BLOCK, int SLOTS, class SP = void>
 __global__ __launch_bounds__ (BLOCK) void real4g_pass_a_kernel (const float2* __restrict__ in, // the real frame as N/2 float2
                                                                float2* __restrict__ work,
                                                                const float2* __restrict__ twtab,
@@ -39,54 +64,65 @@ __global__ __launch_bounds__ (BLOCK) void real4g_pass_a_kernel (const float2* __
     extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
     constexpr int CA = kReal4GTile;
     const int tid = threadIdx.x;
-    const int n2 = plan.n, NR = n2 / 2 + 1;
+    const int n2 = tile_frame_len<SP> (plan), NR = n2 / 2 + 1; // (SP: compile-time stage list of this length, void = the run-time list)
+    if constexpr (! std::is_void<SP>::value)
+        lfs = SP::n + 1;
     float2* bufA = smem;
     float2* bufB = smem + (size_t) CA * lfs;
+    float2* twl = smem + (size_t) 2 * CA * lfs; // the stage twiddles' LDS copy (n2 - 1 entries)
+    lds_table_copy<BLOCK> (twl, twtab + plan.tw_offset[0], n2 - 1, tid);
     const unsigned tiles = n1c / CA;
     const size_t nwork = (size_t) batch * tiles;
-    const int total = CA * n2;
+    const int total = CA * n2, half = CA * NR;
+    float2 pre[SLOTS];
+    const auto request = [&] (size_t w) {
+        const unsigned f = (unsigned) (w / tiles), tile = (unsigned) (w % tiles);
+        const float2* __restrict__ src = in + (size_t) f * in_stride + (size_t) tile * CA;
+        r4g_request<BLOCK> (pre, total, tid, [&] (int e) { return &src[(unsigned) (e / CA) * n1c + (unsigned) (e % CA)]; });
+    };
+    if (blockIdx.x < nwork)
+        request (blockIdx.x);
     for (size_t w = blockIdx.x; w < nwork; w += gridDim.x)
     {
         const unsigned f = (unsigned) (w / tiles), tile = (unsigned) (w % tiles);
-        const float2* __restrict__ src = in + (size_t) f * in_stride + (size_t) tile * CA;
         float4* __restrict__ dst = reinterpret_cast<float4*> (work + (size_t) f * ws_frame_len + (size_t) tile * ((size_t) NR * CA * 2));
         const float4* __restrict__ twp = reinterpret_cast<const float4*> (big_tw + (size_t) tile * ((size_t) NR * CA * 2));
-        __syncthreads(); // previous tile fully stored
-        for (int e0 = tid; e0 < total; e0 += BLOCK * kReal4GLoads)
+        __syncthreads(); // previous tile fully read out of the images
+#pragma unroll
+        for (int u = 0; u < SLOTS; ++u)
         {
-            float2 x[kReal4GLoads];
-#pragma unroll
-            for (int u = 0; u < kReal4GLoads; ++u)
-            {
-                const int e = min (e0 + u * BLOCK, total - 1);
-                x[u] = gload (&src[(size_t) (e / CA) * n1c + (e % CA)]);
-            }
-#pragma unroll
-            for (int u = 0; u < kReal4GLoads; ++u)
-            {
-                const int e = e0 + u * BLOCK;
-                if (e < total)
-                    bufA[(e % CA) * lfs + e / CA] = x[u];
-            }
+            const int e = tid + u * BLOCK;
+            if (e < total)
+                bufA[(e % CA) * lfs + e / CA] = pre[u];
         }
         __syncthreads();
-        const float2* res = generic_core<BLOCK, false, false, false> (plan, twtab, bufA, bufB, nullptr, nullptr, CA, tid, lfs);
-        for (int e = tid; e < CA * NR; e += BLOCK)
+        if (w + gridDim.x < nwork)
+            request (w + gridDim.x);
+        const float2* res = r4g_core<BLOCK, SP> (plan, twl, bufA, bufB, CA, tid, lfs);
+        // the tile's inter-pass twiddles first (half = 16 (R2 / 2 + 1) float4, at most SLOTS / 2 per work-item), then the stores
+        float4 w4[SLOTS / 2];
+#pragma unroll
+        for (int u = 0; u < SLOTS / 2; ++u)
+            w4[u] = twp[min (tid + u * BLOCK, half - 1)];
+#pragma unroll
+        for (int u = 0; u < SLOTS / 2; ++u)
         {
+            const int e = tid + u * BLOCK;
+            if (e >= half)
+                continue;
             const int c = e % CA, kb = e / CA;
             const float2 zk = res[c * lfs + kb];
             const float2 zm = res[c * lfs + (kb == 0 ? 0 : n2 - kb)];
             // even column: (zk + conj zm) / 2;  odd column: (zk - conj zm) / (2 i)
             const float2 ce = make_float2 (0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
             const float2 co = make_float2 (0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));
-            const float4 w4 = twp[e];
-            const float2 re = cmul (ce, make_float2 (w4.x, w4.y)), ro = cmul (co, make_float2 (w4.z, w4.w));
+            const float2 re = cmul (ce, make_float2 (w4[u].x, w4[u].y)), ro = cmul (co, make_float2 (w4[u].z, w4[u].w));
             dst[e] = make_float4 (re.x, re.y, ro.x, ro.y); // plain store: the workspace should stay cached
         }
     }
 }
 
-template <int BLOCK>
+template <int BLOCK, int SLOTS, class SP = void>
 __global__ __launch_bounds__ (BLOCK) void real4g_pass_b_kernel (const float2* __restrict__ work,
                                                                float2* __restrict__ out, // packed spectrum
                                                                const float2* __restrict__ twtab,
@@ -100,45 +136,52 @@ __global__ __launch_bounds__ (BLOCK) void real4g_pass_b_kernel (const float2* __
     extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
     constexpr int CB = kReal4GTile;
     const int tid = threadIdx.x;
-    const int R1 = plan.n;
+    const int R1 = tile_frame_len<SP> (plan);
+    if constexpr (! std::is_void<SP>::value)
+        lfs = SP::n + 1;
     float2* bufA = smem;
     float2* bufB = smem + (size_t) CB * lfs;
+    float2* twl = smem + (size_t) 2 * CB * lfs;
+    lds_table_copy<BLOCK> (twl, twtab + plan.tw_offset[0], R1 - 1, tid);
     const unsigned NR = n2 / 2 + 1;
     const unsigned tiles = (NR + CB - 1) / CB;
     const size_t nwork = (size_t) batch * tiles;
     const int total = CB * R1;
+    float2 pre[SLOTS];
+    const auto request = [&] (size_t w) {
+        const unsigned f = (unsigned) (w / tiles), tile = (unsigned) (w % tiles);
+        const unsigned kb0 = tile * CB;
+        const unsigned last = min ((unsigned) CB, NR - kb0) - 1u;
+        const float2* __restrict__ src = work + (size_t) f * ws_frame_len;
+        // al fastest (32 contiguous values), then the tile's row, then pass A's tile
+        r4g_request<BLOCK> (pre, total, tid, [&] (int e) {
+            const unsigned al = (unsigned) e & 31u, kbl = min (((unsigned) e >> 5) % CB, last), tA = ((unsigned) e >> 5) / CB;
+            return &src[(tA * NR + kb0 + kbl) * 32u + al];
+        });
+    };
+    if (blockIdx.x < nwork)
+        request (blockIdx.x);
     for (size_t w = blockIdx.x; w < nwork; w += gridDim.x)
     {
         const unsigned f = (unsigned) (w / tiles), tile = (unsigned) (w % tiles);
         const unsigned kb0 = tile * CB;
         const int valid = (int) min ((unsigned) CB, NR - kb0);
-        const float2* __restrict__ src = work + (size_t) f * ws_frame_len;
         float2* __restrict__ dst = out + (size_t) f * out_stride;
         __syncthreads();
-        for (int e0 = tid; e0 < total; e0 += BLOCK * kReal4GLoads)
+#pragma unroll
+        for (int u = 0; u < SLOTS; ++u)
         {
-            float2 x[kReal4GLoads];
-#pragma unroll
-            for (int u = 0; u < kReal4GLoads; ++u)
+            const int e = tid + u * BLOCK;
+            if (e < total)
             {
-                // al fastest (32 contiguous values), then the tile's row, then pass A's tile
-                const unsigned e = (unsigned) min (e0 + u * BLOCK, total - 1);
-                const unsigned al = e & 31u, kbl = min ((e >> 5) % CB, (unsigned) (valid - 1)), tA = (e >> 5) / CB;
-                x[u] = src[((size_t) tA * NR + kb0 + kbl) * 32 + al];
-            }
-#pragma unroll
-            for (int u = 0; u < kReal4GLoads; ++u)
-            {
-                const int e = e0 + u * BLOCK;
-                if (e < total)
-                {
-                    const unsigned al = (unsigned) e & 31u, kbl = ((unsigned) e >> 5) % CB, tA = ((unsigned) e >> 5) / CB;
-                    bufA[kbl * lfs + tA * 32 + al] = (int) kbl < valid ? x[u] : make_float2 (0.f, 0.f);
-                }
+                const unsigned al = (unsigned) e & 31u, kbl = ((unsigned) e >> 5) % CB, tA = ((unsigned) e >> 5) / CB;
+                bufA[kbl * lfs + tA * 32 + al] = (int) kbl < valid ? pre[u] : make_float2 (0.f, 0.f);
             }
         }
         __syncthreads();
-        const float2* res = generic_core<BLOCK, false, false, false> (plan, twtab, bufA, bufB, nullptr, nullptr, CB, tid, lfs);
+        if (w + gridDim.x < nwork)
+            request (w + gridDim.x);
+        const float2* res = r4g_core<BLOCK, SP> (plan, twl, bufA, bufB, CB, tid, lfs);
         for (int e = tid; e < total; e += BLOCK)
         {
             const int c = e % CB, k = e / CB;
@@ -151,17 +194,17 @@ __global__ __launch_bounds__ (BLOCK) void real4g_pass_b_kernel (const float2* __
                 if (kb == 0 && k == 0)
                     gstore (&dst[0], make_float2 (y.x, res[c * lfs + R1 / 2].x)); // (X0, X_{N/2}): both real
                 else
-                    gstore (&dst[(size_t) k * n2 + kb], y);
+                    gstore (&dst[(unsigned) k * n2 + kb], y);
             }
             else if (kb != 0 && 2 * kb != n2)
-                gstore (&dst[(size_t) (R1 - 1 - k) * n2 + (n2 - kb)], make_float2 (y.x, -y.y));
+                gstore (&dst[(unsigned) (R1 - 1 - k) * n2 + (n2 - kb)], make_float2 (y.x, -y.y));
         }
     }
 }
 
 // Backward, first sweep: row kb (0 .. R2/2) of the spectrum gathered from the packed input, transformed backward (re <-> im swap on
 // both sides), times conj W_N^{a kb}, into the workspace
-template <int BLOCK>
+template <int BLOCK, int SLOTS, class SP = void>
 __global__ __launch_bounds__ (BLOCK) void real4g_pass_b_inv_kernel (const float2* __restrict__ in, // packed spectrum
                                                                    float2* __restrict__ work,
                                                                    const float2* __restrict__ twtab,
@@ -176,74 +219,93 @@ __global__ __launch_bounds__ (BLOCK) void real4g_pass_b_inv_kernel (const float2
     extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
     constexpr int CB = kReal4GTile;
     const int tid = threadIdx.x;
-    const int R1 = plan.n;
+    const int R1 = tile_frame_len<SP> (plan);
+    if constexpr (! std::is_void<SP>::value)
+        lfs = SP::n + 1;
     float2* bufA = smem;
     float2* bufB = smem + (size_t) CB * lfs;
+    float2* twl = smem + (size_t) 2 * CB * lfs;
+    lds_table_copy<BLOCK> (twl, twtab + plan.tw_offset[0], R1 - 1, tid);
     const unsigned NR = n2 / 2 + 1;
     const unsigned tiles = (NR + CB - 1) / CB;
     const size_t nwork = (size_t) batch * tiles;
     const int total = CB * R1;
+    float2 pre[SLOTS];
+    const auto request = [&] (size_t w) {
+        const unsigned f = (unsigned) (w / tiles), tile = (unsigned) (w % tiles);
+        const unsigned kb0 = tile * CB;
+        const int last = (int) min ((unsigned) CB, NR - kb0) - 1;
+        const float2* __restrict__ src = in + (size_t) f * in_stride;
+        // bins R2 k + kb directly for k < R1/2; X_{N/2} from slot 0; the rest as conjugates of X[N - R2 k - kb] (rows 0 and R2/2 mirror
+        // onto themselves).  Row fastest: 16 contiguous bins per access
+        r4g_request<BLOCK> (pre, total, tid, [&] (int e) {
+            const int c = min (e % CB, last), k = e / CB;
+            const unsigned kb = kb0 + (unsigned) c;
+            unsigned idx; // (frame-local offsets stay far below 2^32: one address register per request)
+            if (k < R1 / 2)
+                idx = (unsigned) k * n2 + kb;
+            else if (kb == 0 && k == R1 / 2)
+                idx = 0;
+            else
+                idx = (kb == 0) ? (unsigned) (R1 - k) * n2 : (unsigned) (R1 - 1 - k) * n2 + (n2 - kb);
+            return &src[idx];
+        });
+    };
+    if (blockIdx.x < nwork)
+        request (blockIdx.x);
     for (size_t w = blockIdx.x; w < nwork; w += gridDim.x)
     {
         const unsigned f = (unsigned) (w / tiles), tile = (unsigned) (w % tiles);
         const unsigned kb0 = tile * CB;
         const int valid = (int) min ((unsigned) CB, NR - kb0);
-        const float2* __restrict__ src = in + (size_t) f * in_stride;
         float2* __restrict__ dst = work + (size_t) f * ws_frame_len;
         __syncthreads();
-        for (int e0 = tid; e0 < total; e0 += BLOCK * kReal4GLoads)
+#pragma unroll
+        for (int u = 0; u < SLOTS; ++u)
         {
-            float2 x[kReal4GLoads];
-#pragma unroll
-            for (int u = 0; u < kReal4GLoads; ++u)
+            const int e = tid + u * BLOCK;
+            if (e >= total)
+                continue;
+            const int c = e % CB, k = e / CB;
+            const unsigned kb = kb0 + (unsigned) c;
+            float2 v = pre[u];
+            if (k < R1 / 2)
             {
-                const int e = min (e0 + u * BLOCK, total - 1);
-                const int c = min (e % CB, valid - 1), k = e / CB; // row fastest: 16 contiguous bins per access
-                const unsigned kb = kb0 + (unsigned) c;
-                // bins R2 k + kb directly for k < R1/2; X_{N/2} from slot 0; the rest as conjugates of X[N - R2 k - kb] (rows 0 and R2/2
-                // mirror onto themselves)
-                size_t idx;
-                if (k < R1 / 2)
-                    idx = (size_t) k * n2 + kb;
-                else if (kb == 0 && k == R1 / 2)
-                    idx = 0;
-                else
-                    idx = (kb == 0) ? (size_t) (R1 - k) * n2 : (size_t) (R1 - 1 - k) * n2 + (n2 - kb);
-                x[u] = gload (&src[idx]);
+                if (kb == 0 && k == 0)
+                    v = make_float2 (v.x, 0.f); // X0 (its slot's second float is X_{N/2})
             }
-#pragma unroll
-            for (int u = 0; u < kReal4GLoads; ++u)
-            {
-                const int e = e0 + u * BLOCK;
-                if (e >= total)
-                    continue;
-                const int c = e % CB, k = e / CB;
-                const unsigned kb = kb0 + (unsigned) c;
-                float2 v = x[u];
-                if (k < R1 / 2)
-                {
-                    if (kb == 0 && k == 0)
-                        v = make_float2 (v.x, 0.f); // X0 (its slot's second float is X_{N/2})
-                }
-                else if (kb == 0 && k == R1 / 2)
-                    v = make_float2 (v.y, 0.f); // X_{N/2}
-                else
-                    v = make_float2 (v.x, -v.y);
-                if (c >= valid)
-                    v = make_float2 (0.f, 0.f);
-                bufA[c * lfs + k] = make_float2 (v.y, v.x); // swapped: backward = swap . forward . swap
-            }
+            else if (kb == 0 && k == R1 / 2)
+                v = make_float2 (v.y, 0.f); // X_{N/2}
+            else
+                v = make_float2 (v.x, -v.y);
+            if (c >= valid)
+                v = make_float2 (0.f, 0.f);
+            bufA[c * lfs + k] = make_float2 (v.y, v.x); // swapped: backward = swap . forward . swap
         }
         __syncthreads();
-        const float2* res = generic_core<BLOCK, false, false, false> (plan, twtab, bufA, bufB, nullptr, nullptr, CB, tid, lfs);
-        for (int e = tid; e < total; e += BLOCK)
+        if (w + gridDim.x < nwork)
+            request (w + gridDim.x);
+        const float2* res = r4g_core<BLOCK, SP> (plan, twl, bufA, bufB, CB, tid, lfs);
+        // the inter-pass twiddles of the whole tile first, then the stores
+        float2 tw[SLOTS];
+#pragma unroll
+        for (int u = 0; u < SLOTS; ++u)
         {
+            const unsigned e = (unsigned) min (tid + u * BLOCK, total - 1);
+            const unsigned al = e & 31u, kbl = min ((e >> 5) % CB, (unsigned) (valid - 1)), tA = (e >> 5) / CB;
+            tw[u] = big_tw[(tA * NR + kb0 + kbl) * 32u + al];
+        }
+#pragma unroll
+        for (int u = 0; u < SLOTS; ++u)
+        {
+            const int e = tid + u * BLOCK;
+            if (e >= total)
+                continue;
             const unsigned al = (unsigned) e & 31u, kbl = ((unsigned) e >> 5) % CB, tA = ((unsigned) e >> 5) / CB;
             if ((int) kbl < valid)
             {
                 const float2 ys = res[kbl * lfs + tA * 32 + al];
-                const size_t idx = ((size_t) tA * NR + kb0 + kbl) * 32 + al;
-                dst[idx] = cmulc (make_float2 (ys.y, ys.x), big_tw[idx]); // un-swap, times conj W_N^{a kb}
+                dst[(tA * NR + kb0 + kbl) * 32u + al] = cmulc (make_float2 (ys.y, ys.x), tw[u]); // un-swap, times conj W_N^{a kb}
             }
         }
     }
@@ -251,7 +313,7 @@ __global__ __launch_bounds__ (BLOCK) void real4g_pass_b_inv_kernel (const float2
 
 // Backward, second sweep: the columns.  Z_c[kb] = C_2c[kb] + i C_2c+1[kb] for kb <= R2/2 and conj C_2c[R2 - kb] + i conj C_2c+1[R2 - kb]
 // above; backward transform over kb, stored as the float2 column c of the real frame.
-template <int BLOCK>
+template <int BLOCK, int SLOTS, class SP = void>
 __global__ __launch_bounds__ (BLOCK) void real4g_pass_a_inv_kernel (const float2* __restrict__ work,
                                                                    float2* __restrict__ out, // the real frame as N/2 float2
                                                                    const float2* __restrict__ twtab,
@@ -265,46 +327,53 @@ __global__ __launch_bounds__ (BLOCK) void real4g_pass_a_inv_kernel (const float2
     extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
     constexpr int CA = kReal4GTile;
     const int tid = threadIdx.x;
-    const int n2 = plan.n, NR = n2 / 2 + 1;
+    const int n2 = tile_frame_len<SP> (plan), NR = n2 / 2 + 1; // (SP: compile-time stage list of this length, void = the run-time list)
+    if constexpr (! std::is_void<SP>::value)
+        lfs = SP::n + 1;
     float2* bufA = smem;
     float2* bufB = smem + (size_t) CA * lfs;
+    float2* twl = smem + (size_t) 2 * CA * lfs;
+    lds_table_copy<BLOCK> (twl, twtab + plan.tw_offset[0], n2 - 1, tid);
     const unsigned tiles = n1c / CA;
     const size_t nwork = (size_t) batch * tiles;
-    const int total = CA * n2;
+    const int total = CA * n2, half = CA * NR;
+    float4 pre[SLOTS / 2];
+    const auto request = [&] (size_t w) {
+        const unsigned f = (unsigned) (w / tiles), tile = (unsigned) (w % tiles);
+        const float4* __restrict__ src = reinterpret_cast<const float4*> (work + (size_t) f * ws_frame_len + (size_t) tile * ((size_t) NR * CA * 2));
+        r4g_request<BLOCK> (pre, half, tid, [&] (int e) { return &src[e]; }); // (C_2c[kb], C_2c+1[kb])
+    };
+    if (blockIdx.x < nwork)
+        request (blockIdx.x);
     for (size_t w = blockIdx.x; w < nwork; w += gridDim.x)
     {
         const unsigned f = (unsigned) (w / tiles), tile = (unsigned) (w % tiles);
-        const float4* __restrict__ src = reinterpret_cast<const float4*> (work + (size_t) f * ws_frame_len + (size_t) tile * ((size_t) NR * CA * 2));
         float2* __restrict__ dst = out + (size_t) f * out_stride + (size_t) tile * CA;
         __syncthreads();
-        for (int e0 = tid; e0 < CA * NR; e0 += BLOCK * 2)
+#pragma unroll
+        for (int u = 0; u < SLOTS / 2; ++u)
         {
-            float4 p[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-                p[u] = src[min (e0 + u * BLOCK, CA * NR - 1)]; // (C_2c[kb], C_2c+1[kb])
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-            {
-                const int e = e0 + u * BLOCK;
-                if (e >= CA * NR)
-                    continue;
-                const int c = e % CA, kb = e / CA;
-                // Z[kb] = Ce + i Co, Z[R2 - kb] = conj Ce + i conj Co; stored swapped for the backward transform
-                const float2 zk = make_float2 (p[u].x - p[u].w, p[u].y + p[u].z);
-                const float2 zm = make_float2 (p[u].x + p[u].w, p[u].z - p[u].y);
-                bufA[c * lfs + kb] = make_float2 (zk.y, zk.x);
-                if (kb != 0 && 2 * kb != n2)
-                    bufA[c * lfs + (n2 - kb)] = make_float2 (zm.y, zm.x);
-            }
+            const int e = tid + u * BLOCK;
+            if (e >= half)
+                continue;
+            const int c = e % CA, kb = e / CA;
+            const float4 p = pre[u];
+            // Z[kb] = Ce + i Co, Z[R2 - kb] = conj Ce + i conj Co; stored swapped for the backward transform
+            const float2 zk = make_float2 (p.x - p.w, p.y + p.z);
+            const float2 zm = make_float2 (p.x + p.w, p.z - p.y);
+            bufA[c * lfs + kb] = make_float2 (zk.y, zk.x);
+            if (kb != 0 && 2 * kb != n2)
+                bufA[c * lfs + (n2 - kb)] = make_float2 (zm.y, zm.x);
         }
         __syncthreads();
-        const float2* res = generic_core<BLOCK, false, false, false> (plan, twtab, bufA, bufB, nullptr, nullptr, CA, tid, lfs);
+        if (w + gridDim.x < nwork)
+            request (w + gridDim.x);
+        const float2* res = r4g_core<BLOCK, SP> (plan, twl, bufA, bufB, CA, tid, lfs);
         for (int e = tid; e < total; e += BLOCK)
         {
             const int c = e % CA, j = e / CA;
             const float2 y = res[c * lfs + j];
-            gstore (&dst[(size_t) j * n1c + c], make_float2 (y.y, y.x));
+            gstore (&dst[(unsigned) j * n1c + (unsigned) c], make_float2 (y.y, y.x));
         }
     }
 }

@@ -174,18 +174,19 @@ bool split_real4 (int n_real, int& r1, int& r2)
     return true;
 }
 
-// option "real4_generic" (initial value: CHOWDSP_FFT_REAL4_GENERIC=1): read when a plan is MADE (the device-table cache keeps plans of
-// either kind apart, host_common.cpp).  Off by default: the form is correct but not yet as fast as the three sweeps it replaces
-// (profiles/r05_real4_generic.txt).
+// option "real4_generic" (initial value: CHOWDSP_FFT_REAL4_GENERIC), read when a plan is MADE (the device-table cache keeps plans of the
+// different kinds apart, host_common.cpp): 1 (default) = where BOTH factors have a compile-time stage list (kernels_real4_static_*.hip:
+// 0.25-0.30 of 8 TB/s against 0.21-0.24 for the three sweeps, profiles/r05_real4_generic.txt); 2 = for every admissible split, run-time
+// lists ONLY (0.17-0.18: slower than the three sweeps -- it keeps the run-time kernels tested and measurable); 0 = off.
 static std::atomic<int> g_real4_generic { -1 };
-void set_real4_generic (int on) { g_real4_generic = on != 0 ? 1 : 0; }
+void set_real4_generic (int mode) { g_real4_generic = (mode >= 0 && mode <= 2) ? mode : 1; }
 int get_real4_generic()
 {
     int v = g_real4_generic.load();
     if (v < 0)
     {
         const char* e = std::getenv ("CHOWDSP_FFT_REAL4_GENERIC");
-        v = (e != nullptr && e[0] == '1') ? 1 : 0;
+        v = (e != nullptr && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
         g_real4_generic = v;
     }
     return v;
@@ -194,7 +195,9 @@ int get_real4_generic()
 bool split_real4_generic (int n_real, int& r1, int& r2)
 {
     r1 = r2 = 0;
-    const bool off = get_real4_generic() == 0;
+    const int mode = get_real4_generic();
+    const bool off = mode == 0;
+    static const bool no_lists = [] { const char* e = std::getenv ("CHOWDSP_FFT_TILE_STATIC"); return e != nullptr && std::atoi (e) == 0; }();
     constexpr int kOnePassMaxComplex = 20000; // (= kGenericMaxComplexLen below: shorter frames stay on chip)
     if (off || n_real <= 2 * kOnePassMaxComplex || is_pow2 (n_real) || (n_real % 64) != 0)
         return false;
@@ -215,6 +218,8 @@ bool split_real4_generic (int n_real, int& r1, int& r2)
         const int b = n_real / a;
         if (b > 639 || b < 16 || (b & 1) != 0)
             continue;
+        if (mode == 1 && (no_lists || ! has_static_tile (a) || ! has_static_tile (b)))
+            continue; // (default: only where both cores have a compile-time stage list)
         const double score = a > b ? (double) a / b : (double) b / a;
         if (score < best)
         {
@@ -577,7 +582,7 @@ bool build_host_tables (int N, int transform, HostTables& out)
             out.core_n = 0;
             out.real4_r1 = g1;
             out.real4_r2 = g2;
-            out.real4_generic = 1;
+            out.real4_generic = get_real4_generic() == 2 ? 2 : 1; // (2: run-time stage lists only, kernels_real4_generic.hip)
             const auto add_list = [&out] (int n, int frames, std::vector<int>& radix, std::vector<int>& offs) {
                 generic_radices (n, radix, frames);
                 int p = 1;

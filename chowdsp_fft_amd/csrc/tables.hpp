@@ -50,9 +50,10 @@ bool split_real4 (int n_real, int& r1, int& r2);
 // Long real frames that are not a power of two (complex length beyond the one-pass kernels): N = r1 x r2 for the real four-step with
 // generic cores -- r1 a multiple of 32 (tiles of 16 complex = 32 real columns), r2 even, both 2^a 3^b 5^c and at most 639 points (two
 // LDS images of 16 frames of r + 1 points).  false where no such split exists (the frame then runs as a complex two-pass transform of
-// N / 2 points + the stand-alone pair stage, three sweeps) -- and while option "real4_generic" is 0 (the default: set_real4_generic).
+// N / 2 points + the stand-alone pair stage, three sweeps).  Option "real4_generic": 1 (default) only splits whose two factors both
+// have a compile-time stage list, 2 every admissible split, 0 none.
 bool split_real4_generic (int n_real, int& r1, int& r2);
-void set_real4_generic (int on);
+void set_real4_generic (int mode);
 int get_real4_generic();
 
 // Size policy shared with the C API.

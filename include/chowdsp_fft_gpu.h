@@ -113,11 +113,12 @@ int fft_gpu_table_cache_info (int device, size_t info[4]);
                         (enforced through the launch's LDS size) -- for complex N = 65536 and real N = 131072; the forms that do not
                         offer it (complex 2^17 / 2^18 groups, the N = 65536 fused convolution) then run their multi-launch composition,
                         which has no in-kernel hand-off.  Results are identical; what the listed form costs: INTEGRATION.md.
-     "real4_generic"    1: plans MADE from now on run long mixed-radix REAL frames (N = R1 x R2 with R1 = 32 j, R2 even, both at most
-                        639 points: 41472, 96000, 245760 ...) by the real four-step with run-time stage lists for both cores -- two
-                        sweeps over the data instead of the complex two-pass transform of N / 2 points + the pair stage (three).
-                        Correct and tested, but its tile kernels are not pipelined yet and measure SLOWER than the three sweeps
-                        (0.13-0.17 against 0.21-0.24 of 8 TB/s, profiles/r05_real4_generic.txt): default 0.
+     "real4_generic"    how plans MADE from now on run long mixed-radix REAL frames (complex length beyond the one-pass kernels) that
+                        split as N = R1 x R2 with R1 = 32 j, R2 even, both at most 639 points (41472, 96000, 245760 ...):
+                        1 (default) the real four-step with generic cores -- two sweeps over the data instead of the complex
+                        two-pass transform of N / 2 points + the pair stage (three) -- where both factors have a compile-time stage
+                        list (0.25-0.30 of 8 TB/s against 0.21-0.24); 2 for every such split and with run-time stage lists only
+                        (0.17-0.18, slower than the three sweeps: it keeps those kernels tested and measurable); 0 never.
      "table_cache_mib"  device memory (MiB) that tables of destroyed plans may keep for re-use (default 64; 0 = none)
    Returns 0, or FFT_GPU_EINVAL for an unknown name / a value out of range. */
 int fft_gpu_set_option (const char* name, long value);

@@ -15,7 +15,7 @@ from conftest import MIXED_RADIX_MAXABS_TOL, assert_frames_close
 from oracle_lib import BACKWARD, FORWARD, REAL
 
 # real lengths with an admissible split N = R1 x R2 (R1 = 32 j <= 639, R2 even <= 639; tables.cpp split_real4_generic picks the one nearest to square)
-SIZES = [41472, 46080, 61440, 76800, 92160, 96000, 122880, 153600, 245760]
+SIZES = [41472, 46080, 61440, 76800, 92160, 96000, 122880, 153600, 245760, 73728, 110592]
 
 
 def _exact(x, n, direction):
@@ -32,32 +32,47 @@ def _exact(x, n, direction):
     return np.fft.irfft(spec, n=n, axis=1) * n
 
 
-@pytest.fixture()
-def real4g():
-    """the form is opt-in (option "real4_generic", read when a plan is made): on for the test, off again afterwards"""
+# lengths with a compile-time stage list (csrc/tables.hpp CFFT_STATIC_TILE_SIZES_A/B/C, at most 639 points)
+STATIC = {48, 80, 96, 144, 160, 192, 240, 288, 320, 384, 400, 432, 480, 576, 150, 162, 180, 200, 216, 225, 243, 250, 256, 270, 300, 324, 360, 375,
+          405, 450, 486, 500, 512, 540, 600, 625}
+
+
+@pytest.fixture(params=[1, 2], ids=["static-lists", "every-split"])
+def real4g(request):
+    """option "real4_generic" (read when a plan is made): 1 = the default, splits whose two factors both have a compile-time stage
+    list; 2 = every admissible split with run-time stage lists only (slower than the three sweeps: keeps those kernels tested)"""
     from chowdsp_fft_amd import api
 
-    assert api.get_option("real4_generic") == 0, "off by default (slower than the path it replaces: profiles/r05_real4_generic.txt)"
-    api.set_option("real4_generic", 1)
+    assert api.get_option("real4_generic") == 1, "the default"
+    api.set_option("real4_generic", request.param)
     yield api
-    api.set_option("real4_generic", 0)
+    api.set_option("real4_generic", 1)
+
+
+def _splits(n, mode):
+    return [(max(a, n // a) / min(a, n // a), a) for a in range(32, 640, 32)
+            if n % a == 0 and (n // a) <= 639 and (n // a) % 2 == 0 and (n // a) >= 16 and _smooth(a)
+            and (mode == 2 or (a in STATIC and (n // a) in STATIC))]
 
 
 def test_split_rule_host_logic(real4g):
     """pure host logic (no GPU): which lengths take the form and with which factors"""
     api = real4g
+    mode = api.get_option("real4_generic")
     for n in SIZES:
         d = api.plan_describe(n, api.FFT_REAL)
+        cands = _splits(n, mode)
+        if not cands:
+            assert d["n1"] * d["n2"] == n // 2, (n, d)  # the complex two-pass plan of N / 2 points
+            continue
         r1, r2 = d["n1"], d["n2"]
         assert d["passes"] == 2 and r1 * r2 == n and r1 % 32 == 0 and r2 % 2 == 0 and r1 <= 639 and r2 <= 639, (n, d)
-        # nearest to square among the admissible splits
-        best = min((max(a, n // a) / min(a, n // a), a) for a in range(32, 640, 32)
-                   if n % a == 0 and (n // a) <= 639 and (n // a) % 2 == 0 and (n // a) >= 16 and _smooth(a))
-        assert r1 == best[1], (n, d, best)
-    # not taken: short frames stay on chip (one pass); powers of two have their own real four-step (power-of-two factors)
+        assert r1 == min(cands)[1], (n, d, min(cands))  # nearest to square among the admissible splits
     api.set_option("real4_generic", 0)
-    assert api.plan_describe(41472, api.FFT_REAL)["n1"] * api.plan_describe(41472, api.FFT_REAL)["n2"] == 41472 // 2, "option off: the complex two-pass plan of N / 2 points"
-    api.set_option("real4_generic", 1)
+    d = api.plan_describe(41472, api.FFT_REAL)
+    assert d["n1"] * d["n2"] == 41472 // 2, "option off: the complex two-pass plan of N / 2 points"
+    api.set_option("real4_generic", mode)
+    # not taken: short frames stay on chip (one pass); powers of two have their own real four-step (power-of-two factors)
     assert api.plan_describe(36864, api.FFT_REAL)["passes"] == 1
     d = api.plan_describe(1 << 17, api.FFT_REAL)
     assert d["passes"] == 2 and d["n1"] & (d["n1"] - 1) == 0 and d["n2"] & (d["n2"] - 1) == 0
