@@ -643,7 +643,8 @@ int big_real4_chunked (Setup* s, bool inverse, const float2* in, float2* out, si
         const int k = (lanes == 2) ? (int) (i & 1) : 0;
         const hipStream_t st = (lanes == 2) ? L->lane[k] : stream;
         const hipError_t e = t->real4_generic
-                                 ? launch_real4_generic (*t, inverse, in + f0 * is2, L->ws[k], out + f0 * os2, nb, lanes, st, is2, os2)
+                                 ? (mul_h != nullptr ? launch_real4_generic_conv (*t, in + f0 * is2, mul_h, mul_scale, L->ws[k], out + f0 * os2, nb, lanes, st, is2, os2)
+                                                     : launch_real4_generic (*t, inverse, in + f0 * is2, L->ws[k], out + f0 * os2, nb, lanes, st, is2, os2))
                              : t->real4_fast
                                  ? launch_real4_fast (r1, r2, inverse, in + f0 * is2, L->ws[k], out + f0 * os2, t->stage_twiddles, t->big_twiddles, nb, lanes, st, is2, os2, mul_h, mul_scale)
                                  : launch_real4 (r1, r2, inverse, in + f0 * is2, L->ws[k], out + f0 * os2, t->stage_twiddles, t->big_twiddles, nb, lanes, st, is2, os2);
@@ -1994,6 +1995,12 @@ int fft_convolve_frames_batch (void* setup, const float* x, const float* dft_fil
         if (rc != FFT_GPU_OK)
             return rc;
         return run_transform (s, y, y, batch, FFT_BACKWARD, (hipStream_t) stream);
+    }
+    if (s->transform == FFT_REAL && t->real4_generic != 0 && g_fused_conv_generic.load() != 0)
+    {
+        // long mixed-radix real frames on the real four-step with generic cores: columns forward, ONE fused row pass (forward rows, product,
+        // backward rows, in place in the workspace), columns backward -- three sweeps (real4_generic_kernels.hpp real4g_rows_conv_kernel)
+        return big_real4_chunked (s, false, (const float2*) x, (float2*) y, batch, (hipStream_t) stream, (size_t) nc, (size_t) nc, (const float2*) dft_filter, scaling);
     }
     if (s->transform == FFT_REAL && t->real4_r1 > 0 && t->real4_fast != 0 && g_fused_conv_group.load() != 0)
     {

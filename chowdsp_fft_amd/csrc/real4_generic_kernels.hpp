@@ -311,6 +311,136 @@ __global__ __launch_bounds__ (BLOCK) void real4g_pass_b_inv_kernel (const float2
     }
 }
 
+// Fused convolution (fft_convolve_frames_batch, round 5): the forward row pass, the product with the filter spectrum and the backward
+// row pass in ONE kernel, in place in the workspace.  Row kb of the forward transform yields X[R2 k + kb] for EVERY k -- exactly the
+// row the backward transform's first sweep gathers (its upper half from the conjugates it would read back) -- so between the two
+// column passes the spectrum never has to exist in memory: pass A -> this kernel -> pass A backward = three sweeps over the data
+// instead of five (forward two, product one, backward two).  H is the packed spectrum of a REAL filter (what the reference's call
+// sequence multiplies by, test/test.cpp:212-218): bins k < N/2 directly, the others as conj H[N - k]; bin 0 and bin N/2 are real
+// products with the two halves of the packed slot 0 (simd/chowdsp_fft_impl_sse.cpp:1640-1644).
+template <int BLOCK, int SLOTS, class SP = void>
+__global__ __launch_bounds__ (BLOCK) void real4g_rows_conv_kernel (float2* __restrict__ work,
+                                                                  const float2* __restrict__ twtab,
+                                                                  const float2* __restrict__ big_tw,
+                                                                  const float2* __restrict__ H, // packed spectrum, N / 2 float2
+                                                                  float scaling,
+                                                                  GenericPlan plan, // n = R1, frames = 16
+                                                                  unsigned n2,
+                                                                  unsigned batch,
+                                                                  unsigned lfs,
+                                                                  size_t ws_frame_len)
+{
+    extern __shared__ __attribute__ ((aligned (16))) float2 smem[];
+    constexpr int CB = kReal4GTile;
+    const int tid = threadIdx.x;
+    const int R1 = tile_frame_len<SP> (plan);
+    if constexpr (! std::is_void<SP>::value)
+        lfs = SP::n + 1;
+    float2* bufA = smem;
+    float2* bufB = smem + (size_t) CB * lfs;
+    float2* twl = smem + (size_t) 2 * CB * lfs;
+    lds_table_copy<BLOCK> (twl, twtab + plan.tw_offset[0], R1 - 1, tid);
+    const unsigned NR = n2 / 2 + 1;
+    const unsigned tiles = (NR + CB - 1) / CB;
+    const size_t nwork = (size_t) batch * tiles;
+    const int total = CB * R1;
+    float2 pre[SLOTS];
+    const auto request = [&] (size_t w) {
+        const unsigned f = (unsigned) (w / tiles), tile = (unsigned) (w % tiles);
+        const unsigned kb0 = tile * CB;
+        const unsigned last = min ((unsigned) CB, NR - kb0) - 1u;
+        const float2* __restrict__ src = work + (size_t) f * ws_frame_len;
+        r4g_request<BLOCK> (pre, total, tid, [&] (int e) {
+            const unsigned al = (unsigned) e & 31u, kbl = min (((unsigned) e >> 5) % CB, last), tA = ((unsigned) e >> 5) / CB;
+            return &src[(tA * NR + kb0 + kbl) * 32u + al];
+        });
+    };
+    if (blockIdx.x < nwork)
+        request (blockIdx.x);
+    for (size_t w = blockIdx.x; w < nwork; w += gridDim.x)
+    {
+        const unsigned f = (unsigned) (w / tiles), tile = (unsigned) (w % tiles);
+        const unsigned kb0 = tile * CB;
+        const int valid = (int) min ((unsigned) CB, NR - kb0);
+        float2* __restrict__ dst = work + (size_t) f * ws_frame_len;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < SLOTS; ++u)
+        {
+            const int e = tid + u * BLOCK;
+            if (e < total)
+            {
+                const unsigned al = (unsigned) e & 31u, kbl = ((unsigned) e >> 5) % CB, tA = ((unsigned) e >> 5) / CB;
+                bufA[kbl * lfs + tA * 32 + al] = (int) kbl < valid ? pre[u] : make_float2 (0.f, 0.f);
+            }
+        }
+        __syncthreads();
+        // this tile's filter bins (element (row c, index k), row fastest: 16 contiguous bins per access) and its inter-pass twiddles FIRST,
+        // the next tile's operands behind them: a wait for the former must not wait for the latter (one in-order counter)
+        float2 hv[SLOTS], tw[SLOTS];
+#pragma unroll
+        for (int u = 0; u < SLOTS; ++u)
+        {
+            const int e = min (tid + u * BLOCK, total - 1);
+            const int c = min (e % CB, valid - 1), k = e / CB;
+            const unsigned kb = kb0 + (unsigned) c;
+            unsigned idx;
+            if (k < R1 / 2)
+                idx = (unsigned) k * n2 + kb;
+            else if (kb == 0 && k == R1 / 2)
+                idx = 0;
+            else
+                idx = (kb == 0) ? (unsigned) (R1 - k) * n2 : (unsigned) (R1 - 1 - k) * n2 + (n2 - kb);
+            hv[u] = H[idx];
+        }
+#pragma unroll
+        for (int u = 0; u < SLOTS; ++u)
+        {
+            const unsigned e = (unsigned) min (tid + u * BLOCK, total - 1);
+            const unsigned al = e & 31u, kbl = min ((e >> 5) % CB, (unsigned) (valid - 1)), tA = (e >> 5) / CB;
+            tw[u] = big_tw[(tA * NR + kb0 + kbl) * 32u + al];
+        }
+        if (w + gridDim.x < nwork)
+            request (w + gridDim.x);
+        float2* res = const_cast<float2*> (r4g_core<BLOCK, SP> (plan, twl, bufA, bufB, CB, tid, lfs));
+        // X[R2 k + kb] * H * scaling, stored swapped (operand of the backward row transform) in place
+#pragma unroll
+        for (int u = 0; u < SLOTS; ++u)
+        {
+            const int e = tid + u * BLOCK;
+            if (e >= total)
+                continue;
+            const int c = e % CB, k = e / CB;
+            const unsigned kb = kb0 + (unsigned) c;
+            const float2 y = res[c * lfs + k];
+            float2 h = hv[u];
+            if (kb == 0 && k == 0)
+                h = make_float2 (h.x, 0.f); // X0 * H0 (both real)
+            else if (kb == 0 && k == R1 / 2)
+                h = make_float2 (h.y, 0.f); // X_{N/2} * H_{N/2}
+            else if (k >= R1 / 2)
+                h = make_float2 (h.x, -h.y); // H[k'] = conj H[N - k'] beyond N/2
+            const float2 z = cmul (y, make_float2 (h.x * scaling, h.y * scaling));
+            res[c * lfs + k] = c < valid ? make_float2 (z.y, z.x) : make_float2 (0.f, 0.f);
+        }
+        __syncthreads();
+        const float2* back = r4g_core<BLOCK, SP> (plan, twl, res, res == bufA ? bufB : bufA, CB, tid, lfs);
+#pragma unroll
+        for (int u = 0; u < SLOTS; ++u)
+        {
+            const int e = tid + u * BLOCK;
+            if (e >= total)
+                continue;
+            const unsigned al = (unsigned) e & 31u, kbl = ((unsigned) e >> 5) % CB, tA = ((unsigned) e >> 5) / CB;
+            if ((int) kbl < valid)
+            {
+                const float2 ys = back[kbl * lfs + tA * 32 + al];
+                dst[(tA * NR + kb0 + kbl) * 32u + al] = cmulc (make_float2 (ys.y, ys.x), tw[u]); // un-swap, times conj W_N^{a kb}
+            }
+        }
+    }
+}
+
 // Backward, second sweep: the columns.  Z_c[kb] = C_2c[kb] + i C_2c+1[kb] for kb <= R2/2 and conj C_2c[R2 - kb] + i conj C_2c+1[R2 - kb]
 // above; backward transform over kb, stored as the float2 column c of the real frame.
 template <int BLOCK, int SLOTS, class SP = void>

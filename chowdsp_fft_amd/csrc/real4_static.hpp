@@ -9,6 +9,7 @@ namespace cfft::host
 // pass A forward / pass B backward (they multiply by the inter-pass twiddles) and pass B forward / pass A backward
 using Real4GTwFn = void (*) (const float2*, float2*, const float2*, const float2*, GenericPlan, unsigned, unsigned, size_t, unsigned, size_t);
 using Real4GFn = void (*) (const float2*, float2*, const float2*, GenericPlan, unsigned, unsigned, size_t, unsigned, size_t);
+using Real4GConvFn = void (*) (float2*, const float2*, const float2*, const float2*, float, GenericPlan, unsigned, unsigned, unsigned, size_t); // the fused row pass of the convolution
 struct Real4GLaunch
 {
     int block;        // work-items per workgroup
@@ -20,7 +21,8 @@ struct Real4GLaunch
     Real4GTwFn pick_real4_cols_fwd_##G (const GenericPlan& plan, size_t lds_per_cu, Real4GLaunch& launch);         \
     Real4GFn pick_real4_cols_inv_##G (const GenericPlan& plan, size_t lds_per_cu, Real4GLaunch& launch);           \
     Real4GFn pick_real4_rows_fwd_##G (const GenericPlan& plan, size_t lds_per_cu, Real4GLaunch& launch);           \
-    Real4GTwFn pick_real4_rows_inv_##G (const GenericPlan& plan, size_t lds_per_cu, Real4GLaunch& launch);
+    Real4GTwFn pick_real4_rows_inv_##G (const GenericPlan& plan, size_t lds_per_cu, Real4GLaunch& launch);           \
+    Real4GConvFn pick_real4_rows_conv_##G (const GenericPlan& plan, size_t lds_per_cu, Real4GLaunch& launch);
 CFFT_R4S_DECLARE (a)
 CFFT_R4S_DECLARE (b)
 CFFT_R4S_DECLARE (c)

@@ -54,9 +54,11 @@ bool real4_tile_matches (const GenericPlan& plan, size_t lds_per_cu)
 #define CFFT_R4S_TRY_cols_real4g_pass_a_inv_kernel_slots_cols(N_) CFFT_R4S_TRY_BODY (N_, cols, real4g_pass_a_inv_kernel, slots_cols)
 #define CFFT_R4S_TRY_rows_real4g_pass_b_kernel_slots_rows(N_) CFFT_R4S_TRY_BODY (N_, rows, real4g_pass_b_kernel, slots_rows)
 #define CFFT_R4S_TRY_rows_real4g_pass_b_inv_kernel_slots_rows(N_) CFFT_R4S_TRY_BODY (N_, rows, real4g_pass_b_inv_kernel, slots_rows)
+#define CFFT_R4S_TRY_rows_real4g_rows_conv_kernel_slots_rows(N_) CFFT_R4S_TRY_BODY (N_, rows, real4g_rows_conv_kernel, slots_rows)
 
 CFFT_R4S_PICK (pick_real4_cols_fwd_, Real4GTwFn, cols, real4g_pass_a_kernel, slots_cols)
 CFFT_R4S_PICK (pick_real4_cols_inv_, Real4GFn, cols, real4g_pass_a_inv_kernel, slots_cols)
 CFFT_R4S_PICK (pick_real4_rows_fwd_, Real4GFn, rows, real4g_pass_b_kernel, slots_rows)
 CFFT_R4S_PICK (pick_real4_rows_inv_, Real4GTwFn, rows, real4g_pass_b_inv_kernel, slots_rows)
+CFFT_R4S_PICK (pick_real4_rows_conv_, Real4GConvFn, rows, real4g_rows_conv_kernel, slots_rows)
 } // namespace cfft::host

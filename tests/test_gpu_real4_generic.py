@@ -187,3 +187,42 @@ def test_special_bins(gpu, real4g):
             want[2 * k] = n / 2
         assert np.abs(got[row] - want).max() <= 2e-6 * n, f"tone at bin {k}: max deviation {np.abs(got[row] - want).max():.3e}"
     api.fft_destroy_setup(s)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,batch", [(41472, 5), (96000, 3), (122880, 2), (41472, 130)])
+def test_fused_convolution_three_sweeps(gpu, oracle, real4g, n, batch):
+    """fft_convolve_frames_batch of these frames: columns forward, ONE fused row pass (forward rows, product with the packed filter
+    spectrum, backward rows, in place in the workspace), columns backward -- == the three-launch composition == the oracle's call
+    sequence (reference test/test.cpp:212-218: real frames, DC / Nyquist as real products simd/chowdsp_fft_impl_sse.cpp:1640-1644);
+    in place; a batch that runs in several chunks on two lanes."""
+    api, torch, dev = gpu
+    s, so = api.fft_new_setup(n, api.FFT_REAL), oracle.new_setup(n, REAL)
+    x = ol.uniform(batch * n, 700 + batch).reshape(batch, n)
+    h = ol.uniform(n, 79).reshape(1, n)
+    xd, hd = torch.from_numpy(x).to(dev), torch.from_numpy(h).to(dev)
+    H = torch.empty_like(hd)
+    api.fft_transform_unordered_batch(s, hd, H, api.FFT_FORWARD)
+    one = torch.full_like(xd, -3.0)
+    api.fft_convolve_frames_batch(s, xd, H, one, 1.0 / n)
+    torch.cuda.synchronize()
+    api.set_option("fused_conv_generic", 0)
+    three = torch.full_like(xd, -5.0)
+    api.fft_convolve_frames_batch(s, xd, H, three, 1.0 / n)
+    torch.cuda.synchronize()
+    api.set_option("fused_conv_generic", 1)
+    inplace = xd.clone()
+    api.fft_convolve_frames_batch(s, inplace, H, inplace, 1.0 / n)
+    torch.cuda.synchronize()
+    assert_frames_close(one.cpu().numpy(), three.cpu().numpy(), tol=3e-7, maxabs_tol=1.5e-6, what=f"real N={n}: three sweeps vs three launches")
+    assert torch.equal(inplace, one), "in place == out of place"
+    # float64: circular convolution of every frame with h
+    pick = sorted({0, batch // 2, batch - 1})
+    want = np.fft.irfft(np.fft.rfft(x[pick].astype(np.float64), axis=1) * np.fft.rfft(h.astype(np.float64), axis=1), n=n, axis=1)
+    assert_frames_close(one.cpu().numpy()[pick], want, what=f"real N={n} fused convolution vs float64 circular convolution", maxabs_tol=MIXED_RADIX_MAXABS_TOL)
+    if n % 25 != 0:
+        hb = oracle.transform(so, h[0], FORWARD, False)
+        ref = np.stack([oracle.transform(so, oracle.convolve(so, oracle.transform(so, x[i], FORWARD, False), hb, np.zeros(n, np.float32), 1.0 / n), BACKWARD, False) for i in pick])
+        assert_frames_close(one.cpu().numpy()[pick], ref, what=f"real N={n} fused convolution vs the oracle's call sequence", maxabs_tol=MIXED_RADIX_MAXABS_TOL)
+    api.fft_destroy_setup(s)
+    oracle.destroy_setup(so)
