@@ -557,7 +557,8 @@ int big_c2c_chunked (Setup* s, int nc, bool inverse, const float2* in, float2* o
             cis = os2;
         }
         if (e == hipSuccess)
-            e = mixed ? launch_mixed_big_c2c (*s->tables, inverse, cin, L->ws[k], out + f0 * os2, nb, lanes, st, cis, os2)
+            e = (mixed && mul_h != nullptr) ? launch_conv4_generic (*s->tables, cin, mul_h, mul_scale, L->ws[k], out + f0 * os2, nb, lanes, st, cis, os2) // (the whole fused convolution: three sweeps)
+                : mixed ? launch_mixed_big_c2c (*s->tables, inverse, cin, L->ws[k], out + f0 * os2, nb, lanes, st, cis, os2)
                 : s->tables->r2_n > 0
                     ? launch_fast_r2_c2c (s->tables->r2_n, inverse, cin, L->ws[k], out + f0 * os2, s->tables->stage_twiddles, s->tables->big_twiddles, nb, lanes, st, cis, os2, mul_h, mul_scale)
                 : s->tables->fast_n1 > 0
@@ -1995,6 +1996,12 @@ int fft_convolve_frames_batch (void* setup, const float* x, const float* dft_fil
         if (rc != FFT_GPU_OK)
             return rc;
         return run_transform (s, y, y, batch, FFT_BACKWARD, (hipStream_t) stream);
+    }
+    if (s->transform == FFT_COMPLEX && t->mixed_n2 > 0 && conv4_generic_applies (*t) && g_fused_conv_generic.load() != 0)
+    {
+        // long mixed-radix complex frames whose two factors are both at most 639 points: columns forward, ONE fused row pass (forward rows,
+        // product, backward rows, in place in the workspace), columns backward -- three sweeps (conv4_generic_kernels.hpp)
+        return big_c2c_chunked (s, nc, false, (const float2*) x, (float2*) y, batch, (hipStream_t) stream, (size_t) nc, (size_t) nc, 0, (const float2*) dft_filter, scaling);
     }
     if (s->transform == FFT_REAL && t->real4_generic != 0 && g_fused_conv_generic.load() != 0)
     {

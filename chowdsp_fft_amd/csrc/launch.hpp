@@ -80,6 +80,9 @@ hipError_t launch_real4_fast (int r1, int r2, bool inverse, const float2* in, fl
 // packed spectrum, both as N/2 float2; work: real4_workspace_frame_len() float2 per frame.
 size_t real4_workspace_frame_len (int r1, int r2);
 // ... with generic cores, for long mixed-radix real frames (kernels_real4_generic.hip; the same workspace layout)
+// complex frames on general two-pass plans whose factors are both at most 639 points: fft_convolve_frames_batch in three sweeps (conv4_generic_kernels.hpp)
+bool conv4_generic_applies (const DeviceTables& t);
+hipError_t launch_conv4_generic (const DeviceTables& t, const float2* in, const float2* H, float scaling, float2* work, float2* out, size_t batch, int grid_divisor, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
 hipError_t launch_real4_generic_conv (const DeviceTables& t, const float2* in, const float2* H, float scaling, float2* work, float2* out, size_t batch, int grid_divisor, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
 hipError_t launch_real4_generic (const DeviceTables& t, bool inverse, const float2* in, float2* work, float2* out, size_t batch, int grid_divisor, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);
 hipError_t launch_real4 (int r1, int r2, bool inverse, const float2* in, float2* work, float2* out, const float2* stage_tw, const float2* big_tw, size_t batch, int grid_divisor, hipStream_t stream, size_t in_stride = 0, size_t out_stride = 0);

@@ -1,7 +1,7 @@
 // The real four-step's tile kernels (real4_generic_kernels.hpp) with compile-time stage lists: chosen by kernels_real4_generic.hip,
 // instantiated in translation units of their own (kernels_real4_static_{a,b,c}.hip, one per group of tables.hpp's lengths).
 #pragma once
-#include "real4_generic_kernels.hpp"
+#include "conv4_generic_kernels.hpp"
 #include "host_common.hpp"
 
 namespace cfft::host
@@ -22,7 +22,11 @@ struct Real4GLaunch
     Real4GFn pick_real4_cols_inv_##G (const GenericPlan& plan, size_t lds_per_cu, Real4GLaunch& launch);           \
     Real4GFn pick_real4_rows_fwd_##G (const GenericPlan& plan, size_t lds_per_cu, Real4GLaunch& launch);           \
     Real4GTwFn pick_real4_rows_inv_##G (const GenericPlan& plan, size_t lds_per_cu, Real4GLaunch& launch);           \
-    Real4GConvFn pick_real4_rows_conv_##G (const GenericPlan& plan, size_t lds_per_cu, Real4GLaunch& launch);
+    Real4GConvFn pick_real4_rows_conv_##G (const GenericPlan& plan, size_t lds_per_cu, Real4GLaunch& launch);         \
+    /* ... and the complex three-sweep fused convolution (conv4_generic_kernels.hpp) */                            \
+    Real4GTwFn pick_conv4_cols_fwd_##G (const GenericPlan& plan, size_t lds_per_cu, Real4GLaunch& launch);         \
+    Real4GConvFn pick_conv4_rows_conv_##G (const GenericPlan& plan, size_t lds_per_cu, Real4GLaunch& launch);      \
+    Real4GFn pick_conv4_cols_inv_##G (const GenericPlan& plan, size_t lds_per_cu, Real4GLaunch& launch);
 CFFT_R4S_DECLARE (a)
 CFFT_R4S_DECLARE (b)
 CFFT_R4S_DECLARE (c)

@@ -13,6 +13,7 @@ struct Real4Tile
 {
     static constexpr bool cols = N_ % 2 == 0 && N_ >= 16 && N_ <= 639;  // column lengths R2: even
     static constexpr bool rows = N_ % 32 == 0 && N_ <= 639;             // row lengths R1: multiples of 32
+    static constexpr bool cplx = N_ % 16 == 0 && N_ <= 639;             // either factor of the complex three-sweep convolution: multiples of 16
     static constexpr size_t images = (size_t) 2 * kReal4GTile * (N_ + 1) * sizeof (float2);
     static constexpr size_t lds = images + (size_t) (N_ - 1) * sizeof (float2);
     // work-items per workgroup as for the complex tiles (tile_static_impl.hpp): 256 where four workgroups fit a CU, 512 where two do, else 1024
@@ -55,10 +56,16 @@ bool real4_tile_matches (const GenericPlan& plan, size_t lds_per_cu)
 #define CFFT_R4S_TRY_rows_real4g_pass_b_kernel_slots_rows(N_) CFFT_R4S_TRY_BODY (N_, rows, real4g_pass_b_kernel, slots_rows)
 #define CFFT_R4S_TRY_rows_real4g_pass_b_inv_kernel_slots_rows(N_) CFFT_R4S_TRY_BODY (N_, rows, real4g_pass_b_inv_kernel, slots_rows)
 #define CFFT_R4S_TRY_rows_real4g_rows_conv_kernel_slots_rows(N_) CFFT_R4S_TRY_BODY (N_, rows, real4g_rows_conv_kernel, slots_rows)
+#define CFFT_R4S_TRY_cplx_c4g_cols_fwd_kernel_slots_rows(N_) CFFT_R4S_TRY_BODY (N_, cplx, c4g_cols_fwd_kernel, slots_rows)
+#define CFFT_R4S_TRY_cplx_c4g_rows_conv_kernel_slots_rows(N_) CFFT_R4S_TRY_BODY (N_, cplx, c4g_rows_conv_kernel, slots_rows)
+#define CFFT_R4S_TRY_cplx_c4g_cols_inv_kernel_slots_rows(N_) CFFT_R4S_TRY_BODY (N_, cplx, c4g_cols_inv_kernel, slots_rows)
 
 CFFT_R4S_PICK (pick_real4_cols_fwd_, Real4GTwFn, cols, real4g_pass_a_kernel, slots_cols)
 CFFT_R4S_PICK (pick_real4_cols_inv_, Real4GFn, cols, real4g_pass_a_inv_kernel, slots_cols)
 CFFT_R4S_PICK (pick_real4_rows_fwd_, Real4GFn, rows, real4g_pass_b_kernel, slots_rows)
 CFFT_R4S_PICK (pick_real4_rows_inv_, Real4GTwFn, rows, real4g_pass_b_inv_kernel, slots_rows)
 CFFT_R4S_PICK (pick_real4_rows_conv_, Real4GConvFn, rows, real4g_rows_conv_kernel, slots_rows)
+CFFT_R4S_PICK (pick_conv4_cols_fwd_, Real4GTwFn, cplx, c4g_cols_fwd_kernel, slots_rows)
+CFFT_R4S_PICK (pick_conv4_rows_conv_, Real4GConvFn, cplx, c4g_rows_conv_kernel, slots_rows)
+CFFT_R4S_PICK (pick_conv4_cols_inv_, Real4GFn, cplx, c4g_cols_inv_kernel, slots_rows)
 } // namespace cfft::host

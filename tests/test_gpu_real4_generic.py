@@ -226,3 +226,47 @@ def test_fused_convolution_three_sweeps(gpu, oracle, real4g, n, batch):
         assert_frames_close(one.cpu().numpy()[pick], ref, what=f"real N={n} fused convolution vs the oracle's call sequence", maxabs_tol=MIXED_RADIX_MAXABS_TOL)
     api.fft_destroy_setup(s)
     oracle.destroy_setup(so)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,batch", [(20736, 5), (46080, 3), (57600, 4), (82944, 2), (38400, 70)])
+def test_complex_fused_convolution_three_sweeps(gpu, oracle, n, batch):
+    """The complex counterpart (csrc/conv4_generic_kernels.hpp): long mixed-radix COMPLEX frames whose general two-pass plan has both
+    factors at most 639 points -- columns forward, one fused row pass in place in the workspace, columns backward -- == the
+    three-launch composition == the oracle's call sequence (reference test/test.cpp:161-166); in place; several chunks."""
+    from oracle_lib import COMPLEX
+
+    api, torch, dev = gpu
+    d = api.plan_describe(n, api.FFT_COMPLEX)
+    assert d["passes"] == 2 and max(d["n1"], d["n2"]) <= 639 and d["n1"] % 16 == 0 and d["n2"] % 16 == 0, d
+    s, so = api.fft_new_setup(n, api.FFT_COMPLEX), oracle.new_setup(n, COMPLEX)
+    x = ol.uniform(batch * 2 * n, 900 + batch).reshape(batch, 2 * n)
+    h = ol.uniform(2 * n, 81).reshape(1, 2 * n)
+    xd, hd = torch.from_numpy(x).to(dev), torch.from_numpy(h).to(dev)
+    H = torch.empty_like(hd)
+    api.fft_transform_unordered_batch(s, hd, H, api.FFT_FORWARD)
+    one = torch.full_like(xd, -3.0)
+    api.fft_convolve_frames_batch(s, xd, H, one, 1.0 / n)
+    torch.cuda.synchronize()
+    api.set_option("fused_conv_generic", 0)
+    three = torch.full_like(xd, -5.0)
+    api.fft_convolve_frames_batch(s, xd, H, three, 1.0 / n)
+    torch.cuda.synchronize()
+    api.set_option("fused_conv_generic", 1)
+    inplace = xd.clone()
+    api.fft_convolve_frames_batch(s, inplace, H, inplace, 1.0 / n)
+    torch.cuda.synchronize()
+    assert_frames_close(one.cpu().numpy(), three.cpu().numpy(), tol=3e-7, maxabs_tol=1.5e-6, what=f"complex N={n}: three sweeps vs three launches")
+    assert torch.equal(inplace, one), "in place == out of place"
+    pick = sorted({0, batch // 2, batch - 1})
+    xc = x[pick][:, 0::2].astype(np.float64) + 1j * x[pick][:, 1::2]
+    hc = h[:, 0::2].astype(np.float64) + 1j * h[:, 1::2]
+    yc = np.fft.ifft(np.fft.fft(xc, axis=1) * np.fft.fft(hc, axis=1), axis=1)
+    want = np.empty((len(pick), 2 * n))
+    want[:, 0::2], want[:, 1::2] = yc.real, yc.imag
+    assert_frames_close(one.cpu().numpy()[pick], want, what=f"complex N={n} fused convolution vs float64 circular convolution", maxabs_tol=MIXED_RADIX_MAXABS_TOL)
+    hb = oracle.transform(so, h[0], FORWARD, False)
+    ref = np.stack([oracle.transform(so, oracle.convolve(so, oracle.transform(so, x[i], FORWARD, False), hb, np.zeros(2 * n, np.float32), 1.0 / n), BACKWARD, False) for i in pick])
+    assert_frames_close(one.cpu().numpy()[pick], ref, what=f"complex N={n} fused convolution vs the oracle's call sequence", maxabs_tol=MIXED_RADIX_MAXABS_TOL)
+    api.fft_destroy_setup(s)
+    oracle.destroy_setup(so)
