@@ -78,3 +78,13 @@ def test_bench_two_ranks_on_one_box():
     for s in line["secondary"]:
         assert s["value"] > 0 and s["frames_per_gpu"] == 1024 and 0 < s["roofline"]["frac"] < 1
     assert "cpu_baseline" not in line  # rank 0 times the CPU baseline at N = 1 only
+
+
+@pytest.mark.gpu
+def test_rccl_one_rank_smoke():
+    """the "nccl" (= RCCL) calls of the N > 1 branch with world size 1 on this box's GPU: communicator bound to the device, all-reduce,
+    all_gather_into_tensor, all_gather_object, barrier (tools/nccl_one_rank_smoke.py) -- started as a fresh child, like the test above"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "nccl_one_rank_smoke.py")], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "all_reduce 1.5" in r.stdout and "all_gather ok True" in r.stdout and r.stdout.strip().endswith("done"), r.stdout[-1000:]
