@@ -1,11 +1,10 @@
-"""The backward row sweep of the long real power-of-two frames (N = 2^19, 2^20: 1024-point rows) walks STRIPS of consecutive
-tiles and carries the one mirrored element per row that lies on the neighbouring 128-byte line
-(pass_b_real_inv_fast_carry_kernel, tile_fast_kernels.hpp).  The strip length depends on the batch (kernels_multipass.hip:
-fewest tile-times on the resident grid), so the batches here are chosen to give strips of one tile, of a few tiles, strips
-that end at the frame's last (one-row) tile, and a chunked call (more frames than one 128 MiB workspace holds).
+"""The backward transform of the long real power-of-two frames with 1024-point rows (N = 2^19, 2^20) at batch sizes that
+exercise the row sweep's work split: one frame, fewer tiles than the resident grid, more, and a chunked call (more frames than
+one 128 MiB workspace holds: 2^19 -> 57 frames, 2^20 -> 29 per chunk).  Written with the carried-element variant of that sweep
+(profiles/r05_real4_carry_experiment.txt: measured, not adopted); the cases hold for whichever kernel the library picks.
 
 Backward parity against the oracle on spectra the oracle made (reference: pffft_transform_ordered BACKWARD,
-/root/reference/chowdsp_fft.h:117-134), plus the forward . backward round trip N x.
+/root/reference/chowdsp_fft.h:117-134), the forward . backward round trip N x, and the X0 / X_{N/2} slot.
 """
 import numpy as np
 import pytest
@@ -18,7 +17,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("n,batch", [(1 << 19, 1), (1 << 19, 16), (1 << 19, 67), (1 << 20, 1), (1 << 20, 8), (1 << 20, 35)])
-def test_backward_strips_vs_oracle(gpu, oracle, n, batch):
+def test_backward_long_rows_vs_oracle(gpu, oracle, n, batch):
     api, torch, dev = gpu
     x = ol.uniform(batch * n, 900 + batch).reshape(batch, n)
     s, so = api.fft_new_setup(n, api.FFT_REAL), oracle.new_setup(n, REAL)
