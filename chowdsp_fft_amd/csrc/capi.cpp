@@ -120,20 +120,29 @@ size_t zerocopy_max_bytes()
 // grow-only scratch for the two-pass sizes, one per (device, stream); bounded by workspace_cap() so that the
 // intermediate of one chunk of frames stays inside the 256 MiB Infinity Cache between pass A and pass B.
 constexpr size_t kWorkspaceCapDefault = 256ull << 20;
-// developer knob for the cap sweep in tools/ (MiB); read once
+// option "workspace_mib" (initial value: CHOWDSP_FFT_WORKSPACE_MIB): the calls made from now on chunk their batches against it; a
+// workspace that is already larger stays (grow-only).  Results do not depend on it (tests/test_gpu_chunking.py).
+static std::atomic<size_t> g_workspace_cap { 0 };
 size_t workspace_cap()
 {
-    static const size_t cap = [] {
+    size_t cap = g_workspace_cap.load();
+    if (cap == 0)
+    {
         const char* e = std::getenv ("CHOWDSP_FFT_WORKSPACE_MIB");
         const long v = e != nullptr ? std::atol (e) : 0;
-        return v > 0 ? (size_t) v << 20 : kWorkspaceCapDefault;
-    }();
+        cap = v > 0 ? (size_t) v << 20 : kWorkspaceCapDefault;
+        g_workspace_cap = cap;
+    }
     return cap;
 }
-// Two-pass plans run as a two-lane software pipeline: chunk i goes to lane i%2 (its own internal stream and
-// workspace), so pass B of one chunk (workspace -> HBM writes) overlaps pass A of the next (HBM reads -> workspace).
-// Lanes fork from / join back into the caller's stream with events, so the call stays asynchronous and ordered
-// on the caller's stream (and capturable into a hipGraph).
+// Two-pass plans work through their batch in CHUNKS of at most workspace_cap() bytes of intermediate.  Since round 5 the chunks run
+// one after the other on the caller's stream, each launch with the whole resident grid (CHOWDSP_FFT_LANES=1, the default).
+// CHOWDSP_FFT_LANES=2 is the form of rounds 1-4: a two-lane software pipeline, chunk i on lane i%2 (its own internal stream and
+// workspace, every launch with HALF the resident grid), so that pass B of one chunk overlaps pass A of the next; the lanes fork from /
+// join back into the caller's stream with events (asynchronous, ordered, capturable).  Measured again with round 5's kernels
+// (profiles/r05_lanes_sweep.txt): one lane is 3-12 % faster on every chunked plan, and two lanes lose a further 20-45 % whenever the
+// runtime maps both lane streams onto ONE hardware queue (a process with several other streams: the half grids then run one after
+// the other).
 struct Lanes
 {
     hipStream_t lane[2] = { nullptr, nullptr };
@@ -188,8 +197,8 @@ int lane_count()
 {
     static const int n = [] {
         const char* e = std::getenv ("CHOWDSP_FFT_LANES");
-        const int v = e != nullptr ? std::atoi (e) : 2;
-        return v == 1 ? 1 : 2;
+        const int v = e != nullptr ? std::atoi (e) : 1;
+        return v == 2 ? 2 : 1;
     }();
     return n;
 }
@@ -200,8 +209,9 @@ Lanes* get_lanes (int device, hipStream_t stream, size_t bytes_each)
     Lanes& L = g_lanes[std::make_pair (device, stream)];
     if (! L.ok)
     {
-        bool good = hipEventCreateWithFlags (&L.start, hipEventDisableTiming) == hipSuccess;
-        for (int k = 0; k < 2 && good; ++k)
+        // (the lane streams and their events exist only in the two-lane form: a process has few hardware queues)
+        bool good = lane_count() < 2 || hipEventCreateWithFlags (&L.start, hipEventDisableTiming) == hipSuccess;
+        for (int k = 0; k < 2 && good && lane_count() == 2; ++k)
             good = hipStreamCreateWithFlags (&L.lane[k], hipStreamNonBlocking) == hipSuccess
                    && hipEventCreateWithFlags (&L.done[k], hipEventDisableTiming) == hipSuccess;
         if (! good)
@@ -224,14 +234,15 @@ Lanes* get_lanes (int device, hipStream_t stream, size_t bytes_each)
         {
             if (L.ws[k] != nullptr)
             {
-                (void) hipStreamSynchronize (L.lane[k]);
+                if (L.lane[k] != nullptr)
+                    (void) hipStreamSynchronize (L.lane[k]);
                 (void) hipStreamSynchronize (stream);
                 (void) hipFree (L.ws[k]);
                 L.ws[k] = nullptr;
             }
         }
         L.bytes = 0;
-        for (int k = 0; k < 2; ++k)
+        for (int k = 0; k < lane_count(); ++k)
         {
             if (hipMalloc ((void**) &L.ws[k], bytes_each) != hipSuccess)
             {
@@ -518,7 +529,7 @@ int big_c2c_chunked (Setup* s, int nc, bool inverse, const float2* in, float2* o
     }
     const size_t frame_bytes = workspace_frame_bytes (s->tables, nc);
     const int want_lanes = lane_count();
-    // the cap covers BOTH workspaces, so that they fit the Infinity Cache together
+    // the cap covers ALL the workspaces of the call (one; two in the two-lane form), so that they fit the Infinity Cache together
     size_t chunk = workspace_cap() / (size_t) want_lanes / frame_bytes;
     if (pair != 0)
         chunk /= pair_chunk_divisor(); // the chunk's output has to stay cached next to the two workspaces
@@ -534,6 +545,7 @@ int big_c2c_chunked (Setup* s, int nc, bool inverse, const float2* in, float2* o
     if (L == nullptr)
         return cf::FFT_GPU_ENOMEM;
     const size_t nchunks = (batch + chunk - 1) / chunk;
+    chunk = (batch + nchunks - 1) / nchunks; // equal chunks (the workspace was sized for the largest): no short last launch
     const int lanes = (nchunks >= 2) ? want_lanes : 1;
     if (lanes == 2)
     {
@@ -630,6 +642,7 @@ int big_real4_chunked (Setup* s, bool inverse, const float2* in, float2* out, si
     if (L == nullptr)
         return cf::FFT_GPU_ENOMEM;
     const size_t nchunks = (batch + chunk - 1) / chunk;
+    chunk = (batch + nchunks - 1) / nchunks; // equal chunks (the workspace was sized for the largest): no short last launch
     const int lanes = (nchunks >= 2) ? want_lanes : 1;
     if (lanes == 2)
     {
@@ -1686,6 +1699,8 @@ int fft_gpu_set_option (const char* name, long value)
         cfft::host::set_real4_generic ((int) value); // plans MADE from now on: long mixed-radix real frames by the real four-step with generic cores
     else if (std::strcmp (name, "group_handoff") == 0 && (value == 0 || value == 1))
         set_group_handoff ((int) value); // 1: the hand-off form the CDNA4 guide lists, for the one-launch forms that offer it (chowdsp_fft_gpu.h)
+    else if (std::strcmp (name, "workspace_mib") == 0 && value >= 1 && value <= (1 << 16))
+        g_workspace_cap = (size_t) value << 20; // chunks of the two-pass plans: at most this much intermediate per chunk
     else if (std::strcmp (name, "table_cache_mib") == 0 && value >= 0 && value <= (1 << 20))
         set_table_cache_limit ((size_t) value << 20); // device tables of destroyed plans kept for re-use: at most this much
     else
@@ -1733,6 +1748,8 @@ long fft_gpu_get_option (const char* name)
         return g_huge_columns.load();
     if (std::strcmp (name, "table_cache_mib") == 0)
         return (long) (table_cache_limit() >> 20);
+    if (std::strcmp (name, "workspace_mib") == 0)
+        return (long) (workspace_cap() >> 20);
     if (std::strcmp (name, "group_handoff") == 0)
         return get_group_handoff();
     if (std::strcmp (name, "real4_generic") == 0)

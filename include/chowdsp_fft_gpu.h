@@ -120,6 +120,10 @@ int fft_gpu_table_cache_info (int device, size_t info[4]);
                         list (0.25-0.30 of 8 TB/s against 0.21-0.24); 2 for every such split and with run-time stage lists only
                         (0.17-0.18, slower than the three sweeps: it keeps those kernels tested and measurable); 0 never.
      "table_cache_mib"  device memory (MiB) that tables of destroyed plans may keep for re-use (default 64; 0 = none)
+     "workspace_mib"    intermediate (MiB) one chunk of a two-pass plan may occupy (default 256 = the Infinity Cache; initial value
+                        CHOWDSP_FFT_WORKSPACE_MIB): calls made from now on work through their batch in chunks of at most this much
+                        workspace, one after the other on the caller's stream.  A workspace that is already larger stays.  Results
+                        do not depend on it; rates do (profiles/r05_lanes_sweep.txt: 64 -> 512 MiB).
    Returns 0, or FFT_GPU_EINVAL for an unknown name / a value out of range. */
 int fft_gpu_set_option (const char* name, long value);
 /* Current value of an option ("fused_two_pass", "fused_min_batch", "fused_lag", "fused_slots", "split16384", "split8192",

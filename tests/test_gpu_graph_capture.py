@@ -1,7 +1,7 @@
 """The batched entry points are plain asynchronous launches on the caller's stream, so a sequence of them can be
 captured into a hipGraph and replayed (what a block-by-block audio host would do to shed per-launch overhead).
-Covers the LDS-resident kernels, the fused convolution, the partitioned engine, and the two-pass plans, whose
-internal two-lane pipeline forks from and joins back into the capturing stream with events.
+Covers the LDS-resident kernels, the fused convolution, the partitioned engine, and the two-pass plans (chunks one after
+the other on the capturing stream; with CHOWDSP_FFT_LANES=2 their two-lane pipeline forks from and joins back into it with events).
 Everything is called once before the capture (plans, occupancy queries and workspaces are created on first use).
 """
 import numpy as np
