@@ -54,8 +54,8 @@ int fft_gpu_stream_synchronize (void* stream);
 /* Last HIP error string seen by this thread inside the library ("" if none). */
 const char* fft_gpu_last_error (void);
 
-/* Two-pass plans cache, per (device, stream) they are called on, two helper streams, three events and their
-   workspaces (fft_gpu_workspace_bytes).  This releases what is cached for `stream` (on every device): call it before
+/* Two-pass plans cache, per (device, stream) they are called on, their workspace (fft_gpu_workspace_bytes; with
+   CHOWDSP_FFT_LANES=2 two of them plus two helper streams and three events).  This releases what is cached for `stream` (on every device): call it before
    destroying the stream -- a recycled handle would inherit the entry -- or to give the memory back.  Waits for the stream.
    Returns the number of entries released.  A workspace that would have to GROW while its stream is being captured into
    a hipGraph makes the call fail with FFT_GPU_ENOMEM (run the same call once outside the capture first). */
