@@ -5,6 +5,14 @@ usage: tools/kres.py file.hip [extra hipcc flags...]
 """
 import re, subprocess, sys
 src = sys.argv[1]
+# the per-unit CFFT_PACKED value of the build (csrc/Makefile PACKED_<unit>): the header's default (1) is NOT what most units are built with
+import os
+unit = os.path.splitext(os.path.basename(src))[0]
+mk = os.path.join(os.path.dirname(os.path.abspath(src)), "Makefile")
+if os.path.exists(mk) and not any(a.startswith("-DCFFT_PACKED") for a in sys.argv[2:]):
+    m = re.search(r"^PACKED_" + re.escape(unit) + r"\s*:=\s*(\d+)", open(mk).read(), re.M)
+    if m:
+        sys.argv.append("-DCFFT_PACKED=" + m.group(1))
 # the library's own flags (csrc/Makefile): without -fno-slp-vectorize / -ffp-contract=fast the register counts are not the build's
 cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-ffp-contract=fast", "-c", src, "-o", "/tmp/kres.o",
        "-Rpass-analysis=kernel-resource-usage"] + sys.argv[2:]
