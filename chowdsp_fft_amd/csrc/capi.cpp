@@ -136,7 +136,8 @@ size_t workspace_cap()
     return cap;
 }
 // Two-pass plans work through their batch in CHUNKS of at most workspace_cap() bytes of intermediate.  Since round 5 the chunks run
-// one after the other on the caller's stream, each launch with the whole resident grid (CHOWDSP_FFT_LANES=1, the default).
+// one after the other on the caller's stream, each launch with the whole resident grid (one lane: the default of every family but
+// one, lane_count below).
 // CHOWDSP_FFT_LANES=2 is the form of rounds 1-4: a two-lane software pipeline, chunk i on lane i%2 (its own internal stream and
 // workspace, every launch with HALF the resident grid), so that pass B of one chunk overlaps pass A of the next; the lanes fork from /
 // join back into the caller's stream with events (asynchronous, ordered, capturable).  Measured again with round 5's kernels
@@ -193,25 +194,34 @@ size_t real4_chunk_divisor()
     return n;
 }
 
-int lane_count()
+// lanes of a chunked call: CHOWDSP_FFT_LANES = 1 / 2 for every plan; unset: ONE, except for the LDS-image 256 x 256 passes (N = 65536 complex as
+// two launches per chunk, option fused_two_pass = 0), the only family that still measures faster on two lanes (0.400 against 0.382 of 8 TB/s:
+// its kernels run below the streaming ceiling on their own and gain from the overlap; profiles/r05_lanes_sweep.txt)
+int lane_count (bool lds_image_passes = false)
 {
     static const int n = [] {
         const char* e = std::getenv ("CHOWDSP_FFT_LANES");
-        const int v = e != nullptr ? std::atoi (e) : 1;
-        return v == 2 ? 2 : 1;
+        const int v = e != nullptr ? std::atoi (e) : 0;
+        return (v == 1 || v == 2) ? v : 0;
     }();
-    return n;
+    return n != 0 ? n : (lds_image_passes ? 2 : 1);
+}
+
+// the two-pass plans whose passes are the LDS-image kernels of both factors (launch_big_c2c: N = 65536 complex as two launches per chunk)
+static bool lds_image_passes (const DeviceTables* t)
+{
+    return t != nullptr && t->mixed_n2 == 0 && t->r2_n == 0 && t->fast_n1 == 0 && t->real4_r1 == 0 && t->huge_r == 0;
 }
 
 // caller holds g_ws_mutex
-Lanes* get_lanes (int device, hipStream_t stream, size_t bytes_each)
+Lanes* get_lanes (int device, hipStream_t stream, size_t bytes_each, int lanes = 1)
 {
     Lanes& L = g_lanes[std::make_pair (device, stream)];
-    if (! L.ok)
+    if (lanes == 2 && ! L.ok)
     {
-        // (the lane streams and their events exist only in the two-lane form: a process has few hardware queues)
-        bool good = lane_count() < 2 || hipEventCreateWithFlags (&L.start, hipEventDisableTiming) == hipSuccess;
-        for (int k = 0; k < 2 && good && lane_count() == 2; ++k)
+        // (the lane streams and their events exist only once a two-lane call has been made: a process has few hardware queues)
+        bool good = hipEventCreateWithFlags (&L.start, hipEventDisableTiming) == hipSuccess;
+        for (int k = 0; k < 2 && good; ++k)
             good = hipStreamCreateWithFlags (&L.lane[k], hipStreamNonBlocking) == hipSuccess
                    && hipEventCreateWithFlags (&L.done[k], hipEventDisableTiming) == hipSuccess;
         if (! good)
@@ -221,7 +231,8 @@ Lanes* get_lanes (int device, hipStream_t stream, size_t bytes_each)
         }
         L.ok = true;
     }
-    if (L.bytes < bytes_each)
+    const bool need_second = lanes == 2 && L.ws[1] == nullptr;
+    if (L.bytes < bytes_each || need_second)
     {
         // growing means waiting for the stream and freeing: neither is legal while the stream is being captured into a graph
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -230,28 +241,33 @@ Lanes* get_lanes (int device, hipStream_t stream, size_t bytes_each)
             set_last_error ("two-pass workspace would have to grow during stream capture: run the same call once outside the capture first");
             return nullptr;
         }
-        for (int k = 0; k < 2; ++k)
+        const size_t want = std::max (L.bytes, bytes_each);
+        const int count = (lanes == 2 || L.ws[1] != nullptr) ? 2 : 1;
+        if (L.bytes < bytes_each)
         {
-            if (L.ws[k] != nullptr)
+            for (int k = 0; k < 2; ++k)
             {
-                if (L.lane[k] != nullptr)
-                    (void) hipStreamSynchronize (L.lane[k]);
-                (void) hipStreamSynchronize (stream);
-                (void) hipFree (L.ws[k]);
-                L.ws[k] = nullptr;
+                if (L.ws[k] != nullptr)
+                {
+                    if (L.lane[k] != nullptr)
+                        (void) hipStreamSynchronize (L.lane[k]);
+                    (void) hipStreamSynchronize (stream);
+                    (void) hipFree (L.ws[k]);
+                    L.ws[k] = nullptr;
+                }
             }
+            L.bytes = 0;
         }
-        L.bytes = 0;
-        for (int k = 0; k < lane_count(); ++k)
+        for (int k = 0; k < count; ++k)
         {
-            if (hipMalloc ((void**) &L.ws[k], bytes_each) != hipSuccess)
+            if (L.ws[k] == nullptr && hipMalloc ((void**) &L.ws[k], want) != hipSuccess)
             {
                 L.ws[k] = nullptr;
                 set_last_error ("workspace allocation failed");
                 return nullptr;
             }
         }
-        L.bytes = bytes_each;
+        L.bytes = want;
     }
     return &L;
 }
@@ -528,7 +544,7 @@ int big_c2c_chunked (Setup* s, int nc, bool inverse, const float2* in, float2* o
         return cf::FFT_GPU_OK;
     }
     const size_t frame_bytes = workspace_frame_bytes (s->tables, nc);
-    const int want_lanes = lane_count();
+    const int want_lanes = lane_count (lds_image_passes (s->tables));
     // the cap covers ALL the workspaces of the call (one; two in the two-lane form), so that they fit the Infinity Cache together
     size_t chunk = workspace_cap() / (size_t) want_lanes / frame_bytes;
     if (pair != 0)
@@ -541,7 +557,7 @@ int big_c2c_chunked (Setup* s, int nc, bool inverse, const float2* in, float2* o
     // default stream) must not interleave "pass A -> workspace -> pass B" of different calls on the same workspace.
     // Only the (microseconds of) enqueueing is serialised; execution order then follows from stream order.
     std::lock_guard<std::recursive_mutex> lock (g_ws_mutex);
-    Lanes* L = get_lanes (s->device, stream, chunk * frame_bytes);
+    Lanes* L = get_lanes (s->device, stream, chunk * frame_bytes, want_lanes);
     if (L == nullptr)
         return cf::FFT_GPU_ENOMEM;
     const size_t nchunks = (batch + chunk - 1) / chunk;
@@ -638,7 +654,7 @@ int big_real4_chunked (Setup* s, bool inverse, const float2* in, float2* out, si
     if (chunk > batch)
         chunk = batch;
     std::lock_guard<std::recursive_mutex> lock (g_ws_mutex);
-    Lanes* L = get_lanes (s->device, stream, chunk * frame_bytes);
+    Lanes* L = get_lanes (s->device, stream, chunk * frame_bytes, want_lanes);
     if (L == nullptr)
         return cf::FFT_GPU_ENOMEM;
     const size_t nchunks = (batch + chunk - 1) / chunk;
@@ -1823,7 +1839,8 @@ size_t fft_gpu_workspace_bytes (void* setup, size_t batch)
     if (s->transform == FFT_COMPLEX && s->tables->mixed_n2 == 0 && fused_form() == 2 && s->tables->fast_n1 > 0 && groupfast_supported (n1, n2) && g_group_fast.load() != 0 && get_group_handoff() == 0
         && batch >= std::max<size_t> (1, fused_min_batch() / 4))
         return groupfast_workspace_bytes (n1, n2) + std::max (fused_state_bytes(), group_state_bytes());
-    size_t chunk = workspace_cap() / (size_t) lane_count() / frame_bytes;
+    const int lanes = lane_count (lds_image_passes (s->tables));
+    size_t chunk = workspace_cap() / (size_t) lanes / frame_bytes;
     if (s->transform == FFT_REAL && s->tables->real4_r1 == 0)
         chunk /= pair_chunk_divisor(); // the pair stage's operands share the cache with the two workspaces
     if (s->transform == FFT_REAL && s->tables->real4_r1 != 0)
@@ -1832,7 +1849,7 @@ size_t fft_gpu_workspace_bytes (void* setup, size_t batch)
         chunk = 1;
     if (chunk > batch)
         chunk = batch;
-    return (size_t) lane_count() * chunk * frame_bytes;
+    return (size_t) lanes * chunk * frame_bytes;
 }
 
 // ---- extension: batched operations ---------------------------------------------------------------

@@ -98,3 +98,35 @@ def test_fused_convolution_does_not_depend_on_the_chunking(gpu, cap, n, tr, batc
         else:
             assert np.array_equal(y, ref), f"fused convolution differs at workspace_mib={mib}"
     api.fft_destroy_setup(s)
+
+
+def test_two_launch_form_of_65536_on_its_two_lanes(gpu, oracle, cap):
+    """N = 65536 complex with option fused_two_pass = 0: two launches per chunk through the LDS-image 256 x 256 passes -- the one family
+    whose chunks still alternate between two lanes by default (capi.cpp lane_count) -- one chunk, a few, many: bit-identical, and equal
+    to the one-launch form's result within the parity bound and to the oracle's"""
+    api, torch, dev = gpu
+    n, batch = 65536, 40
+    x = ol.uniform(batch * 2 * n, 4300).reshape(batch, 2 * n)
+    s, so = api.fft_new_setup(n, api.FFT_COMPLEX), oracle.new_setup(n, COMPLEX)
+    xd = torch.from_numpy(x).to(dev)
+    before = api.get_option("fused_two_pass")
+    api.set_option("fused_two_pass", 0)
+    try:
+        ref = None
+        for mib in (256, 6, 1):
+            cap(mib)
+            yd, zd = torch.empty_like(xd), torch.empty_like(xd)
+            api.fft_transform_batch(s, xd, yd, api.FFT_FORWARD)
+            api.fft_transform_batch(s, yd, zd, api.FFT_BACKWARD)
+            torch.cuda.synchronize()
+            f, b = yd.cpu().numpy(), zd.cpu().numpy()
+            if ref is None:
+                ref = (f, b)
+                assert_frames_close(f, oracle.transform_batch(so, x, FORWARD), what="two-launch 65536 fwd")
+                assert_frames_close(b / n, x, what="two-launch 65536 round trip")
+            else:
+                assert np.array_equal(f, ref[0]) and np.array_equal(b, ref[1]), f"differs at workspace_mib={mib}"
+    finally:
+        api.set_option("fused_two_pass", before)
+    api.fft_destroy_setup(s)
+    oracle.destroy_setup(so)
