@@ -167,16 +167,15 @@ struct Lanes
 std::recursive_mutex g_ws_mutex; // (recursive: a frame beyond 2^21 points runs its factors' two-pass plans while it holds the lock)
 std::map<std::pair<int, hipStream_t>, Lanes> g_lanes;
 
-// CHOWDSP_FFT_PAIR_CHUNK_DIV: how much smaller the chunks of long REAL transforms are than those of complex ones.
-// Measured on MI355X, real N = 32768 / 131072 / 1048576 fwd+inv: pair stage after the whole batch 1.68 / 1.63 / 1.25 TB/s;
-// per chunk inside the two-lane pipeline, divisor 1: 1.83 / 1.67 / 1.25, 2: 1.83 / 1.68 / 1.36, 4: 1.70 / 1.55 / 1.36,
-// 8: 1.53 / 1.34 / 0.91 (launches get too short).
+// CHOWDSP_FFT_PAIR_CHUNK_DIV: how much smaller the chunks of long REAL transforms that run complex two-pass + pair stage are than those of
+// complex ones.  Round 5, one lane (profiles/r05_lanes_sweep.txt): 1 -- r2097152 0.222 / r491520 0.205 / r1310720 0.187 of 8 TB/s against
+// 0.215 / 0.193 / 0.168 with 2 and 0.214 / 0.186 / 0.172 with 4.  (Rounds 1-4, two lanes: 2.)
 size_t pair_chunk_divisor()
 {
     static const size_t n = [] {
         const char* e = std::getenv ("CHOWDSP_FFT_PAIR_CHUNK_DIV");
-        const long v = e != nullptr ? std::atol (e) : 2;
-        return (size_t) (v >= 1 && v <= 64 ? v : 2);
+        const long v = e != nullptr ? std::atol (e) : 1;
+        return (size_t) (v >= 1 && v <= 64 ? v : 1);
     }();
     return n;
 }
