@@ -350,14 +350,33 @@ struct StaticPlan
 #ifndef CFFT_TWO_STAGE_FULL_LINE
 #define CFFT_TWO_STAGE_FULL_LINE 1
 #endif
+// CFFT_GENERIC_LISTS_V2 (round 5): the one-pass lists of 160, 192 and 240 points re-chosen by measurement -- three stages of radix <= 8 instead of
+// two stages of radix 10 ... 16 (12 ... 16 work-items per frame, first-stage reads in runs of 12 / 15 points): c192 +14 %, c240 +14 %, real N = 320
+// +10 % (profiles/r05_generic_lists.txt; the other lengths keep their lists: the same treatment measured -2 ... -9 % on their complex transforms).
+// tables.cpp (generic_radices) carries the same table.
+#ifndef CFFT_GENERIC_LISTS_V2
+#define CFFT_GENERIC_LISTS_V2 1
+#endif
 template <int N_> struct StaticPlanFor { using type = void; };
 template <> struct StaticPlanFor<48> { using type = StaticPlan<48, 6, 8>; };
 template <> struct StaticPlanFor<80> { using type = StaticPlan<80, 10, 8>; };
 template <> struct StaticPlanFor<96> { using type = StaticPlan<96, 12, 8>; };
 template <> struct StaticPlanFor<144> { using type = StaticPlan<144, 12, 12>; };
+#if CFFT_GENERIC_LISTS_V2
+template <> struct StaticPlanFor<160> { using type = StaticPlan<160, 4, 8, 5>; };
+#else
 template <> struct StaticPlanFor<160> { using type = StaticPlan<160, 10, 16>; };
+#endif
+#if CFFT_GENERIC_LISTS_V2
+template <> struct StaticPlanFor<192> { using type = StaticPlan<192, 6, 8, 4>; };
+#else
 template <> struct StaticPlanFor<192> { using type = std::conditional<CFFT_TWO_STAGE_FULL_LINE != 0, StaticPlan<192, 16, 12>, StaticPlan<192, 12, 16>>::type; };
+#endif
+#if CFFT_GENERIC_LISTS_V2
+template <> struct StaticPlanFor<240> { using type = StaticPlan<240, 6, 8, 5>; };
+#else
 template <> struct StaticPlanFor<240> { using type = std::conditional<CFFT_TWO_STAGE_FULL_LINE != 0, StaticPlan<240, 16, 15>, StaticPlan<240, 15, 16>>::type; };
+#endif
 template <> struct StaticPlanFor<288> { using type = std::conditional<CFFT_TWO_STAGE_FULL_LINE != 0, StaticPlan<288, 6, 8, 6>, StaticPlan<288, 6, 6, 8>>::type; };
 template <> struct StaticPlanFor<320> { using type = std::conditional<CFFT_TWO_STAGE_FULL_LINE != 0, StaticPlan<320, 8, 8, 5>, StaticPlan<320, 5, 8, 8>>::type; };
 template <> struct StaticPlanFor<384> { using type = StaticPlan<384, 6, 8, 8>; };
@@ -425,6 +444,9 @@ template <> struct StaticPlanFor<1125> { using type = StaticPlan<1125, 15, 15, 5
 template <> struct StaticPlanFor<2048> { using type = StaticPlan<2048, 16, 16, 8>; };
 // the tile kernels' lists (stages LDS to LDS): the sorted order for the two lengths whose whole-frame kernels use the full-line order
 template <int N_> struct StaticTilePlanFor { using type = typename StaticPlanFor<N_>::type; };
+#if CFFT_GENERIC_LISTS_V2 // (tile kernels keep the planner's tile lists: frames_override > 0 in generic_radices)
+template <> struct StaticTilePlanFor<160> { using type = StaticPlan<160, 10, 16>; };
+#endif
 template <> struct StaticTilePlanFor<192> { using type = StaticPlan<192, 12, 16>; };
 template <> struct StaticTilePlanFor<240> { using type = StaticPlan<240, 15, 16>; };
 template <> struct StaticTilePlanFor<288> { using type = StaticPlan<288, 6, 6, 8>; };

@@ -477,6 +477,59 @@ static void generic_radices (int n, std::vector<int>& radix, int frames_override
             best.push_back (r);
         }
     }
+#ifndef CFFT_GENERIC_LISTS_V2
+#define CFFT_GENERIC_LISTS_V2 1
+#endif
+    if (CFFT_GENERIC_LISTS_V2 && frames_override == 0)
+    {
+        // one-pass lists re-chosen by measurement (generic_kernels.hpp: StaticPlanFor carries the same table)
+        static const struct { int n; std::vector<int> list; } kMeasured[] = { { 160, { 4, 8, 5 } }, { 192, { 6, 8, 4 } }, { 240, { 6, 8, 5 } } };
+        for (const auto& m : kMeasured)
+            if (m.n == n)
+                best = m.list;
+    }
+    // developer override for list sweeps (tools/generic_list_sweep.py), read at every plan construction: CHOWDSP_FFT_GENERIC_LIST="192:6,8,4;240:5,16,3"
+    // -- a list that multiplies out to n and uses radices the kernels have replaces the planner's (such a plan runs the run-time-list kernel
+    // unless it happens to equal the compile-time list of its length)
+    if (const char* ov = std::getenv ("CHOWDSP_FFT_GENERIC_LIST"))
+    {
+        if (frames_override == 0)
+        {
+            const char* q = ov;
+            while (*q != 0)
+            {
+                char* end = nullptr;
+                const long key = std::strtol (q, &end, 10);
+                if (end == q || *end != ':')
+                    break;
+                q = end + 1;
+                std::vector<int> lst;
+                long prod = 1;
+                while (true)
+                {
+                    const long r = std::strtol (q, &end, 10);
+                    if (end == q)
+                        break;
+                    lst.push_back ((int) r);
+                    prod *= r;
+                    q = end;
+                    if (*q == ',')
+                        ++q;
+                    else
+                        break;
+                }
+                bool ok = key == n && prod == n && ! lst.empty() && lst.size() <= 10;
+                for (int r : lst)
+                    ok = ok && (r == 2 || r == 3 || r == 4 || r == 5 || r == 6 || r == 8 || r == 9 || r == 10 || r == 12 || r == 15 || r == 16);
+                if (ok)
+                    best = lst;
+                if (*q == ';')
+                    ++q;
+                else
+                    break;
+            }
+        }
+    }
     radix = best;
 }
 

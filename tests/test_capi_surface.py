@@ -178,7 +178,9 @@ def test_plan_describe_host_logic():
     assert (d["complex_len"], d["passes"], d["n1"], d["n2"]) == (480, 1, 0, 0)
     # ... ordered so that the last stage stores whole 128-byte lines: runs of 480 / 6 = 80 points (tables.cpp: generic_radices)
     assert d["radices"][:3] == [10, 8, 6] and (480 // d["radices"][2]) % 16 == 0
-    assert api.plan_describe(192, api.FFT_COMPLEX)["radices"][:2] == [16, 12] and api.plan_describe(160, api.FFT_COMPLEX)["radices"][:2] == [10, 16]
+    # ... 160, 192 and 240 points: three stages of radix <= 8 by measurement (round 5, profiles/r05_generic_lists.txt), not the fewest stages
+    assert api.plan_describe(192, api.FFT_COMPLEX)["radices"][:3] == [6, 8, 4] and api.plan_describe(160, api.FFT_COMPLEX)["radices"][:3] == [4, 8, 5]
+    assert api.plan_describe(240, api.FFT_COMPLEX)["radices"][:3] == [6, 8, 5] and api.plan_describe(144, api.FFT_COMPLEX)["radices"][:2] == [12, 12]
     assert api.plan_describe(9216, api.FFT_COMPLEX)["radices"] == [12, 12, 8, 8]
     assert api.plan_describe(96, api.FFT_REAL)["complex_len"] == 48
 
@@ -281,10 +283,9 @@ def test_header_is_consumable_and_links(tmp_path, lang, compiler, std, src):
 def test_round3_planner_rules_host_logic():
     """Planner rules of round 3, through fft_gpu_plan_describe (pure host logic).
     (a) single-pass mixed-radix plans: where some order of the plan's radices lets the last stage store whole 128-byte lines
-        (runs of n / r_last points, a multiple of 16), the plan has such an order (tables.cpp: generic_radices; 160 is the one
-        exception: it runs the staged-I/O form with the sorted list);
+        (runs of n / r_last points, a multiple of 16), the plan has such an order (tables.cpp: generic_radices);
     (b) long plans: the pair of tile lengths and which of them is the column length n2 (tables.cpp: split_static_pair)."""
-    for n in (192, 240, 288, 320, 384, 400, 432, 480, 576, 640, 720, 768, 800, 864, 960, 1152, 1280, 1536, 1600, 1920, 2000):
+    for n in (160, 192, 240, 288, 320, 384, 400, 432, 480, 576, 640, 720, 768, 800, 864, 960, 1152, 1280, 1536, 1600, 1920, 2000):
         d = api.plan_describe(n, api.FFT_COMPLEX)
         rad = [r for r in d["radices"] if r]
         prod = 1
@@ -293,7 +294,6 @@ def test_round3_planner_rules_host_logic():
         assert d["passes"] == 1 and prod == n, (n, d)
         if any((n // r) % 16 == 0 for r in rad):
             assert (n // rad[-1]) % 16 == 0, (n, rad)
-    assert api.plan_describe(160, api.FFT_COMPLEX)["radices"][:2] == [10, 16]
     for n, want in ((34992, (243, 144)), (100000, (250, 400)), (48000, (240, 200)), (46080, (240, 192)), (38400, (240, 160)),
                     (20736, (144, 144)), (30000, (375, 80)), (1 << 22, (2048, 2048)), (245760, (1024, 240))):
         d = api.plan_describe(n, api.FFT_COMPLEX)
