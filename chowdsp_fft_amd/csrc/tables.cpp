@@ -483,7 +483,15 @@ static void generic_radices (int n, std::vector<int>& radix, int frames_override
     if (CFFT_GENERIC_LISTS_V2 && frames_override == 0)
     {
         // one-pass lists re-chosen by measurement (generic_kernels.hpp: StaticPlanFor carries the same table)
-        static const struct { int n; std::vector<int> list; } kMeasured[] = { { 160, { 4, 8, 5 } }, { 192, { 6, 8, 4 } }, { 240, { 6, 8, 5 } } };
+        // 160 / 192 / 240: three stages of radix <= 8 instead of two of radix 10 ... 16 (c192 +15 %, c240 +14 %, real N = 320 +11 %).  The in-place lengths:
+        // another ORDER or split of the same factors, found by sweeping every ordered list through the run-time-list kernel and confirmed with the
+        // compile-time lists (c9216 +11.6 % / real N = 18432 +3.9 %, c9600 +12.5 % / r19200 +5.8 %, c4608 +5.1 % / r9216 +9.3 %, c18432 +6.2 %, c6400 +5.3 %,
+        // c2592 and c6912 +2 %); candidates that gained on the run-time kernel but not as compile-time lists are not here (profiles/r05_generic_lists.txt)
+        static const struct { int n; std::vector<int> list; } kMeasured[] = {
+            { 160, { 4, 8, 5 } }, { 192, { 6, 8, 4 } }, { 240, { 6, 8, 5 } },
+            { 2592, { 6, 6, 12, 6 } }, { 4608, { 12, 8, 4, 12 } }, { 6400, { 10, 8, 16, 5 } }, { 6912, { 9, 16, 8, 6 } }, { 9216, { 12, 8, 8, 12 } }, { 9600, { 10, 8, 8, 15 } },
+            { 18432, { 8, 16, 16, 9 } },
+        };
         for (const auto& m : kMeasured)
             if (m.n == n)
                 best = m.list;

@@ -36,7 +36,11 @@ def lists(n, max_stages=4):
     # drop lists with a radix-2 stage unless nothing else exists, and more than 3 stages where a 2- or 3-stage list exists
     good = [l for l in out if 2 not in l and len(l) >= 2]
     short = [l for l in good if len(l) <= 3]
-    return sorted(short or good, key=lambda l: (len(l), l))
+    cand = short or good
+    # long frames have hundreds of ordered lists: keep every order of the MULTISETS with the smallest radix sums (the planner's criterion) only
+    sets = sorted({tuple(sorted(l)) for l in cand}, key=lambda m: (len(m), sum(m)))[: int(os.environ.get("SWEEP_MULTISETS", "1000"))]
+    cand = [l for l in cand if tuple(sorted(l)) in sets]
+    return sorted(cand, key=lambda l: (len(l), l))
 
 
 def rate(n, real=False):
