@@ -32,13 +32,14 @@ bool CFFT_SIPC_ENTRY (bool real, int block, const GenericPlan& plan, const Devic
     if (plan.n == N_)                                                                                             \
     {                                                                                                             \
         using SP = typename StaticInplacePlanFor<N_>::type;                                                       \
-        bool same = plan.ns == SP::ns && block == B_;                                                             \
+        constexpr int CB_ = inplace_conv_block (N_, B_);                                                          \
+        bool same = plan.ns == SP::ns && block == CB_;                                                            \
         for (int i = 0; same && i < SP::ns; ++i)                                                                  \
             same = plan.radix[i] == SP::radix (i);                                                                \
         if (! same)                                                                                               \
             return false;                                                                                         \
-        rc = real ? launch_sipc<true, B_, SP> (plan, t, in, H, out, scaling, batch, stream)                       \
-                  : launch_sipc<false, B_, SP> (plan, t, in, H, out, scaling, batch, stream);                     \
+        rc = real ? launch_sipc<true, CB_, SP> (plan, t, in, H, out, scaling, batch, stream)                      \
+                  : launch_sipc<false, CB_, SP> (plan, t, in, H, out, scaling, batch, stream);                    \
         return true;                                                                                              \
     }
     CFFT_SIP_GROUP (CFFT_TRY)

@@ -70,7 +70,20 @@ inline void generic_geometry (int n, int& frames, int& block, bool real_transfor
     // points in flight; measured: N=480 +4 % with 4 frames, N=640 +86 % with 3).
     if (n > 2048)
     {
-        block = n <= 5120 ? 256 : (n <= 10240 ? 512 : 1024);
+    // Round 5 (profiles/r05_generic_lists.txt step 7): 512 work-items from 2880 points on, not from 5184 -- c2880 ... c5120 +5 ... +17 % (c5120 0.60 -> 0.70 of
+    // 8 TB/s), real N = 6400 / 10240 +6 / +11 %; below (2160 ... 2592 points) 256 work-items stay 4 ... 18 % faster, and 1024 work-items before 10240 points lose
+    // 7 ... 24 % (c8640, c9216, c10240).
+#ifndef CFFT_INPLACE_B256_MAX
+#define CFFT_INPLACE_B256_MAX 2592
+#endif
+#ifndef CFFT_INPLACE_CONV_B256_MAX
+#define CFFT_INPLACE_CONV_B256_MAX 4800
+#endif
+#ifndef CFFT_INPLACE_B512_MAX
+#define CFFT_INPLACE_B512_MAX 10240
+#endif
+        // (the fused convolution keeps 256 work-items up to 4800 points: c2880 / c3840 / real N = 7680 lose 5 ... 7 % with 512, 5120 points gain 7 %)
+        block = n <= (fused_conv ? CFFT_INPLACE_CONV_B256_MAX : CFFT_INPLACE_B256_MAX) ? 256 : (n <= CFFT_INPLACE_B512_MAX ? 512 : 1024);
         frames = 1;
         return;
     }
@@ -107,6 +120,8 @@ inline void generic_geometry (int n, int& frames, int& block, bool real_transfor
     frames = (n <= CFFT_GENERIC_MULTI_MAX) ? (points / n > 1 ? points / n : 1) : 1;
 }
 inline bool generic_uses_inplace (int n) { return n > 2048; }
+// work-items of the fused convolution's in-place kernel for a length whose transform kernel runs `transform_block` (generated lists: X (n, work-items, ...))
+constexpr int inplace_conv_block (int n, int transform_block) { return (n > 2048 && n <= CFFT_INPLACE_CONV_B256_MAX) ? 256 : transform_block; }
 
 // stage radices of the generic mixed-radix kernel for a complex length that is not a power of two
 void generic_plan_radices (int n_complex, std::vector<int>& radix);
