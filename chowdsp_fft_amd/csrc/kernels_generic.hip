@@ -56,10 +56,15 @@ hipError_t launch_generic_mb (const GenericPlan& plan_in, const DeviceTables& t,
         // real modes: the pair twiddles too, for the short frames (several per workgroup).  Measured on MI355X, fraction of 8 TB/s
         // with / without: real N = 96 0.50 / 0.39, 384 0.58 / 0.46, 480 0.56 / 0.45, 1280 0.63 / 0.60 -- but 3072 0.50 / 0.56,
         // 3840 0.31 / 0.45 (one frame per workgroup: the longer copy at kernel start and the LDS it takes cost more than the
-        // loads from L2)
+        // loads from L2).  Round 5 sweep of the bound: real N = 1440 / 1536 / 1600 / 1728 +1 / +5 / +2 / +6 % with the copy, 1920 even, 2304 -25 %.
         GenericPlan plan = plan_in;
         const size_t with_pair = ((size_t) 2 * plan.frames * plan.n + generic_table_len (MODE, plan.n)) * sizeof (float2);
-        plan.pair_lds = (MODE != 0 && plan.n <= 640 && with_pair <= dev.lds_per_cu) ? 1 : 0;
+        static const int pair_lds_max_n = [] { // (developer sweep: CHOWDSP_FFT_PAIR_LDS_MAX_N)
+            const char* e = std::getenv ("CHOWDSP_FFT_PAIR_LDS_MAX_N");
+            const int v = e != nullptr ? std::atoi (e) : 0;
+            return v > 0 ? v : 864; // (640 until round 5; 720 ... 864 points gain 1 ... 6 % with the copy, 960 is even, 1152 collapses: profiles/r05_generic_lists.txt step 8)
+        }();
+        plan.pair_lds = (MODE != 0 && plan.n <= pair_lds_max_n && with_pair <= dev.lds_per_cu) ? 1 : 0;
         // the reference's "other sizes" (generic_kernels.hpp: StaticPlanFor): compile-time stage list where the planner's list
         // (by which the twiddle table is laid out) is the one the template was written for
         static const bool static_off = [] {
