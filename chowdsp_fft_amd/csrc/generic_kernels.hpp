@@ -666,10 +666,24 @@ __device__ __forceinline__ void real_merge_frames (const float2* __restrict__ sr
     }
 }
 
+// The mirrored half X[n - k] of the packed spectrum leaves in descending runs that start one element off a 128-byte line.  With the default cache policy
+// (plain = true) the pieces of a line written by neighbouring instructions meet in L2 before they go out; nontemporal sends each piece on its own.
+// Measured (round 5, profiles/r05_real_mirror_store.txt): workgroups that hold several short frames gain 3-5 % with plain stores (real N = 384 ... 1920),
+// one-frame workgroups lose 1-3 % -- the caller says which it is.  CFFT_REAL_MIRROR_PLAIN = 0: nontemporal everywhere (rounds 1-4).
+#ifndef CFFT_REAL_MIRROR_PLAIN
+#define CFFT_REAL_MIRROR_PLAIN 1
+#endif
+__device__ __forceinline__ void mirror_store (float2* p, float2 v, bool plain)
+{
+    if (CFFT_REAL_MIRROR_PLAIN && plain)
+        *p = v;
+    else
+        gstore (p, v);
+}
 // forward: Z in the LDS image (frame stride n) -> packed spectrum frames in global memory (frame stride `os`)
 template <int BLOCK>
 __device__ __forceinline__ void real_split_frames (const float2* __restrict__ img, float2* __restrict__ dst, unsigned os, const float2* wp, int n,
-                                                   int nframes, int tid)
+                                                   int nframes, int tid, bool plain_mirror = false)
 {
     const int half = n / 2 + 1, total = nframes * half;
     const unsigned magic_half = div_magic ((unsigned) half);
@@ -709,7 +723,7 @@ __device__ __forceinline__ void real_split_frames (const float2* __restrict__ im
                     real_split_pair (A, Zp, W[u], Xk, Xp);
                 gstore (&dst[(size_t) f * os + k], Xk);
                 if (kp != k)
-                    gstore (&dst[(size_t) f * os + kp], Xp);
+                    mirror_store (&dst[(size_t) f * os + kp], Xp, plain_mirror);
             }
         }
     }
@@ -881,7 +895,7 @@ __global__ __launch_bounds__ (BLOCK) void generic_kernel (const float2* __restri
             res = generic_core<BLOCK, IN_GLOBAL, OUT_GLOBAL, (MODE == 2) || INV> (plan, twtab, bufA, bufB, src, dst, nframes, tid, (unsigned) n);
         if (MODE == 1)
         {
-            const auto split_all = [&] (const float2* wp) { real_split_frames<BLOCK> (res, dst, os, wp, n, nframes, tid); };
+            const auto split_all = [&] (const float2* wp) { real_split_frames<BLOCK> (res, dst, os, wp, n, nframes, tid, F >= 2); }; // (several frames per workgroup: plain mirrored stores)
             if (pair_lds)
                 split_all (wlds);
             else

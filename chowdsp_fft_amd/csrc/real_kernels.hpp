@@ -21,6 +21,21 @@
 
 namespace cfft
 {
+// the mirrored bins' stores of the one-pass real forward kernels: default cache policy for the 2048- and 4096-point cores (real N = 4096 / 8192: +5 %, the
+// pieces of a line meet in L2), nontemporal like every other streaming store elsewhere (staged / rotated-lane forms do not come here; 8192 points and more:
+// +-1 %).  profiles/r05_real_mirror_store.txt; CFFT_REAL_MIRROR_PLAIN = 0: nontemporal everywhere (rounds 1-4).
+#ifndef CFFT_REAL_MIRROR_PLAIN
+#define CFFT_REAL_MIRROR_PLAIN 1
+#endif
+template <int M_>
+__device__ __forceinline__ void real_mirror_store (float2* p, float2 v)
+{
+    if (CFFT_REAL_MIRROR_PLAIN && (M_ == 2048 || M_ == 4096))
+        *p = v;
+    else
+        gstore (p, v);
+}
+
 // natural-order LDS image <-> register order helpers
 template <class P>
 __device__ __forceinline__ void lds_store_output_order (const float2 (&v)[P::R], float2* __restrict__ lds, int t)
@@ -210,7 +225,7 @@ __global__ __launch_bounds__ (P::T* FPB) void r2c_kernel (const float2* __restri
                 else if constexpr (LAYOUT == 0)
                 {
                     gstore (&dst[team_out + (unsigned) k], Xk);
-                    gstore (&dst[team_out + kp], Xp);
+                    real_mirror_store<M> (&dst[team_out + kp], Xp);
                 }
                 else
                 {
@@ -225,7 +240,7 @@ __global__ __launch_bounds__ (P::T* FPB) void r2c_kernel (const float2* __restri
                         if constexpr (LAYOUT == 2)
                             gstore (&dst[team_out + (unsigned) (2 * M - k)], make_float2 (Xk.x, -Xk.y));
                     }
-                    gstore (&dst[team_out + kp], Xp);
+                    real_mirror_store<M> (&dst[team_out + kp], Xp);
                     if constexpr (LAYOUT == 2)
                         gstore (&dst[team_out + (unsigned) (2 * M) - kp], make_float2 (Xp.x, -Xp.y));
                 }
@@ -301,7 +316,7 @@ __device__ __forceinline__ void r2c_finish (float2 (&v)[P::R], const TwiddleRegs
         if (! PRED || active)
         {
             gstore (&dst[team_out + (unsigned) k], Xk);
-            gstore (&dst[team_out + (unsigned) (k == 0 ? M / 2 : M - k)], Xp);
+            real_mirror_store<M> (&dst[team_out + (unsigned) (k == 0 ? M / 2 : M - k)], Xp);
         }
     }
 }
@@ -688,7 +703,7 @@ __global__ __launch_bounds__ (P::T) void r2c_kernel_streamed (const float2* __re
                 Xp = make_float2 (Zp.x, -Zp.y);
             }
             gstore (&dst[(unsigned) k], Xk);
-            gstore (&dst[(unsigned) (k == 0 ? M / 2 : M - k)], Xp);
+            real_mirror_store<M> (&dst[(unsigned) (k == 0 ? M / 2 : M - k)], Xp);
         }
     }
 }
