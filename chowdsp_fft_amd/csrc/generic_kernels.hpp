@@ -616,6 +616,12 @@ __device__ __forceinline__ void lds_table_copy (float2* __restrict__ dst, const 
 #endif
 static constexpr int kRealPairBatch = CFFT_REAL_PAIR_BATCH;
 
+// the mirrored bins' LOADS of the backward transform: default cache policy where a workgroup holds five or more short frames (real N = 96 ... 800: +1 ... +5 %,
+// the two pieces of a line are asked for by neighbouring instructions and meet in L2), nontemporal otherwise (real N = 960 at 2 GiB per buffer: -2 ... -4 %
+// with plain loads; longer frames: 0).  profiles/r05_real_mirror_store.txt; CFFT_REAL_MIRROR_LOAD_PLAIN = 0: nontemporal everywhere (rounds 1-4).
+#ifndef CFFT_REAL_MIRROR_LOAD_PLAIN
+#define CFFT_REAL_MIRROR_LOAD_PLAIN 1
+#endif
 // backward: spectrum frames in global memory (frame stride `is`) -> Z, re <-> im swapped, in the LDS image (frame stride n)
 template <int BLOCK>
 __device__ __forceinline__ void real_merge_frames (const float2* __restrict__ src, unsigned is, float2* __restrict__ img, const float2* wp, int n,
@@ -634,7 +640,7 @@ __device__ __forceinline__ void real_merge_frames (const float2* __restrict__ sr
             const int f = nframes == 1 ? 0 : fast_div (idx, magic_half), k = idx - f * half;
             const int kp = (k == 0) ? 0 : n - k;
             A[u] = gload (&src[(size_t) f * is + k]);
-            X[u] = gload (&src[(size_t) f * is + kp]);
+            X[u] = (CFFT_REAL_MIRROR_LOAD_PLAIN && nframes >= 5) ? src[(size_t) f * is + kp] : gload (&src[(size_t) f * is + kp]);
             W[u] = wp[k];
         }
 #pragma unroll

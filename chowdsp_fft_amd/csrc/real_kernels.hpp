@@ -36,6 +36,10 @@ __device__ __forceinline__ void real_mirror_store (float2* p, float2 v)
         gstore (p, v);
 }
 
+// the mirrored bins' LOADS of the power-of-two backward kernels stay nontemporal: the default policy measured 0 +- 0.6 % on them (round 5,
+// profiles/r05_real_mirror_store.txt; the mixed-radix kernel with many short frames per workgroup is where it pays: generic_kernels.hpp)
+__device__ __forceinline__ float2 real_mirror_load (const float2* p) { return gload (p); }
+
 // natural-order LDS image <-> register order helpers
 template <class P>
 __device__ __forceinline__ void lds_store_output_order (const float2 (&v)[P::R], float2* __restrict__ lds, int t)
@@ -486,7 +490,7 @@ __global__ __launch_bounds__ (P::T* FPB, (P::N == 512 && CFFT_C2R512_WAVES5) ? 5
                 const int kn = P::T * qn;
                 const unsigned kp0 = (unsigned) (kn == 0 ? M / 2 : M - kn);
                 const unsigned kp = (t == 0) ? kp0 : (unsigned) (M - (t + P::T * q));
-                xp_l[q] = active ? gload (&src[team_in + kp]) : make_float2 (0.f, 0.f);
+                xp_l[q] = active ? real_mirror_load (&src[team_in + kp]) : make_float2 (0.f, 0.f);
             }
         }
 #pragma unroll
@@ -615,7 +619,7 @@ __global__ __launch_bounds__ (P::T) void c2r_kernel_pf (const float2* __restrict
         {                                                                             \
             const int k_ = t + P::T * q;                                              \
             const float2 a_ = gload (&src_[(unsigned) k_]);                           \
-            const float2 p_ = gload (&src_[(unsigned) (k_ == 0 ? M / 2 : M - k_)]);   \
+            const float2 p_ = real_mirror_load (&src_[(unsigned) (k_ == 0 ? M / 2 : M - k_)]); \
             AX[q] = a_.x;                                                             \
             AY[q] = a_.y;                                                             \
             PX[q] = p_.x;                                                             \
@@ -733,7 +737,7 @@ __global__ __launch_bounds__ (P::T) void c2r_kernel_streamed (const float2* __re
         {
             const int k = t + P::T * q;
             const float2 A = gload (&src[(unsigned) k]);
-            const float2 Xp = gload (&src[(unsigned) (k == 0 ? M / 2 : M - k)]);
+            const float2 Xp = real_mirror_load (&src[(unsigned) (k == 0 ? M / 2 : M - k)]);
             real_merge_pair (A, Xp, wtab[k], zk[q], zp[q]);
             if (k == 0)
             {
