@@ -111,10 +111,12 @@ inline void generic_geometry (int n, int& frames, int& block, bool real_transfor
     {
         // (fused_conv: the one-launch convolution keeps the round-2 choices -- it was not part of the round-3 re-measurement, and
         // c240 lost 5 % with 3072)
-        if (n == 96 || n == 144 || n == 160 || (! real_transform && ! fused_conv && (n == 48 || n == 80)))
+        // Round 5 (profiles/r05_generic_lists.txt step 9, every length at 1536 / 2048 / 3072 / 4096 again): the REAL transforms of the 48- and 80-point cores
+        // do best with 1536 as well (real N = 96 +9 %, 160 +8 %), those of the 240- and 288-point cores +2 / +4 %; complex 480 gains 3 % with 3072.
+        if (n == 96 || n == 144 || n == 160 || (! fused_conv && (n == 48 || n == 80)) || (real_transform && ! fused_conv && (n == 240 || n == 288)))
             points = 1536;
         else if (! real_transform && (n == 192 || n == 432 || n == 576 || n == 768 || n == 800 || n == 960 || (fused_conv && (n == 48 || n == 80))
-                                      || (! fused_conv && (n == 240 || n == 320 || n == 400 || n == 640 || n == 864))))
+                                      || (! fused_conv && (n == 240 || n == 320 || n == 400 || n == 480 || n == 640 || n == 864))))
             points = 3072;
     }
     frames = (n <= CFFT_GENERIC_MULTI_MAX) ? (points / n > 1 ? points / n : 1) : 1;
