@@ -109,8 +109,15 @@ inline void generic_geometry (int n, int& frames, int& block, bool real_transfor
     int points = CFFT_GENERIC_POINTS;
     if (CFFT_GENERIC_POINTS_TUNED)
     {
-        // (fused_conv: the one-launch convolution keeps the round-2 choices -- it was not part of the round-3 re-measurement, and
-        // c240 lost 5 % with 3072)
+        // The fused convolution (two transforms between a group's loads and stores) was measured on its own in round 5 (step 10 of the same file: it had kept
+        // the round-2 choices): 1536 points for most cores up to 432 points and complex 768, 2048 elsewhere (3072 no longer wins anywhere) --
+        // complex 240 +33 %, 768 +26 %, 48 / 192 / 288 +10 ... 13 %, 960 +12 %; real N = 480 / 576 / 864 +11 ... 18 %, 96 +13 %, 768 +9 %.
+        if (fused_conv)
+        {
+            const bool small = n == 48 || n == 80 || n == 96 || n == 144 || n == 160 || n == 240 || n == 288 || n == 384 || n == 400 || n == 432;
+            points = (small || (! real_transform && (n == 192 || n == 768))) ? 1536 : 2048;
+        }
+        else
         // Round 5 (profiles/r05_generic_lists.txt step 9, every length at 1536 / 2048 / 3072 / 4096 again): the REAL transforms of the 48- and 80-point cores
         // do best with 1536 as well (real N = 96 +9 %, 160 +8 %), those of the 240- and 288-point cores +2 / +4 %; complex 480 gains 3 % with 3072.
         if (n == 96 || n == 144 || n == 160 || (! fused_conv && (n == 48 || n == 80)) || (real_transform && ! fused_conv && (n == 240 || n == 288)))

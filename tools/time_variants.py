@@ -4,6 +4,7 @@
 symbol names coexist.
 
 usage: python tools/time_variants.py [--workloads c4096,r1024,c65536,conv4096,c64,c256,c1024] [--rounds 7] lib1.so lib2.so ...
+       (any c<N> / r<N>: fwd + bwd of complex / real frames; v<N> / w<N>: fused convolution of real / complex frames)
        (default libs: chowdsp_fft_amd/libchowdsp_fft_hip.so + chowdsp_fft_amd/variants/*.so)
 """
 import argparse
@@ -87,6 +88,10 @@ def main():
     dev = torch.device("cuda:0")
     stream = int(torch.cuda.current_stream().cuda_stream)
     for wname in args.workloads.split(","):
+        if wname not in WORK and wname[0] in "vw" and wname[1:].isdigit():
+            # fused convolution of any size: v<N> real frames, w<N> complex frames, ~512 MiB of frames
+            nn, trr = int(wname[1:]), (1 if wname[0] == "w" else 0)
+            WORK[wname] = (nn, trr, max(1, (512 << 20) // (4 * (2 * nn if trr else nn))), True)
         if wname not in WORK and wname[0] in "cr" and wname[1:].isdigit():
             # any size: c<N> / r<N>, ~512 MiB of frames
             nn, trr = int(wname[1:]), (1 if wname[0] == "c" else 0)
