@@ -127,6 +127,10 @@ inline void generic_geometry (int n, int& frames, int& block, bool real_transfor
             points = 3072;
     }
     frames = (n <= CFFT_GENERIC_MULTI_MAX) ? (points / n > 1 ? points / n : 1) : 1;
+    // Round 5 (profiles/r05_generic_lists.txt step 12): two frames per workgroup for the complex transforms of 1152, 1280 and 1536 points (+9 / +5 / +7 %); the
+    // other lengths above 1024 points, every real transform and the fused convolution keep one (1200 / 1440 -7 / -10 %, real N = 2304 ... 3072 -9 ... -22 %).
+    if (CFFT_GENERIC_POINTS_TUNED && ! real_transform && ! fused_conv && (n == 1152 || n == 1280 || n == 1536))
+        frames = 2;
 }
 inline bool generic_uses_inplace (int n) { return n > 2048; }
 // work-items of the fused convolution's in-place kernel for a length whose transform kernel runs `transform_block` (generated lists: X (n, work-items, ...))
