@@ -62,6 +62,14 @@ def test_results_do_not_depend_on_the_chunking(gpu, oracle, cap, n, tr, batch, c
         else:
             assert np.array_equal(f, ref_f), f"forward differs at workspace_mib={mib}"
             assert np.array_equal(b, ref_b), f"backward differs at workspace_mib={mib}"
+    # in place, at the smallest cap: a chunk's column sweep has read the chunk's frames before its row sweep overwrites them
+    w = xd.clone()
+    api.fft_transform_batch(s, w, w, api.FFT_FORWARD)
+    torch.cuda.synchronize()
+    assert np.array_equal(w.cpu().numpy(), ref_f), "in-place forward differs"
+    api.fft_transform_batch(s, w, w, api.FFT_BACKWARD)
+    torch.cuda.synchronize()
+    assert np.array_equal(w.cpu().numpy(), ref_b), "in-place backward differs"
     api.fft_destroy_setup(s)
     oracle.destroy_setup(so)
 
